@@ -1,0 +1,79 @@
+"""Numpy restatement of the per-utterance body of each `enhance(args)` loop.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  One function per decode script;
+each takes the model state dict and ONE float waveform (what `sf.read`
+returns) and gives back the float waveform the script hands to `sf.write`
+(before PCM16 quantisation).  `p_in` / `p_out` are the magnitude exponents the
+scripts hard-code (1.0/1.0 "noncprs", 0.5/2.0 "cprs").
+
+The reference feeds the network float32 (`torch.FloatTensor`); `net_dtype`
+selects that (np.float32) or a float64 "truth" run.
+"""
+import numpy as np
+from . import stft as S
+from . import models as M
+
+
+def _frontend_librosa(wav, n_fft, hop):
+    wav = np.asarray(wav, dtype=np.float64)
+    c = S.rms_scale(wav)
+    x = wav * c
+    spec = S.stft(x, n_fft, hop).T                     # [T,F]  (librosa.stft(...).T)
+    return c, x, spec
+
+
+def enhance_lstm(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32, fwd=M.lstm_net_forward):
+    """LSTM/lstm_decode_vb.py:33-52 (and CRN/crn_decode_vb.py:33-52 with fwd=crn)."""
+    c, x, spec = _frontend_librosa(wav, 320, 160)
+    mag, ph = np.abs(spec) ** p_in, np.angle(spec)     # :38
+    est = fwd(sd, mag[None].astype(net_dtype))[0].astype(np.float64)   # :41-45
+    est = est ** p_out                                 # :47
+    de = est * np.exp(1j * ph)                         # :49
+    y = S.istft(de.T, 320, 160, length=len(x))         # :50-51
+    return y / c                                       # :52
+
+
+def enhance_crn(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+    return enhance_lstm(sd, wav, p_in, p_out, net_dtype, fwd=M.crn_net_forward)
+
+
+def enhance_dpcrn(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+    """DPCRN/dpcrn_decode_vb.py:33-60."""
+    c, x, spec = _frontend_librosa(wav, 320, 160)
+    mag, ph = np.abs(spec) ** p_in, np.angle(spec)                       # :41
+    mag32, ph32 = mag.astype(net_dtype), ph.astype(net_dtype)            # torch.FloatTensor :43-44
+    feat = np.stack([mag32 * np.cos(ph32), mag32 * np.sin(ph32)], 0)     # :45
+    est = M.dpcrn_forward(sd, feat[None])                                # :47
+    emag = np.sqrt(est[:, 0] ** 2 + est[:, 1] ** 2)                      # :48
+    eph = np.arctan2(est[:, 1], est[:, 0])                               # :49
+    emag = emag ** p_out                                                 # :53
+    de = emag[0].astype(np.float64) * np.exp(1j * eph[0].astype(np.float64))   # :55-57
+    y = S.istft(de.T, 320, 160, length=len(x))                           # :58-59
+    return y / c
+
+
+def enhance_dccrn(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+    """DCCRN/dccrn_decode_vb.py:25-62.  Output length = padded length (:59-60)."""
+    wav = np.asarray(wav, dtype=np.float64)
+    c = S.rms_scale(wav)                                                 # :27
+    x = S.pad_to_hop(wav * c, 512, 128).astype(net_dtype)                # :28-35 (FloatTensor)
+    spec = S.stft(x, 512, 128)                                           # [F,T] :37-38
+    re, im = spec.real.astype(net_dtype), spec.imag.astype(net_dtype)
+    mag = np.sqrt(re ** 2 + im ** 2) ** p_in                             # :40
+    ph = np.arctan2(im, re)
+    feat = np.stack([mag * np.cos(ph), mag * np.sin(ph)], 0)[None]       # :42  [1,2,F,T]
+    est = M.dccrn_forward(sd, feat)                                      # :44
+    emag = np.sqrt(est[:, 0] ** 2 + est[:, 1] ** 2)                      # :45
+    eph = np.arctan2(est[:, 1], est[:, 0])                               # :46
+    emag = emag ** p_out                                                 # :48
+    de = emag[0].astype(np.float64) * np.exp(1j * eph[0].astype(np.float64))   # :56-58
+    y = S.istft(de, 512, 128, length=len(x))                             # :59-60
+    return y / c                                                         # :62
+
+
+ENHANCE = {
+    'lstm': enhance_lstm,
+    'crn': enhance_crn,
+    'dpcrn': enhance_dpcrn,
+    'dccrn': enhance_dccrn,
+}

@@ -1,0 +1,247 @@
+"""Generate golden fixtures by IMPORTING the reference here (build container only).
+
+TEST INFRASTRUCTURE.  Run:  python -m oracle.gen_golden [names...]
+Needs /root/reference (never present on the GPU box); writes small .npz files
+under tests/golden/.  Fixtures hold inputs and the reference's outputs only -
+synthetic weights are regenerated from (schema, seed) by se_amd.synth.
+
+What is imported from the reference, verbatim, per fixture:
+  stft_*      torch.stft / torch.istft with the reference's arguments
+  lstm_*      LSTM/LSTM.py             lstm_net
+  crn_*       CRN/CRN.py               crn_net
+  dpcrn_*     DPCRN/DPCRN.py           dpcrn   (+ real checkpoint vb_dpcrn_noncprs_model.pth)
+  dccrn_*     DCCRN/DCCRN_cprs.py      DCCRN   (on top of oracle/_complexnn_recall.py - see there)
+The decode-loop bodies (`enhance`) are re-stated around the imported model with
+torch.stft/istft (legacy real-output API shimmed) exactly as SURVEY 8(c) says.
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, ROOT)
+import se_amd  # noqa: E402
+from se_amd import synth  # noqa: E402
+
+
+# ---------------------------------------------------------------- import shims
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    """Import-time stubs for packages absent here; none is touched by forward."""
+    for n in ('librosa', 'soundfile', 'h5py'):
+        if n not in sys.modules:
+            _stub(n)
+    _stub('librosa.filters')
+    _stub('pystoi', stoi=None)
+    _stub('pystoi.stoi', stoi=None)
+    _stub('ptflops', get_model_complexity_info=None)
+    _stub('ptflops.flops_counter', get_model_complexity_info=None)
+    _stub('torch_complex', ComplexTensor=None)
+    _stub('show', show_model=lambda *a, **k: None, show_params=lambda *a, **k: None)
+    from oracle import _complexnn_recall
+    sys.modules['complexnn'] = _complexnn_recall
+    _stub('conv_stft', ConvSTFT=None, ConviSTFT=None)
+
+
+def import_ref(model_dir, module):
+    """Import /root/reference/<model_dir>/<module>.py with that dir first on sys.path.
+    config.py files mkdir ./BEST_MODEL etc. in the CWD -> run from a scratch dir."""
+    install_stubs()
+    scratch = '/tmp/se_golden_scratch'
+    os.makedirs(scratch, exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(scratch)
+    for m in ('Backup', 'config', 'data', 'Step2_config', module):
+        sys.modules.pop(m, None)
+    sys.path.insert(0, os.path.join(REF, model_dir))
+    try:
+        return importlib.import_module(module)
+    finally:
+        sys.path.pop(0)
+        os.chdir(cwd)
+
+
+def load_synth(model, seed):
+    schema = synth.schema_of(model.state_dict())
+    sd = synth.synth_state_dict(schema, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    return schema, sd
+
+
+def t_stft(x, n_fft, hop, win):
+    """Legacy real-output torch.stft ([B,F,T,2]) as the reference calls it."""
+    return torch.view_as_real(torch.stft(x, n_fft, hop, win, window=torch.hann_window(win), return_complex=True))
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print(f'wrote {path}  {os.path.getsize(path) / 1024:.0f} kB')
+
+
+def save_schema(name, schema):
+    with open(os.path.join(GOLD, f'schema_{name}.json'), 'w') as f:
+        json.dump([[k, list(s), d] for k, (s, d) in schema.items()], f)
+
+
+# ---------------------------------------------------------------- generators
+def gen_stft():
+    """torch.stft / torch.istft at the four reference geometries, float32 and float64."""
+    out = {}
+    for (n_fft, hop, win) in ((320, 160, 320), (512, 128, 512), (512, 256, 512), (512, 160, 400)):
+        x = torch.from_numpy(synth.synth_batch(2, "speech", 4000, seed0=7))
+        spec = torch.stft(x.double(), n_fft, hop, win, window=torch.hann_window(win, dtype=torch.float64), return_complex=True)
+        y_len = torch.istft(spec, n_fft, hop, win, window=torch.hann_window(win, dtype=torch.float64), length=4000)
+        y_nolen = torch.istft(spec, n_fft, hop, win, window=torch.hann_window(win, dtype=torch.float64))
+        spec32 = torch.stft(x, n_fft, hop, win, window=torch.hann_window(win), return_complex=True)
+        tag = f'{n_fft}_{hop}_{win}'
+        out[f'x_{tag}'] = x.numpy()
+        out[f'spec_{tag}'] = spec.numpy()
+        out[f'spec32_{tag}'] = spec32.numpy()
+        out[f'ylen_{tag}'] = y_len.numpy()
+        out[f'ynolen_{tag}'] = y_nolen.numpy()
+    save('stft', **out)
+
+
+def _enhance_librosa_family(model, wav, in_kind, p_in=1.0, p_out=1.0):
+    """Loop body shared by LSTM/CRN (in_kind='mag') and DPCRN ('ri'), with the librosa
+    calls replaced by the verified-equivalent float64 torch.stft/istft."""
+    x = torch.from_numpy(np.asarray(wav, dtype=np.float64))
+    c = torch.sqrt(len(x) / torch.sum(x ** 2.0))
+    x = x * c
+    w = torch.hann_window(320, dtype=torch.float64)
+    spec = torch.stft(x, 320, 160, 320, window=w, return_complex=True).T          # [T,F]
+    mag, ph = spec.abs() ** p_in, spec.angle()
+    with torch.no_grad():
+        if in_kind == 'mag':
+            est = model(mag.float()[None])[0].double() ** p_out
+            de = est * torch.exp(1j * ph)
+        else:
+            mag32, ph32 = mag.float(), ph.float()
+            feat = torch.stack((mag32 * torch.cos(ph32), mag32 * torch.sin(ph32)), dim=0)
+            e = model(feat[None])
+            emag = torch.norm(e, dim=1) ** p_out
+            eph = torch.atan2(e[:, 1], e[:, 0])
+            de = emag[0].double() * torch.exp(1j * eph[0].double())
+    y = torch.istft(de.T, 320, 160, 320, window=w, length=len(x))
+    return (y / c).numpy()
+
+
+def gen_lstm():
+    mod = import_ref('LSTM', 'LSTM')
+    model = mod.lstm_net()
+    schema, _ = load_synth(model, 11)
+    save_schema('lstm', schema)
+    rng = np.random.default_rng(5)
+    x = np.abs(rng.standard_normal((2, 12, 161))).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+    wav = synth.synth_clip(3, 'speech', 4000)
+    save('lstm', x=x, y=y, wav=wav, enh=_enhance_librosa_family(model, wav, 'mag'))
+
+
+def gen_crn():
+    mod = import_ref('CRN', 'CRN')
+    model = mod.crn_net()
+    schema, _ = load_synth(model, 12)
+    save_schema('crn', schema)
+    rng = np.random.default_rng(6)
+    x = np.abs(rng.standard_normal((2, 10, 161))).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+    wav = synth.synth_clip(4, 'speech', 4000)
+    save('crn', x=x, y=y, wav=wav, enh=_enhance_librosa_family(model, wav, 'mag'))
+
+
+def gen_dpcrn():
+    mod = import_ref('DPCRN', 'DPCRN')
+    model = mod.dpcrn()
+    schema, _ = load_synth(model, 13)
+    save_schema('dpcrn', schema)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((2, 2, 9, 161)).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+    wav = synth.synth_clip(5, 'speech', 4000)
+    enh = _enhance_librosa_family(model, wav, 'ri')
+    # real checkpoint: the only real-weights anchor of the whole zoo
+    ck = torch.load(os.path.join(REF, 'DPCRN/BEST_MODEL/vb_dpcrn_noncprs_model.pth'), map_location='cpu')
+    model.load_state_dict(ck, strict=True)
+    model.eval()
+    with torch.no_grad():
+        y_real = model(torch.from_numpy(x)).numpy()
+    wav4 = synth.synth_clip(0, 'speech', 64000)
+    enh_real = _enhance_librosa_family(model, wav4, 'ri')
+    ckc = torch.load(os.path.join(REF, 'DPCRN/BEST_MODEL/vb_dpcrn_cprs_model.pth'), map_location='cpu')
+    model.load_state_dict(ckc, strict=True)
+    enh_real_cprs = _enhance_librosa_family(model, wav4, 'ri', 0.5, 2.0)
+    save('dpcrn', x=x, y=y, wav=wav, enh=enh, y_real=y_real, enh_real=enh_real.astype(np.float32),
+         enh_real_cprs=enh_real_cprs.astype(np.float32))
+    # the checkpoints themselves, as data fixtures (fp32, int64 counters dropped -> re-added as zeros)
+    for tag, c in (('noncprs', ck), ('cprs', ckc)):
+        np.savez_compressed(os.path.join(GOLD, f'ckpt_vb_dpcrn_{tag}.npz'),
+                            **{k: v.numpy() for k, v in c.items()})
+
+
+def _enhance_dccrn(model, wav, p_in, p_out):
+    """DCCRN/dccrn_decode_vb.py:25-62 around the imported model; librosa.istft -> float64 torch.istft."""
+    feat_wav = np.asarray(wav, dtype=np.float64)
+    c = np.sqrt(len(feat_wav) / np.sum(feat_wav ** 2.0))
+    feat_wav = feat_wav * c
+    wav_len = len(feat_wav)
+    frame_num = int(np.ceil((wav_len - 512 + 512) / 128 + 1))
+    fake = (frame_num - 1) * 128 + 512 - 512
+    x = torch.FloatTensor(np.concatenate((feat_wav, np.zeros([fake - wav_len])), axis=0))
+    feat_x = t_stft(x.unsqueeze(0), 512, 128, 512).permute(0, 3, 1, 2)
+    mag, ph = torch.norm(feat_x, dim=1) ** p_in, torch.atan2(feat_x[:, 1], feat_x[:, 0])
+    feat_x = torch.stack((mag * torch.cos(ph), mag * torch.sin(ph)), dim=1)
+    with torch.no_grad():
+        esti = model(feat_x)
+    emag = torch.norm(esti, dim=1) ** p_out
+    eph = torch.atan2(esti[:, 1], esti[:, 0])
+    de = emag[0].double() * torch.exp(1j * eph[0].double())
+    y = torch.istft(de, 512, 128, 512, window=torch.hann_window(512, dtype=torch.float64), length=len(x))
+    return (y / c).numpy(), feat_x.numpy(), esti.numpy()
+
+
+def gen_dccrn():
+    mod = import_ref('DCCRN', 'DCCRN_cprs')
+    model = mod.DCCRN(rnn_units=256, masking_mode='E', use_clstm=True, kernel_num=[32, 64, 128, 256, 256, 256])
+    schema, _ = load_synth(model, 14)
+    save_schema('dccrn', schema)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, 2, 257, 7)).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+    wav = synth.synth_clip(6, 'speech', 4000)
+    enh, _, _ = _enhance_dccrn(model, wav, 1.0, 1.0)
+    enh_c, _, _ = _enhance_dccrn(model, wav, 0.5, 2.0)
+    wav4 = synth.synth_clip(1, 'speech', 64000)
+    enh4, _, _ = _enhance_dccrn(model, wav4, 0.5, 2.0)
+    save('dccrn', x=x, y=y, wav=wav, enh=enh, enh_cprs=enh_c, enh4_cprs=enh4.astype(np.float32))
+
+
+GENS = {'stft': gen_stft, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    names = sys.argv[1:] or list(GENS)
+    for n in names:
+        GENS[n]()

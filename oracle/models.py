@@ -1,0 +1,207 @@
+"""Numpy restatement of the reference `nn.Module.forward`s on the hot path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Each function takes the model's
+flat state dict `sd` (name -> numpy array, the key schema of the reference's
+`state_dict()`) and the input in the reference's layout and
+returns what the reference `forward` returns.  Compute dtype = input dtype.
+"""
+import numpy as np
+from . import nnops as nn
+
+
+def _bn(sd, p, x):
+    return nn.batchnorm(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'running_mean'], sd[p + 'running_var'])
+
+
+# ----------------------------------------------------------------------------
+# LSTM   (reference LSTM/LSTM.py:14-28)
+# ----------------------------------------------------------------------------
+def lstm_net_forward(sd, x):
+    """x [B,T,161] magnitude -> [B,T,161] enhanced magnitude (mapping)."""
+    # LSTM.py:25  BatchNorm1d over the feature dim (permute to [B,161,T] and back)
+    x = _bn(sd, 'bn.', np.swapaxes(x, 1, 2))
+    x = np.swapaxes(x, 1, 2)
+    x = nn.lstm(x, sd, 'lstm1.', 1, batch_first=True)          # LSTM.py:26
+    x = nn.lstm(x, sd, 'lstm2.', 2, batch_first=True)          # LSTM.py:27
+    x = nn.softplus(nn.linear(x, sd['fc.0.weight'], sd['fc.0.bias']))   # LSTM.py:20-22,28
+    return x
+
+
+# ----------------------------------------------------------------------------
+# CRN   (reference CRN/CRN.py:16-117)
+# ----------------------------------------------------------------------------
+def _causal_conv_tf(sd, p, x):
+    """ConstantPad2d((0,0,1,0)) + Conv2d(k=(2,3), s=(1,2))   CRN.py:38-42, DPCRN.py:97-101."""
+    x = np.pad(x, ((0, 0), (0, 0), (1, 0), (0, 0)))
+    return nn.conv2d(x, sd[p + 'weight'], sd[p + 'bias'], stride=(1, 2))
+
+
+def crn_net_forward(sd, x):
+    """x [B,T,161] -> [B,T,161]."""
+    x = x[:, None]                                              # CRN.py:24
+    B, _, T, _ = x.shape
+    skips = []
+    for i in range(5):                                          # Encoder CRN.py:35-71
+        x = _causal_conv_tf(sd, f'en.en_module.{i}.1.', x)
+        x = nn.elu(_bn(sd, f'en.en_module.{i}.2.', x))
+        skips.append(x)
+    x = np.transpose(x, (0, 2, 1, 3)).reshape(B, T, -1)         # CRN.py:27-28
+    x = nn.lstm(x, sd, 'lstm.', 2, batch_first=True)            # CRN.py:29
+    x = np.transpose(x.reshape(B, T, 256, 4), (0, 2, 1, 3))     # CRN.py:30-31
+    for i in range(5):                                          # Decoder CRN.py:73-109
+        x = np.concatenate([x, skips[-(i + 1)]], axis=1)        # CRN.py:107
+        p = f'de.de_module.{i}.'
+        x = nn.conv_transpose2d(x, sd[p + '0.weight'], sd[p + '0.bias'], stride=(1, 2))
+        if i == 3:                                              # de4: ConstantPad2d((1,0,0,0)) CRN.py:93-95
+            x = np.pad(x, ((0, 0), (0, 0), (0, 0), (1, 0)))
+            bn = p + '3.'
+        else:
+            bn = p + '2.'
+        x = x[:, :, :-1, :]                                     # Chomp_T(1) CRN.py:112-117
+        x = _bn(sd, bn, x)
+        x = nn.softplus(x) if i == 4 else nn.elu(x)             # CRN.py:99-102
+    return x[:, 0]                                              # squeeze CRN.py:109
+
+
+# ----------------------------------------------------------------------------
+# DPCRN   (reference DPCRN/DPCRN.py:16-174)
+# ----------------------------------------------------------------------------
+def _dprnn(sd, x):
+    """DPRNN.forward DPCRN.py:59-92.  x [B,C=128,T,F=4]."""
+    B, C, T, F = x.shape
+    xp = np.transpose(x, (0, 2, 3, 1))                          # [B,T,F,C]
+    out = xp.reshape(-1, F, C)                                  # [B*T,F,C]
+    out = nn.lstm(out, sd, 'dprnn.intra_rnn.', 2, bidirectional=True, batch_first=True)
+    out = nn.linear(out, sd['dprnn.intra_fc.weight'], sd['dprnn.intra_fc.bias'])
+    out = out.reshape(B, -1, F, C)
+    out = nn.layernorm(out, sd['dprnn.ln1.weight'], sd['dprnn.ln1.bias'], 2)
+    intra = out + xp
+    out = np.transpose(intra, (0, 2, 1, 3)).reshape(-1, T, C)   # [B*F,T,C]
+    out = nn.lstm(out, sd, 'dprnn.inter_rnn.', 2, batch_first=True)
+    out = nn.linear(out, sd['dprnn.inter_fc.weight'], sd['dprnn.inter_fc.bias'])
+    out = np.transpose(out.reshape(B, -1, T, C), (0, 2, 1, 3))  # [B,T,F,C]
+    out = nn.layernorm(out, sd['dprnn.ln2.weight'], sd['dprnn.ln2.bias'], 2)
+    out = out + intra
+    return np.transpose(out, (0, 3, 1, 2))
+
+
+def dpcrn_forward(sd, inpt):
+    """inpt [B,2,T,161] (RI) -> [B,2,T,161] masked RI.  DPCRN.py:23-42."""
+    x = inpt
+    skips = []
+    for i in range(5):                                          # Encoder DPCRN.py:94-130
+        x = _causal_conv_tf(sd, f'en.en_module.{i}.1.', x)
+        x = nn.prelu(_bn(sd, f'en.en_module.{i}.2.', x), sd[f'en.en_module.{i}.3.weight'])
+        skips.append(x)
+    x = _dprnn(sd, x)                                           # DPCRN.py:28-29 (same weights twice)
+    x = _dprnn(sd, x)
+    for i in range(5):                                          # Decoder DPCRN.py:132-166
+        x = np.concatenate([x, skips[-(i + 1)]], axis=1)
+        p = f'de.de_module.{i}.'
+        x = nn.conv_transpose2d(x, sd[p + '0.weight'], sd[p + '0.bias'], stride=(1, 2))
+        off = 1
+        if i == 3:                                              # de4 pad1 DPCRN.py:151-154
+            x = np.pad(x, ((0, 0), (0, 0), (0, 0), (1, 0)))
+            off = 2
+        x = x[:, :, :-1, :]
+        if i < 4:
+            x = nn.prelu(_bn(sd, f'{p}{off + 1}.', x), sd[f'{p}{off + 2}.weight'])
+    mr, mi = x[:, 0], x[:, 1]
+    xr, xi = inpt[:, 0], inpt[:, 1]
+    return np.stack([xr * mr - xi * mi, xr * mi + xi * mr], axis=1)   # DPCRN.py:33-42
+
+
+# ----------------------------------------------------------------------------
+# DCCRN   (reference DCCRN/DCCRN_cprs.py:8-226; operators of the ABSENT
+# third-party `complexnn.py` restated from upstream huyanxin/DeepComplexCRN -
+# PARITY UNPINNED at that boundary, see oracle/_complexnn_recall.py)
+# ----------------------------------------------------------------------------
+def _cplx_conv2d(sd, p, x, pad_f, pad_t):
+    """complexnn.ComplexConv2d(causal=True, complex_axis=1) as called at
+    DCCRN_cprs.py:66-72: time padded on the left only by padding[1], frequency
+    symmetric by padding[0]; two real convs applied to both halves,
+    real = rr - ii, imag = ri + ir (biases combine as in the convs)."""
+    x = np.pad(x, ((0, 0), (0, 0), (0, 0), (pad_t, 0)))
+    r, i = np.split(x, 2, axis=1)
+    wr, br = sd[p + 'real_conv.weight'], sd[p + 'real_conv.bias']
+    wi, bi = sd[p + 'imag_conv.weight'], sd[p + 'imag_conv.bias']
+    conv = lambda a, w, b: nn.conv2d(a, w, b, stride=(2, 1), padding=(pad_f, 0))
+    real = conv(r, wr, br) - conv(i, wi, bi)
+    imag = conv(r, wi, bi) + conv(i, wr, br)
+    return np.concatenate([real, imag], axis=1)
+
+
+def _cplx_deconv2d(sd, p, x):
+    """complexnn.ComplexConvTranspose2d as called at DCCRN_cprs.py:108-115:
+    kernel (5,2), stride (2,1), padding (2,0), output_padding (1,0)."""
+    r, i = np.split(x, 2, axis=1)
+    wr, br = sd[p + 'real_conv.weight'], sd[p + 'real_conv.bias']
+    wi, bi = sd[p + 'imag_conv.weight'], sd[p + 'imag_conv.bias']
+    dc = lambda a, w, b: nn.conv_transpose2d(a, w, b, stride=(2, 1), padding=(2, 0), output_padding=(1, 0))
+    real = dc(r, wr, br) - dc(i, wi, bi)
+    imag = dc(r, wi, bi) + dc(i, wr, br)
+    return np.concatenate([real, imag], axis=1)
+
+
+def _complex_cat(a, b):
+    """complexnn.complex_cat([a, b], 1): real halves together, imag halves together."""
+    ar, ai = np.split(a, 2, axis=1)
+    br, bi = np.split(b, 2, axis=1)
+    return np.concatenate([ar, br, ai, bi], axis=1)
+
+
+def _navie_complex_lstm(sd, p, r, i, proj):
+    """complexnn.NavieComplexLSTM.forward([r, i]) as called at DCCRN_cprs.py:182."""
+    run = lambda x, q: nn.lstm(x, sd, p + q, 1)
+    r2r = run(r, 'real_lstm.')
+    r2i = run(r, 'imag_lstm.')
+    i2r = run(i, 'real_lstm.')
+    i2i = run(i, 'imag_lstm.')
+    ro = r2r - i2i
+    io = i2r + r2i
+    if proj:
+        ro = nn.linear(ro, sd[p + 'r_trans.weight'], sd[p + 'r_trans.bias'])
+        io = nn.linear(io, sd[p + 'i_trans.weight'], sd[p + 'i_trans.bias'])
+    return ro, io
+
+
+def dccrn_forward(sd, inputs, n_layers=6, masking_mode='E'):
+    """inputs [B,2,F=257,T] -> [B,2,257,T].  DCCRN.forward DCCRN_cprs.py:142-226
+    for the decode script's constructor (use_clstm=True, use_cbn=False,
+    kernel_num=[32,64,128,256,256,256], rnn_layers=2; dccrn_decode_vb.py:11)."""
+    real, imag = inputs[:, 0], inputs[:, -1]                    # :163
+    spec_mags = np.sqrt(inputs[:, 0] ** 2 + inputs[:, 1] ** 2)  # torch.norm(dim=1) :164
+    spec_phase = np.arctan2(inputs[:, -1], inputs[:, 0])        # :165
+    out = inputs[:, :, 1:]                                      # drop DC :166
+    enc = []
+    for k in range(n_layers):                                   # :170-173
+        out = _cplx_conv2d(sd, f'encoder.{k}.0.', out, 2, 1)
+        out = nn.prelu(_bn(sd, f'encoder.{k}.1.', out), sd[f'encoder.{k}.2.weight'])
+        enc.append(out)
+    B, C, D, T = out.shape                                      # :175
+    out = np.transpose(out, (3, 0, 1, 2))                       # :176
+    r = out[:, :, :C // 2].reshape(T, B, C // 2 * D)            # :178-181
+    i = out[:, :, C // 2:].reshape(T, B, C // 2 * D)
+    r, i = _navie_complex_lstm(sd, 'enhance.0.', r, i, False)   # :182 (nn.Sequential of 2)
+    r, i = _navie_complex_lstm(sd, 'enhance.1.', r, i, True)
+    r = r.reshape(T, B, C // 2, D)                              # :183-184
+    i = i.reshape(T, B, C // 2, D)
+    out = np.concatenate([r, i], axis=2)                        # :185
+    out = np.transpose(out, (1, 2, 3, 0))                       # :194
+    for k in range(n_layers):                                   # :196-199
+        out = _complex_cat(out, enc[-1 - k])
+        out = _cplx_deconv2d(sd, f'decoder.{k}.0.', out)
+        if k < n_layers - 1:
+            out = nn.prelu(_bn(sd, f'decoder.{k}.1.', out), sd[f'decoder.{k}.2.weight'])
+        out = out[..., 1:]
+    mr = np.pad(out[:, 0], ((0, 0), (1, 0), (0, 0)))            # :201-204
+    mi = np.pad(out[:, 1], ((0, 0), (1, 0), (0, 0)))
+    assert masking_mode == 'E'
+    mm = (mr ** 2 + mi ** 2) ** 0.5                             # :207
+    rp = mr / (mm + 1e-8)
+    ip = mi / (mm + 1e-8)
+    mph = np.arctan2(ip, rp)                                    # :210-213
+    mm = np.tanh(mm)                                            # :216
+    em = mm * spec_mags
+    ep = spec_phase + mph
+    return np.stack([em * np.cos(ep), em * np.sin(ep)], axis=1)  # :219-225

@@ -1,0 +1,85 @@
+"""CPU: the numpy oracle against fixtures generated from the imported reference
+(oracle/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+import se_amd
+from se_amd import synth
+from oracle import stft as S, models as M, decode as D
+from conftest import load_golden, load_schema, rms
+
+GEOMS = [(320, 160, 320), (512, 128, 512), (512, 256, 512), (512, 160, 400)]
+
+
+@pytest.mark.parametrize('g', GEOMS)
+def test_stft_matches_torch(g):
+    n_fft, hop, win = g
+    G = load_golden('stft')
+    tag = f'{n_fft}_{hop}_{win}'
+    x = G[f'x_{tag}']
+    spec = S.stft(x.astype(np.float64), n_fft, hop, win)
+    assert spec.shape == G[f'spec_{tag}'].shape
+    assert np.max(np.abs(spec - G[f'spec_{tag}'])) < 1e-11
+    assert np.max(np.abs(S.stft(x, n_fft, hop, win) - G[f'spec32_{tag}'])) < 2e-5
+    y = S.istft(G[f'spec_{tag}'], n_fft, hop, win, length=x.shape[-1])
+    assert np.max(np.abs(y - G[f'ylen_{tag}'])) < 1e-12
+    y2 = S.istft(G[f'spec_{tag}'], n_fft, hop, win)
+    assert y2.shape == G[f'ynolen_{tag}'].shape
+    assert np.max(np.abs(y2 - G[f'ynolen_{tag}'])) < 1e-12
+
+
+def test_stft_roundtrip_property():
+    x = synth.synth_clip(2, 'speech', 64000).astype(np.float64)
+    for n_fft, hop, win in GEOMS[:3]:
+        y = S.istft(S.stft(x, n_fft, hop, win), n_fft, hop, win, length=len(x))
+        assert np.max(np.abs(y - x)) < 1e-12
+
+
+def _sd(name, seed):
+    return synth.synth_state_dict(load_schema(name), seed)
+
+
+@pytest.mark.parametrize('name,seed,fwd', [
+    ('lstm', 11, M.lstm_net_forward), ('crn', 12, M.crn_net_forward),
+    ('dpcrn', 13, M.dpcrn_forward), ('dccrn', 14, M.dccrn_forward)])
+def test_forward_matches_reference(name, seed, fwd):
+    G = load_golden(name)
+    sd = _sd(name, seed)
+    y32 = fwd(sd, G['x'])
+    y64 = fwd(sd, G['x'].astype(np.float64))
+    scale = rms(G['y'])
+    assert y32.shape == G['y'].shape
+    assert rms(y32 - G['y']) < 2e-6 * max(scale, 1.0), (rms(y32 - G['y']), scale)
+    assert rms(y64 - G['y']) < 2e-6 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize('name,seed', [('lstm', 11), ('crn', 12), ('dpcrn', 13), ('dccrn', 14)])
+def test_enhance_matches_reference(name, seed):
+    G = load_golden(name)
+    sd = _sd(name, seed)
+    y = D.ENHANCE[name](sd, G['wav'])
+    assert y.shape == G['enh'].shape
+    assert rms(y - G['enh']) < 1e-6 * max(rms(G['enh']), 1e-3), (rms(y - G['enh']), rms(G['enh']))
+
+
+def test_dccrn_compressed_variant():
+    G = load_golden('dccrn')
+    y = D.enhance_dccrn(_sd('dccrn', 14), G['wav'], 0.5, 2.0)
+    assert rms(y - G['enh_cprs']) < 1e-6 * max(rms(G['enh_cprs']), 1e-3)
+
+
+def test_dpcrn_real_checkpoint():
+    """The only real-weights anchor: vb_dpcrn_noncprs_model.pth (fixture copy)."""
+    G = load_golden('dpcrn')
+    ck = dict(load_golden('ckpt_vb_dpcrn_noncprs'))
+    y = M.dpcrn_forward(ck, G['x'])
+    assert rms(y - G['y_real']) < 2e-6 * max(rms(G['y_real']), 1.0)
+
+
+@pytest.mark.slow
+def test_dpcrn_real_checkpoint_full_clip():
+    G = load_golden('dpcrn')
+    ck = dict(load_golden('ckpt_vb_dpcrn_noncprs'))
+    wav = synth.synth_clip(0, 'speech', 64000)
+    y = D.enhance_dpcrn(ck, wav)
+    assert rms(y - G['enh_real']) < 1e-5 * rms(G['enh_real'])

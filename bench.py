@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Headline benchmark: DCCRN decode throughput (utterances/s, RTF) on 16 kHz 4 s clips.
+
+One "step" = one pass of the whole hot path (unit-RMS normalise -> STFT -> compress -> DCCRN -> mask ->
+decompress -> iSTFT -> /c) over one batch of B synthetic clips per GPU, inputs resident in HBM, outputs
+device-resident on rank 0 after the RCCL gather of enhanced waveforms (N > 1).  BASELINE.json configs[2]:
+DCCRN complex-mask, compressed input (p_in 0.5 / p_out 2.0), batch 256 per MI355X, utterances sharded across
+ranks (weak scaling: per-GPU batch fixed).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CLIP_SAMPLES = 64000          # 4 s @ 16 kHz
+CLIP_SECONDS = 4.0
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+DCCRN_GFLOP_PER_UTT = 53.4    # algorithmic 2*MAC per 4 s utterance (T = 501)
+
+
+def cpu_baseline(seed, p_in, p_out):
+    """The numpy oracle (a port of the reference decode loop) on the host cores: bounded sample of the same
+    workload (whole-path decode of 4 s clips, one at a time like the reference's batch-1 loop)."""
+    import se_amd  # noqa: F401
+    from se_amd import synth, schemas
+    from oracle import decode as D
+    sd = synth.synth_state_dict(schemas.dccrn_schema(), seed)
+    n, t0 = 0, time.time()
+    while n < 3 and (time.time() - t0) < 20.0:
+        D.enhance_dccrn(sd, synth.synth_clip(n, 'speech', CLIP_SAMPLES), p_in, p_out)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n / dt, 4), "unit": "utt/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} x 4 s clips, batch-1 loop, numpy oracle (oracle/decode.py:enhance_dccrn), "
+                      f"{os.cpu_count()} BLAS threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=256, help='clips per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import se_amd  # noqa: F401
+    from se_amd import synth
+    from se_amd.models import DCCRN
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    B, p_in, p_out, seed = args.batch, 0.5, 2.0, 14
+    model = DCCRN(rnn_units=256, masking_mode='E', use_clstm=True, kernel_num=[32, 64, 128, 256, 256, 256],
+                  device=local_rank, max_batch=B, max_samples=CLIP_SAMPLES, p_in=p_in, p_out=p_out)
+    model.load_synthetic(seed)
+    eng = model.engine
+    # synthetic clips: 16 distinct speech-like clips tiled to the batch, distinct per rank
+    base = synth.synth_batch(16, 'speech', CLIP_SAMPLES, seed0=100 + 16 * rank)
+    wav = torch.from_numpy(np.tile(base, ((B + 15) // 16, 1))[:B].copy()).cuda()
+    n_out = eng.output_samples(CLIP_SAMPLES)
+    out = torch.empty((B, n_out), dtype=torch.float32, device='cuda')
+    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        eng.enhance_batch(wav, out)
+        if world > 1:
+            dist.gather(out, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.get_profile() if not args.no_profile else None
+    eng.set_profiling(False)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        assert bool(torch.isfinite(out).all()), "non-finite output"
+        utts = world * B * args.steps
+        value = utts / dt
+        res = {
+            "metric": "utterances/sec, 16 kHz 4 s clips, DCCRN decode (STFT->network->iSTFT)",
+            "value": round(value, 2), "unit": "utt/s",
+            "rtf": round(dt / (utts * CLIP_SECONDS), 8), "x_realtime": round(value * CLIP_SECONDS, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded speech-like clips; random-init DCCRN weights)",
+            "config": {"workload": "BASELINE configs[2]: DCCRN complex-mask, compressed input (0.5/2.0), "
+                                   "16 kHz x 4 s clips, batch %d per MI355X, utterance-sharded" % B,
+                       "batch_per_gpu": B, "global_batch": B * world, "clip_samples": CLIP_SAMPLES,
+                       "parallelism": "utterance shard x%d + RCCL gather to rank 0" % world},
+        }
+        if prof and prof['gemm_ms'] > 0:
+            ach = prof['gemm_flops'] / (prof['gemm_ms'] * 1e-3) / 1e12
+            res["roofline"] = {
+                "bound": "mfma", "kernel": "se::gc_kernel<BM,BN,..> (f32-MFMA tap-table implicit-GEMM conv)",
+                "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": prof['gemm_launches'],
+                "algorithmic_gflop_per_step": round(prof['gemm_flops'] / 1e9, 1),
+                "kernel_ms_per_step": round(prof['gemm_ms'], 3),
+                "avg_launch_us": round(1e3 * prof['gemm_ms'] / max(prof['gemm_launches'], 1), 2),
+                "share_of_step": round(prof['gemm_ms'] / (1e3 * dt / args.steps), 4),
+            }
+            res["roofline_whole_path"] = {
+                "achieved": round(value / world * DCCRN_GFLOP_PER_UTT / 1e3, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s per GPU (utt/s x 53.4 GFLOP/utt, SURVEY 8(d))",
+                "frac": round(value / world * DCCRN_GFLOP_PER_UTT / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(seed, p_in, p_out)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

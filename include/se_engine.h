@@ -1,0 +1,114 @@
+/* se_engine.h - C ABI of the MI355X (gfx950) speech-enhancement decode engine (libse_engine.so).
+ *
+ * The reference (cszheng-ioa/Sixty-years-of-frequency-domain-monaural-speech-enhancement) has no FFI: its only
+ * seams are Python ones.  Each entry point below states the reference interface it stands in for
+ * (paths relative to the reference root).  Plain C types only; no torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; the message is read with se_last_error().
+ *   - `*_dev` pointers are DEVICE pointers owned by the caller (e.g. torch-ROCm `tensor.data_ptr()`);
+ *     the engine never frees them.  Scratch and weights are engine-owned, sized at create / finalize.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Work is enqueued, not synchronised;
+ *     only se_engine_finalize() and se_engine_destroy() synchronise.
+ *   - one handle per GPU / rank; a handle is not thread-safe.
+ *   - all floating-point data is fp32 (the reference feeds `torch.FloatTensor`).
+ */
+#ifndef SE_ENGINE_H
+#define SE_ENGINE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct se_engine se_engine;
+
+/* One id per reference model class on the decode path (constructor call sites cited). */
+enum se_model_id {
+    SE_MODEL_LSTM = 1,        /* lstm_net()   LSTM/lstm_decode_vb.py:18   (LSTM/LSTM.py:14-28)            */
+    SE_MODEL_CRN = 2,         /* crn_net()    CRN/crn_decode_vb.py:18     (CRN/CRN.py:16-117)             */
+    SE_MODEL_GCRN = 3,        /* Net()        GCRN/gcrn_decode_vb.py:19   (GCRN/GCRN_noncprs.py:86-165)   */
+    SE_MODEL_DPCRN = 4,       /* dpcrn()      DPCRN/dpcrn_decode_vb.py:19 (DPCRN/DPCRN.py:16-174)         */
+    SE_MODEL_DCCRN = 5,       /* DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
+                                 kernel_num=[32,64,128,256,256,256])  DCCRN/dccrn_decode_vb.py:11         */
+    SE_MODEL_FULLSUBNET = 6,  /* Model(...)   FullSubNet/fullsubnet_sa_decode_vb.py:11-24                 */
+    SE_MODEL_CTSNET = 7,      /* Step1_net(), Step2_net(X=6,R=3)  CTSNet/two_stage_com_decode_vb.py:13-14 */
+    SE_MODEL_G2NET = 8,       /* gaf_base(...)  G2Net_VB/com_decode.py:23                                 */
+    SE_MODEL_TAYLORSENET = 9, /* TaylorSENet(...) TaylorSENet/taylorsenet_decode_vb.py:11-13              */
+    SE_MODEL_UFORMER = 10     /* Uformer()    Uformer/uformer_decode_vb.py:19                             */
+};
+
+/* Replaces the module constants + hand-edited exponents of each decode script
+ * (e.g. DCCRN/config.py:5-8 win_size/fft_num/win_shift; `** 1.0` vs `** 0.5 / ** 2.0` at
+ * DCCRN/dccrn_decode_vb.py:40,48 and DCCRN/dccrn_decode.py:44,52).  n_fft/hop/win = 0 selects the
+ * model's own front end. */
+typedef struct se_config {
+    int32_t model;        /* enum se_model_id */
+    int32_t device;       /* HIP device ordinal */
+    int32_t max_batch;    /* utterances per se_enhance_batch call (scratch is sized for this) */
+    int32_t max_samples;  /* longest utterance, samples */
+    float p_in;           /* magnitude exponent applied before the network (1.0 noncprs, 0.5 cprs) */
+    float p_out;          /* magnitude exponent applied after the network  (1.0 noncprs, 2.0 cprs) */
+    int32_t n_fft, hop, win;
+    int32_t flags;        /* reserved, 0 */
+} se_config;
+
+/* Model construction: `model = <Class>(...)` + `.cuda()`. */
+int se_engine_create(const se_config* cfg, se_engine** out);
+int se_engine_destroy(se_engine* e);
+
+/* Error text of the last failing call on this handle (e == NULL: last se_engine_create failure). */
+const char* se_last_error(const se_engine* e);
+
+/* Weight load: one call per entry of `model.load_state_dict(torch.load('./BEST_MODEL/<name>.pth'))`
+ * (e.g. CRN/crn_decode_vb.py:19).  `data` is HOST memory, copied; dtype 0 = float32, 1 = int64
+ * (`num_batches_tracked` buffers: accepted and ignored).  Key names are the reference state-dict keys
+ * (SURVEY.md Appendix D).  Unknown keys are rejected at finalize, like a strict load. */
+int se_engine_set_tensor(se_engine* e, const char* key, const void* data, const int64_t* shape, int32_t ndim,
+                         int32_t dtype);
+/* End of load_state_dict (strict): checks every expected key is present with the right shape, folds
+ * eval-mode BatchNorm into the adjacent convolution, packs weights for the MFMA kernels, uploads. Synchronises. */
+int se_engine_finalize(se_engine* e);
+
+/* `y = model(x)` under torch.no_grad()/eval(): model-only parity hook.  Shapes are the reference's
+ * (SURVEY.md 8(a)), e.g. DCCRN [B,2,257,T] -> [B,2,257,T]; CRN [B,T,161] -> [B,T,161]. */
+int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32_t in_ndim, float* out_dev,
+               void* stream);
+
+/* The per-utterance body of `enhance(args)` for a batch of equal-length clips, device to device:
+ * unit-RMS normalise -> (tail pad) -> STFT -> compress -> network (+mask) -> decompress -> iSTFT -> /c.
+ * wav_in_dev [B][in_pitch] (first n_samples of each row valid), wav_out_dev [B][out_pitch]; the number of
+ * output samples per utterance is se_output_samples(e, n_samples) (DCCRN returns the hop-padded length,
+ * dccrn_decode_vb.py:59-64; Uformer hop*floor(L/hop); others L). */
+int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, int32_t batch, int32_t n_samples,
+                     float* wav_out_dev, int64_t out_pitch, void* stream);
+int64_t se_output_samples(const se_engine* e, int32_t n_samples);
+
+/* Stage hooks, so each oracle-pinned stage can be diffed alone (engine-internal spectrogram layout
+ * [B][2][F][T] re/im planes, T contiguous, row pitch = T).
+ *   se_stft     : torch.stft / librosa.stft call of the model's decode script, fused with x*c and |X|^p_in.
+ *                 c_dev (may be NULL -> no scaling) holds one scale per utterance.
+ *   se_istft    : torch.istft / librosa.istft (+ division by c when c_dev != NULL), n_out samples per row.
+ *   se_rms_scale: c = sqrt(L / sum x^2).
+ *   se_num_frames / se_num_bins: T and F for n_samples. */
+int se_rms_scale(se_engine* e, const float* wav_dev, int64_t pitch, int32_t batch, int32_t n_samples, float* c_dev,
+                 void* stream);
+int se_stft(se_engine* e, const float* wav_dev, int64_t pitch, int32_t batch, int32_t n_samples,
+            const float* c_dev, float p_in, float* spec_dev, void* stream);
+int se_istft(se_engine* e, const float* spec_dev, int32_t batch, int32_t n_frames, const float* c_dev,
+             float* wav_dev, int64_t pitch, int32_t n_out, void* stream);
+int32_t se_num_frames(const se_engine* e, int32_t n_samples);
+int32_t se_num_bins(const se_engine* e);
+
+/* Wall time of the dominant kernel family (f32-MFMA implicit-GEMM convolution) inside the last
+ * se_enhance_batch / se_forward, measured with HIP events on `stream`; enabled by se_set_profiling(e, 1).
+ * Returns accumulated milliseconds and the launch count through the out-params. */
+int se_set_profiling(se_engine* e, int32_t on);
+int se_get_profile(se_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+
+/* ABI version of this header. */
+int32_t se_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE_ENGINE_H */

@@ -1,0 +1,101 @@
+// Shared host-side declarations for the MI355X speech-enhancement engine.
+// gfx950 only: no CUDA shims, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace se {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define SE_STR2(x) #x
+#define SE_STR(x) SE_STR2(x)
+#define SE_CHECK(cond, msg)                                                                 \
+    do {                                                                                    \
+        if (!(cond)) throw ::se::Error(std::string(__FILE__ ":" SE_STR(__LINE__) ": ") + (msg)); \
+    } while (0)
+#define SE_HIP(expr)                                                                         \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            throw ::se::Error(std::string(__FILE__ ":" SE_STR(__LINE__) ": " #expr ": ") +   \
+                              hipGetErrorString(e_));                                       \
+    } while (0)
+
+// Bump allocator over one hipMalloc'd slab: activations / scratch are carved at
+// create time, nothing is allocated on the decode path (graph-capture safe).
+class Arena {
+  public:
+    Arena() = default;
+    ~Arena() { release(); }
+    void reserve(size_t bytes) {
+        release();
+        SE_HIP(hipMalloc(&base_, bytes));
+        cap_ = bytes;
+        off_ = 0;
+    }
+    void release() {
+        if (base_) (void)hipFree(base_);
+        base_ = nullptr;
+        cap_ = off_ = 0;
+    }
+    void reset() { off_ = 0; }
+    // measuring mode: no memory behind the pointers, only the high-water mark is tracked
+    void measure_begin() {
+        release();
+        measuring_ = true;
+        cap_ = ~size_t(0) >> 1;
+        off_ = 0;
+    }
+    size_t measure_end() {
+        size_t u = off_;
+        measuring_ = false;
+        cap_ = off_ = 0;
+        return u;
+    }
+    float* alloc_f(size_t n) { return static_cast<float*>(alloc(n * sizeof(float))); }
+    void* alloc(size_t bytes) {
+        size_t a = (off_ + 255) & ~size_t(255);
+        SE_CHECK(a + bytes <= cap_, "arena exhausted: want " + std::to_string(bytes) + " at " +
+                                        std::to_string(a) + " of " + std::to_string(cap_));
+        off_ = a + bytes;
+        return static_cast<char*>(base_) + a;
+    }
+    size_t used() const { return off_; }
+    size_t capacity() const { return cap_; }
+
+  private:
+    void* base_ = nullptr;
+    size_t cap_ = 0, off_ = 0;
+    bool measuring_ = false;
+};
+
+// A host copy of one state-dict entry (fp32; int64 buffers are accepted and dropped).
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+using StateDict = std::map<std::string, HostTensor>;
+
+inline float* to_device(const std::vector<float>& v) {
+    float* d = nullptr;
+    SE_HIP(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(float)));
+    if (!v.empty()) SE_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+
+}  // namespace se

@@ -1,0 +1,209 @@
+// C ABI of the engine (include/se_engine.h): handle, strict state-dict load, stage hooks.
+#include "../../include/se_engine.h"
+#include "model.h"
+#include <cstring>
+#include <mutex>
+
+using namespace se;
+
+struct se_engine {
+    se_config cfg{};
+    EngineCtx ctx;
+    StateDict sd;
+    std::unique_ptr<Model> model;
+    bool finalized = false;
+    std::string err;
+    float* frames_scratch = nullptr;     // for the se_istft stage hook
+    size_t frames_scratch_n = 0;
+};
+
+static std::string g_create_err;
+
+template <typename F>
+static int guard(se_engine* e, F&& f) {
+    try {
+        if (e) SE_HIP(hipSetDevice(e->cfg.device));
+        f();
+        return 0;
+    } catch (const std::exception& ex) {
+        if (e) e->err = ex.what();
+        else g_create_err = ex.what();
+        return 1;
+    }
+}
+
+extern "C" {
+
+int32_t se_abi_version(void) { return 1; }
+
+const char* se_last_error(const se_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int se_engine_create(const se_config* cfg, se_engine** out) {
+    se_engine* e = nullptr;
+    int rc = guard(nullptr, [&] {
+        SE_CHECK(cfg && out, "null argument");
+        int ndev = 0;
+        SE_HIP(hipGetDeviceCount(&ndev));
+        SE_CHECK(ndev > 0, "no HIP device visible: the engine has no CPU fallback");
+        SE_CHECK(cfg->device >= 0 && cfg->device < ndev, "device ordinal out of range");
+        SE_HIP(hipSetDevice(cfg->device));
+        hipDeviceProp_t prop;
+        SE_HIP(hipGetDeviceProperties(&prop, cfg->device));
+        SE_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0,
+                 std::string("built for gfx950 (MI355X) only, device is ") + prop.gcnArchName);
+        e = new se_engine();
+        e->cfg = *cfg;
+        e->ctx.max_batch = cfg->max_batch > 0 ? cfg->max_batch : 1;
+        e->ctx.max_samples = cfg->max_samples > 0 ? cfg->max_samples : 64000;
+        e->ctx.p_in = cfg->p_in > 0.f ? cfg->p_in : 1.f;
+        e->ctx.p_out = cfg->p_out > 0.f ? cfg->p_out : 1.f;
+        switch (cfg->model) {
+            case SE_MODEL_DCCRN: e->model = make_dccrn(e->ctx); break;
+            default: SE_CHECK(false, "model id " + std::to_string(cfg->model) + " is not built into this engine yet");
+        }
+        e->ctx.geom = e->model->default_geom();
+        if (cfg->n_fft > 0) {
+            SE_CHECK(cfg->n_fft == e->ctx.geom.n_fft, "n_fft override must match the model's front end");
+            e->ctx.geom = StftGeom{cfg->n_fft, cfg->hop > 0 ? cfg->hop : e->ctx.geom.hop, cfg->win > 0 ? cfg->win : cfg->n_fft};
+        }
+        *out = e;
+    });
+    if (rc && e) {
+        delete e;
+    }
+    return rc;
+}
+
+int se_engine_destroy(se_engine* e) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (e->frames_scratch) (void)hipFree(e->frames_scratch);
+    delete e;
+    return 0;
+}
+
+int se_engine_set_tensor(se_engine* e, const char* key, const void* data, const int64_t* shape, int32_t ndim,
+                         int32_t dtype) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(!e->finalized, "set_tensor after finalize");
+        SE_CHECK(key && (data || ndim == 0) && ndim >= 0 && ndim <= 8, "bad argument");
+        HostTensor t;
+        int64_t n = 1;
+        for (int i = 0; i < ndim; ++i) {
+            SE_CHECK(shape[i] >= 0, "negative dim");
+            t.shape.push_back(shape[i]);
+            n *= shape[i];
+        }
+        if (dtype == 0) {
+            t.data.assign(static_cast<const float*>(data), static_cast<const float*>(data) + n);
+        } else if (dtype == 1) {
+            t.data.resize(n);
+            for (int64_t i = 0; i < n; ++i) t.data[i] = (float)static_cast<const int64_t*>(data)[i];
+        } else {
+            SE_CHECK(false, "dtype must be 0 (float32) or 1 (int64)");
+        }
+        e->sd[key] = std::move(t);
+    });
+}
+
+int se_engine_finalize(se_engine* e) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(!e->finalized, "already finalized");
+        TrackedSD tsd(e->sd);
+        e->model->finalize(tsd);
+        tsd.check_all_used();
+        // size the workspace for (max_batch, frames of max_samples)
+        const int T = e->model->num_frames(e->ctx.max_samples);
+        e->ctx.arena.measure_begin();
+        e->model->plan_buffers(e->ctx.max_batch, T);
+        const size_t need = e->ctx.arena.measure_end();
+        e->ctx.arena.reserve(need + (1 << 20));
+        e->model->plan_buffers(e->ctx.max_batch, T);
+        e->sd.clear();
+        SE_HIP(hipDeviceSynchronize());
+        e->finalized = true;
+    });
+}
+
+int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32_t in_ndim, float* out_dev,
+               void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(e->finalized, "engine not finalized");
+        SE_CHECK(in_dev && out_dev && in_shape, "null argument");
+        e->ctx.prof.reset();
+        e->model->forward(in_dev, in_shape, in_ndim, out_dev, static_cast<hipStream_t>(stream));
+    });
+}
+
+int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, int32_t batch, int32_t n_samples,
+                     float* wav_out_dev, int64_t out_pitch, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(e->finalized, "engine not finalized");
+        SE_CHECK(wav_in_dev && wav_out_dev, "null argument");
+        SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
+        SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples,
+                 "n_samples outside [n_fft, max_samples]");
+        SE_CHECK(in_pitch >= n_samples && out_pitch >= e->model->output_samples(n_samples), "row pitch too small");
+        e->ctx.prof.reset();
+        e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch,
+                          static_cast<hipStream_t>(stream));
+    });
+}
+
+int64_t se_output_samples(const se_engine* e, int32_t n_samples) { return e ? e->model->output_samples(n_samples) : -1; }
+int32_t se_num_frames(const se_engine* e, int32_t n_samples) { return e ? e->model->num_frames(n_samples) : -1; }
+int32_t se_num_bins(const se_engine* e) { return e ? e->ctx.geom.F() : -1; }
+
+int se_rms_scale(se_engine* e, const float* wav_dev, int64_t pitch, int32_t batch, int32_t n_samples, float* c_dev,
+                 void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] { launch_rms_scale(wav_dev, batch, n_samples, pitch, c_dev, static_cast<hipStream_t>(stream)); });
+}
+
+int se_stft(se_engine* e, const float* wav_dev, int64_t pitch, int32_t batch, int32_t n_samples, const float* c_dev,
+            float p_in, float* spec_dev, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        const int Lpad = e->model->padded_samples(n_samples);
+        const int T = 1 + Lpad / e->ctx.geom.hop;
+        launch_stft(e->ctx.geom, wav_dev, pitch, batch, n_samples, Lpad, c_dev, p_in, spec_dev, nullptr, T, T,
+                    static_cast<hipStream_t>(stream));
+    });
+}
+
+int se_istft(se_engine* e, const float* spec_dev, int32_t batch, int32_t n_frames, const float* c_dev, float* wav_dev,
+             int64_t pitch, int32_t n_out, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        const size_t need = (size_t)batch * n_frames * e->ctx.geom.n_fft;
+        if (need > e->frames_scratch_n) {
+            if (e->frames_scratch) SE_HIP(hipFree(e->frames_scratch));
+            SE_HIP(hipMalloc(&e->frames_scratch, need * sizeof(float)));
+            e->frames_scratch_n = need;
+        }
+        launch_istft(e->ctx.geom, spec_dev, batch, n_frames, n_frames, e->frames_scratch, c_dev, wav_dev, pitch, n_out,
+                     static_cast<hipStream_t>(stream));
+    });
+}
+
+int se_set_profiling(se_engine* e, int32_t on) {
+    if (!e) return 1;
+    e->ctx.prof.on = on != 0;
+    return 0;
+}
+
+int se_get_profile(se_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        if (gemm_ms) *gemm_ms = e->ctx.prof.total_ms();
+        if (gemm_launches) *gemm_launches = e->ctx.prof.launches;
+        if (gemm_flops) *gemm_flops = e->ctx.prof.flops;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Tap-table implicit-GEMM convolution on f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// One kernel family carries every dense layer of the zoo: Conv2d, the parity
+// classes of a strided ConvTranspose2d, 1x1 convs / Linear layers, the LSTM
+// input projection and the LSTM recurrent step (with the cell update fused in
+// the epilogue).  Activations live as [B][C][F][T] with T contiguous ("features
+// x samples"); a weight matrix is packed K-major so that both MFMA operands are
+// read from LDS with 32 consecutive lanes on 32 consecutive floats.
+//
+//   acc[m](z,b,q,t) = sum_{ci<C0+C1} sum_{j<ntaps} A_z[(ci,j)][m] * X_z(b, ci, q*si + df[j], t + dt[j])
+//   dst_z[b][m][q*so+po][t] = epilogue(acc[m] + bias[m])
+//
+// X is the virtual channel-concat of src0 (C0 channels) and src1 (C1 channels),
+// zero outside [0,Fin) x [0,Tin).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace se {
+
+constexpr int GC_MAX_TAPS = 16;
+constexpr int GC_MAX_ROWS = 8;
+constexpr int GC_MAX_KCP = 48;     // K rows of one staged chunk (even)
+constexpr int GC_MAX_BLD = 18;     // per-lane prefetch registers for the activation patch
+
+enum Act : int { ACT_NONE = 0, ACT_PRELU = 1, ACT_ELU = 2, ACT_SOFTPLUS = 3, ACT_SIGMOID = 4, ACT_TANH = 5, ACT_RELU = 6 };
+enum Epi : int {
+    EPI_ACT = 0,     // dst = act(acc + bias)
+    EPI_LSTM = 1,    // rows are gate-interleaved (4j+{i,f,g,o}); dst = h_t, c updated in place
+    EPI_GLU = 2,     // rows are pair-interleaved (2j, 2j+1): dst[j] = (a+bias) * sigmoid(g+bias)
+    EPI_ADD = 3,     // dst = act(acc + bias) + res   (res laid out like dst)
+};
+
+struct GCParams {
+    const float* A;          // packed weights [nchunks][KCp][Mp]
+    const float* bias;       // [M] or nullptr
+    const float* slope;      // [M] PReLU slopes or nullptr
+    const float* src0;
+    const float* src1;
+    float* dst;
+    const float* aux;        // EPI_LSTM: gate pre-activations gx; EPI_ADD: residual
+    float* cell;             // EPI_LSTM: cell state, laid out like dst (channels = M/4), updated in place
+    long A_z, bias_z, src0_z, src1_z, dst_z, aux_z, cell_z;   // per-z (blockIdx.z) element strides
+    long s0_b, s0_c, s0_f;   // src0 element strides (t stride is 1)
+    long s1_b, s1_c, s1_f;
+    long d_b, d_c, d_f;      // dst strides (also cell strides)
+    long x_b, x_c, x_f;      // aux strides
+    int C0, C1;
+    int Fin, Tin;
+    int B, Q, Tout, M, Mp;
+    int si, so, po;
+    int ntaps, nrows, dtmin, Wp;
+    int CI_C, KC, KCp, nchunks;
+    int act, epi;
+    int n_ttiles, n_mtiles, Z;
+    int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
+    signed char row_df[GC_MAX_ROWS];
+    unsigned char tap_row[GC_MAX_TAPS];
+    signed char tap_dt[GC_MAX_TAPS];
+};
+
+// Host-side description of one dense layer, built once at finalize.
+struct GCPlan {
+    GCParams p{};            // static part (taps, chunking, weights); pointers for activations filled per launch
+    int BM = 128, BN = 128;  // tile config
+    float* dA = nullptr;     // device copies owned by the plan
+    float* dBias = nullptr;
+    float* dSlope = nullptr;
+};
+
+struct TapSpec {
+    int ntaps = 0;
+    int df[GC_MAX_TAPS];
+    int dt[GC_MAX_TAPS];
+};
+
+// Build a plan.  w_logical[m][ci][j] (row-major, M x Cin x ntaps) are the effective real weights
+// (BatchNorm folded, complex structure expanded) for this tap set.  bias/slope may be empty.
+GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w_logical,
+                    const std::vector<float>& bias, const std::vector<float>& slope, int act, int epi,
+                    int si, int so, int po, int tout_hint, int z = 1);
+void gc_free_plan(GCPlan& pl);
+
+// Launch: p must have src/dst pointers, strides, B/Q/Tout/Fin/Tin/C0/C1 filled in.
+void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream);
+
+}  // namespace se

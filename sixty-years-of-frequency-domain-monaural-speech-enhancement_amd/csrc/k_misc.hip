@@ -1,0 +1,98 @@
+// Elementwise / layout kernels of the decode path (HBM-bound; T-contiguous rows, one pass each).
+#include "kernels.h"
+#include "common.h"
+
+namespace se {
+
+// ---- DCCRN 'E' mask + decode-script decompress --------------------------------------------------------------
+// DCCRN/DCCRN_cprs.py:201-225  mask_mags = |M|, mask_phase = atan2(Mi/(|M|+1e-8), Mr/(|M|+1e-8)),
+//   est_mags = tanh(|M|) * |X|, est_phase = angle(X) + mask_phase, DC row of the mask is zero-padded.
+// DCCRN/dccrn_decode_vb.py:45-58  |est|**p_out * exp(j*angle(est)).
+// cos/sin(angle X + angle M) is evaluated as the product of the two unit phasors (no atan2/sincos round trip).
+__global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict__ mask, const float* __restrict__ spec,
+                                                         float* __restrict__ est, int F, int T, int Tp, float p_out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long so = (((long)b * 2) * F + k) * Tp + t;
+    const long plane = (long)F * Tp;
+    float outr = 0.f, outi = 0.f;
+    if (k > 0) {
+        const long mo = (((long)b * 2) * (F - 1) + (k - 1)) * Tp + t;
+        const float mr = mask[mo], mi = mask[mo + (long)(F - 1) * Tp];
+        const float xr = spec[so], xi = spec[so + plane];
+        const float mm = sqrtf(mr * mr + mi * mi);
+        const float xm = sqrtf(xr * xr + xi * xi);
+        float pr = 1.f, pi = 0.f, qr = 1.f, qi = 0.f;
+        if (mm > 0.f) { pr = mr / mm; pi = mi / mm; }
+        if (xm > 0.f) { qr = xr / xm; qi = xi / xm; }
+        float em = tanhf(mm) * xm;
+        if (p_out == 2.f) em = em * em;
+        else if (p_out != 1.f) em = powf(em, p_out);
+        outr = em * (pr * qr - pi * qi);
+        outi = em * (pr * qi + pi * qr);
+    }
+    est[so] = outr;
+    est[so + plane] = outi;
+}
+
+void launch_dccrn_mask(const float* mask, const float* spec, float* est, int B, int F, int T, int Tp, float p_out,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(dccrn_mask_kernel, dim3((T + 255) / 256, F, B), dim3(256), 0, s, mask, spec, est, F, T, Tp, p_out);
+    SE_HIP(hipGetLastError());
+}
+
+// ---- out[t][k][a] = in[a][k][t] : 32x32 LDS tile transpose ------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_akt_kernel(const float* __restrict__ in, float* __restrict__ out, int A,
+                                                            int T, long in_sa, long in_sk, long out_st, long out_sk) {
+    __shared__ float tile[32][33];
+    const int k = blockIdx.z;
+    const int a0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = a0 + ty + 8 * i, t = t0 + tx;
+        tile[ty + 8 * i][tx] = (a < A && t < T) ? in[(long)a * in_sa + (long)k * in_sk + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, a = a0 + tx;
+        if (a < A && t < T) out[(long)t * out_st + (long)k * out_sk + a] = tile[tx][ty + 8 * i];
+    }
+}
+
+void launch_transpose_akt(const float* in, float* out, int A, int K, int T, long in_sa, long in_sk, long out_st,
+                          long out_sk, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_akt_kernel, dim3((T + 31) / 32, (A + 31) / 32, K), dim3(256), 0, s, in, out, A, T,
+                       in_sa, in_sk, out_st, out_sk);
+    SE_HIP(hipGetLastError());
+}
+
+// ---- strided 4-D copy ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy4_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int I,
+                                                    int J, long si_b, long si_c, long si_i, long si_j, long so_b,
+                                                    long so_c, long so_i) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= J) return;
+    const int i = blockIdx.y % I, c = blockIdx.y / I, b = blockIdx.z;
+    out[(long)b * so_b + (long)c * so_c + (long)i * so_i + j] = in[(long)b * si_b + (long)c * si_c + (long)i * si_i + (long)j * si_j];
+}
+
+void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long si_b, long si_c, long si_i, long si_j,
+                  long so_b, long so_c, long so_i, hipStream_t s) {
+    hipLaunchKernelGGL(copy4_kernel, dim3((J + 255) / 256, C * I, B), dim3(256), 0, s, in, out, C, I, J, si_b, si_c,
+                       si_i, si_j, so_b, so_c, so_i);
+    SE_HIP(hipGetLastError());
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill(float* p, long n, float v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    SE_HIP(hipGetLastError());
+}
+
+}  // namespace se

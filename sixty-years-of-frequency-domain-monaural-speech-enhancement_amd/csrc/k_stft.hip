@@ -1,0 +1,327 @@
+// Framed STFT / iSTFT-OLA for gfx950.
+//
+// Reference behaviour (file:line in /root/reference):
+//   torch.stft(x, n_fft, hop, win, window=torch.hann_window(win))   DCCRN/dccrn_decode_vb.py:37-38,
+//       FullSubNet/fullsubnet_sa_decode_vb.py:46-47, CTSNet/two_stage_com_decode_vb.py:70-71,
+//       TaylorSENet/taylorsenet_decode_vb.py:36-37, Uformer/uformer.py:178,182
+//   librosa.stft(x, n_fft=320, hop_length=160, window='hanning')    LSTM/lstm_decode_vb.py:37, CRN/crn_decode_vb.py:36,
+//       GCRN/gcrn_decode_vb.py:37, DPCRN/dpcrn_decode_vb.py:37, G2Net_VB/com_decode.py:49
+//   torch.istft / librosa.istft with Hann synthesis window, window-sum-square normalisation, `length=`.
+// Both front ends are centre=True / reflect pad n_fft/2 / periodic Hann / one-sided.
+//
+// Kernel shape: one 64-lane wave transforms one frame with a Stockham autosort FFT in LDS (radix 4/4/4/4/2 for
+// n_fft=512, 4/4/4/5 for n_fft=320 - the radix-5 and radix-2 tail stages need no twiddles), twiddles and the
+// window staged once per block in LDS.  A block owns 8 consecutive frames so that the [F][T]-major spectrogram
+// is written / read in 32-byte runs along T, and the waveform is read in coalesced rows.
+#include "kernels.h"
+#include "common.h"
+
+namespace se {
+
+constexpr int FPB = 8;   // frames per block
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// one Stockham stage of radix R; s = product of earlier radices (power of two), ncur = N / s
+template <int N, int R, bool INV>
+__device__ __forceinline__ void fft_stage(const float2* __restrict__ x, float2* __restrict__ y,
+                                          const float2* __restrict__ tw, int ncur, int log2s, int lane) {
+    const int s = 1 << log2s;
+    const int m = ncur / R;
+    constexpr int NB = N / R;
+    for (int i = lane; i < NB; i += 64) {
+        const int p = i >> log2s, q = i & (s - 1);
+        float2 in[R], out[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) in[j] = x[q + s * (p + m * j)];
+        if (R == 2) {
+            out[0] = make_float2(in[0].x + in[1].x, in[0].y + in[1].y);
+            out[1] = make_float2(in[0].x - in[1].x, in[0].y - in[1].y);
+        } else if (R == 4) {
+            const float2 a = in[0], b = in[1], c = in[2], d = in[3];
+            const float2 apc = make_float2(a.x + c.x, a.y + c.y), amc = make_float2(a.x - c.x, a.y - c.y);
+            const float2 bpd = make_float2(b.x + d.x, b.y + d.y), bmd = make_float2(b.x - d.x, b.y - d.y);
+            // forward: -i*(b-d) = (bmd.y, -bmd.x);  inverse: +i*(b-d) = (-bmd.y, bmd.x)
+            const float2 jb = INV ? make_float2(-bmd.y, bmd.x) : make_float2(bmd.y, -bmd.x);
+            out[0] = make_float2(apc.x + bpd.x, apc.y + bpd.y);
+            out[1] = make_float2(amc.x + jb.x, amc.y + jb.y);
+            out[2] = make_float2(apc.x - bpd.x, apc.y - bpd.y);
+            out[3] = make_float2(amc.x - jb.x, amc.y - jb.y);
+        } else {   // R == 5
+            constexpr float c1 = 0.30901699437494742f, s1 = 0.95105651629515357f;    // cos/sin 2pi/5
+            constexpr float c2 = -0.80901699437494742f, s2 = 0.58778525229247313f;   // cos/sin 4pi/5
+            const float sg = INV ? 1.f : -1.f;
+            const float2 t1 = make_float2(in[1].x + in[4].x, in[1].y + in[4].y);
+            const float2 t2 = make_float2(in[2].x + in[3].x, in[2].y + in[3].y);
+            const float2 t3 = make_float2(in[1].x - in[4].x, in[1].y - in[4].y);
+            const float2 t4 = make_float2(in[2].x - in[3].x, in[2].y - in[3].y);
+            out[0] = make_float2(in[0].x + t1.x + t2.x, in[0].y + t1.y + t2.y);
+            const float2 m1 = make_float2(in[0].x + c1 * t1.x + c2 * t2.x, in[0].y + c1 * t1.y + c2 * t2.y);
+            const float2 m2 = make_float2(in[0].x + c2 * t1.x + c1 * t2.x, in[0].y + c2 * t1.y + c1 * t2.y);
+            // sg * i * (s1*t3 + s2*t4)  and  sg * i * (s2*t3 - s1*t4)
+            const float2 u1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+            const float2 u2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+            const float2 j1 = make_float2(-sg * u1.y, sg * u1.x);
+            const float2 j2 = make_float2(-sg * u2.y, sg * u2.x);
+            out[1] = make_float2(m1.x + j1.x, m1.y + j1.y);
+            out[4] = make_float2(m1.x - j1.x, m1.y - j1.y);
+            out[2] = make_float2(m2.x + j2.x, m2.y + j2.y);
+            out[3] = make_float2(m2.x - j2.x, m2.y - j2.y);
+        }
+        if (m > 1) {
+            const int step = p * (N / ncur);
+#pragma unroll
+            for (int k = 1; k < R; ++k) {
+                float2 w = tw[step * k];
+                if (INV) w.y = -w.y;
+                out[k] = cmul(out[k], w);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) y[q + s * (R * p + k)] = out[k];
+    }
+}
+
+// Full transform of the frame held in buf0; returns the buffer holding the natural-order result.
+// Every wave of the block must call this the same number of times (block barriers between stages).
+template <int N, bool INV>
+__device__ __forceinline__ float2* fft_frame(float2* buf0, float2* buf1, const float2* tw, int lane) {
+    if (N == 512) {
+        fft_stage<512, 4, INV>(buf0, buf1, tw, 512, 0, lane); __syncthreads();
+        fft_stage<512, 4, INV>(buf1, buf0, tw, 128, 2, lane); __syncthreads();
+        fft_stage<512, 4, INV>(buf0, buf1, tw, 32, 4, lane);  __syncthreads();
+        fft_stage<512, 4, INV>(buf1, buf0, tw, 8, 6, lane);   __syncthreads();
+        fft_stage<512, 2, INV>(buf0, buf1, tw, 2, 8, lane);   __syncthreads();
+        return buf1;
+    } else {   // 320
+        fft_stage<320, 4, INV>(buf0, buf1, tw, 320, 0, lane); __syncthreads();
+        fft_stage<320, 4, INV>(buf1, buf0, tw, 80, 2, lane);  __syncthreads();
+        fft_stage<320, 4, INV>(buf0, buf1, tw, 20, 4, lane);  __syncthreads();
+        fft_stage<320, 5, INV>(buf1, buf0, tw, 5, 6, lane);   __syncthreads();
+        return buf0;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void init_tables(float2* tw, float* win, int win_len, int tid) {
+    const int left = (N - win_len) / 2;
+    for (int j = tid; j < N; j += 256) {
+        double sv, cv;
+        sincospi(2.0 * j / N, &sv, &cv);
+        tw[j] = make_float2((float)cv, (float)(-sv));
+        float w = 0.f;
+        if (j >= left && j < left + win_len) w = (float)(0.5 - 0.5 * cospi(2.0 * (j - left) / win_len));
+        win[j] = w;
+    }
+}
+
+struct StftArgs {
+    const float* wav; long pitch; int B, L, Lpad; const float* c_scale; float p_in;
+    float* spec; float* mag; int T, Tp, hop, win;
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
+    constexpr int F = N / 2 + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float2* tw = reinterpret_cast<float2*>(smem_f);
+    float2* bufs = tw + N;                                  // [FPB][2][N]
+    float* win = reinterpret_cast<float*>(bufs + FPB * 2 * N);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * FPB;
+    init_tables<N>(tw, win, a.win, tid);
+    __syncthreads();
+    const float c = a.c_scale ? a.c_scale[b] : 1.f;
+    const float* x = a.wav + (long)b * a.pitch;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int fi = wave + 4 * rep, t = t0 + fi;
+        float2* b0 = bufs + (fi * 2) * N;
+        float2* b1 = b0 + N;
+        for (int n = lane; n < N; n += 64) {
+            float v = 0.f;
+            if (t < a.T) {
+                int idx = t * a.hop + n - N / 2;
+                if (idx < 0) idx = -idx;
+                if (idx >= a.Lpad) idx = 2 * (a.Lpad - 1) - idx;
+                if (idx >= 0 && idx < a.L) v = x[idx] * c * win[n];
+            }
+            b0[n] = make_float2(v, 0.f);
+        }
+        __syncthreads();
+        fft_frame<N, false>(b0, b1, tw, lane);
+    }
+    // write [F][T]-major: 8 consecutive frames of one bin are 32 contiguous bytes
+    for (int idx = tid; idx < F * FPB; idx += 256) {
+        const int fi = idx & (FPB - 1), k = idx >> 3;
+        const int t = t0 + fi;
+        if (t >= a.T) continue;
+        // natural-order result sits in buf1 after 5 stages (512) / buf0 after 4 stages (320)
+        const float2* src = bufs + (fi * 2) * N + ((N == 512) ? N : 0);
+        float2 v = src[k];
+        const float m = sqrtf(v.x * v.x + v.y * v.y);
+        float mp = m;
+        if (a.p_in != 1.f) {
+            mp = powf(m, a.p_in);
+            const float sc = m > 0.f ? mp / m : 0.f;
+            v.x *= sc;
+            v.y *= sc;
+        }
+        if (a.spec) {
+            a.spec[(((long)b * 2 + 0) * F + k) * a.Tp + t] = v.x;
+            a.spec[(((long)b * 2 + 1) * F + k) * a.Tp + t] = v.y;
+        }
+        if (a.mag) a.mag[((long)b * F + k) * a.Tp + t] = mp;
+    }
+}
+
+struct IstftArgs {
+    const float* spec; int B, T, Tp; float* frames; int win;
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
+    constexpr int F = N / 2 + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float2* tw = reinterpret_cast<float2*>(smem_f);
+    float2* bufs = tw + N;
+    float* win = reinterpret_cast<float*>(bufs + FPB * 2 * N);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * FPB;
+    init_tables<N>(tw, win, a.win, tid);
+    // Hermitian-extended spectrum of 8 frames into buf0 of each frame
+    for (int idx = tid; idx < F * FPB; idx += 256) {
+        const int fi = idx & (FPB - 1), k = idx >> 3;
+        const int t = t0 + fi;
+        float2 v = make_float2(0.f, 0.f);
+        if (t < a.T) {
+            v.x = a.spec[(((long)b * 2 + 0) * F + k) * a.Tp + t];
+            v.y = a.spec[(((long)b * 2 + 1) * F + k) * a.Tp + t];
+        }
+        float2* b0 = bufs + (fi * 2) * N;
+        if (k == 0 || k == N / 2) {
+            b0[k] = make_float2(v.x, 0.f);          // C2R ignores the imaginary part of DC / Nyquist
+        } else {
+            b0[k] = v;
+            b0[N - k] = make_float2(v.x, -v.y);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int fi = wave + 4 * rep;
+        float2* b0 = bufs + (fi * 2) * N;
+        fft_frame<N, true>(b0, b0 + N, tw, lane);
+    }
+    const float invN = 1.f / N;
+    for (int idx = tid; idx < N * FPB; idx += 256) {
+        const int fi = idx / N, n = idx - fi * N;
+        const int t = t0 + fi;
+        if (t >= a.T) continue;
+        const float2* src = bufs + (fi * 2) * N + ((N == 512) ? N : 0);
+        a.frames[((long)b * a.T + t) * N + n] = src[n].x * invN * win[n];
+    }
+}
+
+struct OlaArgs {
+    const float* frames; int B, T, N, hop, win; const float* c_scale; float* out; long out_pitch; int Lout;
+};
+
+__global__ void ola_kernel(const OlaArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= a.Lout) return;
+    const int pos = i + a.N / 2;
+    int tlo = (pos - a.N + a.hop) / a.hop;       // ceil((pos - N + 1) / hop) for pos-N+1 possibly negative
+    if (pos - a.N + 1 <= 0) tlo = 0;
+    int thi = pos / a.hop;
+    if (thi > a.T - 1) thi = a.T - 1;
+    const int left = (a.N - a.win) / 2;
+    float acc = 0.f, env = 0.f;
+    for (int t = tlo; t <= thi; ++t) {
+        const int n = pos - t * a.hop;
+        if (n >= a.N) continue;
+        acc += a.frames[((long)b * a.T + t) * a.N + n];
+        float w = 0.f;
+        if (n >= left && n < left + a.win) w = (float)(0.5 - 0.5 * cospi(2.0 * (n - left) / a.win));
+        env += w * w;
+    }
+    float y = env > 1e-11f ? acc / env : acc;
+    if (a.c_scale) y /= a.c_scale[b];
+    a.out[(long)b * a.out_pitch + i] = y;
+}
+
+__global__ __launch_bounds__(256) void rms_scale_kernel(const float* wav, int L, long pitch, float* c_out) {
+    const int b = blockIdx.x;
+    const float* x = wav + (long)b * pitch;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const double v = x[i];
+        s += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = part[0] + part[1] + part[2] + part[3];
+        c_out[b] = (float)sqrt((double)L / tot);
+    }
+}
+
+void launch_rms_scale(const float* wav, int B, int L, long pitch, float* c_out, hipStream_t s) {
+    hipLaunchKernelGGL(rms_scale_kernel, dim3(B), dim3(256), 0, s, wav, L, pitch, c_out);
+    SE_HIP(hipGetLastError());
+}
+
+template <int N>
+static size_t fft_lds_bytes() { return (size_t)N * 8 + (size_t)FPB * 2 * N * 8 + (size_t)N * 4; }
+
+template <typename K>
+static void set_lds_attr(K kernel, size_t bytes) {
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes));
+}
+
+void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, int Lpad, const float* c_scale,
+                 float p_in, float* spec_ri, float* mag, int T, int Tp, hipStream_t s) {
+    StftArgs a{wav, pitch, B, L, Lpad, c_scale, p_in, spec_ri, mag, T, Tp, g.hop, g.win};
+    dim3 grid((T + FPB - 1) / FPB, B);
+    if (g.n_fft == 512) {
+        static bool once = (set_lds_attr(stft_kernel<512>, fft_lds_bytes<512>()), true);
+        (void)once;
+        hipLaunchKernelGGL(stft_kernel<512>, grid, dim3(256), fft_lds_bytes<512>(), s, a);
+    } else if (g.n_fft == 320) {
+        static bool once = (set_lds_attr(stft_kernel<320>, fft_lds_bytes<320>()), true);
+        (void)once;
+        hipLaunchKernelGGL(stft_kernel<320>, grid, dim3(256), fft_lds_bytes<320>(), s, a);
+    } else {
+        SE_CHECK(false, "unsupported n_fft (320 and 512 are the reference geometries)");
+    }
+    SE_HIP(hipGetLastError());
+}
+
+void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* frames, const float* c_scale,
+                  float* wav_out, long out_pitch, int Lout, hipStream_t s) {
+    IstftArgs a{spec_ri, B, T, Tp, frames, g.win};
+    dim3 grid((T + FPB - 1) / FPB, B);
+    if (g.n_fft == 512) {
+        static bool once = (set_lds_attr(istft_frames_kernel<512>, fft_lds_bytes<512>()), true);
+        (void)once;
+        hipLaunchKernelGGL(istft_frames_kernel<512>, grid, dim3(256), fft_lds_bytes<512>(), s, a);
+    } else if (g.n_fft == 320) {
+        static bool once = (set_lds_attr(istft_frames_kernel<320>, fft_lds_bytes<320>()), true);
+        (void)once;
+        hipLaunchKernelGGL(istft_frames_kernel<320>, grid, dim3(256), fft_lds_bytes<320>(), s, a);
+    } else {
+        SE_CHECK(false, "unsupported n_fft");
+    }
+    SE_HIP(hipGetLastError());
+    OlaArgs o{frames, B, T, g.n_fft, g.hop, g.win, c_scale, wav_out, out_pitch, Lout};
+    hipLaunchKernelGGL(ola_kernel, dim3((Lout + 255) / 256, B), dim3(256), 0, s, o);
+    SE_HIP(hipGetLastError());
+}
+
+}  // namespace se

@@ -1,0 +1,45 @@
+// Front/back-end and auxiliary kernels (launchers).  All tensors are fp32 device pointers.
+// Engine-internal spectrogram layout: [B][C][F][Tp] with T contiguous, Tp = row pitch (>= T).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace se {
+
+struct StftGeom {
+    int n_fft, hop, win;   // win <= n_fft (window centred in n_fft, torch.stft convention)
+    int F() const { return n_fft / 2 + 1; }
+};
+
+// c[b] = sqrt(L / sum_t x[b][t]^2)  (reference: `c = np.sqrt(len(x) / np.sum(x ** 2.0))`, every *_decode_vb.py);
+// recip=1 stores 1/c instead (G2Net_VB/com_decode.py:43-44 normalises with x / c, c = RMS).
+void launch_rms_scale(const float* wav, int B, int L, long pitch, float* c_out, hipStream_t s);
+
+// Framed, centred (reflect-padded) STFT with periodic Hann window, fused with the unit-RMS scaling and the
+// magnitude power-compression |X|^p * e^{j angle X}.
+//   wav [B][pitch] (first L samples valid; samples in [L, Lpad) are the decode scripts' zero tail pad)
+//   spec_ri [B][2][F][Tp]   (may be null)     mag [B][F][Tp] = |X|^p (may be null)
+void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, int Lpad, const float* c_scale,
+                 float p_in, float* spec_ri, float* mag, int T, int Tp, hipStream_t s);
+
+// Inverse: spec_ri [B][2][F][Tp] -> windowed frames [B][T][n_fft] (scratch) -> overlap-add, divide by the
+// overlap-added squared window, drop n_fft/2 head, write Lout samples, divide by c.
+void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* frames_scratch,
+                  const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s);
+
+// DCCRN 'E' mask (DCCRN_cprs.py:201-225) + the decode script's mag/phase/decompress (dccrn_decode_vb.py:45-58):
+//   mask [B][2][F-1][Tp] (bins 1..F-1), spec [B][2][F][Tp] -> est [B][2][F][Tp], DC bin = 0.
+void launch_dccrn_mask(const float* mask, const float* spec, float* est, int B, int F, int T, int Tp, float p_out,
+                       hipStream_t s);
+
+// Generic tiled transpose of the outer and inner dims:  out[t][k][a] = in[a][k][t]
+//   in element (a,k,t) at a*in_sa + k*in_sk + t ; out element (t,k,a) at t*out_st + k*out_sk + a
+void launch_transpose_akt(const float* in, float* out, int A, int K, int T, long in_sa, long in_sk, long out_st,
+                          long out_sk, hipStream_t s);
+
+// y = x  (strided 4-D copy / layout change):  out[b][c][i][j] at strides so_*, in at si_*; inner j contiguous in out.
+void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long si_b, long si_c, long si_i, long si_j,
+                  long so_b, long so_c, long so_i, hipStream_t s);
+
+void launch_fill(float* p, long n, float v, hipStream_t s);
+
+}  // namespace se

@@ -1,0 +1,92 @@
+// Host-side weight preparation: turns reference state-dict tensors (torch layouts) into the effective real
+// weight matrices the tap-table implicit-GEMM kernel consumes (eval-mode BatchNorm folded, complex convs
+// expanded to real 2x2 block form, transposed convs split into output-parity classes, LSTM gates interleaved).
+#pragma once
+#include "common.h"
+#include "gemmconv.h"
+
+namespace se {
+
+// Effective real weights of one dense layer: w[m][ci][j], j indexes taps (kf-major: j = kf_idx * nkt + kt_idx).
+struct DenseW {
+    int M = 0, Cin = 0, nkf = 1, nkt = 1;
+    std::vector<float> w;      // [M][Cin][nkf*nkt]
+    std::vector<float> bias;   // [M] (always present; zeros if the layer has none)
+    int ntaps() const { return nkf * nkt; }
+    float& at(int m, int ci, int kf, int kt) { return w[((size_t)m * Cin + ci) * ntaps() + kf * nkt + kt]; }
+    float at(int m, int ci, int kf, int kt) const { return w[((size_t)m * Cin + ci) * ntaps() + kf * nkt + kt]; }
+};
+
+const HostTensor& sd_get(const StateDict& sd, const std::string& key, std::vector<int64_t> shape = {});
+
+// nn.Conv2d weight [Co][Ci][k0][k1]; tf_order: (k0,k1) = (time,freq) as in CRN/DPCRN; else (freq,time) as in DCCRN.
+DenseW conv_weights(const HostTensor& w, const HostTensor* b, bool tf_order);
+// nn.ConvTranspose2d weight [Ci][Co][k0][k1] -> M = Co, Cin = Ci (taps still indexed by the kernel position).
+DenseW deconv_weights(const HostTensor& w, const HostTensor* b, bool tf_order);
+// nn.Linear / 1x1: weight [M][Cin]
+DenseW linear_weights(const HostTensor& w, const HostTensor* b);
+// complexnn-style complex layer from its real_conv / imag_conv halves (channels = [real half ; imag half]):
+//   out_r = Wr*x_r - Wi*x_i + (br - bi);  out_i = Wi*x_r + Wr*x_i + (br + bi)
+DenseW complex_expand(const DenseW& wr, const DenseW& wi);
+// eval-mode BatchNorm on the output channels, folded into w / bias.
+void fold_bn(DenseW& d, const HostTensor& gamma, const HostTensor& beta, const HostTensor& mean,
+             const HostTensor& var, float eps = 1e-5f);
+// eval-mode BatchNorm on the INPUT channels of a pointwise layer (BatchNorm1d before an LSTM, LSTM/LSTM.py:25).
+void fold_bn_input(DenseW& d, const HostTensor& gamma, const HostTensor& beta, const HostTensor& mean,
+                   const HostTensor& var, float eps = 1e-5f);
+// new input channel c reads old channel perm[c]
+void permute_cin(DenseW& d, const std::vector<int>& perm);
+// rows: new row r = old row perm[r]
+void permute_rows(DenseW& d, const std::vector<int>& perm);
+// LSTM gate interleave: torch rows [i;f;g;o] (each H) -> row 4j+g
+std::vector<int> lstm_gate_perm(int H);
+// concatenate along K (input channels) / along M (rows)
+DenseW concat_cin(const DenseW& a, const DenseW& b, float scale_b = 1.f);
+DenseW concat_rows(const DenseW& a, const DenseW& b);
+std::vector<float> prelu_slopes(const HostTensor& w, int M);
+
+// Regular conv: out[f][t] = sum w[kf][kt] x[f*sf - pf + kf*dil_f][t - pt_left + kt*dil_t]
+GCPlan make_conv_plan(const DenseW& d, int sf, int pf, int pt_left, int dil_f, int dil_t, int act,
+                      const std::vector<float>& slope, int epi, int tout_hint);
+
+// Transposed conv with frequency stride sf (time stride 1):
+//   out[fo][to] = sum_{kf,kt: (fo+pf-kf) % sf == 0} x[(fo+pf-kf)/sf][to + toff - kt] w[kf][kt]
+// split in sf output-parity classes, each a dense tap-table conv.  pf < 0 expresses a left frequency pad.
+struct DeconvPlan {
+    std::vector<GCPlan> par;   // one per parity class (classes with no taps are dropped -> bias-only rows unsupported)
+    int sf = 1;
+};
+DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, const std::vector<float>& slope,
+                            int tout_hint);
+void free_deconv_plan(DeconvPlan& p);
+
+// Convenience launcher for [B][C][F][T]-layout tensors (row pitch Tp).
+struct Act4 {          // a view of an activation tensor
+    const float* p = nullptr;
+    int C = 0, F = 0;
+    long sb = 0, sc = 0, sf = 0;   // element strides; t stride 1
+};
+inline Act4 act4(const float* p, int C, int F, int Tp) { return Act4{p, C, F, (long)C * F * Tp, (long)F * Tp, (long)Tp}; }
+
+struct Profiler;
+void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
+              hipStream_t st, Profiler* prof = nullptr);
+void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
+                int Tp, hipStream_t st, Profiler* prof = nullptr);
+
+// HIP-event timing of the dominant kernel family (gemmconv launches) on the launch stream.
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    double flops = 0.0;
+    long launches = 0;
+    void begin(hipStream_t st);
+    void end(hipStream_t st, double fl);
+    void reset() { used = 0; flops = 0.0; launches = 0; }
+    double total_ms();
+    ~Profiler();
+};
+void gc_launch_prof(const GCPlan& pl, const GCParams& p, hipStream_t st, Profiler* prof);
+
+}  // namespace se

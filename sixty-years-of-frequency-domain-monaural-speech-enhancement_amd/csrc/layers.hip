@@ -1,0 +1,340 @@
+#include "layers.h"
+#include <algorithm>
+#include <cmath>
+
+namespace se {
+
+const HostTensor& sd_get(const StateDict& sd, const std::string& key, std::vector<int64_t> shape) {
+    auto it = sd.find(key);
+    SE_CHECK(it != sd.end(), "missing state-dict key '" + key + "'");
+    if (!shape.empty()) {
+        bool ok = it->second.shape.size() == shape.size();
+        for (size_t i = 0; ok && i < shape.size(); ++i) ok = it->second.shape[i] == shape[i];
+        if (!ok) {
+            std::string got, want;
+            for (auto s : it->second.shape) got += std::to_string(s) + ",";
+            for (auto s : shape) want += std::to_string(s) + ",";
+            SE_CHECK(false, "shape mismatch for '" + key + "': got [" + got + "] want [" + want + "]");
+        }
+    }
+    return it->second;
+}
+
+static void fill_bias(DenseW& d, const HostTensor* b) {
+    d.bias.assign(d.M, 0.f);
+    if (b) {
+        SE_CHECK((int)b->numel() == d.M, "bias length");
+        std::copy(b->data.begin(), b->data.end(), d.bias.begin());
+    }
+}
+
+DenseW conv_weights(const HostTensor& w, const HostTensor* b, bool tf_order) {
+    SE_CHECK(w.shape.size() == 4, "conv weight must be 4-D");
+    DenseW d;
+    d.M = (int)w.shape[0];
+    d.Cin = (int)w.shape[1];
+    const int k0 = (int)w.shape[2], k1 = (int)w.shape[3];
+    d.nkf = tf_order ? k1 : k0;
+    d.nkt = tf_order ? k0 : k1;
+    d.w.resize((size_t)d.M * d.Cin * k0 * k1);
+    for (int m = 0; m < d.M; ++m)
+        for (int c = 0; c < d.Cin; ++c)
+            for (int a = 0; a < k0; ++a)
+                for (int e = 0; e < k1; ++e) {
+                    const int kf = tf_order ? e : a, kt = tf_order ? a : e;
+                    d.at(m, c, kf, kt) = w.data[(((size_t)m * d.Cin + c) * k0 + a) * k1 + e];
+                }
+    fill_bias(d, b);
+    return d;
+}
+
+DenseW deconv_weights(const HostTensor& w, const HostTensor* b, bool tf_order) {
+    SE_CHECK(w.shape.size() == 4, "deconv weight must be 4-D");
+    DenseW d;
+    d.Cin = (int)w.shape[0];
+    d.M = (int)w.shape[1];
+    const int k0 = (int)w.shape[2], k1 = (int)w.shape[3];
+    d.nkf = tf_order ? k1 : k0;
+    d.nkt = tf_order ? k0 : k1;
+    d.w.resize((size_t)d.M * d.Cin * k0 * k1);
+    for (int c = 0; c < d.Cin; ++c)
+        for (int m = 0; m < d.M; ++m)
+            for (int a = 0; a < k0; ++a)
+                for (int e = 0; e < k1; ++e) {
+                    const int kf = tf_order ? e : a, kt = tf_order ? a : e;
+                    d.at(m, c, kf, kt) = w.data[(((size_t)c * d.M + m) * k0 + a) * k1 + e];
+                }
+    fill_bias(d, b);
+    return d;
+}
+
+DenseW linear_weights(const HostTensor& w, const HostTensor* b) {
+    SE_CHECK(w.shape.size() == 2, "linear weight must be 2-D");
+    DenseW d;
+    d.M = (int)w.shape[0];
+    d.Cin = (int)w.shape[1];
+    d.w = w.data;
+    fill_bias(d, b);
+    return d;
+}
+
+DenseW complex_expand(const DenseW& wr, const DenseW& wi) {
+    SE_CHECK(wr.M == wi.M && wr.Cin == wi.Cin && wr.nkf == wi.nkf && wr.nkt == wi.nkt, "complex halves differ");
+    DenseW d;
+    d.M = 2 * wr.M;
+    d.Cin = 2 * wr.Cin;
+    d.nkf = wr.nkf;
+    d.nkt = wr.nkt;
+    const int nt = d.ntaps();
+    d.w.assign((size_t)d.M * d.Cin * nt, 0.f);
+    d.bias.assign(d.M, 0.f);
+    for (int m = 0; m < wr.M; ++m) {
+        for (int c = 0; c < wr.Cin; ++c)
+            for (int j = 0; j < nt; ++j) {
+                const float r = wr.w[((size_t)m * wr.Cin + c) * nt + j], i = wi.w[((size_t)m * wr.Cin + c) * nt + j];
+                d.w[((size_t)m * d.Cin + c) * nt + j] = r;                                // real out <- real in
+                d.w[((size_t)m * d.Cin + wr.Cin + c) * nt + j] = -i;                       // real out <- imag in
+                d.w[((size_t)(wr.M + m) * d.Cin + c) * nt + j] = i;                       // imag out <- real in
+                d.w[((size_t)(wr.M + m) * d.Cin + wr.Cin + c) * nt + j] = r;              // imag out <- imag in
+            }
+        d.bias[m] = wr.bias[m] - wi.bias[m];
+        d.bias[wr.M + m] = wr.bias[m] + wi.bias[m];
+    }
+    return d;
+}
+
+void fold_bn(DenseW& d, const HostTensor& gamma, const HostTensor& beta, const HostTensor& mean, const HostTensor& var,
+             float eps) {
+    SE_CHECK((int)gamma.numel() == d.M && (int)var.numel() == d.M, "BatchNorm channel count");
+    const size_t per = (size_t)d.Cin * d.ntaps();
+    for (int m = 0; m < d.M; ++m) {
+        const double s = (double)gamma.data[m] / std::sqrt((double)var.data[m] + (double)eps);
+        for (size_t i = 0; i < per; ++i) d.w[m * per + i] = (float)(d.w[m * per + i] * s);
+        d.bias[m] = (float)(((double)d.bias[m] - mean.data[m]) * s + beta.data[m]);
+    }
+}
+
+void fold_bn_input(DenseW& d, const HostTensor& gamma, const HostTensor& beta, const HostTensor& mean,
+                   const HostTensor& var, float eps) {
+    SE_CHECK((int)gamma.numel() == d.Cin && d.ntaps() == 1, "input BatchNorm fold needs a pointwise layer");
+    for (int m = 0; m < d.M; ++m) {
+        double badd = 0.0;
+        for (int c = 0; c < d.Cin; ++c) {
+            const double s = (double)gamma.data[c] / std::sqrt((double)var.data[c] + (double)eps);
+            const double sh = (double)beta.data[c] - (double)mean.data[c] * s;
+            const double w = d.w[(size_t)m * d.Cin + c];
+            badd += w * sh;
+            d.w[(size_t)m * d.Cin + c] = (float)(w * s);
+        }
+        d.bias[m] = (float)(d.bias[m] + badd);
+    }
+}
+
+void permute_cin(DenseW& d, const std::vector<int>& perm) {
+    SE_CHECK((int)perm.size() == d.Cin, "cin perm size");
+    const int nt = d.ntaps();
+    std::vector<float> nw(d.w.size());
+    for (int m = 0; m < d.M; ++m)
+        for (int c = 0; c < d.Cin; ++c)
+            for (int j = 0; j < nt; ++j) nw[((size_t)m * d.Cin + c) * nt + j] = d.w[((size_t)m * d.Cin + perm[c]) * nt + j];
+    d.w.swap(nw);
+}
+
+void permute_rows(DenseW& d, const std::vector<int>& perm) {
+    SE_CHECK((int)perm.size() == d.M, "row perm size");
+    const size_t per = (size_t)d.Cin * d.ntaps();
+    std::vector<float> nw(d.w.size()), nb(d.M);
+    for (int m = 0; m < d.M; ++m) {
+        std::copy(d.w.begin() + perm[m] * per, d.w.begin() + (perm[m] + 1) * per, nw.begin() + m * per);
+        nb[m] = d.bias[perm[m]];
+    }
+    d.w.swap(nw);
+    d.bias.swap(nb);
+}
+
+std::vector<int> lstm_gate_perm(int H) {
+    std::vector<int> p(4 * H);
+    for (int j = 0; j < H; ++j)
+        for (int g = 0; g < 4; ++g) p[4 * j + g] = g * H + j;
+    return p;
+}
+
+DenseW concat_cin(const DenseW& a, const DenseW& b, float scale_b) {
+    SE_CHECK(a.M == b.M && a.ntaps() == b.ntaps(), "concat_cin shape");
+    DenseW d = a;
+    d.Cin = a.Cin + b.Cin;
+    const int nt = a.ntaps();
+    d.w.assign((size_t)d.M * d.Cin * nt, 0.f);
+    for (int m = 0; m < d.M; ++m) {
+        std::copy(a.w.begin() + (size_t)m * a.Cin * nt, a.w.begin() + (size_t)(m + 1) * a.Cin * nt,
+                  d.w.begin() + (size_t)m * d.Cin * nt);
+        for (size_t i = 0; i < (size_t)b.Cin * nt; ++i)
+            d.w[(size_t)m * d.Cin * nt + (size_t)a.Cin * nt + i] = scale_b * b.w[(size_t)m * b.Cin * nt + i];
+    }
+    return d;
+}
+
+DenseW concat_rows(const DenseW& a, const DenseW& b) {
+    SE_CHECK(a.Cin == b.Cin && a.ntaps() == b.ntaps(), "concat_rows shape");
+    DenseW d = a;
+    d.M = a.M + b.M;
+    d.w.insert(d.w.end(), b.w.begin(), b.w.end());
+    d.bias.insert(d.bias.end(), b.bias.begin(), b.bias.end());
+    return d;
+}
+
+std::vector<float> prelu_slopes(const HostTensor& w, int M) {
+    std::vector<float> s(M);
+    SE_CHECK(w.numel() == 1 || w.numel() == M, "PReLU parameter count");
+    for (int m = 0; m < M; ++m) s[m] = w.numel() == 1 ? w.data[0] : w.data[m];
+    return s;
+}
+
+GCPlan make_conv_plan(const DenseW& d, int sf, int pf, int pt_left, int dil_f, int dil_t, int act,
+                      const std::vector<float>& slope, int epi, int tout_hint) {
+    TapSpec ts;
+    ts.ntaps = d.ntaps();
+    for (int kf = 0; kf < d.nkf; ++kf)
+        for (int kt = 0; kt < d.nkt; ++kt) {
+            ts.df[kf * d.nkt + kt] = kf * dil_f - pf;
+            ts.dt[kf * d.nkt + kt] = kt * dil_t - pt_left;
+        }
+    return gc_make_plan(d.M, d.Cin, ts, d.w, d.bias, slope, act, epi, sf, 1, 0, tout_hint);
+}
+
+DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, const std::vector<float>& slope,
+                            int tout_hint) {
+    DeconvPlan out;
+    out.sf = sf;
+    for (int par = 0; par < sf; ++par) {
+        TapSpec ts;
+        std::vector<int> sel;
+        for (int kf = 0; kf < d.nkf; ++kf) {
+            int num = par + pf - kf;
+            if (((num % sf) + sf) % sf != 0) continue;
+            const int df = num / sf;   // exact
+            for (int kt = 0; kt < d.nkt; ++kt) {
+                ts.df[ts.ntaps] = df;
+                ts.dt[ts.ntaps] = toff - kt;
+                ts.ntaps++;
+                sel.push_back(kf * d.nkt + kt);
+            }
+        }
+        SE_CHECK(ts.ntaps > 0, "transposed-conv parity class without taps");
+        std::vector<float> w((size_t)d.M * d.Cin * ts.ntaps);
+        for (int m = 0; m < d.M; ++m)
+            for (int c = 0; c < d.Cin; ++c)
+                for (int j = 0; j < ts.ntaps; ++j)
+                    w[((size_t)m * d.Cin + c) * ts.ntaps + j] = d.w[((size_t)m * d.Cin + c) * d.ntaps() + sel[j]];
+        out.par.push_back(gc_make_plan(d.M, d.Cin, ts, w, d.bias, slope, act, EPI_ACT, 1, sf, par, tout_hint));
+    }
+    return out;
+}
+
+void free_deconv_plan(DeconvPlan& p) {
+    for (auto& g : p.par) gc_free_plan(g);
+    p.par.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ profiler
+void Profiler::begin(hipStream_t st) {
+    if (!on) return;
+    if (used + 2 > ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            SE_HIP(hipEventCreate(&e));
+            ev.push_back(e);
+        }
+    }
+    SE_HIP(hipEventRecord(ev[used], st));
+}
+void Profiler::end(hipStream_t st, double fl) {
+    if (!on) return;
+    SE_HIP(hipEventRecord(ev[used + 1], st));
+    used += 2;
+    flops += fl;
+    launches += 1;
+}
+double Profiler::total_ms() {
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < used; i += 2) {
+        SE_HIP(hipEventSynchronize(ev[i + 1]));
+        float ms = 0.f;
+        SE_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        tot += ms;
+    }
+    return tot;
+}
+Profiler::~Profiler() {
+    for (auto e : ev) (void)hipEventDestroy(e);
+}
+
+void gc_launch_prof(const GCPlan& pl, const GCParams& p, hipStream_t st, Profiler* prof) {
+    if (prof && prof->on) {
+        prof->begin(st);
+        gc_launch(pl, p, st);
+        const double nch = (p.epi == EPI_LSTM && p.first_step) ? 0.0 : (double)(p.C0 + p.C1);
+        prof->end(st, 2.0 * p.M * nch * p.ntaps * (double)p.Z * p.B * p.Q * p.Tout);
+    } else {
+        gc_launch(pl, p, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+static void fill_src(GCParams& p, const Act4& s0, const Act4* s1) {
+    p.src0 = s0.p;
+    p.C0 = s0.C;
+    p.s0_b = s0.sb;
+    p.s0_c = s0.sc;
+    p.s0_f = s0.sf;
+    if (s1) {
+        p.src1 = s1->p;
+        p.C1 = s1->C;
+        p.s1_b = s1->sb;
+        p.s1_c = s1->sc;
+        p.s1_f = s1->sf;
+    } else {
+        p.src1 = nullptr;
+        p.C1 = 0;
+    }
+}
+
+void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
+              hipStream_t st, Profiler* prof) {
+    GCParams p = pl.p;
+    const int cin_plan = p.C0 + p.C1;
+    fill_src(p, s0, s1);
+    SE_CHECK(p.C0 + p.C1 == cin_plan, "run_conv: channel count differs from plan");
+    p.Fin = s0.F;
+    p.Tin = T;
+    p.B = B;
+    p.Q = Fout;
+    p.Tout = T;
+    p.dst = dst;
+    p.d_b = (long)dstC * Fout * Tp;
+    p.d_c = (long)Fout * Tp;
+    p.d_f = Tp;
+    gc_launch_prof(pl, p, st, prof);
+}
+
+void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
+                int Tp, hipStream_t st, Profiler* prof) {
+    for (const auto& g : pl.par) {
+        GCParams p = g.p;
+        const int cin_plan = p.C0 + p.C1;
+        fill_src(p, s0, s1);
+        SE_CHECK(p.C0 + p.C1 == cin_plan, "run_deconv: channel count differs from plan");
+        p.Fin = s0.F;
+        p.Tin = T;
+        p.B = B;
+        p.Q = (Fout - p.po + p.so - 1) / p.so;
+        p.Tout = T;
+        p.dst = dst;
+        p.d_b = (long)dstC * Fout * Tp;
+        p.d_c = (long)Fout * Tp;
+        p.d_f = Tp;
+        if (p.Q > 0) gc_launch_prof(g, p, st, prof);
+    }
+}
+
+}  // namespace se

@@ -1,0 +1,61 @@
+// Model interface of the engine: one subclass per reference model class (include/se_engine.h se_model_id).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include "layers.h"
+#include <memory>
+#include <set>
+
+namespace se {
+
+struct EngineCtx {
+    int max_batch = 1, max_samples = 64000;
+    float p_in = 1.f, p_out = 1.f;
+    StftGeom geom{0, 0, 0};
+    Arena arena;
+    Profiler prof;
+};
+
+// State dict with use tracking, so finalize can reject unexpected keys like a strict load_state_dict.
+struct TrackedSD {
+    const StateDict& sd;
+    mutable std::set<std::string> used;
+    explicit TrackedSD(const StateDict& s) : sd(s) {}
+    const HostTensor& get(const std::string& k, std::vector<int64_t> shape = {}) const {
+        used.insert(k);
+        return sd_get(sd, k, std::move(shape));
+    }
+    bool has(const std::string& k) const { return sd.count(k) != 0; }
+    void check_all_used() const {
+        for (const auto& kv : sd) {
+            const std::string& k = kv.first;
+            const bool nbt = k.size() >= 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0;
+            SE_CHECK(nbt || used.count(k), "unexpected key in state dict: '" + k + "'");
+        }
+    }
+};
+
+class Model {
+  public:
+    explicit Model(EngineCtx& c) : ctx(c) {}
+    virtual ~Model() {}
+    virtual StftGeom default_geom() const = 0;
+    virtual void finalize(const TrackedSD& sd) = 0;
+    // y = model(x) in the reference's tensor layout
+    virtual void forward(const float* in, const int64_t* shape, int ndim, float* out, hipStream_t st) = 0;
+    // body of enhance(args) for B equal-length clips
+    virtual void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) = 0;
+    // carve the activation workspace for (B clips, T frames) out of ctx.arena (also used to size it)
+    virtual void plan_buffers(int B, int T) = 0;
+    virtual int64_t output_samples(int L) const { return L; }
+    // samples the STFT sees (decode scripts that tail-pad to a hop multiple)
+    virtual int padded_samples(int L) const { return L; }
+    int num_frames(int L) const { return 1 + padded_samples(L) / ctx.geom.hop; }
+
+  protected:
+    EngineCtx& ctx;
+};
+
+std::unique_ptr<Model> make_dccrn(EngineCtx& ctx);
+
+}  // namespace se

@@ -1,0 +1,307 @@
+// DCCRN on the MI355X engine.
+//
+// Reference: DCCRN/DCCRN_cprs.py:8-226 (class DCCRN, forward :142-226) as constructed at
+// DCCRN/dccrn_decode_vb.py:11  DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
+// kernel_num=[32,64,128,256,256,256]); decode loop body dccrn_decode_vb.py:25-64.
+// The operator semantics of the reference's absent third-party `complexnn` (ComplexConv2d,
+// ComplexConvTranspose2d, NavieComplexLSTM, complex_cat) follow upstream huyanxin/DeepComplexCRN as
+// documented in oracle/_complexnn_recall.py (parity unpinned at that boundary).
+//
+// MI355X mapping
+//   * every complex (de)conv is ONE real tap-table implicit GEMM on f32 MFMA: the [real;imag] channel halves
+//     make the complex product a 2x2 block real weight matrix, BatchNorm(eval) is folded into it, PReLU is the
+//     epilogue; complex_cat skip connections are a two-source K loop (no concat buffer is ever written);
+//   * the stride-2 transposed convs run as two output-parity dense convs;
+//   * the complex LSTM = 2 real LSTMs x 2 parts: input projections are two big GEMMs over all frames in a
+//     time-major [T][feature][sequence] layout, the recurrence is one fused MFMA GEMM + LSTM-cell epilogue per
+//     frame covering both LSTMs (blockIdx.z) and all 2B sequences; r-i / r+i combinations are folded into the
+//     next layer's weights ([W,-W] / [W,W] two-source GEMMs).
+#include "model.h"
+
+namespace se {
+
+namespace {
+
+constexpr int NL = 6;
+constexpr int KN[NL + 1] = {2, 32, 64, 128, 256, 256, 256};
+constexpr int NFFT = 512, HOP = 128, NBIN = 257;
+
+struct Bufs {
+    int B = 0, T = 0;
+    float *c = nullptr, *spec = nullptr, *est = nullptr, *frames = nullptr;
+    float* E[NL] = {};
+    float* D[NL + 1] = {};
+    float *X1 = nullptr, *G = nullptr, *H1 = nullptr, *H2 = nullptr, *C1 = nullptr, *C2 = nullptr, *P = nullptr;
+};
+
+class Dccrn final : public Model {
+  public:
+    explicit Dccrn(EngineCtx& c) : Model(c) {}
+    ~Dccrn() override {
+        for (auto& p : enc) gc_free_plan(p);
+        for (auto& p : dec) free_deconv_plan(p);
+        gc_free_plan(g1);
+        gc_free_plan(g2);
+        gc_free_plan(st1);
+        gc_free_plan(st2);
+        gc_free_plan(proj);
+    }
+    StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
+    int padded_samples(int L) const override {
+        // dccrn_decode_vb.py:32-35: frame_num = ceil(L/128 + 1); padded length (frame_num-1)*128
+        const int frame_num = (L + HOP - 1) / HOP + 1;
+        return (frame_num - 1) * HOP;
+    }
+    int64_t output_samples(int L) const override { return padded_samples(L); }   // :59-64 (not trimmed to L)
+
+    void finalize(const TrackedSD& sd) override {
+        const int tout = 501;
+        // ---- encoder (DCCRN_cprs.py:62-77): ComplexConv2d(k=(5,2), s=(2,1), pad=(2,1) causal) + BN + PReLU
+        for (int k = 0; k < NL; ++k) {
+            const std::string p = "encoder." + std::to_string(k) + ".";
+            const int ci = KN[k] / 2, co = KN[k + 1] / 2;
+            DenseW wr = conv_weights(sd.get(p + "0.real_conv.weight", {co, ci, 5, 2}), &sd.get(p + "0.real_conv.bias", {co}), false);
+            DenseW wi = conv_weights(sd.get(p + "0.imag_conv.weight", {co, ci, 5, 2}), &sd.get(p + "0.imag_conv.bias", {co}), false);
+            DenseW w = complex_expand(wr, wi);
+            fold_bn(w, sd.get(p + "1.weight", {2 * co}), sd.get(p + "1.bias", {2 * co}), sd.get(p + "1.running_mean", {2 * co}),
+                    sd.get(p + "1.running_var", {2 * co}));
+            enc[k] = make_conv_plan(w, 2, 2, 1, 1, 1, ACT_PRELU, prelu_slopes(sd.get(p + "2.weight"), 2 * co), EPI_ACT, tout);
+        }
+        // ---- decoder (:98-137): ComplexConvTranspose2d(k=(5,2), s=(2,1), pad=(2,0), out_pad=(1,0)) [+ BN + PReLU]
+        for (int k = 0; k < NL; ++k) {
+            const int idx = NL - k;
+            const std::string p = "decoder." + std::to_string(k) + ".";
+            const int ci = KN[idx], co = KN[idx - 1] / 2;     // per-half channel counts (input = cat -> 2*KN/2)
+            DenseW wr = deconv_weights(sd.get(p + "0.real_conv.weight", {ci, co, 5, 2}), &sd.get(p + "0.real_conv.bias", {co}), false);
+            DenseW wi = deconv_weights(sd.get(p + "0.imag_conv.weight", {ci, co, 5, 2}), &sd.get(p + "0.imag_conv.bias", {co}), false);
+            DenseW w = complex_expand(wr, wi);
+            // reference channel order after complex_cat([out, skip]) (:197): [out_r, skip_r, out_i, skip_i];
+            // engine order (two-source K loop): [out_r, out_i | skip_r, skip_i]
+            const int h = ci / 2;
+            std::vector<int> perm(4 * h);
+            for (int c = 0; c < h; ++c) {
+                perm[c] = c;
+                perm[h + c] = 2 * h + c;
+                perm[2 * h + c] = h + c;
+                perm[3 * h + c] = 3 * h + c;
+            }
+            permute_cin(w, perm);
+            std::vector<float> slope;
+            int act = ACT_NONE;
+            if (k < NL - 1) {
+                fold_bn(w, sd.get(p + "1.weight", {2 * co}), sd.get(p + "1.bias", {2 * co}),
+                        sd.get(p + "1.running_mean", {2 * co}), sd.get(p + "1.running_var", {2 * co}));
+                slope = prelu_slopes(sd.get(p + "2.weight"), 2 * co);
+                act = ACT_PRELU;
+            }
+            dec[k] = make_deconv_plan(w, 2, 2, /*toff: out[..., 1:] :199*/ 1, act, slope, tout);
+        }
+        // ---- complex LSTM x2 (:80-94), NavieComplexLSTM(1024|256 -> 256 [-> proj 1024])
+        auto lstm_w = [&](const std::string& p, int in, DenseW& wih, DenseW& whh) {
+            wih = linear_weights(sd.get(p + "weight_ih_l0", {512, in}), nullptr);
+            const HostTensor& bi = sd.get(p + "bias_ih_l0", {512});
+            const HostTensor& bh = sd.get(p + "bias_hh_l0", {512});
+            for (int i = 0; i < 512; ++i) wih.bias[i] = bi.data[i] + bh.data[i];
+            whh = linear_weights(sd.get(p + "weight_hh_l0", {512, 128}), nullptr);
+            const auto perm = lstm_gate_perm(128);
+            permute_rows(wih, perm);
+            permute_rows(whh, perm);
+        };
+        TapSpec one;
+        one.ntaps = 1;
+        one.df[0] = 0;
+        one.dt[0] = 0;
+        auto stack_z = [](const DenseW& a, const DenseW& b, std::vector<float>& w, std::vector<float>& bias) {
+            w = a.w;
+            w.insert(w.end(), b.w.begin(), b.w.end());
+            bias = a.bias;
+            bias.insert(bias.end(), b.bias.begin(), b.bias.end());
+        };
+        {
+            DenseW rih, rhh, iih, ihh;
+            lstm_w("enhance.0.real_lstm.", 512, rih, rhh);
+            lstm_w("enhance.0.imag_lstm.", 512, iih, ihh);
+            DenseW both = concat_rows(rih, iih);                   // rows: real_lstm gates, imag_lstm gates
+            g1 = gc_make_plan(1024, 512, one, both.w, both.bias, {}, ACT_NONE, EPI_ACT, 1, 1, 0, 512);
+            std::vector<float> w, b;
+            stack_z(rhh, ihh, w, b);
+            st1 = gc_make_plan(512, 128, one, w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, 512, 2);
+        }
+        {
+            DenseW rih, rhh, iih, ihh;
+            lstm_w("enhance.1.real_lstm.", 128, rih, rhh);
+            lstm_w("enhance.1.imag_lstm.", 128, iih, ihh);
+            DenseW both = concat_rows(rih, iih);                   // [1024][128]
+            // z=0 (real part'):  input r2r - i2i -> [W, -W];   z=1 (imag part'): input i2r + r2i -> [W, W]
+            DenseW z0 = concat_cin(both, both, -1.f), z1 = concat_cin(both, both, 1.f);
+            std::vector<float> w, b;
+            stack_z(z0, z1, w, b);
+            g2 = gc_make_plan(1024, 256, one, w, b, {}, ACT_NONE, EPI_ACT, 1, 1, 0, 256, 2);
+            stack_z(rhh, ihh, w, b);
+            st2 = gc_make_plan(512, 128, one, w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, 512, 2);
+            DenseW rt = linear_weights(sd.get("enhance.1.r_trans.weight", {512, 128}), &sd.get("enhance.1.r_trans.bias", {512}));
+            DenseW it = linear_weights(sd.get("enhance.1.i_trans.weight", {512, 128}), &sd.get("enhance.1.i_trans.bias", {512}));
+            DenseW p0 = concat_cin(rt, rt, -1.f), p1 = concat_cin(it, it, 1.f);
+            stack_z(p0, p1, w, b);
+            proj = gc_make_plan(512, 256, one, w, b, {}, ACT_NONE, EPI_ACT, 1, 1, 0, 256, 2);
+        }
+    }
+
+    void forward(const float* in, const int64_t* shape, int ndim, float* out, hipStream_t st) override {
+        SE_CHECK(ndim == 4 && shape[1] == 2 && shape[2] == NBIN, "DCCRN forward expects [B,2,257,T]");
+        const int B = (int)shape[0], T = (int)shape[3];
+        Bufs& b = bufs(B, T);
+        network(b, in, st);
+        launch_dccrn_mask(b.D[NL], in, out, B, NBIN, T, T, 1.f, st);
+    }
+
+    void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
+        const int Lpad = padded_samples(L);
+        const int T = 1 + Lpad / HOP;
+        Bufs& b = bufs(B, T);
+        launch_rms_scale(wav, B, L, pitch, b.c, st);                                           // :27
+        launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, nullptr, T, T, st);   // :28-42
+        network(b, b.spec, st);                                                                // :44
+        launch_dccrn_mask(b.D[NL], b.spec, b.est, B, NBIN, T, T, ctx.p_out, st);               // model :201-225 + :45-58
+        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, Lpad, st);       // :59-62
+    }
+
+    void plan_buffers(int B, int T) override {
+        cur.B = 0;
+        bufs(B, T);
+    }
+
+  private:
+    GCPlan enc[NL], g1, g2, st1, st2, proj;
+    DeconvPlan dec[NL];
+    Bufs cur;
+
+    Bufs& bufs(int B, int T) {
+        if (cur.B == B && cur.T == T) return cur;
+        Arena& a = ctx.arena;
+        a.reset();
+        Bufs b;
+        b.B = B;
+        b.T = T;
+        const size_t BT = (size_t)B * T;
+        b.c = a.alloc_f(B);
+        b.spec = a.alloc_f(BT * 2 * NBIN);
+        b.est = a.alloc_f(BT * 2 * NBIN);
+        b.frames = a.alloc_f(BT * NFFT);
+        int F = 256;
+        for (int k = 0; k < NL; ++k) {
+            F /= 2;
+            b.E[k] = a.alloc_f(BT * KN[k + 1] * F);
+        }
+        F = 4;
+        b.D[0] = a.alloc_f(BT * 256 * 4);
+        for (int k = 0; k < NL; ++k) {
+            F *= 2;
+            b.D[k + 1] = a.alloc_f(BT * KN[NL - k - 1] * F);
+        }
+        const size_t S = 2 * (size_t)B;
+        b.X1 = a.alloc_f((size_t)T * 512 * S);
+        b.G = a.alloc_f((size_t)T * 1024 * S);
+        b.H1 = a.alloc_f((size_t)T * 256 * S);
+        b.H2 = a.alloc_f((size_t)T * 256 * S);
+        b.C1 = a.alloc_f(256 * S);
+        b.C2 = a.alloc_f(256 * S);
+        b.P = a.alloc_f((size_t)T * 1024 * B);
+        cur = b;
+        return cur;
+    }
+
+    void lstm_steps(const GCPlan& stp, float* H, float* C, const float* G, int T, int S, hipStream_t st) {
+        for (int t = 0; t < T; ++t) {
+            GCParams p = stp.p;
+            p.first_step = (t == 0);
+            p.src0 = t > 0 ? H + (size_t)(t - 1) * 256 * S : H;
+            p.src0_z = 128L * S;
+            p.s0_b = 0;
+            p.s0_c = S;
+            p.s0_f = 0;
+            p.C0 = 128;
+            p.C1 = 0;
+            p.Fin = 1;
+            p.Tin = S;
+            p.B = 1;
+            p.Q = 1;
+            p.Tout = S;
+            p.aux = G + (size_t)t * 1024 * S;
+            p.aux_z = 512L * S;
+            p.x_b = 0;
+            p.x_c = S;
+            p.x_f = 0;
+            p.dst = H + (size_t)t * 256 * S;
+            p.dst_z = 128L * S;
+            p.d_b = 0;
+            p.d_c = S;
+            p.d_f = 0;
+            p.cell = C;
+            p.cell_z = 128L * S;
+            gc_launch_prof(stp, p, st, &ctx.prof);
+        }
+    }
+
+    // spec [B][2][257][T] -> mask in b.D[NL] ([B][2][256][T])
+    void network(Bufs& b, const float* spec, hipStream_t st) {
+        const int B = b.B, T = b.T;
+        Profiler* pf = &ctx.prof;
+        // encoder; first layer reads bins 1..256 (:166)
+        Act4 x{spec + T, 2, 256, 2L * NBIN * T, (long)NBIN * T, (long)T};
+        int F = 256;
+        for (int k = 0; k < NL; ++k) {
+            run_conv(enc[k], x, nullptr, b.E[k], KN[k + 1], F / 2, B, T, T, st, pf);
+            F /= 2;
+            x = act4(b.E[k], KN[k + 1], F, T);
+        }
+        // ---- complex LSTM (:175-185), time-major, sequences s = part*B + b
+        const int S = 2 * B;
+        for (int part = 0; part < 2; ++part)
+            launch_transpose_akt(b.E[NL - 1] + (size_t)part * 512 * T, b.X1 + (size_t)part * B, B, 512, T, 1024L * T, T,
+                                 512L * S, S, st);
+        {   // G1[t][1024][S] = [Wih_real; Wih_imag] x X1[t]
+            GCParams p = g1.p;
+            p.src0 = b.X1; p.s0_b = 512L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 512; p.C1 = 0;
+            p.Fin = 1; p.Tin = S; p.B = T; p.Q = 1; p.Tout = S;
+            p.dst = b.G; p.d_b = 1024L * S; p.d_c = S; p.d_f = 0;
+            gc_launch_prof(g1, p, st, pf);
+        }
+        lstm_steps(st1, b.H1, b.C1, b.G, T, S, st);
+        {   // G2: z = output part';  src0/src1 select (lstm, part) pairs, see file header
+            GCParams p = g2.p;
+            p.src0 = b.H1; p.src0_z = B; p.s0_b = 256L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 128;
+            p.src1 = b.H1 + 128L * S + B; p.src1_z = -(long)B; p.s1_b = 256L * S; p.s1_c = S; p.s1_f = 0; p.C1 = 128;
+            p.Fin = 1; p.Tin = B; p.B = T; p.Q = 1; p.Tout = B;
+            p.dst = b.G; p.dst_z = B; p.d_b = 1024L * S; p.d_c = S; p.d_f = 0;
+            gc_launch_prof(g2, p, st, pf);
+        }
+        lstm_steps(st2, b.H2, b.C2, b.G, T, S, st);
+        {   // projection r_trans / i_trans -> P[t][part'][512][B]
+            GCParams p = proj.p;
+            p.src0 = b.H2; p.src0_z = B; p.s0_b = 256L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 128;
+            p.src1 = b.H2 + 128L * S + B; p.src1_z = -(long)B; p.s1_b = 256L * S; p.s1_c = S; p.s1_f = 0; p.C1 = 128;
+            p.Fin = 1; p.Tin = B; p.B = T; p.Q = 1; p.Tout = B;
+            p.dst = b.P; p.dst_z = 512L * B; p.d_b = 1024L * B; p.d_c = B; p.d_f = 0;
+            gc_launch_prof(proj, p, st, pf);
+        }
+        for (int part = 0; part < 2; ++part)
+            launch_transpose_akt(b.P + (size_t)part * 512 * B, b.D[0] + (size_t)part * 512 * T, T, 512, B, 1024L * B, B,
+                                 1024L * T, T, st);
+        // ---- decoder with two-source skips (:196-199)
+        F = 4;
+        for (int k = 0; k < NL; ++k) {
+            const int cin = KN[NL - k];
+            Act4 a0 = act4(b.D[k], cin, F, T);
+            Act4 a1 = act4(b.E[NL - 1 - k], cin, F, T);
+            run_deconv(dec[k], a0, &a1, b.D[k + 1], KN[NL - k - 1], 2 * F, B, T, T, st, pf);
+            F *= 2;
+        }
+    }
+};
+
+}  // namespace
+
+std::unique_ptr<Model> make_dccrn(EngineCtx& ctx) { return std::unique_ptr<Model>(new Dccrn(ctx)); }
+
+}  // namespace se

@@ -1,0 +1,132 @@
+"""Python handle over the C-ABI engine.  torch is used only for device memory and streams."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One engine handle = one model replica on one GPU (one per rank)."""
+
+    def __init__(self, model, device=0, max_batch=1, max_samples=64000, p_in=1.0, p_out=1.0,
+                 n_fft=0, hop=0, win=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.model = model
+        cfg = _lib.SeConfig(_lib.MODEL_IDS[model], device, max_batch, max_samples, p_in, p_out, n_fft, hop, win, 0)
+        if self._lib.se_engine_create(C.byref(cfg), C.byref(self._h)):
+            raise EngineError(self._lib.se_last_error(None).decode())
+        self.device = device
+        self.max_batch, self.max_samples = max_batch, max_samples
+        self.finalized = False
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc:
+            raise EngineError(self._lib.se_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.se_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd):
+        """Strict load of a flat state dict (numpy arrays or torch tensors), then finalize."""
+        for k, v in sd.items():
+            a = v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)
+            if a.dtype == np.int64:
+                dt = 1
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                dt = 0
+            a = np.ascontiguousarray(a)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            self._check(self._lib.se_engine_set_tensor(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), shape,
+                                                       a.ndim, dt))
+        self._check(self._lib.se_engine_finalize(self._h))
+        self.finalized = True
+
+    # ------------------------------------------------------------------ compute (torch tensors on the GPU)
+    def forward(self, x, out_shape=None):
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        out = torch.empty(out_shape or x.shape, dtype=torch.float32, device=x.device)
+        shape = (C.c_int64 * x.dim())(*x.shape)
+        self._check(self._lib.se_forward(self._h, C.c_void_p(x.data_ptr()), shape, x.dim(),
+                                         C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def output_samples(self, n):
+        return int(self._lib.se_output_samples(self._h, n))
+
+    def num_frames(self, n):
+        return int(self._lib.se_num_frames(self._h, n))
+
+    def num_bins(self):
+        return int(self._lib.se_num_bins(self._h))
+
+    def enhance_batch(self, wav, out=None):
+        """wav [B, L] float32 cuda tensor -> [B, output_samples(L)]."""
+        import torch
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.stride(1) == 1
+        B, L = wav.shape
+        n_out = self.output_samples(L)
+        if out is None:
+            out = torch.empty((B, n_out), dtype=torch.float32, device=wav.device)
+        self._check(self._lib.se_enhance_batch(self._h, C.c_void_p(wav.data_ptr()), wav.stride(0), B, L,
+                                               C.c_void_p(out.data_ptr()), out.stride(0), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ stage hooks
+    def rms_scale(self, wav):
+        import torch
+        c = torch.empty(wav.shape[0], dtype=torch.float32, device=wav.device)
+        self._check(self._lib.se_rms_scale(self._h, C.c_void_p(wav.data_ptr()), wav.stride(0), wav.shape[0],
+                                           wav.shape[1], C.c_void_p(c.data_ptr()), self._stream()))
+        return c
+
+    def stft(self, wav, c=None, p_in=1.0):
+        import torch
+        B, L = wav.shape
+        T, F = self.num_frames(L), self.num_bins()
+        spec = torch.empty((B, 2, F, T), dtype=torch.float32, device=wav.device)
+        self._check(self._lib.se_stft(self._h, C.c_void_p(wav.data_ptr()), wav.stride(0), B, L,
+                                      C.c_void_p(c.data_ptr()) if c is not None else None, p_in,
+                                      C.c_void_p(spec.data_ptr()), self._stream()))
+        return spec
+
+    def istft(self, spec, n_out, c=None):
+        import torch
+        B, _, F, T = spec.shape
+        assert spec.is_contiguous()
+        wav = torch.empty((B, n_out), dtype=torch.float32, device=spec.device)
+        self._check(self._lib.se_istft(self._h, C.c_void_p(spec.data_ptr()), B, T,
+                                       C.c_void_p(c.data_ptr()) if c is not None else None,
+                                       C.c_void_p(wav.data_ptr()), wav.stride(0), n_out, self._stream()))
+        return wav
+
+    # ------------------------------------------------------------------ profiling
+    def set_profiling(self, on):
+        self._check(self._lib.se_set_profiling(self._h, 1 if on else 0))
+
+    def get_profile(self):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self._lib.se_get_profile(self._h, C.byref(ms), C.byref(n), C.byref(fl)))
+        return {'gemm_ms': ms.value, 'gemm_launches': n.value, 'gemm_flops': fl.value}

@@ -1,0 +1,82 @@
+"""Host-side mirrors of the reference's model classes.
+
+Same class names, constructor arguments, `load_state_dict` key schema, `eval()/cuda()` chaining and
+`forward()` tensor shapes as the reference `nn.Module`s, but every forward runs in the HIP engine
+(libse_engine.so) - these classes hold no parameters and do no arithmetic themselves.
+"""
+import numpy as np
+
+from . import schemas, synth
+from .engine import Engine
+
+
+class _EngineModule:
+    """Common plumbing: lazy engine creation, strict state-dict load, torch-like call surface."""
+    _model = None          # key into _lib.MODEL_IDS / schemas.SCHEMAS
+    p_in = 1.0             # magnitude exponents the decode script applies around the network
+    p_out = 1.0
+
+    def __init__(self, device=0, max_batch=1, max_samples=64000, p_in=None, p_out=None):
+        self._device = device
+        self._max_batch = max_batch
+        self._max_samples = max_samples
+        if p_in is not None:
+            self.p_in = p_in
+        if p_out is not None:
+            self.p_out = p_out
+        self.engine = None
+
+    # -- reference-compatible surface -------------------------------------------------------------
+    @classmethod
+    def state_dict_schema(cls):
+        return schemas.SCHEMAS[cls._model]()
+
+    def load_state_dict(self, sd, strict=True):
+        assert strict, "the engine only supports strict loads (as every reference decode script does)"
+        want = self.state_dict_schema()
+        missing = [k for k in want if k not in sd]
+        unexpected = [k for k in sd if k not in want]
+        if missing or unexpected:
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        self.engine = Engine(self._model, self._device, self._max_batch, self._max_samples, self.p_in, self.p_out)
+        self.engine.load_state_dict(sd)
+        return self
+
+    def load_synthetic(self, seed=0):
+        """Deterministic random-init weights (no checkpoints ship with the reference)."""
+        return self.load_state_dict(synth.synth_state_dict(self.state_dict_schema(), seed))
+
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, x):
+        return self.forward(x)
+
+    def forward(self, x):
+        if self.engine is None:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        return self.engine.forward(x.contiguous())
+
+    def enhance_batch(self, wav):
+        return self.engine.enhance_batch(wav)
+
+
+class DCCRN(_EngineModule):
+    """DCCRN/DCCRN_cprs.py:8 as built by DCCRN/dccrn_decode_vb.py:11.  forward: [B,2,257,T] -> [B,2,257,T]."""
+    _model = 'dccrn'
+
+    def __init__(self, rnn_layers=2, rnn_units=128, win_len=512, win_inc=128, fft_len=512, win_type='hanning',
+                 masking_mode='E', use_clstm=False, use_cbn=False, kernel_size=5,
+                 kernel_num=(16, 32, 64, 128, 256, 256), **kw):
+        cfg = (rnn_layers, rnn_units, win_len, win_inc, fft_len, masking_mode, use_clstm, use_cbn, kernel_size,
+               tuple(kernel_num))
+        if cfg != (2, 256, 512, 128, 512, 'E', True, False, 5, (32, 64, 128, 256, 256, 256)):
+            raise NotImplementedError("the engine builds the decode script's DCCRN configuration "
+                                      "(dccrn_decode_vb.py:11); got " + repr(cfg))
+        super().__init__(**kw)

@@ -1,0 +1,127 @@
+"""State-dict key schemas of the reference models, built programmatically.
+
+A schema is an OrderedDict name -> (shape, 'f32' | 'i64') in the reference's `state_dict()` order; it drives
+strict loading and the deterministic synthetic weights (`synth.synth_state_dict`).  tests/test_schemas.py
+checks each one against the schema captured from the imported reference (tests/golden/schema_*.json).
+"""
+from collections import OrderedDict
+
+
+def _bn(d, p, c):
+    d[p + 'weight'] = ((c,), 'f32')
+    d[p + 'bias'] = ((c,), 'f32')
+    d[p + 'running_mean'] = ((c,), 'f32')
+    d[p + 'running_var'] = ((c,), 'f32')
+    d[p + 'num_batches_tracked'] = ((), 'i64')
+
+
+def _lstm(d, p, inp, hid, layers=1, bidir=False):
+    for k in range(layers):
+        i = inp if k == 0 else hid * (2 if bidir else 1)
+        for suf in (('', '_reverse') if bidir else ('',)):
+            d[f'{p}weight_ih_l{k}{suf}'] = ((4 * hid, i), 'f32')
+            d[f'{p}weight_hh_l{k}{suf}'] = ((4 * hid, hid), 'f32')
+            d[f'{p}bias_ih_l{k}{suf}'] = ((4 * hid,), 'f32')
+            d[f'{p}bias_hh_l{k}{suf}'] = ((4 * hid,), 'f32')
+
+
+def _conv(d, p, co, ci, k):
+    d[p + 'weight'] = ((co, ci) + tuple(k), 'f32')
+    d[p + 'bias'] = ((co,), 'f32')
+
+
+def _deconv(d, p, ci, co, k):
+    d[p + 'weight'] = ((ci, co) + tuple(k), 'f32')
+    d[p + 'bias'] = ((co,), 'f32')
+
+
+def lstm_schema():
+    """LSTM/LSTM.py:14-22."""
+    d = OrderedDict()
+    _bn(d, 'bn.', 161)
+    _lstm(d, 'lstm1.', 161, 1024, 1)
+    _lstm(d, 'lstm2.', 1024, 1024, 2)
+    d['fc.0.weight'] = ((161, 1024), 'f32')
+    d['fc.0.bias'] = ((161,), 'f32')
+    return d
+
+
+def _crn_like(en_ch, de_ch, lstm_fn, act_prelu):
+    d = OrderedDict()
+    for i in range(5):
+        p = f'en.en_module.{i}.'
+        _conv(d, p + '1.', en_ch[i + 1], en_ch[i], (2, 3))
+        _bn(d, p + '2.', en_ch[i + 1])
+        if act_prelu:
+            d[p + '3.weight'] = ((1,), 'f32')
+    lstm_fn(d)
+    for i in range(5):
+        p = f'de.de_module.{i}.'
+        _deconv(d, p + '0.', de_ch[i][0], de_ch[i][1], (2, 3))
+        off = 3 if i == 3 else 2
+        has_bn = de_ch[i][2]
+        if has_bn:
+            _bn(d, f'{p}{off}.', de_ch[i][1])
+            if act_prelu:
+                d[f'{p}{off + 1}.weight'] = ((1,), 'f32')
+    return d
+
+
+def crn_schema():
+    """CRN/CRN.py:16-109."""
+    return _crn_like([1, 16, 32, 64, 128, 256],
+                     [(512, 128, True), (256, 64, True), (128, 32, True), (64, 16, True), (32, 1, True)],
+                     lambda d: _lstm(d, 'lstm.', 1024, 1024, 2), False)
+
+
+def dpcrn_schema():
+    """DPCRN/DPCRN.py:16-166."""
+    def rnn(d):
+        _lstm(d, 'dprnn.intra_rnn.', 128, 64, 2, bidir=True)
+        d['dprnn.intra_fc.weight'] = ((128, 128), 'f32')
+        d['dprnn.intra_fc.bias'] = ((128,), 'f32')
+        _lstm(d, 'dprnn.inter_rnn.', 128, 128, 2)
+        d['dprnn.inter_fc.weight'] = ((128, 128), 'f32')
+        d['dprnn.inter_fc.bias'] = ((128,), 'f32')
+        for n in ('ln1', 'ln2'):
+            d[f'dprnn.{n}.weight'] = ((4, 128), 'f32')
+            d[f'dprnn.{n}.bias'] = ((4, 128), 'f32')
+    return _crn_like([2, 32, 32, 32, 64, 128],
+                     [(256, 64, True), (128, 32, True), (64, 32, True), (64, 32, True), (64, 2, False)], rnn, True)
+
+
+def dccrn_schema(kernel_num=(32, 64, 128, 256, 256, 256), rnn_units=256, fft_len=512):
+    """DCCRN/DCCRN_cprs.py:47-137 with the decode script's constructor (dccrn_decode_vb.py:11); operator
+    sub-keys (`real_conv`, `imag_conv`, `real_lstm`, `imag_lstm`, `r_trans`, `i_trans`) are upstream complexnn's."""
+    kn = [2] + list(kernel_num)
+    d = OrderedDict()
+    for k in range(len(kn) - 1):
+        p = f'encoder.{k}.'
+        _conv(d, p + '0.real_conv.', kn[k + 1] // 2, kn[k] // 2, (5, 2))
+        _conv(d, p + '0.imag_conv.', kn[k + 1] // 2, kn[k] // 2, (5, 2))
+        _bn(d, p + '1.', kn[k + 1])
+        d[p + '2.weight'] = ((1,), 'f32')
+    for n, idx in enumerate(range(len(kn) - 1, 0, -1)):
+        p = f'decoder.{n}.'
+        _deconv(d, p + '0.real_conv.', kn[idx], kn[idx - 1] // 2, (5, 2))
+        _deconv(d, p + '0.imag_conv.', kn[idx], kn[idx - 1] // 2, (5, 2))
+        if idx != 1:
+            _bn(d, p + '1.', kn[idx - 1])
+            d[p + '2.weight'] = ((1,), 'f32')
+    # `self.enhance` is registered after both ModuleLists (DCCRN_cprs.py:60-61,94)
+    hidden_dim = fft_len // (2 ** len(kn))
+    inp = hidden_dim * kn[-1]
+    for li in range(2):
+        p = f'enhance.{li}.'
+        i = (inp if li == 0 else rnn_units) // 2
+        _lstm(d, p + 'real_lstm.', i, rnn_units // 2)
+        _lstm(d, p + 'imag_lstm.', i, rnn_units // 2)
+        if li == 1:
+            d[p + 'r_trans.weight'] = ((inp // 2, rnn_units // 2), 'f32')
+            d[p + 'r_trans.bias'] = ((inp // 2,), 'f32')
+            d[p + 'i_trans.weight'] = ((inp // 2, rnn_units // 2), 'f32')
+            d[p + 'i_trans.bias'] = ((inp // 2,), 'f32')
+    return d
+
+
+SCHEMAS = {'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}

@@ -27,7 +27,7 @@ def load_schema(name):
 
 
 def rms(a):
-    a = np.asarray(a, dtype=np.float64)
+    a = np.abs(np.asarray(a)).astype(np.float64)
     return float(np.sqrt(np.mean(a * a)))
 
 

@@ -1,0 +1,84 @@
+"""GPU parity: the HIP engine (through the C ABI) vs the numpy oracle and the reference-generated fixtures."""
+import numpy as np
+import pytest
+
+import se_amd
+from se_amd import synth
+from conftest import load_golden, rms
+
+pytestmark = pytest.mark.gpu
+
+CTOR = dict(rnn_units=256, masking_mode='E', use_clstm=True, kernel_num=[32, 64, 128, 256, 256, 256])
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+def test_stft_istft_stage_hooks():
+    torch = _torch()
+    from se_amd.models import DCCRN
+    from oracle import stft as S
+    eng = DCCRN(**CTOR).load_synthetic(14).engine
+    x = synth.synth_batch(3, 'speech', 4096, seed0=20)          # multiple of hop -> no tail pad
+    xd = torch.from_numpy(x).cuda()
+    spec = eng.stft(xd).cpu().numpy()                            # [B,2,F,T]
+    ref = S.stft(x.astype(np.float64), 512, 128)
+    assert spec.shape == (3, 2, 257, ref.shape[-1])
+    err = rms((spec[:, 0] + 1j * spec[:, 1]) - ref)
+    assert err < 2e-6 * rms(np.abs(ref)), err
+    # power compression
+    spec_c = eng.stft(xd, p_in=0.5).cpu().numpy()
+    refc = np.abs(ref) ** 0.5 * np.exp(1j * np.angle(ref))
+    assert rms((spec_c[:, 0] + 1j * spec_c[:, 1]) - refc) < 5e-6 * rms(np.abs(refc))
+    # inverse round trip (size-independent property)
+    y = eng.istft(torch.from_numpy(np.ascontiguousarray(spec)).cuda(), 4096).cpu().numpy()
+    assert rms(y - x) < 2e-6 * rms(x)
+    c = eng.rms_scale(xd).cpu().numpy()
+    assert np.allclose(c, S.rms_scale(x), rtol=1e-6)
+
+
+def test_forward_matches_reference_fixture():
+    torch = _torch()
+    from se_amd.models import DCCRN
+    G = load_golden('dccrn')
+    m = DCCRN(**CTOR).load_synthetic(14)
+    y = m(torch.from_numpy(G['x']).cuda()).cpu().numpy()
+    assert y.shape == G['y'].shape
+    err = rms(y - G['y'])
+    assert err < 1e-5 * max(rms(G['y']), 1.0), (err, rms(G['y']))
+
+
+@pytest.mark.parametrize('p_in,p_out,key', [(1.0, 1.0, 'enh'), (0.5, 2.0, 'enh_cprs')])
+def test_enhance_matches_reference_fixture(p_in, p_out, key):
+    torch = _torch()
+    from se_amd.models import DCCRN
+    G = load_golden('dccrn')
+    m = DCCRN(**CTOR, p_in=p_in, p_out=p_out, max_batch=2).load_synthetic(14)
+    wav = torch.from_numpy(np.stack([G['wav'], G['wav']])).cuda()
+    y = m.enhance_batch(wav).cpu().numpy()
+    assert y.shape[1] == G[key].shape[0]
+    for b in range(2):
+        err = rms(y[b] - G[key])
+        assert err < 1e-4, err                       # north_star: <= 1e-4 RMS on the waveform
+        assert err < 5e-4 * max(rms(G[key]), 1e-3), (err, rms(G[key]))
+
+
+def test_enhance_vs_oracle_batch_and_lengths():
+    """Batched decode == per-utterance oracle decode; ragged length (not a hop multiple) exercises the tail pad."""
+    torch = _torch()
+    from se_amd.models import DCCRN
+    from oracle import decode as D
+    m = DCCRN(**CTOR, p_in=0.5, p_out=2.0, max_batch=3, max_samples=6000).load_synthetic(14)
+    sd = synth.synth_state_dict(m.state_dict_schema(), 14)
+    for L, kinds in ((5000, ('speech', 'white', 'gap')), (1500, ('quiet', 'speech', 'white'))):
+        x = np.stack([synth.synth_clip(30 + i, k, L) for i, k in enumerate(kinds)])
+        y = m.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+        for b in range(3):
+            ref = D.enhance_dccrn(sd, x[b], 0.5, 2.0)
+            assert y[b].shape == ref.shape
+            e = rms(y[b] - ref)
+            print(L, kinds[b], "rms err", e, "rms ref", rms(ref))
+            assert e < 1e-4 and e < 5e-4 * max(rms(ref), 1e-3), (L, kinds[b], e, rms(ref))

@@ -1,0 +1,14 @@
+"""CPU: programmatic state-dict schemas == schemas captured from the imported reference modules."""
+import pytest
+import se_amd
+from se_amd import schemas
+from conftest import load_schema
+
+
+@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'dccrn'])
+def test_schema_matches_reference(name):
+    ref = load_schema(name)
+    mine = schemas.SCHEMAS[name]()
+    assert list(mine.keys()) == list(ref.keys())
+    for k in ref:
+        assert tuple(mine[k][0]) == tuple(ref[k][0]) and mine[k][1] == ref[k][1], k

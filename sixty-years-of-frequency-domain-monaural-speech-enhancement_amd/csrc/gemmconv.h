@@ -54,9 +54,7 @@ struct GCParams {
     int act, epi;
     int n_ttiles, n_mtiles, Z;
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
-    signed char row_df[GC_MAX_ROWS];
-    unsigned char tap_row[GC_MAX_TAPS];
-    signed char tap_dt[GC_MAX_TAPS];
+    const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS]
 };
 
 // Host-side description of one dense layer, built once at finalize.
@@ -66,6 +64,7 @@ struct GCPlan {
     float* dA = nullptr;     // device copies owned by the plan
     float* dBias = nullptr;
     float* dSlope = nullptr;
+    int* dTab = nullptr;
 };
 
 struct TapSpec {
@@ -78,7 +77,7 @@ struct TapSpec {
 // (BatchNorm folded, complex structure expanded) for this tap set.  bias/slope may be empty.
 GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w_logical,
                     const std::vector<float>& bias, const std::vector<float>& slope, int act, int epi,
-                    int si, int so, int po, int tout_hint, int z = 1);
+                    int si, int so, int po, int tout_hint, int z = 1, int C0split = -1);
 void gc_free_plan(GCPlan& pl);
 
 // Launch: p must have src/dst pointers, strides, B/Q/Tout/Fin/Tin/C0/C1 filled in.

@@ -13,10 +13,21 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace se {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: indices are constants at the IR level, so per-thread arrays always live in registers
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
@@ -31,14 +42,18 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gc_kernel(const GCParams p) {
+// Per-thread staging descriptors are chunk-invariant: element e = (row rr = wave + 4*i, column w = lane + 64*j)
+// of the activation patch reads  base_chunk[boff[e]]  (always an in-bounds address) and is zeroed when its validity
+// bit is clear, so the per-chunk staging code is one load + one select per element with a uniform 64-bit base.
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int A_IT = (GC_MAX_KCP * BM / 4 + 255) / 256;
     constexpr int ROW_IT = 6;
     constexpr int W_IT = 3;
-    static_assert(ROW_IT * W_IT <= GC_MAX_BLD, "prefetch budget");
+    constexpr int NB = ROW_IT * W_IT;
+    static_assert(NB <= GC_MAX_BLD, "prefetch budget");
     static_assert(WM * WN == 4, "4 waves");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -75,76 +90,31 @@ __global__ __launch_bounds__(256) void gc_kernel(const GCParams p) {
     const int m0 = mt * BM;
 
     const float* __restrict__ Ag = p.A + (long)z * p.A_z + m0;
-    const float* __restrict__ s0 = p.src0 ? p.src0 + (long)z * p.src0_z + (long)b * p.s0_b : nullptr;
-    const float* __restrict__ s1 = p.src1 ? p.src1 + (long)z * p.src1_z + (long)b * p.s1_b : nullptr;
-    const int Cin = p.C0 + p.C1;
 
-    // tap offset table for one chunk (identical for every chunk)
-    for (int k = tid; k < p.KCp; k += 256) {
+    // tap offset table for one chunk (identical for every chunk); 4 padding entries for the operand prefetch
+    for (int k = tid; k < p.KCp + 4; k += 256) {
         int off = 0;
         if (k < p.KC) {
             const int cil = k / p.ntaps, j = k - cil * p.ntaps;
-            off = cil * (p.nrows * p.Wp) + p.tap_row[j] * p.Wp + (p.tap_dt[j] - p.dtmin);
+            off = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
         }
         koff[k] = off;
     }
 
-    float4 preA[A_IT];
-    float preB[ROW_IT * W_IT];
+    // ---- chunk-invariant staging descriptors
     const int nA4 = p.KCp * (BM / 4);
-
-    auto load_chunk = [&](int chunk) {
-        const float* Ac = Ag + (long)chunk * p.KCp * p.Mp;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < nA4) {
-                const int k = idx / (BM / 4), m4 = idx % (BM / 4);
-                preA[i] = *reinterpret_cast<const float4*>(Ac + (long)k * p.Mp + m4 * 4);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < ROW_IT; ++i) {
-            const int rr = wave + 4 * i;
-            if (rr < rows) {
-                const int cil = rr / p.nrows, r = rr - cil * p.nrows;
-                const int ci = chunk * p.CI_C + cil;
-                const int f = q * p.si + p.row_df[r];
-                const bool rowok = (ci < Cin) && (f >= 0) && (f < p.Fin);
-                const float* rp = nullptr;
-                if (rowok) rp = (ci < p.C0) ? s0 + (long)ci * p.s0_c + (long)f * p.s0_f
-                                            : s1 + (long)(ci - p.C0) * p.s1_c + (long)f * p.s1_f;
-#pragma unroll
-                for (int j = 0; j < W_IT; ++j) {
-                    const int w = lane + 64 * j;
-                    const int t = t0 + p.dtmin + w;
-                    float v = 0.f;
-                    if (rowok && w < p.Wp && t >= 0 && t < p.Tin) v = rp[t];
-                    preB[i * W_IT + j] = v;
-                }
-            }
-        }
-    };
-    auto store_chunk = [&](int buf) {
-        float* Ad = As + buf * As_sz;
-        float* Bd = Bs + buf * Bs_sz;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < nA4) *reinterpret_cast<float4*>(Ad + idx * 4) = preA[i];
-        }
-#pragma unroll
-        for (int i = 0; i < ROW_IT; ++i) {
-            const int rr = wave + 4 * i;
-            if (rr < rows) {
-#pragma unroll
-                for (int j = 0; j < W_IT; ++j) {
-                    const int w = lane + 64 * j;
-                    if (w < p.Wp) Bd[rr * p.Wp + w] = preB[i * W_IT + j];
-                }
-            }
-        }
-    };
+    int aoff[A_IT];
+    unsigned amask = 0;
+    static_for<A_IT>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        int idx = tid + i * 256;
+        if (idx < nA4) amask |= 1u << i;
+        else idx = nA4 - 1;
+        aoff[i] = (idx / (BM / 4)) * p.Mp + (idx % (BM / 4)) * 4;
+    });
+    int boff[NB];
+    unsigned vmask = 0;      // bit e: element contributes (inside the tensor)
+    unsigned smask = 0;      // bit e: element is staged (inside the patch)
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -158,45 +128,135 @@ __global__ __launch_bounds__(256) void gc_kernel(const GCParams p) {
     const int am = wm * (TM * 32) + l31;      // A column base inside the tile
     const int bn = wn * (TN * 32) + l31;      // B column base inside the tile
 
-    if (p.nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
-    __syncthreads();
+    floatx4 preA[A_IT];
+    float preB[NB];
+    int gchunk = 0;          // global chunk counter (weights are packed segment after segment)
+    int buf = 0;
 
-    for (int c = 0; c < p.nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < p.nchunks) load_chunk(c + 1);
-        const float* Ab = As + buf * As_sz + hi * BM + am;
-        const float* Bb = Bs + buf * Bs_sz + bn;
-        const int* kb = koff + hi;
-        const int npair = p.KCp >> 1;
-#pragma unroll 2
-        for (int kp = 0; kp < npair; ++kp) {
-            const int ob = kb[2 * kp];
-            float a[TM], bb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ab[(2 * kp) * BM + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bb[j] = Bb[ob + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
-        }
-        if (c + 1 < p.nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+#define GC_MAKE_DESC(LIM)                                                                          \
+    {                                                                                              \
+        const int lim_ = (LIM);                                                                    \
+        vmask = 0;                                                                                 \
+        smask = 0;                                                                                 \
+        static_for<ROW_IT>([&](auto I) {                                                           \
+            constexpr int i = decltype(I)::value;                                                  \
+            const int rr = wave + 4 * i;                                                           \
+            const int cil = rr / p.nrows, r = rr - cil * p.nrows;                                  \
+            const int f = q * p.si + p.tab[r];                                                     \
+            const bool rowin = rr < rows;                                                          \
+            const bool rowok = rowin && (cil < lim_) && (f >= 0) && (f < p.Fin);                   \
+            const int fc = f < 0 ? 0 : (f >= p.Fin ? p.Fin - 1 : f);                               \
+            const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
+            static_for<W_IT>([&](auto J) {                                                         \
+                constexpr int j = decltype(J)::value;                                              \
+                constexpr int e = i * W_IT + j;                                                    \
+                const int w = lane + 64 * j;                                                       \
+                const int t = t0 + p.dtmin + w;                                                    \
+                const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                           \
+                boff[e] = (int)((long)cc * s_c + (long)fc * s_f + tc);                             \
+                if (rowin && w < p.Wp) smask |= 1u << e;                                           \
+                if (rowok && w < p.Wp && t >= 0 && t < p.Tin) vmask |= 1u << e;                    \
+            });                                                                                    \
+        });                                                                                        \
     }
+#define GC_LOAD_CHUNK(CH)                                                                          \
+    {                                                                                              \
+        const float* __restrict__ Ac = Ag + (long)(gchunk + (CH)) * p.KCp * p.Mp;                  \
+        static_for<A_IT>([&](auto I) {                                                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            preA[i] = *reinterpret_cast<const floatx4*>(Ac + aoff[i]);                              \
+        });                                                                                        \
+        const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
+        static_for<NB>([&](auto E) {                                                               \
+            constexpr int e = decltype(E)::value;                                                  \
+            const float v = Bc[boff[e]];                                                           \
+            preB[e] = ((vmask >> e) & 1u) ? v : 0.f;                                               \
+        });                                                                                        \
+    }
+#define GC_STORE_CHUNK(BUF)                                                                        \
+    {                                                                                              \
+        float* Ad = As + (BUF) * As_sz;                                                            \
+        float* Bd = Bs + (BUF) * Bs_sz;                                                            \
+        static_for<A_IT>([&](auto I) {                                                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            if ((amask >> i) & 1u) *reinterpret_cast<floatx4*>(Ad + (tid + i * 256) * 4) = preA[i];\
+        });                                                                                        \
+        static_for<NB>([&](auto E) {                                                               \
+            constexpr int e = decltype(E)::value;                                                  \
+            constexpr int i = e / W_IT, j = e % W_IT;                                              \
+            if ((smask >> e) & 1u) Bd[(wave + 4 * i) * p.Wp + lane + 64 * j] = preB[e];            \
+        });                                                                                        \
+    }
+
+    for (int seg = 0; seg < 2; ++seg) {
+        const int Cseg = seg ? p.C1 : p.C0;
+        if (Cseg <= 0) continue;
+        const float* __restrict__ sbase =
+            (seg ? p.src1 + (long)z * p.src1_z + (long)b * p.s1_b : p.src0 + (long)z * p.src0_z + (long)b * p.s0_b);
+        const long s_c = seg ? p.s1_c : p.s0_c, s_f = seg ? p.s1_f : p.s0_f;
+        const int nch = (Cseg + p.CI_C - 1) / p.CI_C;
+        const int tail = Cseg - (nch - 1) * p.CI_C;       // channels in the last chunk
+
+        GC_MAKE_DESC(nch > 1 ? p.CI_C : tail);
+        GC_LOAD_CHUNK(0);
+        __syncthreads();                 // previous segment's readers are done with `buf`
+        GC_STORE_CHUNK(buf);
+        __syncthreads();
+
+        for (int c = 0; c < nch; ++c) {
+            if (c + 1 < nch) {
+                if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
+                GC_LOAD_CHUNK(c + 1);
+            }
+            // ---- MFMA over the staged chunk, operands prefetched one k-pair ahead
+            const float* Ab = As + buf * As_sz + hi * BM + am;
+            const float* Bb = Bs + buf * Bs_sz + bn;
+            const int* kb = koff + hi;
+            const int npair = p.KCp >> 1;
+            float a[TM], bb[TN], na[TM], nb[TN];
+            int o_nxt = kb[2];
+            {
+                const int o0 = kb[0];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = Ab[i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bb[j] = Bb[o0 + j * 32];
+            }
+            for (int kp = 0; kp < npair; ++kp) {
+                const int o_n2 = kb[2 * kp + 4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) na[i] = Ab[(2 * kp + 2) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) nb[j] = Bb[o_nxt + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = na[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bb[j] = nb[j];
+                o_nxt = o_n2;
+            }
+            if (c + 1 < nch) GC_STORE_CHUNK(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        gchunk += nch;
+    }
+#undef GC_MAKE_DESC
+#undef GC_LOAD_CHUNK
+#undef GC_STORE_CHUNK
 
     // ---------------------------------------------------------------- epilogue
     const float* __restrict__ bias = p.bias ? p.bias + (long)z * p.bias_z : nullptr;
     const int fo = q * p.so + p.po;
     float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
 
-    if (p.epi == EPI_ACT || p.epi == EPI_ADD) {
+    if (EPI == EPI_ACT || EPI == EPI_ADD) {
         const float* __restrict__ res =
-            (p.epi == EPI_ADD) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+            (EPI == EPI_ADD) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -208,12 +268,12 @@ __global__ __launch_bounds__(256) void gc_kernel(const GCParams p) {
                     if (m < p.M && t < p.Tout) {
                         float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
                         v = act_apply(v, p.act, p.slope ? p.slope[m] : 0.f);
-                        if (res) v += res[(long)m * p.x_c + t];
+                        if (EPI == EPI_ADD) v += res[(long)m * p.x_c + t];
                         dst[(long)m * p.d_c + t] = v;
                     }
                 }
             }
-    } else if (p.epi == EPI_GLU) {
+    } else if (EPI == EPI_GLU) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -262,11 +322,13 @@ __global__ __launch_bounds__(256) void gc_kernel(const GCParams p) {
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM) {
-    return (size_t)(2 * p.KCp * BM + 2 * p.CI_C * p.nrows * p.Wp) * 4 + (size_t)p.KCp * 4;
+    return (size_t)(2 * p.KCp * BM + 2 * p.CI_C * p.nrows * p.Wp) * 4 + (size_t)(p.KCp + 4) * 4 + 64;
 }
 
 GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w, const std::vector<float>& bias,
-                    const std::vector<float>& slope, int act, int epi, int si, int so, int po, int tout_hint, int Z) {
+                    const std::vector<float>& slope, int act, int epi, int si, int so, int po, int tout_hint, int Z,
+                    int C0split) {
+    const int C0 = (C0split < 0 || C0split > Cin) ? Cin : C0split;
     SE_CHECK(taps.ntaps >= 1 && taps.ntaps <= GC_MAX_TAPS, "tap count");
     SE_CHECK((long)w.size() == (long)Z * M * Cin * taps.ntaps, "weight size mismatch in gc_make_plan");
     GCPlan pl;
@@ -288,24 +350,31 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.dtmin = dtmin;
     p.Wp = pl.BN + (dtmax - dtmin);
     SE_CHECK(p.Wp <= 192, "time span of taps too wide for one patch");
-    for (int r = 0; r < p.nrows; ++r) p.row_df[r] = (signed char)rows[r];
-    for (int j = 0; j < taps.ntaps; ++j) {
-        p.tap_row[j] = (unsigned char)(std::find(rows.begin(), rows.end(), taps.df[j]) - rows.begin());
-        p.tap_dt[j] = (signed char)taps.dt[j];
+    {
+        std::vector<int> tab(GC_MAX_ROWS + 2 * GC_MAX_TAPS, 0);
+        for (int r = 0; r < p.nrows; ++r) tab[r] = rows[r];
+        for (int j = 0; j < taps.ntaps; ++j) {
+            tab[GC_MAX_ROWS + j] = (int)(std::find(rows.begin(), rows.end(), taps.df[j]) - rows.begin());
+            tab[GC_MAX_ROWS + GC_MAX_TAPS + j] = taps.dt[j];
+        }
+        SE_HIP(hipMalloc(&pl.dTab, tab.size() * sizeof(int)));
+        SE_HIP(hipMemcpy(pl.dTab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        p.tab = pl.dTab;
     }
     // chunking: largest CI_C within the staging budgets
     const int wit = (p.Wp + 63) / 64;
     int cic = 1;
-    for (int c = 1; c <= std::max(Cin, 1); ++c) {
-        int kcp = (c * taps.ntaps + 1) & ~1;
+    for (int c = 1; c <= std::max(std::max(C0, Cin - C0), 1); ++c) {
+        int kcp = (c * taps.ntaps + 3) & ~3;
         int rit = (c * p.nrows + 3) / 4;
         if (kcp <= GC_MAX_KCP && rit <= 6 && rit * wit <= GC_MAX_BLD) cic = c;
     }
     p.CI_C = cic;
     p.KC = cic * taps.ntaps;
-    p.KCp = (p.KC + 1) & ~1;
+    p.KCp = (p.KC + 3) & ~3;
     SE_CHECK(p.KCp <= GC_MAX_KCP, "single-channel chunk exceeds K budget");
-    p.nchunks = Cin > 0 ? (Cin + cic - 1) / cic : 0;
+    const int nch0 = (C0 + cic - 1) / cic, nch1 = (Cin - C0 + cic - 1) / cic;
+    p.nchunks = nch0 + nch1;
     p.M = M;
     p.Mp = ((M + pl.BM - 1) / pl.BM) * pl.BM;
     p.n_mtiles = p.Mp / pl.BM;
@@ -315,16 +384,17 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.so = so;
     p.po = po;
     p.Z = Z;
-    p.C0 = Cin;
-    p.C1 = 0;
-    // pack weights: [z][chunk][k_local][Mp]
+    p.C0 = C0;
+    p.C1 = Cin - C0;
+    // pack weights: [z][chunk][k_local][Mp]; chunks of segment 0 (channels < C0) first, then segment 1
     const size_t per_z = (size_t)std::max(p.nchunks, 1) * p.KCp * p.Mp;
     std::vector<float> packed(per_z * Z, 0.f);
     for (int z = 0; z < Z; ++z)
         for (int m = 0; m < M; ++m)
             for (int ci = 0; ci < Cin; ++ci)
                 for (int j = 0; j < taps.ntaps; ++j) {
-                    const int chunk = ci / cic, cil = ci % cic;
+                    const int cs = ci < C0 ? ci : ci - C0;
+                    const int chunk = (ci < C0 ? 0 : nch0) + cs / cic, cil = cs % cic;
                     const size_t dst = z * per_z + ((size_t)chunk * p.KCp + (cil * taps.ntaps + j)) * p.Mp + m;
                     packed[dst] = w[(((size_t)z * M + m) * Cin + ci) * taps.ntaps + j];
                 }
@@ -349,27 +419,41 @@ void gc_free_plan(GCPlan& pl) {
     if (pl.dA) (void)hipFree(pl.dA);
     if (pl.dBias) (void)hipFree(pl.dBias);
     if (pl.dSlope) (void)hipFree(pl.dSlope);
+    if (pl.dTab) (void)hipFree(pl.dTab);
+    pl.dTab = nullptr;
     pl.dA = pl.dBias = pl.dSlope = nullptr;
 }
 
-template <int BM, int BN, int WM, int WN>
-static void gc_launch_t(const GCParams& p, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int EPI>
+static void gc_launch_e(const GCParams& p, hipStream_t stream) {
     const size_t lds = gc_lds_bytes(p, BM);
     static bool attr_set = false;
     if (!attr_set) {
-        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN>),
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
-    hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN, EPI>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
     SE_HIP(hipGetLastError());
+}
+
+template <int BM, int BN, int WM, int WN>
+static void gc_launch_t(const GCParams& p, hipStream_t stream) {
+    switch (p.epi) {
+        case EPI_ACT: gc_launch_e<BM, BN, WM, WN, EPI_ACT>(p, stream); break;
+        case EPI_ADD: gc_launch_e<BM, BN, WM, WN, EPI_ADD>(p, stream); break;
+        case EPI_GLU: gc_launch_e<BM, BN, WM, WN, EPI_GLU>(p, stream); break;
+        case EPI_LSTM: gc_launch_e<BM, BN, WM, WN, EPI_LSTM>(p, stream); break;
+        default: SE_CHECK(false, "unknown epilogue");
+    }
 }
 
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     p.n_ttiles = (p.Tout + pl.BN - 1) / pl.BN;
-    if (p.epi == EPI_LSTM && p.first_step) p.nchunks = 0;
+    SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
+    if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;
     if (pl.BM == 128 && pl.BN == 128) gc_launch_t<128, 128, 2, 2>(p, stream);
     else if (pl.BM == 64 && pl.BN == 128) gc_launch_t<64, 128, 2, 2>(p, stream);
     else if (pl.BM == 32 && pl.BN == 128) gc_launch_t<32, 128, 1, 4>(p, stream);

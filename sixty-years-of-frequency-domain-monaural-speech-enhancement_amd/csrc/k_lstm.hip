@@ -1,0 +1,133 @@
+// Persistent LSTM recurrence for small hidden sizes (H = 64 / 128): one launch walks all time steps.
+//
+// Reference: torch.nn.LSTM cell (gate order i,f,g,o; c' = sig(f) c + sig(i) tanh(g); h = sig(o) tanh(c')) as used by
+// DCCRN's NavieComplexLSTM (DCCRN/DCCRN_cprs.py:82-92, hidden 128) and DPCRN's intra/inter LSTMs
+// (DPCRN/DPCRN.py:51-54, hidden 64 / 128).  The input projection W_ih x + b is a separate big GEMM (gemmconv);
+// this kernel adds the recurrent term and runs the cell.
+//
+// MI355X mapping: a workgroup owns 16 sequences (MFMA N = 16) of one LSTM for the whole utterance.  W_hh (4H x H
+// fp32 = 256 KB at H = 128) does not fit LDS, so it lives in REGISTERS as v_mfma_f32_16x16x4_f32 A-fragments:
+// wave w holds the 4H/4 gate rows of its H/4 units (H*H/64 VGPRs per lane = 256 at H = 128, one wave per SIMD),
+// h_{t-1} is the B operand read from an 8 KB LDS tile, the cell state never leaves registers, and the gate
+// pre-activations of step t+1 are prefetched from HBM while step t runs on the matrix pipe.  Rows are
+// gate-interleaved (row 4u+g) so that a lane's four accumulator registers are exactly the i,f,g,o gates of one
+// (unit, sequence) pair and the cell update is lane-local.
+#include "kernels.h"
+#include "common.h"
+#include <type_traits>
+
+namespace se {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for_l(F&& f) {
+    if constexpr (N > 0) {
+        static_for_l<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistArgs a) {
+    constexpr int MT = H / 16;     // 16-row M tiles per wave (wave owns H gate rows = H/4 units)
+    constexpr int KG = H / 4;      // k groups of 4
+    __shared__ float hs[2][H * 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int z = blockIdx.y % a.Z, o = blockIdx.y / a.Z;
+    const int n = n0 + l15;
+    const bool col_ok = n < a.S;
+
+    // ---- W_hh fragments -> registers (row-major [4H][H], rows gate-interleaved)
+    const float* __restrict__ W = a.whh + (long)z * a.whh_z;
+    float wa[MT][KG];
+    static_for_l<MT>([&](auto M_) {
+        constexpr int mt = decltype(M_)::value;
+        static_for_l<KG>([&](auto K_) {
+            constexpr int kg = decltype(K_)::value;
+            wa[mt][kg] = W[(long)(wave * H + mt * 16 + l15) * H + 4 * kg + l4];
+        });
+    });
+
+    const float* __restrict__ gx = a.gx + (long)z * a.gx_z + (long)o * a.gx_o + n;
+    float* __restrict__ out = a.out + (long)z * a.out_z + (long)o * a.out_o + n;
+
+    float c[MT];
+    float gcur[MT][4], gnxt[MT][4];
+    static_for_l<MT>([&](auto M_) {
+        constexpr int mt = decltype(M_)::value;
+        c[mt] = 0.f;
+    });
+    for (int i = tid; i < H * 16; i += 256) hs[0][i] = 0.f;
+
+    auto load_gx = [&](int step, float (&g)[MT][4]) {
+        const int t = a.reverse ? a.T - 1 - step : step;
+        const float* gp = gx + (long)t * a.gx_t;
+        static_for_l<MT>([&](auto M_) {
+            constexpr int mt = decltype(M_)::value;
+            const int row = wave * H + mt * 16 + l4 * 4;          // row of gate i of this lane's unit
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) g[mt][g4] = col_ok ? gp[(long)(row + g4) * a.gx_row] : 0.f;
+        });
+    };
+    load_gx(0, gcur);
+    __syncthreads();
+
+    for (int step = 0; step < a.T; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < a.T) load_gx(step + 1, gnxt);
+        floatx4 acc[MT];
+        static_for_l<MT>([&](auto M_) {
+            constexpr int mt = decltype(M_)::value;
+            acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        });
+        if (step > 0) {
+            const float* hb = &hs[cur][l4 * 16 + l15];
+            static_for_l<KG>([&](auto K_) {
+                constexpr int kg = decltype(K_)::value;
+                const float bv = hb[kg * 64];
+                static_for_l<MT>([&](auto M_) {
+                    constexpr int mt = decltype(M_)::value;
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][kg], bv, acc[mt], 0, 0, 0);
+                });
+            });
+        }
+        const int t = a.reverse ? a.T - 1 - step : step;
+        float* op = out + (long)t * a.out_t;
+        static_for_l<MT>([&](auto M_) {
+            constexpr int mt = decltype(M_)::value;
+            const int u = wave * (H / 4) + mt * 4 + l4;
+            const float gi = acc[mt][0] + gcur[mt][0];
+            const float gf = acc[mt][1] + gcur[mt][1];
+            const float gg = acc[mt][2] + gcur[mt][2];
+            const float go = acc[mt][3] + gcur[mt][3];
+            const float cn = fast_sigmoid(gf) * c[mt] + fast_sigmoid(gi) * fast_tanh(gg);
+            c[mt] = cn;
+            const float h = fast_sigmoid(go) * fast_tanh(cn);
+            hs[cur ^ 1][u * 16 + l15] = h;
+            if (col_ok) op[(long)u * a.out_row] = h;
+        });
+        static_for_l<MT>([&](auto M_) {
+            constexpr int mt = decltype(M_)::value;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) gcur[mt][g4] = gnxt[mt][g4];
+        });
+        __syncthreads();
+    }
+}
+
+void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s) {
+    SE_CHECK(a.H == 64 || a.H == 128, "persistent LSTM kernel is built for H = 64 / 128");
+    dim3 grid((a.S + 15) / 16, a.Z * a.O);
+    if (a.H == 128) hipLaunchKernelGGL(lstm_persist_kernel<128>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(lstm_persist_kernel<64>, grid, dim3(256), 0, s, a);
+    SE_HIP(hipGetLastError());
+}
+
+}  // namespace se

@@ -42,4 +42,18 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
 
 void launch_fill(float* p, long n, float v, hipStream_t s);
 
+// Persistent LSTM recurrence (k_lstm.hip): all T steps of Z x O x ceil(S/16) independent sequence tiles in one launch.
+//   gx  : gate pre-activations W_ih x + b_ih + b_hh, rows gate-interleaved (4u+g); element (o, z, t, row, n) at
+//         gx + o*gx_o + z*gx_z + t*gx_t + row*gx_row + n          (n = sequence index, contiguous)
+//   whh : [Z][4H][H] row-major, rows gate-interleaved
+//   out : h_t, element (o, z, t, u, n) at out + o*out_o + z*out_z + t*out_t + u*out_row + n
+struct LstmPersistArgs {
+    const float* gx; const float* whh; float* out;
+    long gx_o, gx_z, gx_t, gx_row;
+    long whh_z;
+    long out_o, out_z, out_t, out_row;
+    int H, T, S, Z, O, reverse;
+};
+void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s);
+
 }  // namespace se

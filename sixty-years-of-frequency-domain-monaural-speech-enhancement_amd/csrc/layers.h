@@ -47,7 +47,7 @@ std::vector<float> prelu_slopes(const HostTensor& w, int M);
 
 // Regular conv: out[f][t] = sum w[kf][kt] x[f*sf - pf + kf*dil_f][t - pt_left + kt*dil_t]
 GCPlan make_conv_plan(const DenseW& d, int sf, int pf, int pt_left, int dil_f, int dil_t, int act,
-                      const std::vector<float>& slope, int epi, int tout_hint);
+                      const std::vector<float>& slope, int epi, int tout_hint, int C0split = -1);
 
 // Transposed conv with frequency stride sf (time stride 1):
 //   out[fo][to] = sum_{kf,kt: (fo+pf-kf) % sf == 0} x[(fo+pf-kf)/sf][to + toff - kt] w[kf][kt]
@@ -57,7 +57,7 @@ struct DeconvPlan {
     int sf = 1;
 };
 DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, const std::vector<float>& slope,
-                            int tout_hint);
+                            int tout_hint, int C0split = -1);
 void free_deconv_plan(DeconvPlan& p);
 
 // Convenience launcher for [B][C][F][T]-layout tensors (row pitch Tp).

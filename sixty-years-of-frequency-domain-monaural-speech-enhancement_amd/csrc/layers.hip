@@ -191,7 +191,7 @@ std::vector<float> prelu_slopes(const HostTensor& w, int M) {
 }
 
 GCPlan make_conv_plan(const DenseW& d, int sf, int pf, int pt_left, int dil_f, int dil_t, int act,
-                      const std::vector<float>& slope, int epi, int tout_hint) {
+                      const std::vector<float>& slope, int epi, int tout_hint, int C0split) {
     TapSpec ts;
     ts.ntaps = d.ntaps();
     for (int kf = 0; kf < d.nkf; ++kf)
@@ -199,11 +199,11 @@ GCPlan make_conv_plan(const DenseW& d, int sf, int pf, int pt_left, int dil_f, i
             ts.df[kf * d.nkt + kt] = kf * dil_f - pf;
             ts.dt[kf * d.nkt + kt] = kt * dil_t - pt_left;
         }
-    return gc_make_plan(d.M, d.Cin, ts, d.w, d.bias, slope, act, epi, sf, 1, 0, tout_hint);
+    return gc_make_plan(d.M, d.Cin, ts, d.w, d.bias, slope, act, epi, sf, 1, 0, tout_hint, 1, C0split);
 }
 
 DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, const std::vector<float>& slope,
-                            int tout_hint) {
+                            int tout_hint, int C0split) {
     DeconvPlan out;
     out.sf = sf;
     for (int par = 0; par < sf; ++par) {
@@ -226,7 +226,7 @@ DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, 
             for (int c = 0; c < d.Cin; ++c)
                 for (int j = 0; j < ts.ntaps; ++j)
                     w[((size_t)m * d.Cin + c) * ts.ntaps + j] = d.w[((size_t)m * d.Cin + c) * d.ntaps() + sel[j]];
-        out.par.push_back(gc_make_plan(d.M, d.Cin, ts, w, d.bias, slope, act, EPI_ACT, 1, sf, par, tout_hint));
+        out.par.push_back(gc_make_plan(d.M, d.Cin, ts, w, d.bias, slope, act, EPI_ACT, 1, sf, par, tout_hint, 1, C0split));
     }
     return out;
 }
@@ -302,9 +302,7 @@ static void fill_src(GCParams& p, const Act4& s0, const Act4* s1) {
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
               hipStream_t st, Profiler* prof) {
     GCParams p = pl.p;
-    const int cin_plan = p.C0 + p.C1;
     fill_src(p, s0, s1);
-    SE_CHECK(p.C0 + p.C1 == cin_plan, "run_conv: channel count differs from plan");
     p.Fin = s0.F;
     p.Tin = T;
     p.B = B;
@@ -321,9 +319,7 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
                 int Tp, hipStream_t st, Profiler* prof) {
     for (const auto& g : pl.par) {
         GCParams p = g.p;
-        const int cin_plan = p.C0 + p.C1;
         fill_src(p, s0, s1);
-        SE_CHECK(p.C0 + p.C1 == cin_plan, "run_deconv: channel count differs from plan");
         p.Fin = s0.F;
         p.Tin = T;
         p.B = B;

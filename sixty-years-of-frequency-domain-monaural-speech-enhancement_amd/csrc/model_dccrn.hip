@@ -42,9 +42,9 @@ class Dccrn final : public Model {
         for (auto& p : dec) free_deconv_plan(p);
         gc_free_plan(g1);
         gc_free_plan(g2);
-        gc_free_plan(st1);
-        gc_free_plan(st2);
         gc_free_plan(proj);
+        if (whh1) (void)hipFree(whh1);
+        if (whh2) (void)hipFree(whh2);
     }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
     int padded_samples(int L) const override {
@@ -94,7 +94,7 @@ class Dccrn final : public Model {
                 slope = prelu_slopes(sd.get(p + "2.weight"), 2 * co);
                 act = ACT_PRELU;
             }
-            dec[k] = make_deconv_plan(w, 2, 2, /*toff: out[..., 1:] :199*/ 1, act, slope, tout);
+            dec[k] = make_deconv_plan(w, 2, 2, /*toff: out[..., 1:] :199*/ 1, act, slope, tout, /*C0 = out channels*/ 2 * h);
         }
         // ---- complex LSTM x2 (:80-94), NavieComplexLSTM(1024|256 -> 256 [-> proj 1024])
         auto lstm_w = [&](const std::string& p, int in, DenseW& wih, DenseW& whh) {
@@ -124,8 +124,8 @@ class Dccrn final : public Model {
             DenseW both = concat_rows(rih, iih);                   // rows: real_lstm gates, imag_lstm gates
             g1 = gc_make_plan(1024, 512, one, both.w, both.bias, {}, ACT_NONE, EPI_ACT, 1, 1, 0, 512);
             std::vector<float> w, b;
-            stack_z(rhh, ihh, w, b);
-            st1 = gc_make_plan(512, 128, one, w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, 512, 2);
+            stack_z(rhh, ihh, w, b);          // [2][512][128] gate-interleaved rows, for the persistent recurrence
+            whh1 = to_device(w);
         }
         {
             DenseW rih, rhh, iih, ihh;
@@ -136,14 +136,14 @@ class Dccrn final : public Model {
             DenseW z0 = concat_cin(both, both, -1.f), z1 = concat_cin(both, both, 1.f);
             std::vector<float> w, b;
             stack_z(z0, z1, w, b);
-            g2 = gc_make_plan(1024, 256, one, w, b, {}, ACT_NONE, EPI_ACT, 1, 1, 0, 256, 2);
+            g2 = gc_make_plan(1024, 256, one, w, b, {}, ACT_NONE, EPI_ACT, 1, 1, 0, 256, 2, 128);
             stack_z(rhh, ihh, w, b);
-            st2 = gc_make_plan(512, 128, one, w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, 512, 2);
+            whh2 = to_device(w);
             DenseW rt = linear_weights(sd.get("enhance.1.r_trans.weight", {512, 128}), &sd.get("enhance.1.r_trans.bias", {512}));
             DenseW it = linear_weights(sd.get("enhance.1.i_trans.weight", {512, 128}), &sd.get("enhance.1.i_trans.bias", {512}));
             DenseW p0 = concat_cin(rt, rt, -1.f), p1 = concat_cin(it, it, 1.f);
             stack_z(p0, p1, w, b);
-            proj = gc_make_plan(512, 256, one, w, b, {}, ACT_NONE, EPI_ACT, 1, 1, 0, 256, 2);
+            proj = gc_make_plan(512, 256, one, w, b, {}, ACT_NONE, EPI_ACT, 1, 1, 0, 256, 2, 128);
         }
     }
 
@@ -172,7 +172,8 @@ class Dccrn final : public Model {
     }
 
   private:
-    GCPlan enc[NL], g1, g2, st1, st2, proj;
+    GCPlan enc[NL], g1, g2, proj;
+    float *whh1 = nullptr, *whh2 = nullptr;
     DeconvPlan dec[NL];
     Bufs cur;
 
@@ -211,36 +212,15 @@ class Dccrn final : public Model {
         return cur;
     }
 
-    void lstm_steps(const GCPlan& stp, float* H, float* C, const float* G, int T, int S, hipStream_t st) {
-        for (int t = 0; t < T; ++t) {
-            GCParams p = stp.p;
-            p.first_step = (t == 0);
-            p.src0 = t > 0 ? H + (size_t)(t - 1) * 256 * S : H;
-            p.src0_z = 128L * S;
-            p.s0_b = 0;
-            p.s0_c = S;
-            p.s0_f = 0;
-            p.C0 = 128;
-            p.C1 = 0;
-            p.Fin = 1;
-            p.Tin = S;
-            p.B = 1;
-            p.Q = 1;
-            p.Tout = S;
-            p.aux = G + (size_t)t * 1024 * S;
-            p.aux_z = 512L * S;
-            p.x_b = 0;
-            p.x_c = S;
-            p.x_f = 0;
-            p.dst = H + (size_t)t * 256 * S;
-            p.dst_z = 128L * S;
-            p.d_b = 0;
-            p.d_c = S;
-            p.d_f = 0;
-            p.cell = C;
-            p.cell_z = 128L * S;
-            gc_launch_prof(stp, p, st, &ctx.prof);
-        }
+    // both real LSTMs (z) x all 2B sequences, all T steps in one persistent launch (k_lstm.hip)
+    void lstm_steps(const float* whh, float* H, const float* G, int T, int S, hipStream_t st) {
+        LstmPersistArgs a{};
+        a.gx = G; a.whh = whh; a.out = H;
+        a.gx_o = 0; a.gx_z = 512L * S; a.gx_t = 1024L * S; a.gx_row = S;
+        a.whh_z = 512L * 128;
+        a.out_o = 0; a.out_z = 128L * S; a.out_t = 256L * S; a.out_row = S;
+        a.H = 128; a.T = T; a.S = S; a.Z = 2; a.O = 1; a.reverse = 0;
+        launch_lstm_persist(a, st);
     }
 
     // spec [B][2][257][T] -> mask in b.D[NL] ([B][2][256][T])
@@ -267,7 +247,7 @@ class Dccrn final : public Model {
             p.dst = b.G; p.d_b = 1024L * S; p.d_c = S; p.d_f = 0;
             gc_launch_prof(g1, p, st, pf);
         }
-        lstm_steps(st1, b.H1, b.C1, b.G, T, S, st);
+        lstm_steps(whh1, b.H1, b.G, T, S, st);
         {   // G2: z = output part';  src0/src1 select (lstm, part) pairs, see file header
             GCParams p = g2.p;
             p.src0 = b.H1; p.src0_z = B; p.s0_b = 256L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 128;
@@ -276,7 +256,7 @@ class Dccrn final : public Model {
             p.dst = b.G; p.dst_z = B; p.d_b = 1024L * S; p.d_c = S; p.d_f = 0;
             gc_launch_prof(g2, p, st, pf);
         }
-        lstm_steps(st2, b.H2, b.C2, b.G, T, S, st);
+        lstm_steps(whh2, b.H2, b.G, T, S, st);
         {   // projection r_trans / i_trans -> P[t][part'][512][B]
             GCParams p = proj.p;
             p.src0 = b.H2; p.src0_z = B; p.s0_b = 256L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 128;

@@ -58,11 +58,15 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int rows = p.CI_C * p.nrows;
-    const int As_sz = p.KCp * BM;
-    const int Bs_sz = rows * p.Wp;
+    const int rit = (rows + 3) >> 2;                 // patch rows per wave (uniform)
+    const int wit = (p.Wp + 63) >> 6;                // 64-column groups per patch row (last one may be partial)
+    const int nA4 = p.KCp * (BM / 4);
+    const int ait = (nA4 + 255) >> 8;                // float4 groups of the weight chunk per thread (uniform)
+    const int As_sz = ait * 1024;                    // padded so that every thread stores unconditionally
+    const int Bs_sz = rit * 4 * p.Wp;
+    const int nbuf = p.dbuf ? 2 : 1;
     float* As = smem;
-    float* Bs = smem + 2 * As_sz;
-    int* koff = reinterpret_cast<int*>(Bs + 2 * Bs_sz);
+    float* Bs = smem + nbuf * As_sz;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,30 +95,28 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 
     const float* __restrict__ Ag = p.A + (long)z * p.A_z + m0;
 
-    // tap offset table for one chunk (identical for every chunk); 4 padding entries for the operand prefetch
-    for (int k = tid; k < p.KCp + 4; k += 256) {
-        int off = 0;
+    // tap offsets of one chunk (identical for every chunk) live in ONE register spread over the wave: lane l < 32
+    // holds the patch offset of k = 2l (first row of k-pair l), lane 32 + l that of k = 2l + 1; the MFMA loop fetches
+    // them with v_readlane (uniform pair index), so no operand address ever depends on an LDS read.
+    int kreg = 0;
+    {
+        const int k = 2 * l31 + hi;
         if (k < p.KC) {
             const int cil = k / p.ntaps, j = k - cil * p.ntaps;
-            off = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
+            kreg = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
         }
-        koff[k] = off;
     }
 
-    // ---- chunk-invariant staging descriptors
-    const int nA4 = p.KCp * (BM / 4);
-    int aoff[A_IT];
-    unsigned amask = 0;
+    // ---- chunk-invariant staging descriptors (all staging loops have uniform bounds: no exec masking)
+    unsigned aoff[A_IT];
     static_for<A_IT>([&](auto I) {
         constexpr int i = decltype(I)::value;
         int idx = tid + i * 256;
-        if (idx < nA4) amask |= 1u << i;
-        else idx = nA4 - 1;
-        aoff[i] = (idx / (BM / 4)) * p.Mp + (idx % (BM / 4)) * 4;
+        if (idx >= nA4) idx = nA4 - 1;
+        aoff[i] = (unsigned)((idx / (BM / 4)) * p.Mp + (idx % (BM / 4)) * 4);
     });
-    int boff[NB];
-    unsigned vmask = 0;      // bit e: element contributes (inside the tensor)
-    unsigned smask = 0;      // bit e: element is staged (inside the patch)
+    unsigned boff[NB];
+    bool vok[NB];            // element lies inside the tensor (else it is a zero of the padding)
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -136,26 +138,22 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 #define GC_MAKE_DESC(LIM)                                                                          \
     {                                                                                              \
         const int lim_ = (LIM);                                                                    \
-        vmask = 0;                                                                                 \
-        smask = 0;                                                                                 \
         static_for<ROW_IT>([&](auto I) {                                                           \
             constexpr int i = decltype(I)::value;                                                  \
             const int rr = wave + 4 * i;                                                           \
             const int cil = rr / p.nrows, r = rr - cil * p.nrows;                                  \
             const int f = q * p.si + p.tab[r];                                                     \
-            const bool rowin = rr < rows;                                                          \
-            const bool rowok = rowin && (cil < lim_) && (f >= 0) && (f < p.Fin);                   \
+            const bool rowok = (rr < rows) && (cil < lim_) && (f >= 0) && (f < p.Fin);             \
             const int fc = f < 0 ? 0 : (f >= p.Fin ? p.Fin - 1 : f);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
             static_for<W_IT>([&](auto J) {                                                         \
                 constexpr int j = decltype(J)::value;                                              \
                 constexpr int e = i * W_IT + j;                                                    \
-                const int w = lane + 64 * j;                                                       \
-                const int t = t0 + p.dtmin + w;                                                    \
+                const int t = t0 + p.dtmin + lane + 64 * j;                                        \
                 const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                           \
-                boff[e] = (int)((long)cc * s_c + (long)fc * s_f + tc);                             \
-                if (rowin && w < p.Wp) smask |= 1u << e;                                           \
-                if (rowok && w < p.Wp && t >= 0 && t < p.Tin) vmask |= 1u << e;                    \
+                const bool staged = (rr < rows) && (lane + 64 * j < p.Wp);                         \
+                boff[e] = staged ? (unsigned)((long)cc * s_c + (long)fc * s_f + tc) : 0u;          \
+                vok[e] = rowok && t >= 0 && t < p.Tin;                                             \
             });                                                                                    \
         });                                                                                        \
     }
@@ -164,27 +162,29 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
         const float* __restrict__ Ac = Ag + (long)(gchunk + (CH)) * p.KCp * p.Mp;                  \
         static_for<A_IT>([&](auto I) {                                                             \
             constexpr int i = decltype(I)::value;                                                  \
-            preA[i] = *reinterpret_cast<const floatx4*>(Ac + aoff[i]);                              \
+            preA[i] = *reinterpret_cast<const floatx4*>(Ac + aoff[i]);                             \
         });                                                                                        \
         const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
         static_for<NB>([&](auto E) {                                                               \
             constexpr int e = decltype(E)::value;                                                  \
-            const float v = Bc[boff[e]];                                                           \
-            preB[e] = ((vmask >> e) & 1u) ? v : 0.f;                                               \
+            preB[e] = Bc[boff[e]];                                                                 \
         });                                                                                        \
     }
 #define GC_STORE_CHUNK(BUF)                                                                        \
     {                                                                                              \
-        float* Ad = As + (BUF) * As_sz;                                                            \
-        float* Bd = Bs + (BUF) * Bs_sz;                                                            \
+        float* Ad = As + (BUF) * As_sz + tid * 4;                                                  \
+        float* Bd = Bs + (BUF) * Bs_sz + wave * p.Wp + lane;                                       \
         static_for<A_IT>([&](auto I) {                                                             \
             constexpr int i = decltype(I)::value;                                                  \
-            if ((amask >> i) & 1u) *reinterpret_cast<floatx4*>(Ad + (tid + i * 256) * 4) = preA[i];\
+            if (i < ait) *reinterpret_cast<floatx4*>(Ad + i * 1024) = preA[i];                     \
         });                                                                                        \
-        static_for<NB>([&](auto E) {                                                               \
-            constexpr int e = decltype(E)::value;                                                  \
-            constexpr int i = e / W_IT, j = e % W_IT;                                              \
-            if ((smask >> e) & 1u) Bd[(wave + 4 * i) * p.Wp + lane + 64 * j] = preB[e];            \
+        static_for<ROW_IT>([&](auto I) {                                                           \
+            constexpr int i = decltype(I)::value;                                                  \
+            if (i < rit) static_for<W_IT>([&](auto J) {                                            \
+                constexpr int j = decltype(J)::value;                                              \
+                constexpr int e = i * W_IT + j;                                                    \
+                if (j < wit && lane + 64 * j < p.Wp) Bd[4 * i * p.Wp + 64 * j] = vok[e] ? preB[e] : 0.f; \
+            });                                                                                    \
         });                                                                                        \
     }
 
@@ -204,44 +204,54 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
         __syncthreads();
 
         for (int c = 0; c < nch; ++c) {
-            if (c + 1 < nch) {
+            if (c + 1 < nch && !(p.dbg & 1)) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
                 GC_LOAD_CHUNK(c + 1);
             }
-            // ---- MFMA over the staged chunk, operands prefetched one k-pair ahead
+            // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
             const float* Ab = As + buf * As_sz + hi * BM + am;
             const float* Bb = Bs + buf * Bs_sz + bn;
-            const int* kb = koff + hi;
             const int npair = p.KCp >> 1;
-            float a[TM], bb[TN], na[TM], nb[TN];
-            int o_nxt = kb[2];
-            {
-                const int o0 = kb[0];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = Ab[i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bb[j] = Bb[o0 + j * 32];
+            // software pipeline, depth 1: the operands of k-pair kp+1 are fetched (ds_read2_b32) before the MFMAs of
+            // k-pair kp issue; sched_group_barrier pins "2 DS reads, then 4 MFMAs" so the LDS latency sits under
+            // 256 cycles of matrix work.  Reads one pair past the chunk (valid LDS, result unused).
+#define GC_FETCH(KP, AR, BR)                                                                       \
+    {                                                                                              \
+        const int olo_ = __builtin_amdgcn_readlane(kreg, (KP)), ohi_ = __builtin_amdgcn_readlane(kreg, (KP) + 32); \
+        const int o_ = hi ? ohi_ : olo_;                                                           \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) AR[i] = Ab[(2 * (KP)) * BM + i * 32];       \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) BR[j] = Bb[o_ + j * 32];                    \
+    }
+#define GC_MMA(AR, BR)                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[i], BR[j], acc[i][j], 0, 0, 0);
+            if (!(p.dbg & 4)) {
+                float ax[TM], bx[TN], ay[TM], by[TN];
+                GC_FETCH(0, ax, bx);
+                for (int kp = 0; kp < npair; kp += 2) {
+                    GC_FETCH(kp + 1, ay, by);
+                    __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);
+                    GC_MMA(ax, bx);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                    GC_FETCH(kp + 2, ax, bx);
+                    __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);
+                    GC_MMA(ay, by);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                }
             }
-            for (int kp = 0; kp < npair; ++kp) {
-                const int o_n2 = kb[2 * kp + 4];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) na[i] = Ab[(2 * kp + 2) * BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) nb[j] = Bb[o_nxt + j * 32];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = na[i];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bb[j] = nb[j];
-                o_nxt = o_n2;
+#undef GC_FETCH
+#undef GC_MMA
+            if (p.dbg & 2) {
+            } else if (p.dbuf) {
+                if (c + 1 < nch) GC_STORE_CHUNK(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            } else {
+                __syncthreads();
+                if (c + 1 < nch) GC_STORE_CHUNK(0);
+                __syncthreads();
             }
-            if (c + 1 < nch) GC_STORE_CHUNK(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
         }
         gchunk += nch;
     }
@@ -322,7 +332,8 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM) {
-    return (size_t)(2 * p.KCp * BM + 2 * p.CI_C * p.nrows * p.Wp) * 4 + (size_t)(p.KCp + 4) * 4 + 64;
+    const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows + 3) / 4) * 4 * p.Wp;
+    return (p.dbuf ? 2 : 1) * (as + bs) * 4 + 64;
 }
 
 GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w, const std::vector<float>& bias,
@@ -348,7 +359,7 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.ntaps = taps.ntaps;
     p.nrows = (int)rows.size();
     p.dtmin = dtmin;
-    p.Wp = pl.BN + (dtmax - dtmin);
+    p.Wp = (pl.BN + (dtmax - dtmin) + 3) & ~3;             // LDS row stride of the patch
     SE_CHECK(p.Wp <= 192, "time span of taps too wide for one patch");
     {
         std::vector<int> tab(GC_MAX_ROWS + 2 * GC_MAX_TAPS, 0);
@@ -361,13 +372,16 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
         SE_HIP(hipMemcpy(pl.dTab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
         p.tab = pl.dTab;
     }
-    // chunking: largest CI_C within the staging budgets
+    // chunking: largest CI_C within the staging budgets (SE_GC_KCP / SE_GC_DBUF: tuning overrides)
+    static const int kcp_cap = getenv("SE_GC_KCP") ? atoi(getenv("SE_GC_KCP")) : GC_MAX_KCP;
+    static const int dbuf_env = getenv("SE_GC_DBUF") ? atoi(getenv("SE_GC_DBUF")) : 1;
+    p.dbuf = dbuf_env;
     const int wit = (p.Wp + 63) / 64;
     int cic = 1;
     for (int c = 1; c <= std::max(std::max(C0, Cin - C0), 1); ++c) {
         int kcp = (c * taps.ntaps + 3) & ~3;
         int rit = (c * p.nrows + 3) / 4;
-        if (kcp <= GC_MAX_KCP && rit <= 6 && rit * wit <= GC_MAX_BLD) cic = c;
+        if (kcp <= std::min(GC_MAX_KCP, kcp_cap) && rit <= 6 && rit * wit <= GC_MAX_BLD) cic = c;
     }
     p.CI_C = cic;
     p.KC = cic * taps.ntaps;
@@ -452,6 +466,8 @@ static void gc_launch_t(const GCParams& p, hipStream_t stream) {
 
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     p.n_ttiles = (p.Tout + pl.BN - 1) / pl.BN;
+    static const int dbg_env = getenv("SE_GC_DBG") ? atoi(getenv("SE_GC_DBG")) : 0;
+    p.dbg = dbg_env;
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
     if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;
     if (pl.BM == 128 && pl.BN == 128) gc_launch_t<128, 128, 2, 2>(p, stream);

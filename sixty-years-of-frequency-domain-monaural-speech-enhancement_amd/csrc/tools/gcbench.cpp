@@ -1,0 +1,42 @@
+// Micro-benchmark of the tap-table implicit-GEMM conv on one DCCRN layer shape (tuning tool, not product path).
+//   gcbench <Cin> <Cout> <Fin> <B> [T=501] [deconv=0]
+#include "../layers.h"
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+using namespace se;
+int main(int argc, char** argv) {
+    int Cin = argc > 1 ? atoi(argv[1]) : 128, Cout = argc > 2 ? atoi(argv[2]) : 256, Fin = argc > 3 ? atoi(argv[3]) : 32;
+    int B = argc > 4 ? atoi(argv[4]) : 64, T = argc > 5 ? atoi(argv[5]) : 501;
+    int Fout = Fin / 2;
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    DenseW d;
+    d.M = Cout; d.Cin = Cin; d.nkf = 5; d.nkt = 2;
+    d.w.resize((size_t)Cout * Cin * 10);
+    for (auto& v : d.w) v = U(rng) * 0.05f;
+    d.bias.assign(Cout, 0.1f);
+    GCPlan pl = make_conv_plan(d, 2, 2, 1, 1, 1, ACT_PRELU, std::vector<float>(Cout, 0.25f), EPI_ACT, T);
+    size_t nin = (size_t)B * Cin * Fin * T, nout = (size_t)B * Cout * Fout * T;
+    std::vector<float> hin(nin);
+    for (auto& v : hin) v = U(rng);
+    float *din, *dout;
+    SE_HIP(hipMalloc(&din, nin * 4 + 4096));
+    SE_HIP(hipMalloc(&dout, nout * 4));
+    SE_HIP(hipMemcpy(din, hin.data(), nin * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    Act4 a = act4(din, Cin, Fin, T);
+    for (int it = 0; it < 2; ++it) run_conv(pl, a, nullptr, dout, Cout, Fout, B, T, T, 0);
+    SE_HIP(hipDeviceSynchronize());
+    const int reps = 5;
+    hipEventRecord(e0, 0);
+    for (int it = 0; it < reps; ++it) run_conv(pl, a, nullptr, dout, Cout, Fout, B, T, T, 0);
+    hipEventRecord(e1, 0);
+    SE_HIP(hipEventSynchronize(e1));
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    double fl = 2.0 * Cout * Cin * 10.0 * B * Fout * T;
+    printf("Cin=%d Cout=%d Fin=%d B=%d T=%d BM=%d BN=%d CI_C=%d KCp=%d: %.3f ms  %.1f TFLOP/s\n", Cin, Cout, Fin, B, T, pl.BM, pl.BN,
+           pl.p.CI_C, pl.p.KCp, ms, fl / ms / 1e9);
+    return 0;
+}

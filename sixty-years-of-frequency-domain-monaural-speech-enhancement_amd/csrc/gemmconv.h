@@ -35,6 +35,8 @@ struct GCParams {
     const float* A;          // packed weights [nchunks][KCp][Mp]
     const float* bias;       // [M] or nullptr
     const float* slope;      // [M] PReLU slopes or nullptr
+    const float* bias_pad;   // bias for output rows fo < pad_lo (a zero-padded frequency row: no conv bias, only the folded BN shift)
+    int pad_lo;
     const float* src0;
     const float* src1;
     float* dst;
@@ -67,6 +69,7 @@ struct GCPlan {
     float* dBias = nullptr;
     float* dSlope = nullptr;
     int* dTab = nullptr;
+    float* dBiasPad = nullptr;
 };
 
 struct TapSpec {

@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 #undef GC_STORE_CHUNK
 
     // ---------------------------------------------------------------- epilogue
-    const float* __restrict__ bias = p.bias ? p.bias + (long)z * p.bias_z : nullptr;
     const int fo = q * p.so + p.po;
+    const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
     float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
 
     if (EPI == EPI_ACT || EPI == EPI_ADD) {
@@ -434,7 +434,9 @@ void gc_free_plan(GCPlan& pl) {
     if (pl.dBias) (void)hipFree(pl.dBias);
     if (pl.dSlope) (void)hipFree(pl.dSlope);
     if (pl.dTab) (void)hipFree(pl.dTab);
+    if (pl.dBiasPad) (void)hipFree(pl.dBiasPad);
     pl.dTab = nullptr;
+    pl.dBiasPad = nullptr;
     pl.dA = pl.dBias = pl.dSlope = nullptr;
 }
 

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     const int n0 = blockIdx.x * 16;
     const int z = blockIdx.y % a.Z, o = blockIdx.y / a.Z;
     const int n = n0 + l15;
+    const bool rev = (a.reverse >> z) & 1;
     const bool col_ok = n < a.S;
 
     // ---- W_hh fragments -> registers (row-major [4H][H], rows gate-interleaved)
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     for (int i = tid; i < H * 16; i += 256) hs[0][i] = 0.f;
 
     auto load_gx = [&](int step, float (&g)[MT][4]) {
-        const int t = a.reverse ? a.T - 1 - step : step;
+        const int t = rev ? a.T - 1 - step : step;
         const float* gp = gx + (long)t * a.gx_t;
         static_for_l<MT>([&](auto M_) {
             constexpr int mt = decltype(M_)::value;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
                 });
             });
         }
-        const int t = a.reverse ? a.T - 1 - step : step;
+        const int t = rev ? a.T - 1 - step : step;
         float* op = out + (long)t * a.out_t;
         static_for_l<MT>([&](auto M_) {
             constexpr int mt = decltype(M_)::value;

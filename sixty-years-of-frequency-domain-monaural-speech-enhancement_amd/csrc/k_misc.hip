@@ -86,6 +86,88 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
     SE_HIP(hipGetLastError());
 }
 
+// ---- LayerNorm over (C, F) per (b, t) + residual ------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           const float* __restrict__ w, const float* __restrict__ bb,
+                                                           float* __restrict__ out, int C, int F, int T, float eps) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= T) return;
+    const long base = (long)b * C * F * T + t;
+    const int n = C * F;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += x[base + (long)i * T];
+    const float mu = s / n;
+    float v = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float d = x[base + (long)i * T] - mu;
+        v += d * d;
+    }
+    const float rs = rsqrtf(v / n + eps);
+    for (int c = 0; c < C; ++c)
+        for (int f = 0; f < F; ++f) {
+            const long o = base + ((long)c * F + f) * T;
+            float y = (x[o] - mu) * rs * w[f * C + c] + bb[f * C + c];
+            if (res) y += res[o];
+            out[o] = y;
+        }
+}
+void launch_layernorm_cf(const float* x, const float* res, const float* w, const float* b, float* out, int B, int C,
+                         int F, int T, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_cf_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, res, w, b, out, C, F, T, eps);
+    SE_HIP(hipGetLastError());
+}
+
+__device__ __forceinline__ float pow_scale(float m, float p) {   // m^p / m
+    if (p == 1.f) return 1.f;
+    if (m <= 0.f) return 0.f;
+    return (p == 2.f) ? m : powf(m, p - 1.f);
+}
+
+__global__ __launch_bounds__(256) void cmask_apply_kernel(const float* __restrict__ mask, const float* __restrict__ spec,
+                                                          float* __restrict__ out, long plane, long total, float p_out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / plane, r = i - b * plane;
+    const long o = b * 2 * plane + r;
+    const float mr = mask[o], mi = mask[o + plane], xr = spec[o], xi = spec[o + plane];
+    float er = xr * mr - xi * mi, ei = xr * mi + xi * mr;
+    const float sc = pow_scale(sqrtf(er * er + ei * ei), p_out);
+    out[o] = er * sc;
+    out[o + plane] = ei * sc;
+}
+void launch_cmask_apply(const float* mask, const float* spec, float* out, int B, int F, int T, float p_out,
+                        hipStream_t s) {
+    const long plane = (long)F * T, total = plane * B;
+    hipLaunchKernelGGL(cmask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mask, spec, out, plane,
+                       total, p_out);
+    SE_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void mag_phase_kernel(const float* __restrict__ mag, const float* __restrict__ spec,
+                                                        float* __restrict__ out, long plane, long total, float p_out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / plane, r = i - b * plane;
+    const long o = b * 2 * plane + r;
+    float m = mag[i];
+    if (p_out == 2.f) m = m * m;
+    else if (p_out != 1.f) m = powf(m, p_out);
+    const float xr = spec[o], xi = spec[o + plane];
+    const float xm = sqrtf(xr * xr + xi * xi);
+    float pr = 1.f, pi = 0.f;                 // np.angle(0) = 0
+    if (xm > 0.f) { pr = xr / xm; pi = xi / xm; }
+    out[o] = m * pr;
+    out[o + plane] = m * pi;
+}
+void launch_mag_phase(const float* mag, const float* spec, float* out, int B, int F, int T, float p_out,
+                      hipStream_t s) {
+    const long plane = (long)F * T, total = plane * B;
+    hipLaunchKernelGGL(mag_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mag, spec, out, plane,
+                       total, p_out);
+    SE_HIP(hipGetLastError());
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;

@@ -42,6 +42,22 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
 
 void launch_fill(float* p, long n, float v, hipStream_t s);
 
+// nn.LayerNorm([F, C]) over the (C, F) plane of every (b, t) column of a [B][C][F][T] tensor, affine weight/bias
+// indexed [f][c] (DPCRN/DPCRN.py:56-57 ln1/ln2), fused with the residual add that follows it (:74, :88):
+//   out = LN(x) * w + b + res
+void launch_layernorm_cf(const float* x, const float* res, const float* w, const float* b, float* out, int B, int C,
+                         int F, int T, float eps, hipStream_t s);
+
+// Complex ratio mask applied to the network input (DPCRN/DPCRN.py:33-42) + decode-script decompress
+// (dpcrn_decode_vb.py:48-57): est = (X * M); out = |est|^p_out * est / |est|.   All [B][2][F][T].
+void launch_cmask_apply(const float* mask, const float* spec, float* out, int B, int F, int T, float p_out,
+                        hipStream_t s);
+
+// Magnitude mapping back end (LSTM/lstm_decode_vb.py:47-49, CRN/crn_decode_vb.py:46-49):
+//   out = mag^p_out * exp(j * angle(X_noisy));  mag [B][F][T], spec/out [B][2][F][T].
+void launch_mag_phase(const float* mag, const float* spec, float* out, int B, int F, int T, float p_out,
+                      hipStream_t s);
+
 // Persistent LSTM recurrence (k_lstm.hip): all T steps of Z x O x ceil(S/16) independent sequence tiles in one launch.
 //   gx  : gate pre-activations W_ih x + b_ih + b_hh, rows gate-interleaved (4u+g); element (o, z, t, row, n) at
 //         gx + o*gx_o + z*gx_z + t*gx_t + row*gx_row + n          (n = sequence index, contiguous)
@@ -52,7 +68,7 @@ struct LstmPersistArgs {
     long gx_o, gx_z, gx_t, gx_row;
     long whh_z;
     long out_o, out_z, out_t, out_row;
-    int H, T, S, Z, O, reverse;
+    int H, T, S, Z, O, reverse;   // reverse: bit z set -> LSTM z walks the steps backwards (BiLSTM)
 };
 void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s);
 

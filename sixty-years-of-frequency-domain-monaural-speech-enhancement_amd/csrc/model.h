@@ -57,5 +57,8 @@ class Model {
 };
 
 std::unique_ptr<Model> make_dccrn(EngineCtx& ctx);
+std::unique_ptr<Model> make_crn(EngineCtx& ctx);
+std::unique_ptr<Model> make_lstm(EngineCtx& ctx);
+std::unique_ptr<Model> make_dpcrn(EngineCtx& ctx);
 
 }  // namespace se

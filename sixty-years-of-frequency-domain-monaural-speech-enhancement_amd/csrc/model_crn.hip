@@ -1,0 +1,239 @@
+// CRN and LSTM (magnitude-mapping models with a 320/160 librosa front end) on the MI355X engine.
+//
+// Reference:
+//   CRN/CRN.py:16-117 (crn_net: causal conv encoder x5 -> LSTM(1024,1024,2) -> deconv decoder x5, BN + ELU /
+//     Softplus), decode loop CRN/crn_decode_vb.py:33-52.
+//   LSTM/LSTM.py:14-28 (lstm_net: BatchNorm1d(161) -> LSTM(161,1024) -> LSTM(1024,1024,2) -> Linear + Softplus),
+//     decode loop LSTM/lstm_decode_vb.py:33-52.
+// Both map |X|^p_in -> enhanced magnitude and re-use the noisy phase (":49  est * exp(1j * phase)").
+//
+// Engine mapping: convs / deconvs are tap-table implicit GEMMs with BatchNorm folded and the activation in the
+// epilogue, skip concatenations are two-source K loops; the 1024-wide LSTMs run time-major ([T][feature][B]) as one
+// input-projection GEMM over all frames plus one fused GEMM + cell-update launch per frame.
+#include "rnn.h"
+
+namespace se {
+
+namespace {
+
+constexpr int NFFT = 320, HOP = 160, NBIN = 161;
+
+// ------------------------------------------------------------------------------------------------ CRN
+class Crn final : public Model {
+  public:
+    explicit Crn(EngineCtx& c) : Model(c) {}
+    ~Crn() override {
+        for (auto& p : enc) gc_free_plan(p);
+        for (auto& p : dec) free_deconv_plan(p);
+        for (auto& l : lstm) l.free();
+    }
+    StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
+
+    void finalize(const TrackedSD& sd) override {
+        const int EC[6] = {1, 16, 32, 64, 128, 256};
+        for (int i = 0; i < 5; ++i) {   // CRN.py:35-71  pad(top 1 frame) + Conv2d((2,3),(1,2)) + BN + ELU
+            const std::string p = "en.en_module." + std::to_string(i) + ".";
+            DenseW w = conv_weights(sd.get(p + "1.weight", {EC[i + 1], EC[i], 2, 3}), &sd.get(p + "1.bias", {EC[i + 1]}), true);
+            fold_bn(w, sd.get(p + "2.weight"), sd.get(p + "2.bias"), sd.get(p + "2.running_mean"), sd.get(p + "2.running_var"));
+            enc[i] = make_conv_plan(w, 2, 0, 1, 1, 1, ACT_ELU, {}, EPI_ACT, 401);
+        }
+        for (int l = 0; l < 2; ++l) lstm[l].build(load_lstm(sd, "lstm.", l, "", 1024, 1024), ctx.max_batch);   // :20
+        const int DC[5][2] = {{512, 128}, {256, 64}, {128, 32}, {64, 16}, {32, 1}};
+        for (int i = 0; i < 5; ++i) {   // CRN.py:73-109  ConvTranspose2d((2,3),(1,2)) [+ left freq pad] + chomp + BN + ELU|Softplus
+            const std::string p = "de.de_module." + std::to_string(i) + ".";
+            DenseW w = deconv_weights(sd.get(p + "0.weight", {DC[i][0], DC[i][1], 2, 3}), &sd.get(p + "0.bias", {DC[i][1]}), true);
+            const std::string bn = p + (i == 3 ? "3." : "2.");
+            DenseW wz = w;                       // zero conv bias: the value BN sees on the zero-padded frequency row
+            wz.bias.assign(wz.M, 0.f);
+            fold_bn(w, sd.get(bn + "weight"), sd.get(bn + "bias"), sd.get(bn + "running_mean"), sd.get(bn + "running_var"));
+            fold_bn(wz, sd.get(bn + "weight"), sd.get(bn + "bias"), sd.get(bn + "running_mean"), sd.get(bn + "running_var"));
+            dec[i] = make_deconv_plan(w, 2, i == 3 ? -1 : 0, 0, i == 4 ? ACT_SOFTPLUS : ACT_ELU, {}, 401, DC[i][0] / 2,
+                                      &wz.bias);
+        }
+    }
+
+    void plan_buffers(int B, int T) override {
+        cur.B = 0;
+        bufs(B, T);
+    }
+
+    void forward(const float* in, const int64_t* shape, int ndim, float* out, hipStream_t st) override {
+        SE_CHECK(ndim == 3 && shape[2] == NBIN, "CRN forward expects [B,T,161]");
+        const int B = (int)shape[0], T = (int)shape[1];
+        Bufs& b = bufs(B, T);
+        // [B][T][F] -> [B][F][T]
+        launch_transpose_akt(in, b.mag, T, B, NBIN, NBIN, (long)T * NBIN, T, (long)NBIN * T, st);
+        network(b, st);
+        launch_transpose_akt(b.D[5], out, NBIN, B, T, T, (long)NBIN * T, NBIN, (long)T * NBIN, st);
+    }
+
+    void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
+        const int T = 1 + L / HOP;
+        Bufs& b = bufs(B, T);
+        launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // crn_decode_vb.py:34-35
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, b.mag, T, T, st);        // :36-39
+        network(b, st);                                                                            // :43
+        launch_mag_phase(b.D[5], b.spec, b.est, B, NBIN, T, ctx.p_out, st);                        // :46-49
+        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :50-52
+    }
+
+  private:
+    struct Bufs {
+        int B = 0, T = 0;
+        float *c, *spec, *mag, *est, *frames, *E[5], *D[6], *X, *G, *Hs[2], *cell;
+    } cur;
+    GCPlan enc[5];
+    DeconvPlan dec[5];
+    LstmBig lstm[2];
+
+    Bufs& bufs(int B, int T) {
+        if (cur.B == B && cur.T == T) return cur;
+        Arena& a = ctx.arena;
+        a.reset();
+        Bufs b;
+        b.B = B;
+        b.T = T;
+        const size_t BT = (size_t)B * T;
+        b.c = a.alloc_f(B);
+        b.spec = a.alloc_f(BT * 2 * NBIN);
+        b.mag = a.alloc_f(BT * NBIN);
+        b.est = a.alloc_f(BT * 2 * NBIN);
+        b.frames = a.alloc_f(BT * NFFT);
+        const int EC[5] = {16, 32, 64, 128, 256}, EF[5] = {80, 39, 19, 9, 4};
+        for (int i = 0; i < 5; ++i) b.E[i] = a.alloc_f(BT * EC[i] * EF[i]);
+        const int DCo[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
+        b.D[0] = a.alloc_f(BT * 1024);
+        for (int i = 0; i < 5; ++i) b.D[i + 1] = a.alloc_f(BT * DCo[i] * DF[i]);
+        b.X = a.alloc_f(BT * 1024);
+        b.G = a.alloc_f(BT * 4096);
+        b.Hs[0] = a.alloc_f(BT * 1024);
+        b.Hs[1] = a.alloc_f(BT * 1024);
+        b.cell = a.alloc_f((size_t)1024 * B);
+        cur = b;
+        return cur;
+    }
+
+    // b.mag [B][161][T] -> b.D[5] [B][1][161][T]
+    void network(Bufs& b, hipStream_t st) {
+        const int B = b.B, T = b.T;
+        Profiler* pf = &ctx.prof;
+        const int EC[5] = {16, 32, 64, 128, 256}, EF[5] = {80, 39, 19, 9, 4};
+        Act4 x = act4(b.mag, 1, NBIN, T);
+        for (int i = 0; i < 5; ++i) {
+            run_conv(enc[i], x, nullptr, b.E[i], EC[i], EF[i], B, T, T, st, pf);
+            x = act4(b.E[i], EC[i], EF[i], T);
+        }
+        // CRN.py:27-31  [B,256,T,4] -> [B,T,1024] -> LSTM x2 -> back;  engine: [B][1024][T] <-> [T][1024][B]
+        launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, 1024L * B, B, st);
+        lstm[0].run(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
+        lstm[1].run(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+        launch_transpose_akt(b.Hs[1], b.D[0], T, 1024, B, 1024L * B, B, 1024L * T, T, st);
+        const int DCo[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
+        int cin = 256, fin = 4;
+        for (int i = 0; i < 5; ++i) {
+            Act4 a0 = act4(b.D[i], cin, fin, T);
+            Act4 a1 = act4(b.E[4 - i], cin, fin, T);
+            run_deconv(dec[i], a0, &a1, b.D[i + 1], DCo[i], DF[i], B, T, T, st, pf);
+            cin = DCo[i];
+            fin = DF[i];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ LSTM
+class LstmNet final : public Model {
+  public:
+    explicit LstmNet(EngineCtx& c) : Model(c) {}
+    ~LstmNet() override {
+        for (auto& l : lstm) l.free();
+        gc_free_plan(fc);
+    }
+    StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
+
+    void finalize(const TrackedSD& sd) override {
+        LstmW w0 = load_lstm(sd, "lstm1.", 0, "", NBIN, 1024);
+        // LSTM.py:25  BatchNorm1d over the 161 features, folded into the first input projection
+        fold_bn_input(w0.wih, sd.get("bn.weight", {NBIN}), sd.get("bn.bias", {NBIN}), sd.get("bn.running_mean", {NBIN}),
+                      sd.get("bn.running_var", {NBIN}));
+        lstm[0].build(w0, ctx.max_batch);
+        lstm[1].build(load_lstm(sd, "lstm2.", 0, "", 1024, 1024), ctx.max_batch);
+        lstm[2].build(load_lstm(sd, "lstm2.", 1, "", 1024, 1024), ctx.max_batch);
+        DenseW f = linear_weights(sd.get("fc.0.weight", {NBIN, 1024}), &sd.get("fc.0.bias", {NBIN}));
+        fc = make_pointwise_plan(f, ACT_SOFTPLUS, {}, ctx.max_batch);       // :20-22
+    }
+
+    void plan_buffers(int B, int T) override {
+        cur.B = 0;
+        bufs(B, T);
+    }
+
+    void forward(const float* in, const int64_t* shape, int ndim, float* out, hipStream_t st) override {
+        SE_CHECK(ndim == 3 && shape[2] == NBIN, "LSTM forward expects [B,T,161]");
+        const int B = (int)shape[0], T = (int)shape[1];
+        Bufs& b = bufs(B, T);
+        // [B][T*161] -> [T*161][B]
+        launch_transpose_akt(in, b.X, B, 1, T * NBIN, (long)T * NBIN, 0, B, 0, st);
+        network(b, st);
+        launch_transpose_akt(b.Y, out, T * NBIN, 1, B, B, 0, (long)T * NBIN, 0, st);
+    }
+
+    void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
+        const int T = 1 + L / HOP;
+        Bufs& b = bufs(B, T);
+        launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // lstm_decode_vb.py:35-36
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, b.mag, T, T, st);        // :37-38
+        launch_transpose_akt(b.mag, b.X, B, NBIN, T, (long)NBIN * T, T, (long)NBIN * B, B, st);    // [B][161][T] -> [T][161][B]
+        network(b, st);                                                                            // :44
+        launch_transpose_akt(b.Y, b.mag, T, NBIN, B, (long)NBIN * B, B, (long)NBIN * T, T, st);
+        launch_mag_phase(b.mag, b.spec, b.est, B, NBIN, T, ctx.p_out, st);                         // :47-49
+        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :50-52
+    }
+
+  private:
+    struct Bufs {
+        int B = 0, T = 0;
+        float *c, *spec, *mag, *est, *frames, *X, *Y, *G, *Hs[2], *cell;
+    } cur;
+    LstmBig lstm[3];
+    GCPlan fc;
+
+    Bufs& bufs(int B, int T) {
+        if (cur.B == B && cur.T == T) return cur;
+        Arena& a = ctx.arena;
+        a.reset();
+        Bufs b;
+        b.B = B;
+        b.T = T;
+        const size_t BT = (size_t)B * T;
+        b.c = a.alloc_f(B);
+        b.spec = a.alloc_f(BT * 2 * NBIN);
+        b.mag = a.alloc_f(BT * NBIN);
+        b.est = a.alloc_f(BT * 2 * NBIN);
+        b.frames = a.alloc_f(BT * NFFT);
+        b.X = a.alloc_f(BT * NBIN);
+        b.Y = a.alloc_f(BT * NBIN);
+        b.G = a.alloc_f(BT * 4096);
+        b.Hs[0] = a.alloc_f(BT * 1024);
+        b.Hs[1] = a.alloc_f(BT * 1024);
+        b.cell = a.alloc_f((size_t)1024 * B);
+        cur = b;
+        return cur;
+    }
+
+    // b.X [T][161][B] -> b.Y [T][161][B]
+    void network(Bufs& b, hipStream_t st) {
+        const int B = b.B, T = b.T;
+        Profiler* pf = &ctx.prof;
+        lstm[0].run(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
+        lstm[1].run(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+        lstm[2].run(b.Hs[1], b.G, b.cell, b.Hs[0], T, B, st, pf);
+        run_pointwise(fc, b.Hs[0], 1024L * B, B, b.Y, (long)NBIN * B, B, T, B, st, pf);
+    }
+};
+
+}  // namespace
+
+std::unique_ptr<Model> make_crn(EngineCtx& ctx) { return std::unique_ptr<Model>(new Crn(ctx)); }
+std::unique_ptr<Model> make_lstm(EngineCtx& ctx) { return std::unique_ptr<Model>(new LstmNet(ctx)); }
+
+}  // namespace se

@@ -1,0 +1,113 @@
+// LSTM layer helpers shared by the models.
+//   * weights come from torch.nn.LSTM state-dict entries (gate order i,f,g,o; b_ih + b_hh folded into the input
+//     projection); rows are gate-interleaved (4u+g) for the fused cell epilogues.
+//   * time-major activations: x [T][I][S], gates G [T][4H][S], h [T][H][S]  (S sequences contiguous).
+#pragma once
+#include "model.h"
+
+namespace se {
+
+struct LstmW {
+    DenseW wih;   // [4H][I], rows interleaved, bias = b_ih + b_hh
+    DenseW whh;   // [4H][H], rows interleaved
+    int I = 0, H = 0;
+};
+
+inline LstmW load_lstm(const TrackedSD& sd, const std::string& prefix, int layer, const std::string& suffix, int I,
+                       int H) {
+    const std::string l = "_l" + std::to_string(layer) + suffix;
+    LstmW w;
+    w.I = I;
+    w.H = H;
+    w.wih = linear_weights(sd.get(prefix + "weight_ih" + l, {4 * H, I}), nullptr);
+    const HostTensor& bi = sd.get(prefix + "bias_ih" + l, {4 * H});
+    const HostTensor& bh = sd.get(prefix + "bias_hh" + l, {4 * H});
+    for (int i = 0; i < 4 * H; ++i) w.wih.bias[i] = bi.data[i] + bh.data[i];
+    w.whh = linear_weights(sd.get(prefix + "weight_hh" + l, {4 * H, H}), nullptr);
+    const auto perm = lstm_gate_perm(H);
+    permute_rows(w.wih, perm);
+    permute_rows(w.whh, perm);
+    return w;
+}
+
+inline TapSpec one_tap() {
+    TapSpec t;
+    t.ntaps = 1;
+    t.df[0] = 0;
+    t.dt[0] = 0;
+    return t;
+}
+
+// Pointwise (1x1 / Linear) plan over channels.
+inline GCPlan make_pointwise_plan(const DenseW& d, int act, const std::vector<float>& slope, int tout_hint,
+                                  int epi = EPI_ACT) {
+    return gc_make_plan(d.M, d.Cin, one_tap(), d.w, d.bias, slope, act, epi, 1, 1, 0, tout_hint);
+}
+
+// Launch a pointwise plan on a time-major / generic 3-level tensor: element (o, c, n) at o*s_o + c*s_c + n.
+inline void run_pointwise(const GCPlan& pl, const float* src, long s_o, long s_c, float* dst, long d_o, long d_c, int O,
+                          int N, hipStream_t st, Profiler* prof) {
+    GCParams p = pl.p;
+    p.src0 = src;
+    p.s0_b = s_o;
+    p.s0_c = s_c;
+    p.s0_f = 0;
+    p.src1 = nullptr;
+    p.Fin = 1;
+    p.Tin = N;
+    p.B = O;
+    p.Q = 1;
+    p.Tout = N;
+    p.dst = dst;
+    p.d_b = d_o;
+    p.d_c = d_c;
+    p.d_f = 0;
+    gc_launch_prof(pl, p, st, prof);
+}
+
+// LSTM layer with a hidden size too large for register-resident weights (H = 1024 in LSTM/CRN): input projection
+// as one GEMM over all steps, then one fused GEMM + LSTM-cell launch per step (weights stream from L2 / Infinity Cache).
+struct LstmBig {
+    GCPlan gin, step;
+    int I = 0, H = 0;
+    void build(const LstmW& w, int s_hint) {
+        I = w.I;
+        H = w.H;
+        gin = make_pointwise_plan(w.wih, ACT_NONE, {}, s_hint);
+        step = gc_make_plan(4 * H, H, one_tap(), w.whh.w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, s_hint);
+    }
+    void free() {
+        gc_free_plan(gin);
+        gc_free_plan(step);
+    }
+    // x [T][I][S] -> out [T][H][S];  G scratch [T][4H][S];  cell scratch [H][S]
+    void run(const float* x, float* G, float* cell, float* out, int T, int S, hipStream_t st, Profiler* prof) const {
+        run_pointwise(gin, x, (long)I * S, S, G, 4L * H * S, S, T, S, st, prof);
+        for (int t = 0; t < T; ++t) {
+            GCParams p = step.p;
+            p.first_step = (t == 0);
+            p.src0 = t > 0 ? out + (size_t)(t - 1) * H * S : out;
+            p.s0_b = 0;
+            p.s0_c = S;
+            p.s0_f = 0;
+            p.src1 = nullptr;
+            p.Fin = 1;
+            p.Tin = S;
+            p.B = 1;
+            p.Q = 1;
+            p.Tout = S;
+            p.aux = G + (size_t)t * 4 * H * S;
+            p.x_b = 0;
+            p.x_c = S;
+            p.x_f = 0;
+            p.dst = out + (size_t)t * H * S;
+            p.d_b = 0;
+            p.d_c = S;
+            p.d_f = 0;
+            p.cell = cell;
+            gc_launch_prof(step, p, st, prof);
+        }
+    }
+};
+
+}  // namespace se

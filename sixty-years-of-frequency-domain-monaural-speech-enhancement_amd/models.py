@@ -80,3 +80,23 @@ class DCCRN(_EngineModule):
             raise NotImplementedError("the engine builds the decode script's DCCRN configuration "
                                       "(dccrn_decode_vb.py:11); got " + repr(cfg))
         super().__init__(**kw)
+
+
+class lstm_net(_EngineModule):
+    """LSTM/LSTM.py:14 `lstm_net()`.  forward: magnitude [B,T,161] -> enhanced magnitude [B,T,161]."""
+    _model = 'lstm'
+
+
+class crn_net(_EngineModule):
+    """CRN/CRN.py:16 `crn_net()`.  forward: magnitude [B,T,161] -> enhanced magnitude [B,T,161]."""
+    _model = 'crn'
+
+
+class dpcrn(_EngineModule):
+    """DPCRN/DPCRN.py:16 `dpcrn()`.  forward: RI [B,2,T,161] -> masked RI [B,2,T,161]."""
+    _model = 'dpcrn'
+
+
+MODEL_CLASSES = {'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
+                 'dccrn': lambda **kw: DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
+                                             kernel_num=[32, 64, 128, 256, 256, 256], **kw)}

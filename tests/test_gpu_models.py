@@ -1,0 +1,85 @@
+"""GPU parity for LSTM / CRN / DPCRN: engine (through the C ABI) vs reference-generated fixtures and the numpy oracle.
+DPCRN additionally runs with the reference's REAL checkpoints (fixture copies of DPCRN/BEST_MODEL/vb_dpcrn_*.pth)."""
+import numpy as np
+import pytest
+
+import se_amd
+from se_amd import synth
+from conftest import load_golden, rms
+
+pytestmark = pytest.mark.gpu
+SEEDS = {'lstm': 11, 'crn': 12, 'dpcrn': 13}
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn'])
+def test_forward_matches_reference_fixture(name):
+    torch = _torch()
+    from se_amd.models import MODEL_CLASSES
+    G = load_golden(name)
+    m = MODEL_CLASSES[name](max_batch=2, max_samples=4000).load_synthetic(SEEDS[name])
+    y = m(torch.from_numpy(G['x']).cuda()).cpu().numpy()
+    assert y.shape == G['y'].shape
+    err = rms(y - G['y'])
+    print(name, 'forward rms err', err, 'rms ref', rms(G['y']))
+    assert err < 2e-5 * max(rms(G['y']), 1.0), (err, rms(G['y']))
+
+
+@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn'])
+def test_enhance_matches_reference_fixture(name):
+    torch = _torch()
+    from se_amd.models import MODEL_CLASSES
+    G = load_golden(name)
+    m = MODEL_CLASSES[name](max_batch=2, max_samples=4000).load_synthetic(SEEDS[name])
+    wav = torch.from_numpy(np.stack([G['wav'], G['wav'][::-1].copy()])).cuda()
+    y = m.enhance_batch(wav).cpu().numpy()
+    err = rms(y[0] - G['enh'])
+    print(name, 'enhance rms err', err, 'rms ref', rms(G['enh']))
+    assert y.shape[1] == G['enh'].shape[0]
+    assert err < 1e-4 and err < 5e-4 * max(rms(G['enh']), 1e-3), (err, rms(G['enh']))
+
+
+def test_dpcrn_real_checkpoint_forward_and_decode():
+    """Real weights: vb_dpcrn_noncprs (1.0/1.0) and vb_dpcrn_cprs (0.5/2.0) on a full 4 s clip."""
+    torch = _torch()
+    from se_amd.models import dpcrn
+    G = load_golden('dpcrn')
+    ck = dict(load_golden('ckpt_vb_dpcrn_noncprs'))
+    m = dpcrn(max_batch=2, max_samples=64000)
+    m.load_state_dict(ck)
+    y = m(torch.from_numpy(G['x']).cuda()).cpu().numpy()
+    e = rms(y - G['y_real'])
+    print('dpcrn real ckpt forward rms err', e, rms(G['y_real']))
+    assert e < 2e-5 * max(rms(G['y_real']), 1.0)
+    wav4 = synth.synth_clip(0, 'speech', 64000)
+    x = torch.from_numpy(np.stack([wav4, synth.synth_clip(9, 'white', 64000)])).cuda()
+    out = m.enhance_batch(x).cpu().numpy()
+    e = rms(out[0] - G['enh_real'])
+    print('dpcrn real ckpt decode rms err', e, rms(G['enh_real']))
+    assert e < 1e-4 and e < 5e-4 * rms(G['enh_real'])
+    mc = dpcrn(max_batch=1, max_samples=64000, p_in=0.5, p_out=2.0)
+    mc.load_state_dict(dict(load_golden('ckpt_vb_dpcrn_cprs')))
+    out = mc.enhance_batch(x[:1]).cpu().numpy()
+    e = rms(out[0] - G['enh_real_cprs'])
+    print('dpcrn real cprs ckpt decode rms err', e, rms(G['enh_real_cprs']))
+    assert e < 1e-4 and e < 5e-4 * rms(G['enh_real_cprs'])
+
+
+def test_strict_load_errors():
+    _torch()
+    from se_amd.models import crn_net
+    from se_amd.engine import EngineError
+    sd = synth.synth_state_dict(crn_net.state_dict_schema(), 1)
+    bad = dict(sd)
+    bad.pop('lstm.weight_hh_l1')
+    with pytest.raises(RuntimeError):
+        crn_net().load_state_dict(bad)
+    bad = dict(sd)
+    bad['lstm.weight_hh_l1'] = bad['lstm.weight_hh_l1'][:, :100]
+    with pytest.raises(EngineError):
+        crn_net().load_state_dict(bad)

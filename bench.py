@@ -84,12 +84,13 @@ def main():
     wav = torch.from_numpy(np.tile(base, ((B + 15) // 16, 1))[:B].copy()).cuda()
     n_out = eng.output_samples(CLIP_SAMPLES)
     out = torch.empty((B, n_out), dtype=torch.float32, device='cuda')
-    gathered = [torch.empty_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from se_amd import shard
 
     def step():
         eng.enhance_batch(wav, out)
-        if world > 1:
-            dist.gather(out, gathered, dst=0)
+        if world > 1:       # RCCL gather of this rank's enhanced waveforms to rank 0 (se_amd/shard.py)
+            return shard.gather_waveforms(out, B * world, dst=0)
+        return out
 
     def fence():
         if world > 1:

@@ -1,0 +1,79 @@
+"""CPU: host-side logic - library symbols, WAV I/O, sharding + gather over gloo (world_size 2)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import se_amd
+from se_amd import _lib, wavio, shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'se_engine.h')).read()
+    declared = set(re.findall(r'\b(se_[a-z_]+)\s*\(', hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.se_abi_version() == 1
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from se_amd.engine import Engine, EngineError
+    with pytest.raises(EngineError):
+        Engine('dccrn')
+
+
+def test_wav_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    y = np.clip(0.3 * rng.standard_normal(1234), -1, 1)
+    p = str(tmp_path / 'a.wav')
+    wavio.write_wav_pcm16(p, y, 16000)
+    x, fs = wavio.read_wav(p)
+    assert fs == 16000 and x.shape == y.shape
+    assert np.max(np.abs(x - y)) <= 0.5 / 32768 + 1e-12
+    wavio.write_wav_pcm16(p, np.array([2.0, -2.0, 0.0]), 16000)           # clipping like PCM_16
+    x, _ = wavio.read_wav(p)
+    assert x[0] == 32767 / 32768 and x[1] == -1.0 and x[2] == 0.0
+
+
+def test_shard_ranges_cover():
+    for n in (0, 1, 7, 256, 257):
+        for w in (1, 2, 3, 8):
+            spans = [shard.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, n_items, tmp):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    wav = torch.arange(n_items * 5, dtype=torch.float32).reshape(n_items, 5)
+    out = shard.run_sharded(lambda x: x * 2.0 + 1.0, wav)
+    if rank == 0:
+        torch.save(out, os.path.join(tmp, 'out.pt'))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_items', [6, 7])
+def test_sharded_decode_gather_gloo(tmp_path, n_items):
+    """The N > 1 path of bench.py / decode: contiguous utterance shards, gather to rank 0 (even and uneven)."""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 1000) + n_items
+    mp.spawn(_worker, args=(2, port, n_items, str(tmp_path)), nprocs=2, join=True)
+    out = torch.load(os.path.join(str(tmp_path), 'out.pt'))
+    ref = torch.arange(n_items * 5, dtype=torch.float32).reshape(n_items, 5) * 2.0 + 1.0
+    assert torch.equal(out, ref)

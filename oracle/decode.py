@@ -77,3 +77,28 @@ ENHANCE = {
     'dpcrn': enhance_dpcrn,
     'dccrn': enhance_dccrn,
 }
+
+
+def enhance_fullsubnet(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+    """FullSubNet/fullsubnet_sa_decode_vb.py:37-72 (the computed tail pad :42-45 is never applied)."""
+    wav = np.asarray(wav, dtype=np.float64)
+    c = S.rms_scale(wav)                                                 # :38
+    x = (wav * c).astype(net_dtype)                                      # :39,45 FloatTensor
+    spec = S.stft(x, 512, 256)                                           # :46-47
+    re, im = spec.real.astype(net_dtype), spec.imag.astype(net_dtype)
+    mag = np.sqrt(re ** 2 + im ** 2) ** p_in                             # :50
+    ph = np.arctan2(im, re)
+    fr, fi = mag * np.cos(ph), mag * np.sin(ph)                          # :52
+    fmag = np.sqrt(fr ** 2 + fi ** 2)[None, None]                        # :54
+    mask = M.fullsubnet_forward(sd, fmag)                                # :56
+    mr, mi = mask[0, 0], mask[0, 1]
+    er = mr * fr - mi * fi                                               # :59-60
+    ei = mr * fi + mi * fr
+    emag = np.sqrt(er ** 2 + ei ** 2) ** p_out                           # :64
+    eph = np.arctan2(ei, er)
+    de = emag.astype(np.float64) * np.exp(1j * eph.astype(np.float64))
+    y = S.istft(de, 512, 256, length=len(x))                             # :69
+    return y / c
+
+
+ENHANCE['fullsubnet'] = enhance_fullsubnet

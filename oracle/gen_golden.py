@@ -238,7 +238,65 @@ def gen_dccrn():
     save('dccrn', x=x, y=y, wav=wav, enh=enh, enh_cprs=enh_c, enh4_cprs=enh4.astype(np.float32))
 
 
-GENS = {'stft': gen_stft, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+def _fsn_model():
+    install_stubs()
+    scratch = '/tmp/se_golden_scratch'
+    os.makedirs(scratch, exist_ok=True)
+    for m in list(sys.modules):
+        if m.startswith('fullsubnet_net_sa'):
+            sys.modules.pop(m)
+    sys.path.insert(0, os.path.join(REF, 'FullSubNet'))
+    try:
+        mod = importlib.import_module('fullsubnet_net_sa.model')
+    finally:
+        sys.path.pop(0)
+    return mod.Model(sb_num_neighbors=15, fb_num_neighbors=0, num_freqs=257, look_ahead=2, sequence_model="LSTM",
+                     fb_output_activate_function="ReLU", sb_output_activate_function=None, fb_model_hidden_size=512,
+                     sb_model_hidden_size=384, weight_init=True, norm_type="offline_laplace_norm",
+                     num_groups_in_drop_band=2)
+
+
+def _enhance_fullsubnet(model, wav, p_in, p_out):
+    """FullSubNet/fullsubnet_sa_decode_vb.py:37-72 around the imported model (B = 1)."""
+    feat_wav = np.asarray(wav, dtype=np.float64)
+    c = np.sqrt(len(feat_wav) / np.sum(feat_wav ** 2.0))
+    feat_wav = feat_wav * c
+    wav_len = len(feat_wav)
+    x = torch.FloatTensor(feat_wav)
+    feat_x = t_stft(x.unsqueeze(0), 512, 256, 512).permute(0, 3, 1, 2)
+    mag = torch.norm(feat_x, dim=1) ** p_in
+    ph = torch.atan2(feat_x[:, 1], feat_x[:, 0])
+    feat_x = torch.stack((mag * torch.cos(ph), mag * torch.sin(ph)), dim=1)
+    feat_mag = torch.norm(feat_x, dim=1, keepdim=True)
+    with torch.no_grad():
+        mask = model(feat_mag)
+    mr, mi = mask[:, 0], mask[:, -1]
+    fr, fi = feat_x[:, 0], feat_x[:, -1]
+    er, ei = mr * fr - mi * fi, mr * fi + mi * fr
+    esti = torch.stack((er, ei), dim=1)
+    emag = torch.norm(esti, dim=1) ** p_out
+    eph = torch.atan2(esti[:, 1], esti[:, 0])
+    de = emag[0].double() * torch.exp(1j * eph[0].double())
+    y = torch.istft(de, 512, 256, 512, window=torch.hann_window(512, dtype=torch.float64), length=wav_len)
+    return (y / c).numpy()
+
+
+def gen_fullsubnet():
+    model = _fsn_model()
+    schema, _ = load_synth(model, 15)
+    save_schema('fullsubnet', schema)
+    rng = np.random.default_rng(9)
+    x = np.abs(rng.standard_normal((1, 1, 257, 9))).astype(np.float32)
+    x2 = np.abs(rng.standard_normal((1, 1, 257, 9))).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+        y2 = model(torch.from_numpy(x2)).numpy()
+    wav = synth.synth_clip(7, 'speech', 4000)
+    save('fullsubnet', x=np.concatenate([x, x2]), y=np.concatenate([y, y2]), wav=wav,
+         enh=_enhance_fullsubnet(model, wav, 1.0, 1.0), enh_cprs=_enhance_fullsubnet(model, wav, 0.5, 2.0))
+
+
+GENS = {'stft': gen_stft, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

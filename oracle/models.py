@@ -205,3 +205,47 @@ def dccrn_forward(sd, inputs, n_layers=6, masking_mode='E'):
     em = mm * spec_mags
     ep = spec_phase + mph
     return np.stack([em * np.cos(ep), em * np.sin(ep)], axis=1)  # :219-225
+
+
+# ----------------------------------------------------------------------------
+# FullSubNet   (reference FullSubNet/fullsubnet_net_sa/model.py:68-118, base_model.py:13-42,197-209,
+# sequence_model.py:66-84) for the decode script's constructor (fullsubnet_sa_decode_vb.py:11-24).
+# ALWAYS batch-1 semantics: `drop_band` (model.py:101-104) runs whenever batch_size > 1 even in eval(), which is a
+# training-time trick and changes the output shape; the engine computes B independent batch-1 results instead.
+# ----------------------------------------------------------------------------
+def _fsn_unfold(x, nn_):
+    """BaseModel.unfold: x [B,1,F,T] -> [B,F,2n+1,T] (reflect pad along F, sliding windows)."""
+    B, _, F, T = x.shape
+    if nn_ < 1:
+        return np.transpose(x, (0, 2, 1, 3))                        # [B,F,1,T]
+    xp = np.pad(x[:, 0], ((0, 0), (nn_, nn_), (0, 0)), mode='reflect')   # [B,F+2n,T]
+    idx = np.arange(F)[:, None] + np.arange(2 * nn_ + 1)[None, :]        # [F, 2n+1]
+    return xp[:, idx, :]                                                  # [B,F,2n+1,T]
+
+
+def _fsn_seq(sd, p, x, act):
+    """SequenceModel.forward: x [B,F,T] -> [B,O,T] (LSTM x2 -> Linear -> act)."""
+    o = nn.lstm(np.swapaxes(x, 1, 2), sd, p + 'sequence_model.', 2, batch_first=True)
+    o = nn.linear(o, sd[p + 'fc_output_layer.weight'], sd[p + 'fc_output_layer.bias'])
+    if act == 'ReLU':
+        o = nn.relu(o)
+    return np.swapaxes(o, 1, 2)
+
+
+def fullsubnet_forward(sd, noisy_mag, look_ahead=2, sb_nn=15, fb_nn=0):
+    """noisy_mag [B,1,257,T] -> complex mask [B,2,257,T]; every utterance processed with batch-1 semantics."""
+    outs = []
+    for b in range(noisy_mag.shape[0]):
+        x = np.pad(noisy_mag[b:b + 1], ((0, 0), (0, 0), (0, 0), (0, look_ahead)))          # :79
+        _, _, F, T = x.shape
+        norm = lambda a: a / (a.mean(axis=(1, 2, 3), keepdims=True) + 1e-5)               # offline_laplace_norm
+        fb_in = norm(x).reshape(1, F, T)                                                  # :84
+        fb_out = _fsn_seq(sd, 'fb_model.', fb_in, 'ReLU').reshape(1, 1, F, T)             # :85
+        fb_unf = _fsn_unfold(fb_out, fb_nn).reshape(1, F, 2 * fb_nn + 1, T)               # :88-89
+        nz_unf = _fsn_unfold(x, sb_nn).reshape(1, F, 2 * sb_nn + 1, T)                    # :92-93
+        sb_in = norm(np.concatenate([nz_unf, fb_unf], axis=2))                            # :96-97
+        sb_in = sb_in.reshape(F, 2 * sb_nn + 1 + 2 * fb_nn + 1, T)                        # :106-110
+        m = _fsn_seq(sd, 'sb_model.', sb_in, None)                                        # :113
+        m = np.transpose(m.reshape(1, F, 2, T), (0, 2, 1, 3))                             # :114
+        outs.append(m[:, :, :, look_ahead:])                                              # :117
+    return np.concatenate(outs, axis=0)

@@ -60,5 +60,6 @@ std::unique_ptr<Model> make_dccrn(EngineCtx& ctx);
 std::unique_ptr<Model> make_crn(EngineCtx& ctx);
 std::unique_ptr<Model> make_lstm(EngineCtx& ctx);
 std::unique_ptr<Model> make_dpcrn(EngineCtx& ctx);
+std::unique_ptr<Model> make_fullsubnet(EngineCtx& ctx);
 
 }  // namespace se

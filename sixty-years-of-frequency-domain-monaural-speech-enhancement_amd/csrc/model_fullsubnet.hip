@@ -1,0 +1,237 @@
+// FullSubNet on the MI355X engine.
+//
+// Reference: FullSubNet/fullsubnet_net_sa/model.py:68-118 (Model.forward), base_model.py:13-42 (unfold),
+// :197-209 (offline_laplace_norm), sequence_model.py:66-84; constructor and decode loop
+// FullSubNet/fullsubnet_sa_decode_vb.py:11-24, :37-72 (complex mask applied in the script, :56-61).
+//
+// Batch semantics: the reference only ever decodes B = 1 and its forward runs the training-time `drop_band`
+// (model.py:101-104) whenever batch_size > 1; the engine therefore computes B INDEPENDENT batch-1 results (per-
+// utterance normalisation statistics, no band dropping), see SURVEY.md 0.8.
+//
+// Engine mapping (time-major, sequences contiguous):
+//   full-band LSTM  : [T+2][257][B]      (B sequences, hidden 512)
+//   sub-band LSTM   : [T+2][32][257*B]   (sequence s = n*B + b: sub-band n of utterance b, hidden 384) - the one
+//                     place a recurrent step is a large GEMM (M = 1536, K = 384, N = 257*B), run on f32 MFMA with the
+//                     LSTM cell fused in the epilogue.
+#include "rnn.h"
+
+namespace se {
+
+namespace {
+
+constexpr int NFFT = 512, HOP = 256, NBIN = 257, LA = 2, SBN = 15, SBW = 2 * SBN + 2;   // 31 noisy + 1 full-band
+
+// sum over (f, t) of mag[b][f][t]  ->  mu[b] = sum / (F * (T + LA))   (the look-ahead pad frames are zeros)
+__global__ __launch_bounds__(256) void fsn_mean_kernel(const float* __restrict__ mag, int n, float denom,
+                                                       float* __restrict__ mu) {
+    const int b = blockIdx.x;
+    const float* x = mag + (long)b * n;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) mu[b] = (float)((part[0] + part[1] + part[2] + part[3]) / denom);
+}
+
+// y[i] = x[i] / (mu[i % B] + 1e-5)   for time-major tensors whose innermost index is the utterance
+__global__ __launch_bounds__(256) void fsn_scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                        int B, const float* __restrict__ mu) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = x[i] / (mu[i % B] + 1e-5f);
+}
+
+// sub-band input before normalisation: sb[t][k][n*B + b];  k < 31: noisy mag of bin reflect(n - 15 + k)
+// (base_model.py:29-42, reflect pad), k = 31: full-band output of bin n (model.py:88-96)
+__global__ __launch_bounds__(256) void fsn_build_sb_kernel(const float* __restrict__ magT, const float* __restrict__ fbo,
+                                                           float* __restrict__ sb, int B) {
+    const int S = NBIN * B;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y, t = blockIdx.z;
+    if (s >= S) return;
+    const int n = s / B, b = s - n * B;
+    float v;
+    if (k == SBW - 1) {
+        v = fbo[((long)t * NBIN + n) * B + b];
+    } else {
+        int f = n - SBN + k;
+        if (f < 0) f = -f;
+        if (f >= NBIN) f = 2 * (NBIN - 1) - f;
+        v = magT[((long)t * NBIN + f) * B + b];
+    }
+    sb[((long)t * SBW + k) * S + s] = v;
+}
+
+// column sums of a [rows][B] matrix (utterance = innermost index) -> mu[b] = sum / rows
+__global__ __launch_bounds__(256) void fsn_colsum_kernel(const float* __restrict__ x, long rows, int B,
+                                                         float* __restrict__ acc) {
+    // thread handles column (tid % B) of rows tid / B + k * (256 / B)  (B divides 256 or is handled by the guard)
+    const int per = 256 / B;
+    if (per == 0) return;
+    const int b = threadIdx.x % B, r0 = threadIdx.x / B;
+    if (r0 >= per) return;
+    float s = 0.f;
+    for (long r = (long)blockIdx.x * per + r0; r < rows; r += (long)gridDim.x * per) s += x[r * B + b];
+    atomicAdd(&acc[b], s);
+}
+__global__ void fsn_finish_mean_kernel(float* acc, float denom, int B) {
+    const int b = threadIdx.x;
+    if (b < B) acc[b] = acc[b] / denom;
+}
+
+// out[b][c][n][t] = mask[(n*B + b)][c][t + LA]                       (forward hook), or
+// est = mask (x) spec, decompressed (fullsubnet_sa_decode_vb.py:56-66)  (decode path)
+__global__ __launch_bounds__(256) void fsn_mask_kernel(const float* __restrict__ maskBT, const float* __restrict__ spec,
+                                                       float* __restrict__ out, int B, int T, float p_out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const int Tp = T + LA;
+    const float* m = maskBT + ((long)(n * B + b) * 2) * Tp + t + LA;
+    const float mr = m[0], mi = m[Tp];
+    const long o = (((long)b * 2) * NBIN + n) * T + t;
+    const long plane = (long)NBIN * T;
+    if (!spec) {
+        out[o] = mr;
+        out[o + plane] = mi;
+        return;
+    }
+    const float xr = spec[o], xi = spec[o + plane];
+    float er = mr * xr - mi * xi, ei = mr * xi + mi * xr;
+    if (p_out != 1.f) {
+        const float mg = sqrtf(er * er + ei * ei);
+        const float sc = mg > 0.f ? ((p_out == 2.f) ? mg : powf(mg, p_out - 1.f)) : 0.f;
+        er *= sc;
+        ei *= sc;
+    }
+    out[o] = er;
+    out[o + plane] = ei;
+}
+
+class FullSubNet final : public Model {
+  public:
+    explicit FullSubNet(EngineCtx& c) : Model(c) {}
+    ~FullSubNet() override {
+        for (auto& l : fb) l.free();
+        for (auto& l : sbl) l.free();
+        gc_free_plan(fb_fc);
+        gc_free_plan(sb_fc);
+    }
+    StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
+
+    void finalize(const TrackedSD& sd) override {
+        const int S = NBIN * ctx.max_batch;
+        fb[0].build(load_lstm(sd, "fb_model.sequence_model.", 0, "", NBIN, 512), ctx.max_batch);
+        fb[1].build(load_lstm(sd, "fb_model.sequence_model.", 1, "", 512, 512), ctx.max_batch);
+        fb_fc = make_pointwise_plan(linear_weights(sd.get("fb_model.fc_output_layer.weight", {NBIN, 512}),
+                                                   &sd.get("fb_model.fc_output_layer.bias", {NBIN})),
+                                    ACT_RELU, {}, ctx.max_batch);
+        sbl[0].build(load_lstm(sd, "sb_model.sequence_model.", 0, "", SBW, 384), S);
+        sbl[1].build(load_lstm(sd, "sb_model.sequence_model.", 1, "", 384, 384), S);
+        sb_fc = make_pointwise_plan(linear_weights(sd.get("sb_model.fc_output_layer.weight", {2, 384}),
+                                                   &sd.get("sb_model.fc_output_layer.bias", {2})),
+                                    ACT_NONE, {}, S);
+    }
+
+    void plan_buffers(int B, int T) override {
+        cur.B = 0;
+        bufs(B, T);
+    }
+
+    void forward(const float* in, const int64_t* shape, int ndim, float* out, hipStream_t st) override {
+        SE_CHECK(ndim == 4 && shape[1] == 1 && shape[2] == NBIN, "FullSubNet forward expects [B,1,257,T]");
+        const int B = (int)shape[0], T = (int)shape[3];
+        Bufs& b = bufs(B, T);
+        network(b, in, st);
+        hipLaunchKernelGGL(fsn_mask_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, b.maskBT, nullptr, out, B, T, 1.f);
+        SE_HIP(hipGetLastError());
+    }
+
+    void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
+        const int T = 1 + L / HOP;
+        Bufs& b = bufs(B, T);
+        launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // :38-39
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, b.mag, T, T, st);        // :46-54
+        network(b, b.mag, st);                                                                     // :56
+        hipLaunchKernelGGL(fsn_mask_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, b.maskBT, b.spec, b.est, B, T,
+                           ctx.p_out);                                                             // :57-66
+        SE_HIP(hipGetLastError());
+        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :69-72
+    }
+
+  private:
+    struct Bufs {
+        int B = 0, T = 0;
+        float *c, *spec, *mag, *est, *frames, *mu, *mu2;
+        float *magT, *xfb, *G, *h[2], *cell, *fbo, *sb, *maskT, *maskBT;
+    } cur;
+    LstmBig fb[2], sbl[2];
+    GCPlan fb_fc, sb_fc;
+
+    Bufs& bufs(int B, int T) {
+        if (cur.B == B && cur.T == T) return cur;
+        Arena& a = ctx.arena;
+        a.reset();
+        Bufs b;
+        b.B = B;
+        b.T = T;
+        const size_t BT = (size_t)B * T, Tp = T + LA, S = (size_t)NBIN * B;
+        b.c = a.alloc_f(B);
+        b.mu = a.alloc_f(B);
+        b.mu2 = a.alloc_f(B);
+        b.spec = a.alloc_f(BT * 2 * NBIN);
+        b.mag = a.alloc_f(BT * NBIN);
+        b.est = a.alloc_f(BT * 2 * NBIN);
+        b.frames = a.alloc_f(BT * NFFT);
+        b.magT = a.alloc_f(Tp * S);
+        b.xfb = a.alloc_f(Tp * S);
+        b.fbo = a.alloc_f(Tp * S);
+        b.sb = a.alloc_f(Tp * SBW * S);
+        b.G = a.alloc_f(Tp * 1536 * S);                 // also holds the full-band gates [Tp][2048][B]
+        b.h[0] = a.alloc_f(Tp * 384 * S);               // also the full-band hidden [Tp][512][B]
+        b.h[1] = a.alloc_f(Tp * 384 * S);
+        b.cell = a.alloc_f(384 * S + 512 * (size_t)B);
+        b.maskT = a.alloc_f(Tp * 2 * S);
+        b.maskBT = a.alloc_f(Tp * 2 * S);
+        cur = b;
+        return cur;
+    }
+
+    // mag [B][257][T] -> maskBT [n*B+b][2][T+2]
+    void network(Bufs& b, const float* mag, hipStream_t st) {
+        const int B = b.B, T = b.T, Tp = T + LA, S = NBIN * B;
+        Profiler* pf = &ctx.prof;
+        // ---- full-band model (model.py:84-85): utterance-mean normalisation, LSTM(257->512)x2, Linear + ReLU
+        hipLaunchKernelGGL(fsn_mean_kernel, dim3(B), dim3(256), 0, st, mag, NBIN * T, (float)NBIN * Tp, b.mu);
+        SE_HIP(hipMemsetAsync(b.magT + (size_t)T * S, 0, (size_t)LA * S * sizeof(float), st));     // look-ahead pad :79
+        launch_transpose_akt(mag, b.magT, B, NBIN, T, (long)NBIN * T, T, (long)NBIN * B, B, st);
+        const long nfb = (long)Tp * S;
+        hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nfb + 255) / 256)), dim3(256), 0, st, b.magT, b.xfb, nfb, B, b.mu);
+        fb[0].run(b.xfb, b.G, b.cell, b.h[0], Tp, B, st, pf);
+        fb[1].run(b.h[0], b.G, b.cell, b.h[1], Tp, B, st, pf);
+        run_pointwise(fb_fc, b.h[1], 512L * B, B, b.fbo, (long)NBIN * B, B, Tp, B, st, pf);
+        // ---- sub-band input (:88-97): unfold(noisy, 15) ++ unfold(fb_out, 0), normalised by its utterance mean
+        hipLaunchKernelGGL(fsn_build_sb_kernel, dim3((S + 255) / 256, SBW, Tp), dim3(256), 0, st, b.magT, b.fbo, b.sb, B);
+        SE_HIP(hipMemsetAsync(b.mu2, 0, B * sizeof(float), st));
+        const long rows = (long)Tp * SBW * NBIN;
+        SE_CHECK(B <= 256, "FullSubNet batch per call is limited to 256 utterances");
+        hipLaunchKernelGGL(fsn_colsum_kernel, dim3(1024), dim3(256), 0, st, b.sb, rows, B, b.mu2);
+        hipLaunchKernelGGL(fsn_finish_mean_kernel, dim3(1), dim3(256), 0, st, b.mu2, (float)rows, B);
+        const long nsb = rows * B;
+        hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, st, b.sb, b.sb, nsb, B, b.mu2);
+        SE_HIP(hipGetLastError());
+        // ---- sub-band model (:106-114): LSTM(32->384)x2 over 257*B sequences, Linear(384->2)
+        sbl[0].run(b.sb, b.G, b.cell + 512 * (size_t)B, b.h[0], Tp, S, st, pf);
+        sbl[1].run(b.h[0], b.G, b.cell + 512 * (size_t)B, b.h[1], Tp, S, st, pf);
+        run_pointwise(sb_fc, b.h[1], 384L * S, S, b.maskT, 2L * S, S, Tp, S, st, pf);
+        // [Tp][2][S] -> [S][2][Tp]
+        launch_transpose_akt(b.maskT, b.maskBT, Tp, 2, S, 2L * S, S, 2L * Tp, Tp, st);
+    }
+};
+
+}  // namespace
+
+std::unique_ptr<Model> make_fullsubnet(EngineCtx& ctx) { return std::unique_ptr<Model>(new FullSubNet(ctx)); }
+
+}  // namespace se

@@ -97,6 +97,26 @@ class dpcrn(_EngineModule):
     _model = 'dpcrn'
 
 
-MODEL_CLASSES = {'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
+class Model(_EngineModule):
+    """FullSubNet/fullsubnet_net_sa/model.py:9 `Model(...)` as built at fullsubnet_sa_decode_vb.py:11-24.
+    forward: magnitude [B,1,257,T] -> complex mask [B,2,257,T]; each utterance gets batch-1 semantics."""
+    _model = 'fullsubnet'
+
+    def __init__(self, num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                 fb_output_activate_function="ReLU", sb_output_activate_function=None, fb_model_hidden_size=512,
+                 sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=2,
+                 weight_init=True, **kw):
+        cfg = (num_freqs, look_ahead, sequence_model, fb_num_neighbors, sb_num_neighbors, fb_output_activate_function,
+               sb_output_activate_function, fb_model_hidden_size, sb_model_hidden_size, norm_type)
+        if cfg != (257, 2, "LSTM", 0, 15, "ReLU", None, 512, 384, "offline_laplace_norm"):
+            raise NotImplementedError("the engine builds the decode script's FullSubNet configuration; got " + repr(cfg))
+        super().__init__(**kw)
+
+    def forward(self, x):
+        B, _, F, T = x.shape
+        return self.engine.forward(x.contiguous(), out_shape=(B, 2, F, T))
+
+
+MODEL_CLASSES = {'fullsubnet': Model, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
                  'dccrn': lambda **kw: DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
                                              kernel_num=[32, 64, 128, 256, 256, 256], **kw)}

@@ -124,4 +124,16 @@ def dccrn_schema(kernel_num=(32, 64, 128, 256, 256, 256), rnn_units=256, fft_len
     return d
 
 
-SCHEMAS = {'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
+def fullsubnet_schema():
+    """FullSubNet/fullsubnet_net_sa/model.py:38-56 with the decode script's sizes (fullsubnet_sa_decode_vb.py:11-24)."""
+    d = OrderedDict()
+    _lstm(d, 'fb_model.sequence_model.', 257, 512, 2)
+    d['fb_model.fc_output_layer.weight'] = ((257, 512), 'f32')
+    d['fb_model.fc_output_layer.bias'] = ((257,), 'f32')
+    _lstm(d, 'sb_model.sequence_model.', 32, 384, 2)
+    d['sb_model.fc_output_layer.weight'] = ((2, 384), 'f32')
+    d['sb_model.fc_output_layer.bias'] = ((2,), 'f32')
+    return d
+
+
+SCHEMAS = {'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}

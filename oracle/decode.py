@@ -102,3 +102,20 @@ def enhance_fullsubnet(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
 
 
 ENHANCE['fullsubnet'] = enhance_fullsubnet
+
+
+def enhance_gcrn(sd, wav, p_in=0.5, p_out=2.0, net_dtype=np.float32):
+    """GCRN/gcrn_decode_vb.py:34-58 (checked in with the compressed exponents 0.5 / 2.0, :40,:51)."""
+    c, x, spec = _frontend_librosa(wav, 320, 160)
+    mag, ph = np.abs(spec) ** p_in, np.angle(spec)                       # :40
+    mag32, ph32 = mag.astype(net_dtype), ph.astype(net_dtype)
+    feat = np.stack([mag32 * np.cos(ph32), mag32 * np.sin(ph32)], 0)     # :44
+    est = M.gcrn_forward(sd, feat[None])                                 # :46
+    emag = np.sqrt(est[:, 0] ** 2 + est[:, 1] ** 2) ** p_out             # :47,:51
+    eph = np.arctan2(est[:, 1], est[:, 0])                               # :48
+    de = emag[0].astype(np.float64) * np.exp(1j * eph[0].astype(np.float64))
+    y = S.istft(de.T, 320, 160, length=len(x))                           # :56-57
+    return y / c
+
+
+ENHANCE['gcrn'] = enhance_gcrn

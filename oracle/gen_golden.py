@@ -296,7 +296,20 @@ def gen_fullsubnet():
          enh=_enhance_fullsubnet(model, wav, 1.0, 1.0), enh_cprs=_enhance_fullsubnet(model, wav, 0.5, 2.0))
 
 
-GENS = {'stft': gen_stft, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+def gen_gcrn():
+    mod = import_ref('GCRN', 'GCRN_noncprs')
+    model = mod.Net()
+    schema, _ = load_synth(model, 16)
+    save_schema('gcrn', schema)
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal((2, 2, 8, 161)).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+    wav = synth.synth_clip(8, 'speech', 4000)
+    save('gcrn', x=x, y=y, wav=wav, enh=_enhance_librosa_family(model, wav, 'ri', 0.5, 2.0))
+
+
+GENS = {'stft': gen_stft, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

@@ -249,3 +249,54 @@ def fullsubnet_forward(sd, noisy_mag, look_ahead=2, sb_nn=15, fb_nn=0):
         m = np.transpose(m.reshape(1, F, 2, T), (0, 2, 1, 3))                             # :114
         outs.append(m[:, :, :, look_ahead:])                                              # :117
     return np.concatenate(outs, axis=0)
+
+
+# ----------------------------------------------------------------------------
+# GCRN   (reference GCRN/GCRN_noncprs.py:5-165)
+# ----------------------------------------------------------------------------
+def _glu_conv(sd, p, x):
+    """GluConv2d (GCRN_noncprs.py:42-60): conv1(x) * sigmoid(conv2(x)), kernel (1,3), stride (1,2)."""
+    a = nn.conv2d(x, sd[p + 'conv1.weight'], sd[p + 'conv1.bias'], stride=(1, 2))
+    g = nn.conv2d(x, sd[p + 'conv2.weight'], sd[p + 'conv2.bias'], stride=(1, 2))
+    return a * nn.sigmoid(g)
+
+
+def _glu_deconv(sd, p, x, out_pad=0):
+    """GluConvTranspose2d (:63-83)."""
+    a = nn.conv_transpose2d(x, sd[p + 'conv1.weight'], sd[p + 'conv1.bias'], stride=(1, 2), output_padding=(0, out_pad))
+    g = nn.conv_transpose2d(x, sd[p + 'conv2.weight'], sd[p + 'conv2.bias'], stride=(1, 2), output_padding=(0, out_pad))
+    return a * nn.sigmoid(g)
+
+
+def _glstm(sd, x):
+    """GLSTM.forward (:22-39).  x [B,256,T,4]."""
+    B, C, T, F = x.shape
+    out = np.transpose(x, (0, 2, 1, 3)).reshape(B, T, -1)
+    ch = np.split(out, 2, axis=-1)
+    hs = [nn.lstm(ch[i], sd, f'glstm.lstm_list1.{i}.', 1, batch_first=True) for i in range(2)]
+    out = np.stack(hs, axis=-1).reshape(B, T, -1)                # stack on a new last dim, then flatten: interleave
+    out = nn.layernorm(out, sd['glstm.ln1.weight'], sd['glstm.ln1.bias'], 1)
+    ch = np.split(out, 2, axis=-1)
+    out = np.concatenate([nn.lstm(ch[i], sd, f'glstm.lstm_list2.{i}.', 1, batch_first=True) for i in range(2)], axis=-1)
+    out = nn.layernorm(out, sd['glstm.ln2.weight'], sd['glstm.ln2.bias'], 1)
+    return np.transpose(out.reshape(B, T, C, F), (0, 2, 1, 3))
+
+
+def gcrn_forward(sd, x):
+    """x [B,2,T,161] (RI) -> [B,2,T,161] (RI mapping).  Net.forward GCRN_noncprs.py:135-165."""
+    e = []
+    out = x
+    for k in range(1, 6):                                       # :137-141
+        out = nn.elu(_bn(sd, f'bn{k}.', _glu_conv(sd, f'conv{k}.', out)))
+        e.append(out)
+    out = _glstm(sd, out)                                       # :145
+    out = np.concatenate([out, e[4]], axis=1)                   # :147
+    res = []
+    for br in (1, 2):                                           # :149-159
+        d = out
+        for k in (5, 4, 3, 2):
+            y = _bn(sd, f'bn{k}_t_{br}.', _glu_deconv(sd, f'conv{k}_t_{br}.', d, 1 if k == 2 else 0))
+            d = nn.elu(np.concatenate([y, e[k - 2]], axis=1))
+        d = nn.elu(_bn(sd, f'bn1_t_{br}.', _glu_deconv(sd, f'conv1_t_{br}.', d)))
+        res.append(nn.linear(d, sd[f'fc{br}.weight'], sd[f'fc{br}.bias']))   # :161-162 (over the F axis)
+    return np.concatenate(res, axis=1)                          # :163

@@ -35,6 +35,8 @@ struct GCParams {
     const float* A;          // packed weights [nchunks][KCp][Mp]
     const float* bias;       // [M] or nullptr
     const float* slope;      // [M] PReLU slopes or nullptr
+    const float* post_scale; // EPI_GLU: per output channel scale / shift applied after the gate product (eval BatchNorm)
+    const float* post_shift;
     const float* bias_pad;   // bias for output rows fo < pad_lo (a zero-padded frequency row: no conv bias, only the folded BN shift)
     int pad_lo;
     const float* src0;
@@ -70,6 +72,8 @@ struct GCPlan {
     float* dSlope = nullptr;
     int* dTab = nullptr;
     float* dBiasPad = nullptr;
+    float* dPostScale = nullptr;
+    float* dPostShift = nullptr;
 };
 
 struct TapSpec {

@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
                     if (m + 1 < p.M && t < p.Tout) {
                         const float a = acc[i][j][r] + (bias ? bias[m] : 0.f);
                         const float g = acc[i][j][r + 1] + (bias ? bias[m + 1] : 0.f);
-                        dst[(long)(m >> 1) * p.d_c + t] = a * sigmoidf_(g);
+                        float v = a * sigmoidf_(g);
+                        if (p.post_scale) v = v * p.post_scale[m >> 1] + p.post_shift[m >> 1];
+                        dst[(long)(m >> 1) * p.d_c + t] = act_apply(v, p.act, p.slope ? p.slope[m >> 1] : 0.f);
                     }
                 }
             }
@@ -435,6 +437,9 @@ void gc_free_plan(GCPlan& pl) {
     if (pl.dSlope) (void)hipFree(pl.dSlope);
     if (pl.dTab) (void)hipFree(pl.dTab);
     if (pl.dBiasPad) (void)hipFree(pl.dBiasPad);
+    if (pl.dPostScale) (void)hipFree(pl.dPostScale);
+    if (pl.dPostShift) (void)hipFree(pl.dPostShift);
+    pl.dPostScale = pl.dPostShift = nullptr;
     pl.dTab = nullptr;
     pl.dBiasPad = nullptr;
     pl.dA = pl.dBias = pl.dSlope = nullptr;

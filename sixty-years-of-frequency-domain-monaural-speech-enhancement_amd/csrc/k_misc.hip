@@ -168,6 +168,35 @@ void launch_mag_phase(const float* mag, const float* spec, float* out, int B, in
     SE_HIP(hipGetLastError());
 }
 
+__global__ __launch_bounds__(256) void elu_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float v = x[i];
+        y[i] = v > 0.f ? v : expm1f(v);
+    }
+}
+void launch_elu(const float* x, float* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(elu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
+    SE_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void polar_pow_kernel(const float* __restrict__ x, float* __restrict__ out, long plane,
+                                                        long total, float p_out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / plane, r = i - b * plane;
+    const long o = b * 2 * plane + r;
+    const float er = x[o], ei = x[o + plane];
+    const float sc = pow_scale(sqrtf(er * er + ei * ei), p_out);
+    out[o] = er * sc;
+    out[o + plane] = ei * sc;
+}
+void launch_polar_pow(const float* x, float* out, int B, int F, int T, float p_out, hipStream_t s) {
+    const long plane = (long)F * T, total = plane * B;
+    hipLaunchKernelGGL(polar_pow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, plane, total, p_out);
+    SE_HIP(hipGetLastError());
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;

@@ -42,6 +42,12 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
 
 void launch_fill(float* p, long n, float v, hipStream_t s);
 
+// y = elu(x)  (GCRN applies ELU to the skip tensors again inside every concat, GCRN_noncprs.py:149-158)
+void launch_elu(const float* x, float* y, long n, hipStream_t s);
+
+// Decode-script decompress of a complex-mapping output (GCRN/gcrn_decode_vb.py:47-55): out = |e|^p * e / |e|.
+void launch_polar_pow(const float* x, float* out, int B, int F, int T, float p_out, hipStream_t s);
+
 // nn.LayerNorm([F, C]) over the (C, F) plane of every (b, t) column of a [B][C][F][T] tensor, affine weight/bias
 // indexed [f][c] (DPCRN/DPCRN.py:56-57 ln1/ln2), fused with the residual add that follows it (:74, :88):
 //   out = LN(x) * w + b + res

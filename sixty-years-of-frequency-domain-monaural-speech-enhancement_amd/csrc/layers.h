@@ -43,6 +43,11 @@ std::vector<int> lstm_gate_perm(int H);
 // concatenate along K (input channels) / along M (rows)
 DenseW concat_cin(const DenseW& a, const DenseW& b, float scale_b = 1.f);
 DenseW concat_rows(const DenseW& a, const DenseW& b);
+// rows a0,b0,a1,b1,... (GLU pairs: value row 2j, gate row 2j+1)
+DenseW interleave_rows(const DenseW& a, const DenseW& b);
+// attach an eval-BatchNorm (applied AFTER the gate product) to a GLU plan
+void set_post_bn(GCPlan& pl, const HostTensor& gamma, const HostTensor& beta, const HostTensor& mean, const HostTensor& var,
+                 float eps = 1e-5f);
 std::vector<float> prelu_slopes(const HostTensor& w, int M);
 
 // Regular conv: out[f][t] = sum w[kf][kt] x[f*sf - pf + kf*dil_f][t - pt_left + kt*dil_t]

@@ -183,6 +183,37 @@ DenseW concat_rows(const DenseW& a, const DenseW& b) {
     return d;
 }
 
+DenseW interleave_rows(const DenseW& a, const DenseW& b) {
+    SE_CHECK(a.M == b.M && a.Cin == b.Cin && a.ntaps() == b.ntaps(), "interleave_rows shape");
+    DenseW d = a;
+    d.M = 2 * a.M;
+    const size_t per = (size_t)a.Cin * a.ntaps();
+    d.w.resize(2 * a.w.size());
+    d.bias.resize(2 * a.M);
+    for (int m = 0; m < a.M; ++m) {
+        std::copy(a.w.begin() + m * per, a.w.begin() + (m + 1) * per, d.w.begin() + (2 * m) * per);
+        std::copy(b.w.begin() + m * per, b.w.begin() + (m + 1) * per, d.w.begin() + (2 * m + 1) * per);
+        d.bias[2 * m] = a.bias[m];
+        d.bias[2 * m + 1] = b.bias[m];
+    }
+    return d;
+}
+
+void set_post_bn(GCPlan& pl, const HostTensor& gamma, const HostTensor& beta, const HostTensor& mean, const HostTensor& var,
+                 float eps) {
+    const int C = (int)gamma.numel();
+    std::vector<float> sc(C), sh(C);
+    for (int c = 0; c < C; ++c) {
+        const double s = (double)gamma.data[c] / std::sqrt((double)var.data[c] + (double)eps);
+        sc[c] = (float)s;
+        sh[c] = (float)((double)beta.data[c] - (double)mean.data[c] * s);
+    }
+    pl.dPostScale = to_device(sc);
+    pl.dPostShift = to_device(sh);
+    pl.p.post_scale = pl.dPostScale;
+    pl.p.post_shift = pl.dPostShift;
+}
+
 std::vector<float> prelu_slopes(const HostTensor& w, int M) {
     std::vector<float> s(M);
     SE_CHECK(w.numel() == 1 || w.numel() == M, "PReLU parameter count");

@@ -82,13 +82,19 @@ struct LstmBig {
     }
     // x [T][I][S] -> out [T][H][S];  G scratch [T][4H][S];  cell scratch [H][S]
     void run(const float* x, float* G, float* cell, float* out, int T, int S, hipStream_t st, Profiler* prof) const {
-        run_pointwise(gin, x, (long)I * S, S, G, 4L * H * S, S, T, S, st, prof);
+        run_strided(x, (long)I * S, G, cell, out, (long)H * S, 1, T, S, st, prof);
+    }
+    // general form: x rows are a slice of a wider tensor (per-step stride x_t), h_t unit j is written to row
+    // j * out_rs of a tensor with per-step stride out_t (out_rs = 2 interleaves two groups, GCRN_noncprs.py:28-29)
+    void run_strided(const float* x, long x_t, float* G, float* cell, float* out, long out_t, int out_rs, int T, int S,
+                     hipStream_t st, Profiler* prof) const {
+        run_pointwise(gin, x, x_t, S, G, 4L * H * S, S, T, S, st, prof);
         for (int t = 0; t < T; ++t) {
             GCParams p = step.p;
             p.first_step = (t == 0);
-            p.src0 = t > 0 ? out + (size_t)(t - 1) * H * S : out;
+            p.src0 = t > 0 ? out + (size_t)(t - 1) * out_t : out;
             p.s0_b = 0;
-            p.s0_c = S;
+            p.s0_c = (long)out_rs * S;
             p.s0_f = 0;
             p.src1 = nullptr;
             p.Fin = 1;
@@ -100,9 +106,9 @@ struct LstmBig {
             p.x_b = 0;
             p.x_c = S;
             p.x_f = 0;
-            p.dst = out + (size_t)t * H * S;
+            p.dst = out + (size_t)t * out_t;
             p.d_b = 0;
-            p.d_c = S;
+            p.d_c = (long)out_rs * S;
             p.d_f = 0;
             p.cell = cell;
             gc_launch_prof(step, p, st, prof);

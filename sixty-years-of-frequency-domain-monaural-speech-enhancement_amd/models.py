@@ -117,6 +117,14 @@ class Model(_EngineModule):
         return self.engine.forward(x.contiguous(), out_shape=(B, 2, F, T))
 
 
-MODEL_CLASSES = {'fullsubnet': Model, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
+class Net(_EngineModule):
+    """GCRN/GCRN_noncprs.py:86 `Net()`.  forward: RI [B,2,T,161] -> RI estimate [B,2,T,161] (complex mapping).
+    The decode script is checked in with the compressed exponents (gcrn_decode_vb.py:40,51)."""
+    _model = 'gcrn'
+    p_in = 0.5
+    p_out = 2.0
+
+
+MODEL_CLASSES = {'fullsubnet': Model, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
                  'dccrn': lambda **kw: DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
                                              kernel_num=[32, 64, 128, 256, 256, 256], **kw)}

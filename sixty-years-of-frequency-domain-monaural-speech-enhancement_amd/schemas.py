@@ -136,4 +136,33 @@ def fullsubnet_schema():
     return d
 
 
-SCHEMAS = {'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
+def gcrn_schema():
+    """GCRN/GCRN_noncprs.py:86-133 (registration order of Net.__init__)."""
+    d = OrderedDict()
+    ec = [2, 16, 32, 64, 128, 256]
+    for k in range(1, 6):
+        for c in ('conv1', 'conv2'):
+            _conv(d, f'conv{k}.{c}.', ec[k], ec[k - 1], (1, 3))
+    for lst in ('lstm_list1', 'lstm_list2'):
+        for i in range(2):
+            _lstm(d, f'glstm.{lst}.{i}.', 512, 512)
+    for n in ('ln1', 'ln2'):
+        d[f'glstm.{n}.weight'] = ((1024,), 'f32')
+        d[f'glstm.{n}.bias'] = ((1024,), 'f32')
+    dci, dco = [512, 256, 128, 64, 32], [128, 64, 32, 16, 1]
+    for br in (1, 2):
+        for i, k in enumerate((5, 4, 3, 2, 1)):
+            for c in ('conv1', 'conv2'):
+                _deconv(d, f'conv{k}_t_{br}.{c}.', dci[i], dco[i], (1, 3))
+    for k in range(1, 6):
+        _bn(d, f'bn{k}.', ec[k])
+    for br in (1, 2):
+        for i, k in enumerate((5, 4, 3, 2, 1)):
+            _bn(d, f'bn{k}_t_{br}.', dco[i])
+    for br in (1, 2):
+        d[f'fc{br}.weight'] = ((161, 161), 'f32')
+        d[f'fc{br}.bias'] = ((161,), 'f32')
+    return d
+
+
+SCHEMAS = {'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}

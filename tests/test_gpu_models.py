@@ -8,7 +8,7 @@ from se_amd import synth
 from conftest import load_golden, rms
 
 pytestmark = pytest.mark.gpu
-SEEDS = {'lstm': 11, 'crn': 12, 'dpcrn': 13, 'fullsubnet': 15}
+SEEDS = {'lstm': 11, 'crn': 12, 'dpcrn': 13, 'fullsubnet': 15, 'gcrn': 16}
 
 
 def _torch():
@@ -17,7 +17,7 @@ def _torch():
     return torch
 
 
-@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'fullsubnet'])
+@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'fullsubnet', 'gcrn'])
 def test_forward_matches_reference_fixture(name):
     torch = _torch()
     from se_amd.models import MODEL_CLASSES
@@ -30,7 +30,7 @@ def test_forward_matches_reference_fixture(name):
     assert err < 2e-5 * max(rms(G['y']), 1.0), (err, rms(G['y']))
 
 
-@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'fullsubnet'])
+@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'fullsubnet', 'gcrn'])
 def test_enhance_matches_reference_fixture(name):
     torch = _torch()
     from se_amd.models import MODEL_CLASSES

@@ -95,17 +95,21 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 
     const float* __restrict__ Ag = p.A + (long)z * p.A_z + m0;
 
-    // tap offsets of one chunk (identical for every chunk) live in ONE register spread over the wave: lane l < 32
-    // holds the patch offset of k = 2l (first row of k-pair l), lane 32 + l that of k = 2l + 1; the MFMA loop fetches
-    // them with v_readlane (uniform pair index), so no operand address ever depends on an LDS read.
-    int kreg = 0;
-    {
-        const int k = 2 * l31 + hi;
+    // patch offsets of the K rows of one chunk (identical for every chunk): lane half `hi` serves row 2*kp + hi of
+    // k-pair kp.  They live in registers indexed at compile time (the MFMA loop is fully unrolled over k-pairs), so no
+    // operand address depends on an LDS read or a v_readlane (both measured slower, tools/mfmabench.cpp).
+    constexpr int NPAIR = GC_MAX_KCP / 2;
+    int koffv[NPAIR];
+    static_for<NPAIR>([&](auto KP) {
+        constexpr int kp = decltype(KP)::value;
+        const int k = 2 * kp + hi;
+        int off = 0;
         if (k < p.KC) {
             const int cil = k / p.ntaps, j = k - cil * p.ntaps;
-            kreg = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
+            off = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
         }
-    }
+        koffv[kp] = off;
+    });
 
     // ---- chunk-invariant staging descriptors (all staging loops have uniform bounds: no exec masking)
     unsigned aoff[A_IT];
@@ -217,8 +221,7 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
             // 256 cycles of matrix work.  Reads one pair past the chunk (valid LDS, result unused).
 #define GC_FETCH(KP, AR, BR)                                                                       \
     {                                                                                              \
-        const int olo_ = __builtin_amdgcn_readlane(kreg, (KP)), ohi_ = __builtin_amdgcn_readlane(kreg, (KP) + 32); \
-        const int o_ = hi ? ohi_ : olo_;                                                           \
+        const int o_ = koffv[(KP) < NPAIR ? (KP) : NPAIR - 1];                                     \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) AR[i] = Ab[(2 * (KP)) * BM + i * 32];       \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) BR[j] = Bb[o_ + j * 32];                    \
     }
@@ -229,16 +232,19 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
             if (!(p.dbg & 4)) {
                 float ax[TM], bx[TN], ay[TM], by[TN];
                 GC_FETCH(0, ax, bx);
-                for (int kp = 0; kp < npair; kp += 2) {
-                    GC_FETCH(kp + 1, ay, by);
-                    __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);
-                    GC_MMA(ax, bx);
-                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-                    GC_FETCH(kp + 2, ax, bx);
-                    __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);
-                    GC_MMA(ay, by);
-                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-                }
+                static_for<NPAIR / 2>([&](auto KP2) {
+                    constexpr int kp = 2 * decltype(KP2)::value;
+                    if (kp < npair) {
+                        GC_FETCH(kp + 1, ay, by);
+                        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);
+                        GC_MMA(ax, bx);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                        GC_FETCH(kp + 2, ax, bx);
+                        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);
+                        GC_MMA(ay, by);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                    }
+                });
             }
 #undef GC_FETCH
 #undef GC_MMA
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 #undef GC_STORE_CHUNK
 
     // ---------------------------------------------------------------- epilogue
+    if (p.dbg & 8) return;
     const int fo = q * p.so + p.po;
     const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
     float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;

@@ -46,24 +46,24 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // of the activation patch reads  base_chunk[boff[e]]  (always an in-bounds address) and is zeroed when its validity
 // bit is clear, so the per-chunk staging code is one load + one select per element with a uniform 64-bit base.
 template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
+__global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    constexpr int A_IT = (GC_MAX_KCP * BM / 4 + 255) / 256;
-    constexpr int ROW_IT = 6;
-    constexpr int W_IT = 3;
-    constexpr int NB = ROW_IT * W_IT;
-    static_assert(NB <= GC_MAX_BLD, "prefetch budget");
+    // small-M tiles do little MFMA work per staged K row, so they stage twice the K depth per barrier to keep the
+    // global-load latency under the matrix work
+    constexpr int KCP_MAX = gc_kcp_max(BM);
+    constexpr int A_IT = (KCP_MAX * BM / 4 + 255) / 256;
+    constexpr int NB = gc_bld_max(BM);     // patch elements staged per thread (flat index e = tid + 256 * i)
     static_assert(WM * WN == 4, "4 waves");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int rows = p.CI_C * p.nrows;
-    const int rit = (rows + 3) >> 2;                 // patch rows per wave (uniform)
-    const int wit = (p.Wp + 63) >> 6;                // 64-column groups per patch row (last one may be partial)
+    const int npatch = rows * p.Wp;                  // floats of one staged activation patch
+    const int bit = (npatch + 255) >> 8;             // patch elements per thread (uniform)
     const int nA4 = p.KCp * (BM / 4);
     const int ait = (nA4 + 255) >> 8;                // float4 groups of the weight chunk per thread (uniform)
     const int As_sz = ait * 1024;                    // padded so that every thread stores unconditionally
-    const int Bs_sz = rit * 4 * p.Wp;
+    const int Bs_sz = bit * 256;                     // padded: every thread stores unconditionally
     const int nbuf = p.dbuf ? 2 : 1;
     float* As = smem;
     float* Bs = smem + nbuf * As_sz;
@@ -98,18 +98,31 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
     // patch offsets of the K rows of one chunk (identical for every chunk): lane half `hi` serves row 2*kp + hi of
     // k-pair kp.  They live in registers indexed at compile time (the MFMA loop is fully unrolled over k-pairs), so no
     // operand address depends on an LDS read or a v_readlane (both measured slower, tools/mfmabench.cpp).
-    constexpr int NPAIR = GC_MAX_KCP / 2;
-    int koffv[NPAIR];
-    static_for<NPAIR>([&](auto KP) {
-        constexpr int kp = decltype(KP)::value;
-        const int k = 2 * kp + hi;
-        int off = 0;
-        if (k < p.KC) {
-            const int cil = k / p.ntaps, j = k - cil * p.ntaps;
-            off = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
+    constexpr int NPAIR = KCP_MAX / 2;
+    constexpr bool KOFF_REGS = (BM >= 128);      // small-M tiles keep the table in LDS: registers buy occupancy there
+    int koffv[KOFF_REGS ? NPAIR : 1];
+    int* koff_lds = reinterpret_cast<int*>(Bs + nbuf * Bs_sz);
+    if constexpr (KOFF_REGS) {
+        static_for<NPAIR>([&](auto KP) {
+            constexpr int kp = decltype(KP)::value;
+            const int k = 2 * kp + hi;
+            int off = 0;
+            if (k < p.KC) {
+                const int cil = k / p.ntaps, j = k - cil * p.ntaps;
+                off = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
+            }
+            koffv[kp] = off;
+        });
+    } else {
+        for (int k = tid; k < KCP_MAX + 4; k += 256) {
+            int off = 0;
+            if (k < p.KC) {
+                const int cil = k / p.ntaps, j = k - cil * p.ntaps;
+                off = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
+            }
+            koff_lds[k] = off;
         }
-        koffv[kp] = off;
-    });
+    }
 
     // ---- chunk-invariant staging descriptors (all staging loops have uniform bounds: no exec masking)
     unsigned aoff[A_IT];
@@ -134,7 +147,6 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
     const int am = wm * (TM * 32) + l31;      // A column base inside the tile
     const int bn = wn * (TN * 32) + l31;      // B column base inside the tile
 
-    floatx4 preA[A_IT];
     float preB[NB];
     int gchunk = 0;          // global chunk counter (weights are packed segment after segment)
     int buf = 0;
@@ -142,31 +154,30 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 #define GC_MAKE_DESC(LIM)                                                                          \
     {                                                                                              \
         const int lim_ = (LIM);                                                                    \
-        static_for<ROW_IT>([&](auto I) {                                                           \
-            constexpr int i = decltype(I)::value;                                                  \
-            const int rr = wave + 4 * i;                                                           \
+        static_for<NB>([&](auto E) {                                                               \
+            constexpr int e = decltype(E)::value;                                                  \
+            const int fe = tid + 256 * e;                 /* flat patch index = LDS slot */        \
+            const int rr = fe / p.Wp, w = fe - rr * p.Wp;                                          \
             const int cil = rr / p.nrows, r = rr - cil * p.nrows;                                  \
-            const int f = q * p.si + p.tab[r];                                                     \
-            const bool rowok = (rr < rows) && (cil < lim_) && (f >= 0) && (f < p.Fin);             \
+            const bool staged = fe < npatch;                                                       \
+            const int f = q * p.si + p.tab[staged ? r : 0];                                        \
+            const int t = t0 + p.dtmin + w;                                                        \
             const int fc = f < 0 ? 0 : (f >= p.Fin ? p.Fin - 1 : f);                               \
+            const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
-            static_for<W_IT>([&](auto J) {                                                         \
-                constexpr int j = decltype(J)::value;                                              \
-                constexpr int e = i * W_IT + j;                                                    \
-                const int t = t0 + p.dtmin + lane + 64 * j;                                        \
-                const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                           \
-                const bool staged = (rr < rows) && (lane + 64 * j < p.Wp);                         \
-                boff[e] = staged ? (unsigned)((long)cc * s_c + (long)fc * s_f + tc) : 0u;          \
-                vok[e] = rowok && t >= 0 && t < p.Tin;                                             \
-            });                                                                                    \
+            boff[e] = staged ? (unsigned)((long)cc * s_c + (long)fc * s_f + tc) : 0u;              \
+            vok[e] = staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin); \
         });                                                                                        \
     }
-#define GC_LOAD_CHUNK(CH)                                                                          \
+#define GC_LOAD_CHUNK(CH, BUF)                                                                     \
     {                                                                                              \
         const float* __restrict__ Ac = Ag + (long)(gchunk + (CH)) * p.KCp * p.Mp;                  \
+        float* Adw = As + (BUF) * As_sz + wave * 256;   /* wave-uniform LDS base of this wave's 1 KB slice */ \
         static_for<A_IT>([&](auto I) {                                                             \
             constexpr int i = decltype(I)::value;                                                  \
-            preA[i] = *reinterpret_cast<const floatx4*>(Ac + aoff[i]);                             \
+            if (i < ait)                                                                           \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ac + aoff[i]), \
+                                                 (__attribute__((address_space(3))) void*)(Adw + i * 1024), 16, 0, 0); \
         });                                                                                        \
         const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
         static_for<NB>([&](auto E) {                                                               \
@@ -176,19 +187,10 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
     }
 #define GC_STORE_CHUNK(BUF)                                                                        \
     {                                                                                              \
-        float* Ad = As + (BUF) * As_sz + tid * 4;                                                  \
-        float* Bd = Bs + (BUF) * Bs_sz + wave * p.Wp + lane;                                       \
-        static_for<A_IT>([&](auto I) {                                                             \
-            constexpr int i = decltype(I)::value;                                                  \
-            if (i < ait) *reinterpret_cast<floatx4*>(Ad + i * 1024) = preA[i];                     \
-        });                                                                                        \
-        static_for<ROW_IT>([&](auto I) {                                                           \
-            constexpr int i = decltype(I)::value;                                                  \
-            if (i < rit) static_for<W_IT>([&](auto J) {                                            \
-                constexpr int j = decltype(J)::value;                                              \
-                constexpr int e = i * W_IT + j;                                                    \
-                if (j < wit && lane + 64 * j < p.Wp) Bd[4 * i * p.Wp + 64 * j] = vok[e] ? preB[e] : 0.f; \
-            });                                                                                    \
+        float* Bd = Bs + (BUF) * Bs_sz + tid;                                                      \
+        static_for<NB>([&](auto E) {                                                               \
+            constexpr int e = decltype(E)::value;                                                  \
+            if (e < bit) Bd[256 * e] = vok[e] ? preB[e] : 0.f;                                     \
         });                                                                                        \
     }
 
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
         const int tail = Cseg - (nch - 1) * p.CI_C;       // channels in the last chunk
 
         GC_MAKE_DESC(nch > 1 ? p.CI_C : tail);
-        GC_LOAD_CHUNK(0);
+        GC_LOAD_CHUNK(0, buf);
         __syncthreads();                 // previous segment's readers are done with `buf`
         GC_STORE_CHUNK(buf);
         __syncthreads();
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
         for (int c = 0; c < nch; ++c) {
             if (c + 1 < nch && !(p.dbg & 1)) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
-                GC_LOAD_CHUNK(c + 1);
+                GC_LOAD_CHUNK(c + 1, p.dbuf ? (buf ^ 1) : 0);
             }
             // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
             const float* Ab = As + buf * As_sz + hi * BM + am;
@@ -221,7 +223,9 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
             // 256 cycles of matrix work.  Reads one pair past the chunk (valid LDS, result unused).
 #define GC_FETCH(KP, AR, BR)                                                                       \
     {                                                                                              \
-        const int o_ = koffv[(KP) < NPAIR ? (KP) : NPAIR - 1];                                     \
+        int o_;                                                                                    \
+        if constexpr (KOFF_REGS) o_ = koffv[(KP) < NPAIR ? (KP) : NPAIR - 1];                      \
+        else o_ = koff_lds[2 * (KP) + hi];                                                         \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) AR[i] = Ab[(2 * (KP)) * BM + i * 32];       \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) BR[j] = Bb[o_ + j * 32];                    \
     }
@@ -341,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GCParams p) {
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM) {
-    const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows + 3) / 4) * 4 * p.Wp;
-    return (p.dbuf ? 2 : 1) * (as + bs) * 4 + 64;
+    const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
+    return (p.dbuf ? 2 : 1) * (as + bs) * 4 + (GC_MAX_KCP + 8) * 4 + 64;
 }
 
 GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w, const std::vector<float>& bias,
@@ -385,17 +389,15 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     static const int kcp_cap = getenv("SE_GC_KCP") ? atoi(getenv("SE_GC_KCP")) : GC_MAX_KCP;
     static const int dbuf_env = getenv("SE_GC_DBUF") ? atoi(getenv("SE_GC_DBUF")) : 1;
     p.dbuf = dbuf_env;
-    const int wit = (p.Wp + 63) / 64;
     int cic = 1;
     for (int c = 1; c <= std::max(std::max(C0, Cin - C0), 1); ++c) {
         int kcp = (c * taps.ntaps + 3) & ~3;
-        int rit = (c * p.nrows + 3) / 4;
-        if (kcp <= std::min(GC_MAX_KCP, kcp_cap) && rit <= 6 && rit * wit <= GC_MAX_BLD) cic = c;
+        if (kcp <= std::min(gc_kcp_max(pl.BM), kcp_cap) && c * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256) cic = c;
     }
     p.CI_C = cic;
     p.KC = cic * taps.ntaps;
     p.KCp = (p.KC + 3) & ~3;
-    SE_CHECK(p.KCp <= GC_MAX_KCP, "single-channel chunk exceeds K budget");
+    SE_CHECK(p.KCp <= gc_kcp_max(pl.BM), "single-channel chunk exceeds K budget");
     const int nch0 = (C0 + cic - 1) / cic, nch1 = (Cin - C0 + cic - 1) / cic;
     p.nchunks = nch0 + nch1;
     p.M = M;

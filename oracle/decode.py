@@ -119,3 +119,24 @@ def enhance_gcrn(sd, wav, p_in=0.5, p_out=2.0, net_dtype=np.float32):
 
 
 ENHANCE['gcrn'] = enhance_gcrn
+
+
+def enhance_ctsnet(sd1, sd2, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+    """CTSNet/two_stage_com_decode_vb.py:62-96: two chained models, torch.stft 320/160, istft without `length`."""
+    wav = np.asarray(wav, dtype=np.float64)
+    c = S.rms_scale(wav)                                                 # :63
+    L = len(wav)
+    x = S.pad_to_hop(wav * c, 320, 160).astype(net_dtype)                # :65-69
+    spec = S.stft(x, 320, 160).T                                         # [T,F]   :70-71 permute(0,3,2,1)
+    re, im = spec.real.astype(net_dtype), spec.imag.astype(net_dtype)
+    mag = np.sqrt(re ** 2 + im ** 2) ** p_in                             # :73
+    ph = np.arctan2(im, re)
+    feat = np.stack([mag * np.cos(ph), mag * np.sin(ph)], 0)[None]       # :75  [1,2,T,F]
+    est1 = M.cts_step1_forward(sd1, np.sqrt(feat[:, 0] ** 2 + feat[:, 1] ** 2))   # :79
+    s1 = np.stack([est1 * np.cos(ph), est1 * np.sin(ph)], 1)             # :80-81
+    s2 = M.cts_step2_forward(sd2, np.concatenate([feat, s1], 1)) + s1    # :82-84
+    emag = np.sqrt(s2[:, 0] ** 2 + s2[:, 1] ** 2) ** p_out               # :87
+    eph = np.arctan2(s2[:, 1], s2[:, 0])
+    de = emag[0].astype(np.float64) * np.exp(1j * eph[0].astype(np.float64))
+    y = S.istft(de.T, 320, 160)[:L]                                      # :93-95
+    return y / c

@@ -309,7 +309,45 @@ def gen_gcrn():
     save('gcrn', x=x, y=y, wav=wav, enh=_enhance_librosa_family(model, wav, 'ri', 0.5, 2.0))
 
 
-GENS = {'stft': gen_stft, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+def gen_ctsnet():
+    m1 = import_ref('CTSNet', 'Step1_network').Step1_net()
+    sch1, _ = load_synth(m1, 17)
+    m2 = import_ref('CTSNet', 'Step2_network').Step2_net(X=6, R=3)
+    sch2, _ = load_synth(m2, 18)
+    save_schema('cts_step1', sch1)
+    save_schema('cts_step2', sch2)
+    rng = np.random.default_rng(11)
+    x1 = np.abs(rng.standard_normal((2, 40, 161))).astype(np.float32)
+    x2 = rng.standard_normal((2, 4, 40, 161)).astype(np.float32)
+    with torch.no_grad():
+        y1 = m1(torch.from_numpy(x1)).numpy()
+        y2 = m2(torch.from_numpy(x2)).numpy()
+
+    def enh(wav, p_in, p_out):
+        feat_wav = np.asarray(wav, dtype=np.float64)
+        c = np.sqrt(len(feat_wav) / np.sum(feat_wav ** 2.0))
+        feat_wav = feat_wav * c
+        wav_len = len(feat_wav)
+        frame_num = int(np.ceil((wav_len - 320 + 320) / 160 + 1))
+        fake = (frame_num - 1) * 160
+        xw = torch.FloatTensor(np.concatenate((feat_wav, np.zeros([fake - wav_len])), axis=0))
+        feat_x_ = t_stft(xw.unsqueeze(0), 320, 160, 320).permute(0, 3, 2, 1)
+        mag, ph = torch.norm(feat_x_, dim=1) ** p_in, torch.atan2(feat_x_[:, 1], feat_x_[:, 0])
+        feat_x = torch.stack((mag * torch.cos(ph), mag * torch.sin(ph)), dim=1)
+        with torch.no_grad():
+            e1 = m1(torch.norm(feat_x, dim=1))
+            s1 = torch.stack((e1 * torch.cos(ph), e1 * torch.sin(ph)), dim=1)
+            s2 = m2(torch.cat((feat_x, s1), dim=1)) + s1
+        emag = torch.norm(s2, dim=1) ** p_out
+        eph = torch.atan2(s2[:, 1], s2[:, 0])
+        de = emag[0].double() * torch.exp(1j * eph[0].double())          # [T,F]
+        y = torch.istft(de.T, 320, 160, 320, window=torch.hann_window(320, dtype=torch.float64))[:wav_len]
+        return (y / c).numpy()
+    wav = synth.synth_clip(9, 'speech', 8000)
+    save('ctsnet', x1=x1, y1=y1, x2=x2, y2=y2, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
+
+
+GENS = {'stft': gen_stft, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

@@ -300,3 +300,100 @@ def gcrn_forward(sd, x):
         d = nn.elu(_bn(sd, f'bn1_t_{br}.', _glu_deconv(sd, f'conv1_t_{br}.', d)))
         res.append(nn.linear(d, sd[f'fc{br}.weight'], sd[f'fc{br}.bias']))   # :161-162 (over the F axis)
     return np.concatenate(res, axis=1)                          # :163
+
+
+# ----------------------------------------------------------------------------
+# CTSNet   (reference CTSNet/Step1_network.py:12-211, CTSNet/Step2_network.py:13-210)
+# ----------------------------------------------------------------------------
+def _in2d(sd, p, x):
+    return nn.instancenorm(x, sd[p + 'weight'], sd[p + 'bias'])
+
+
+def _cts_gate_conv(sd, p, x, stride=(1, 2)):
+    """Gate_Conv de_flag=0 (Step1_network.py:121-133): pad one frame on top, conv * sigmoid(gate_conv)."""
+    x = np.pad(x, ((0, 0), (0, 0), (1, 0), (0, 0)))
+    a = nn.conv2d(x, sd[p + 'conv.1.weight'], sd[p + 'conv.1.bias'], stride=stride)
+    g = nn.conv2d(x, sd[p + 'gate_conv.1.weight'], sd[p + 'gate_conv.1.bias'], stride=stride)
+    return a * nn.sigmoid(g)
+
+
+def _cts_gate_deconv(sd, p, x):
+    """Gate_Conv de_flag=1 (:134-145): ConvTranspose2d + Chomp_T(1) on both branches."""
+    a = nn.conv_transpose2d(x, sd[p + 'conv.0.weight'], sd[p + 'conv.0.bias'], stride=(1, 2))[:, :, :-1]
+    g = nn.conv_transpose2d(x, sd[p + 'gate_conv.0.weight'], sd[p + 'gate_conv.0.bias'], stride=(1, 2))[:, :, :-1]
+    return a * nn.sigmoid(g)
+
+
+def _share_sep_conv(w, x):
+    """ShareSepConv (:190-204): one FIR shared by all channels, causal left pad K-1.  x [B,C,T], w [1,1,K]."""
+    K = w.shape[-1]
+    xp = np.pad(x, ((0, 0), (0, 0), (K - 1, 0)))
+    out = np.zeros_like(x)
+    for k in range(K):
+        out += w[0, 0, k].astype(x.dtype) * xp[:, :, k:k + x.shape[-1]]
+    return out
+
+
+def _cts_glu(sd, p, x, d, left='left_conv', right='right_conv'):
+    """Glu / glu block (Step1_network.py:158-188, Step2_network.py:126-158).  x [B,256,T]."""
+    resi = x
+    x = nn.conv1d(x, sd[p + 'in_conv.weight'])
+
+    def branch(name):
+        y = nn.prelu(x, sd[p + name + '.0.weight'])
+        y = nn.instancenorm(y, sd[p + name + '.1.weight'], sd[p + name + '.1.bias'])
+        y = _share_sep_conv(sd[p + name + '.2.weight'], y)
+        y = np.pad(y, ((0, 0), (0, 0), (4 * d, 0)))
+        return nn.conv1d(y, sd[p + name + '.4.weight'], dilation=d)
+    x = branch(left) * nn.sigmoid(branch(right))
+    y = nn.prelu(x, sd[p + 'out_conv.0.weight'])
+    y = nn.instancenorm(y, sd[p + 'out_conv.1.weight'], sd[p + 'out_conv.1.bias'])
+    return nn.conv1d(y, sd[p + 'out_conv.2.weight']) + resi
+
+
+def _cts_encoder(sd, p, x):
+    skips = []
+    for i in range(5):
+        x = _cts_gate_conv(sd, f'{p}{i}.0.', x)
+        x = nn.prelu(_in2d(sd, f'{p}{i}.1.', x), sd[f'{p}{i}.2.weight'])
+        skips.append(x)
+    return x, skips
+
+
+def _cts_decoder(sd, p, p6, x, skips, softplus):
+    for i in range(5):
+        x = np.concatenate([x, skips[-(i + 1)]], axis=1)
+        x = _cts_gate_deconv(sd, f'{p}{i}.0.', x)
+        x = nn.prelu(_in2d(sd, f'{p}{i}.1.', x), sd[f'{p}{i}.2.weight'])
+    x = nn.linear(x[:, 0], sd[p6 + '0.weight'], sd[p6 + '0.bias'])
+    return nn.softplus(x) if softplus else x
+
+
+def cts_step1_forward(sd, x):
+    """Step1_net.forward (Step1_network.py:21-40): magnitude [B,T,161] -> magnitude [B,T,161]."""
+    x, skips = _cts_encoder(sd, 'en.en.', x[:, None])
+    B, _, T, _ = x.shape
+    x = np.transpose(x, (0, 1, 3, 2)).reshape(B, -1, T)
+    acc = np.zeros_like(x)
+    for k in (1, 2, 3):
+        for i in range(6):
+            x = _cts_glu(sd, f'tcm{k}.tcm_list.{i}.', x, 2 ** i)
+        acc = acc + x
+    x = np.transpose(acc.reshape(B, 64, 4, T), (0, 1, 3, 2))
+    return _cts_decoder(sd, 'de.de.', 'de.de6.', x, skips, True)
+
+
+def cts_step2_forward(sd, inpt, R=3, X=6):
+    """Step2_net.forward (Step2_network.py:23-38): [B,4,T,161] -> [B,2,T,161]."""
+    x, skips = _cts_encoder(sd, 'en.en_module.', inpt)
+    B, _, T, _ = x.shape
+    x = np.transpose(x, (0, 1, 3, 2)).reshape(B, -1, T)
+    acc = np.zeros_like(x)
+    for r in range(R):
+        for i in range(X):
+            x = _cts_glu(sd, f'tcm_list.{r}.glu_list.{i}.', x, 2 ** i, 'ori_conv', 'att_ori')
+        acc = acc + x
+    x = np.transpose(acc.reshape(B, 64, 4, T), (0, 1, 3, 2))
+    xr = _cts_decoder(sd, 'de_r.de_list.', 'de_r.de6.', x, skips, False)
+    xi = _cts_decoder(sd, 'de_i.de_list.', 'de_i.de6.', x, skips, False)
+    return np.stack([xr, xi], axis=1)

@@ -34,6 +34,7 @@ enum Epi : int {
     EPI_LSTM = 1,    // rows are gate-interleaved (4j+{i,f,g,o}); dst = h_t, c updated in place
     EPI_GLU = 2,     // rows are pair-interleaved (2j, 2j+1): dst[j] = (a+bias) * sigmoid(g+bias)
     EPI_ADD = 3,     // dst = act(acc + bias) + res   (res laid out like dst)
+    EPI_MUL = 4,     // dst = act(acc + bias) * aux   (gated TCM branches, CTSNet/Step1_network.py:184)
 };
 
 struct GCParams {

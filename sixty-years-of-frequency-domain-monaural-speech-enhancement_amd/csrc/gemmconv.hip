@@ -275,9 +275,9 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
     float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
 
-    if (EPI == EPI_ACT || EPI == EPI_ADD) {
+    if (EPI == EPI_ACT || EPI == EPI_ADD || EPI == EPI_MUL) {
         const float* __restrict__ res =
-            (EPI == EPI_ADD) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+            (EPI != EPI_ACT) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
                         float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
                         v = act_apply(v, p.act, p.slope ? p.slope[m] : 0.f);
                         if (EPI == EPI_ADD) v += res[(long)m * p.x_c + t];
+                        if (EPI == EPI_MUL) v *= res[(long)m * p.x_c + t];
                         dst[(long)m * p.d_c + t] = v;
                     }
                 }
@@ -373,7 +374,7 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.nrows = (int)rows.size();
     p.dtmin = dtmin;
     p.Wp = (pl.BN + (dtmax - dtmin) + 3) & ~3;             // LDS row stride of the patch
-    SE_CHECK(p.Wp <= 192, "time span of taps too wide for one patch");
+    SE_CHECK(p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256, "tap span too wide for one staged patch");
     {
         std::vector<int> tab(GC_MAX_ROWS + 2 * GC_MAX_TAPS, 0);
         for (int r = 0; r < p.nrows; ++r) tab[r] = rows[r];
@@ -474,6 +475,7 @@ static void gc_launch_t(const GCParams& p, hipStream_t stream) {
     switch (p.epi) {
         case EPI_ACT: gc_launch_e<BM, BN, WM, WN, EPI_ACT>(p, stream); break;
         case EPI_ADD: gc_launch_e<BM, BN, WM, WN, EPI_ADD>(p, stream); break;
+        case EPI_MUL: gc_launch_e<BM, BN, WM, WN, EPI_MUL>(p, stream); break;
         case EPI_GLU: gc_launch_e<BM, BN, WM, WN, EPI_GLU>(p, stream); break;
         case EPI_LSTM: gc_launch_e<BM, BN, WM, WN, EPI_LSTM>(p, stream); break;
         default: SE_CHECK(false, "unknown epilogue");

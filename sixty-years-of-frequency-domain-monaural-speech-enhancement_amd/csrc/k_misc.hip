@@ -197,6 +197,103 @@ void launch_polar_pow(const float* x, float* out, int B, int F, int T, float p_o
     SE_HIP(hipGetLastError());
 }
 
+// ---- InstanceNorm over a contiguous plane + PReLU ------------------------------------------------------------
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ slope, int C, int P) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x % C;
+    const float* xp = x + (long)blockIdx.x * P;
+    float* yp = y + (long)blockIdx.x * P;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < P; i += 256) s += xp[i];
+    const double mu = block_sum_d(s, sh) / P;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        const double d = xp[i] - mu;
+        v += d * d;
+    }
+    const double var = block_sum_d(v, sh) / P;
+    const float rs = (float)(1.0 / sqrt(var + 1e-5)), muf = (float)mu;
+    const float g = gamma[c], bt = beta[c], sl = slope ? slope[c] : 1.f;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        float o = (xp[i] - muf) * rs * g + bt;
+        yp[i] = o >= 0.f ? o : sl * o;
+    }
+}
+void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
+                           int C, int P, hipStream_t s) {
+    hipLaunchKernelGGL(instnorm_prelu_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, C, P);
+    SE_HIP(hipGetLastError());
+}
+
+// ---- PReLU -> InstanceNorm1d -> shared causal FIR, one block per (b, c) row -----------------------------------
+__global__ __launch_bounds__(256) void tcm_head_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ slope, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ fir, int K,
+                                                       int C, int T) {
+    extern __shared__ float row[];      // [T] normalised row, then FIR input
+    __shared__ double sh[4];
+    const int c = blockIdx.x % C;
+    const float* xp = x + (long)blockIdx.x * T;
+    float* yp = y + (long)blockIdx.x * T;
+    const float sl = slope[c];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < T; i += 256) {
+        float v = xp[i];
+        v = v >= 0.f ? v : sl * v;
+        row[i] = v;
+        s += v;
+    }
+    const double mu = block_sum_d(s, sh) / T;
+    double vv = 0.0;
+    for (int i = threadIdx.x; i < T; i += 256) {
+        const double d = row[i] - mu;
+        vv += d * d;
+    }
+    const double var = block_sum_d(vv, sh) / T;
+    const float rs = (float)(1.0 / sqrt(var + 1e-5)), muf = (float)mu, g = gamma[c], bt = beta[c];
+    for (int i = threadIdx.x; i < T; i += 256) row[i] = (row[i] - muf) * rs * g + bt;
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        float o;
+        if (K <= 0) {
+            o = row[t];
+        } else {
+            o = 0.f;
+            for (int k = 0; k < K; ++k) {      // y[t] = sum_k w[k] * x[t - (K-1) + k]
+                const int ti = t - (K - 1) + k;
+                if (ti >= 0) o += fir[k] * row[ti];
+            }
+        }
+        yp[t] = o;
+    }
+}
+void launch_tcm_head(const float* x, float* y, const float* slope, const float* gamma, const float* beta,
+                     const float* fir, int K, int B, int C, int T, hipStream_t s) {
+    SE_CHECK((size_t)T * 4 <= 60000, "TCM row too long for the LDS-resident head kernel");
+    hipLaunchKernelGGL(tcm_head_kernel, dim3(B * C), dim3(256), (size_t)T * 4, s, x, y, slope, gamma, beta, fir, K, C, T);
+    SE_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i];
+}
+void launch_add(const float* a, const float* b, float* y, long n, hipStream_t s) {
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, y, n);
+    SE_HIP(hipGetLastError());
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;

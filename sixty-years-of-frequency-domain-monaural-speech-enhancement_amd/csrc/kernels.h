@@ -42,6 +42,20 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
 
 void launch_fill(float* p, long n, float v, hipStream_t s);
 
+// nn.InstanceNorm2d / InstanceNorm1d (affine, per-utterance statistics, biased variance, eps 1e-5) over the contiguous
+// plane of P values of every (b, c), optionally followed by a per-channel PReLU; in place allowed.
+//   x [B][C][P];  gamma/beta [C];  slope [C] or null
+void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
+                           int C, int P, hipStream_t s);
+
+// TCM branch head (CTSNet/Step1_network.py:161-176): y = ShareSepConv( InstanceNorm1d( PReLU(x) ) ) per (b, c) row of
+// T frames; fir [K] is the single FIR shared by all channels (causal, left pad K-1), K = 0 -> no FIR.
+void launch_tcm_head(const float* x, float* y, const float* slope, const float* gamma, const float* beta,
+                     const float* fir, int K, int B, int C, int T, hipStream_t s);
+
+// y = a + b (n elements);  y may alias a
+void launch_add(const float* a, const float* b, float* y, long n, hipStream_t s);
+
 // y = elu(x)  (GCRN applies ELU to the skip tensors again inside every concat, GCRN_noncprs.py:149-158)
 void launch_elu(const float* x, float* y, long n, hipStream_t s);
 

@@ -62,7 +62,8 @@ struct DeconvPlan {
     int sf = 1;
 };
 DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, const std::vector<float>& slope,
-                            int tout_hint, int C0split = -1, const std::vector<float>* bias_pad = nullptr);
+                            int tout_hint, int C0split = -1, const std::vector<float>* bias_pad = nullptr,
+                            int epi = EPI_ACT);
 void free_deconv_plan(DeconvPlan& p);
 
 // Convenience launcher for [B][C][F][T]-layout tensors (row pitch Tp).

@@ -234,7 +234,7 @@ GCPlan make_conv_plan(const DenseW& d, int sf, int pf, int pt_left, int dil_f, i
 }
 
 DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, const std::vector<float>& slope,
-                            int tout_hint, int C0split, const std::vector<float>* bias_pad) {
+                            int tout_hint, int C0split, const std::vector<float>* bias_pad, int epi) {
     SE_CHECK(pf >= 0 || bias_pad, "a left frequency pad needs the bias of the padded rows");
     DeconvPlan out;
     out.sf = sf;
@@ -258,7 +258,7 @@ DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, 
             for (int c = 0; c < d.Cin; ++c)
                 for (int j = 0; j < ts.ntaps; ++j)
                     w[((size_t)m * d.Cin + c) * ts.ntaps + j] = d.w[((size_t)m * d.Cin + c) * d.ntaps() + sel[j]];
-        out.par.push_back(gc_make_plan(d.M, d.Cin, ts, w, d.bias, slope, act, EPI_ACT, 1, sf, par, tout_hint, 1, C0split));
+        out.par.push_back(gc_make_plan(d.M, d.Cin, ts, w, d.bias, slope, act, epi, 1, sf, par, tout_hint, 1, C0split));
         if (pf < 0) {
             GCPlan& g = out.par.back();
             g.dBiasPad = to_device(*bias_pad);

@@ -62,5 +62,6 @@ std::unique_ptr<Model> make_lstm(EngineCtx& ctx);
 std::unique_ptr<Model> make_dpcrn(EngineCtx& ctx);
 std::unique_ptr<Model> make_fullsubnet(EngineCtx& ctx);
 std::unique_ptr<Model> make_gcrn(EngineCtx& ctx);
+std::unique_ptr<Model> make_ctsnet(EngineCtx& ctx);
 
 }  // namespace se

@@ -125,6 +125,73 @@ class Net(_EngineModule):
     p_out = 2.0
 
 
+class _CtsStage(_EngineModule):
+    """One CTSNet stage; the engine model `ctsnet` holds both stages under the key prefixes step1. / step2."""
+    _model = 'ctsnet'
+    _prefix = ''
+    _schema = ''
+
+    @classmethod
+    def state_dict_schema(cls):
+        return schemas.SCHEMAS[cls._schema]()
+
+    def load_state_dict(self, sd, strict=True):
+        want = self.state_dict_schema()
+        missing = [k for k in want if k not in sd]
+        unexpected = [k for k in sd if k not in want]
+        if missing or unexpected:
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        self._sd = {self._prefix + k: v for k, v in sd.items()}
+        self.engine = Engine('ctsnet', self._device, self._max_batch, self._max_samples, self.p_in, self.p_out)
+        self.engine.load_state_dict(self._sd)
+        return self
+
+
+class Step1_net(_CtsStage):
+    """CTSNet/Step1_network.py:12 `Step1_net()`.  forward: magnitude [B,T,161] -> magnitude [B,T,161]."""
+    _prefix = 'step1.'
+    _schema = 'cts_step1'
+
+
+class Step2_net(_CtsStage):
+    """CTSNet/Step2_network.py:13 `Step2_net(X=6, R=3)`.  forward: [B,4,T,161] -> [B,2,T,161]."""
+    _prefix = 'step2.'
+    _schema = 'cts_step2'
+
+    def __init__(self, X=6, R=3, **kw):
+        if (X, R) != (6, 3):
+            raise NotImplementedError("the engine builds the decode script's Step2_net(X=6, R=3)")
+        super().__init__(**kw)
+
+    def forward(self, x):
+        B, _, T, F = x.shape
+        return self.engine.forward(x.contiguous(), out_shape=(B, 2, T, F))
+
+
+class CTSNet:
+    """The two chained stages of CTSNet/two_stage_com_decode_vb.py:13-16,78-84 in one engine (decode path)."""
+
+    def __init__(self, **kw):
+        self._kw = kw
+        self.engine = None
+
+    def load_state_dicts(self, sd1, sd2):
+        kw = dict(self._kw)
+        sd = {'step1.' + k: v for k, v in sd1.items()}
+        sd.update({'step2.' + k: v for k, v in sd2.items()})
+        self.engine = Engine('ctsnet', kw.get('device', 0), kw.get('max_batch', 1), kw.get('max_samples', 64000),
+                             kw.get('p_in', 1.0), kw.get('p_out', 1.0))
+        self.engine.load_state_dict(sd)
+        return self
+
+    def load_synthetic(self, seed1=17, seed2=18):
+        return self.load_state_dicts(synth.synth_state_dict(schemas.cts_step1_schema(), seed1),
+                                     synth.synth_state_dict(schemas.cts_step2_schema(), seed2))
+
+    def enhance_batch(self, wav):
+        return self.engine.enhance_batch(wav)
+
+
 MODEL_CLASSES = {'fullsubnet': Model, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
                  'dccrn': lambda **kw: DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
                                              kernel_num=[32, 64, 128, 256, 256, 256], **kw)}

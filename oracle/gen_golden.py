@@ -347,7 +347,39 @@ def gen_ctsnet():
     save('ctsnet', x1=x1, y1=y1, x2=x2, y2=y2, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
 
 
-GENS = {'stft': gen_stft, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+def gen_taylorsenet():
+    mod = import_ref('TaylorSENet', 'TaylorSENet')
+    model = mod.TaylorSENet(cin=2, k1=(1, 3), k2=(2, 3), c=64, kd1=5, cd1=64, d_feat=256, dilations=[1, 2, 5, 9], p=2,
+                            fft_num=320, order_num=3, intra_connect='cat', inter_connect='cat', is_causal=True,
+                            is_conformer=False, is_u2=True, is_param_share=False, is_encoder_share=False)
+    schema, _ = load_synth(model, 19)
+    save_schema('taylorsenet', schema)
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((2, 2, 30, 161)).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+
+    def enh(wav, p_in, p_out):
+        feat_wav = np.asarray(wav, dtype=np.float64)
+        c = np.sqrt(len(feat_wav) / np.sum(feat_wav ** 2.0))
+        feat_wav = feat_wav * c
+        wav_len = len(feat_wav)
+        frame_num = int(np.ceil((wav_len - 320 + 320) / 160 + 1))
+        xw = torch.FloatTensor(np.concatenate((feat_wav, np.zeros([(frame_num - 1) * 160 - wav_len])), axis=0))
+        feat_x = t_stft(xw.unsqueeze(0), 320, 160, 320).permute(0, 3, 2, 1)
+        mag, ph = torch.norm(feat_x, dim=1) ** p_in, torch.atan2(feat_x[:, -1], feat_x[:, 0])
+        fc = torch.stack((mag * torch.cos(ph), mag * torch.sin(ph)), dim=1)
+        with torch.no_grad():
+            e = model(fc)
+        emag, eph = torch.norm(e, dim=1) ** p_out, torch.atan2(e[:, -1], e[:, 0])
+        de = emag[0].double() * torch.exp(1j * eph[0].double())
+        y = torch.istft(de.T, 320, 160, 320, window=torch.hann_window(320, dtype=torch.float64), length=wav_len)
+        return (y / c).numpy()
+    wav = synth.synth_clip(10, 'speech', 6000)
+    save('taylorsenet', x=x, y=y, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
+
+
+GENS = {'stft': gen_stft, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

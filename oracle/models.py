@@ -397,3 +397,124 @@ def cts_step2_forward(sd, inpt, R=3, X=6):
     xr = _cts_decoder(sd, 'de_r.de_list.', 'de_r.de6.', x, skips, False)
     xi = _cts_decoder(sd, 'de_i.de_list.', 'de_i.de6.', x, skips, False)
     return np.stack([xr, xi], axis=1)
+
+
+# ----------------------------------------------------------------------------
+# TaylorSENet   (reference TaylorSENet/TaylorSENet.py:8-693) for the decode script's constructor
+# (taylorsenet_decode_vb.py:11-13): k1=(1,3), k2=(2,3), c=64, kd1=5, cd1=64, d_feat=256, dilations [1,2,5,9], p=2,
+# order_num=3, intra/inter 'cat', causal, no conformer, U2 encoder, no sharing.
+# ----------------------------------------------------------------------------
+def _in_prelu(sd, p_in, p_pr, x):
+    return nn.prelu(nn.instancenorm(x, sd[p_in + 'weight'], sd[p_in + 'bias']), sd[p_pr + 'weight'])
+
+
+def _gate_conv2d(sd, p, x, kt):
+    """GateConv2d (TaylorSENet.py:549-575): ONE conv to 2C channels, out * sigmoid(gate); top pad kt-1 frames."""
+    key = p + ('conv.1.' if kt > 1 else 'conv.')
+    if kt > 1:
+        x = np.pad(x, ((0, 0), (0, 0), (kt - 1, 0), (0, 0)))
+    y = nn.conv2d(x, sd[key + 'weight'], sd[key + 'bias'], stride=(1, 2))
+    a, g = np.split(y, 2, axis=1)
+    return a * nn.sigmoid(g)
+
+
+def _gate_deconv2d(sd, p, x, kt):
+    """GateConvTranspose2d (:577-603) with Chomp_T(kt-1)."""
+    key = p + ('conv.0.' if kt > 1 else 'conv.')
+    y = nn.conv_transpose2d(x, sd[key + 'weight'], sd[key + 'bias'], stride=(1, 2))
+    if kt > 1:
+        y = y[:, :, :-(kt - 1)]
+    a, g = np.split(y, 2, axis=1)
+    return a * nn.sigmoid(g)
+
+
+def _en_unet_module(sd, p, x, k1t, scale, de_flag):
+    """En_unet_module.forward (:480-496)."""
+    y = _gate_deconv2d(sd, p + 'in_conv.0.', x, k1t) if de_flag else _gate_conv2d(sd, p + 'in_conv.0.', x, k1t)
+    x_resi = _in_prelu(sd, p + 'in_conv.1.', p + 'in_conv.2.', y)
+    x = x_resi
+    xs = []
+    for i in range(scale):                                       # Conv2dunit k2=(2,3) (:498-519)
+        q = f'{p}enco.{i}.conv.'
+        x = nn.conv2d(np.pad(x, ((0, 0), (0, 0), (1, 0), (0, 0))), sd[q + '1.weight'], sd[q + '1.bias'], stride=(1, 2))
+        x = _in_prelu(sd, q + '2.', q + '3.', x)
+        xs.append(x)
+    for i in range(scale):                                       # Deconv2dunit (:521-547)
+        q = f'{p}deco.{i}.deconv.'
+        if i > 0:
+            x = np.concatenate([x, xs[-(i + 1)]], axis=1)
+        x = nn.conv_transpose2d(x, sd[q + '0.weight'], sd[q + '0.bias'], stride=(1, 2))[:, :, :-1]
+        x = _in_prelu(sd, q + '2.', q + '3.', x)
+    return x_resi + x
+
+
+def _u2net_encoder(sd, p, x):
+    """U2Net_Encoder.forward (:363-370)."""
+    ens = []
+    for i, (k1t, scale) in enumerate(((2, 4), (1, 3), (1, 2), (1, 1))):
+        x = _en_unet_module(sd, f'{p}meta_unet_list.{i}.', x, k1t, scale, False)
+        ens.append(x)
+    x = _in_prelu(sd, p + 'last_conv.1.', p + 'last_conv.2.', _gate_conv2d(sd, p + 'last_conv.0.', x, 1))
+    ens.append(x)
+    return x, ens
+
+
+def _u2net_decoder(sd, p, x, ens):
+    """U2Net_Decoder.forward, inter_connect='cat' (:426-439)."""
+    for i in range(4):
+        x = _en_unet_module(sd, f'{p}meta_unet_list.{i}.', np.concatenate([x, ens[-(i + 1)]], axis=1), 1, i + 1, True)
+    x = np.concatenate([x, ens[0]], axis=1)
+    x = _in_prelu(sd, p + 'last_conv.1.', p + 'last_conv.2.', _gate_deconv2d(sd, p + 'last_conv.0.', x, 2))
+    x = nn.sigmoid(nn.conv2d(x, sd[p + 'last_conv.3.weight'], sd[p + 'last_conv.3.bias']))
+    return x[:, 0]
+
+
+def _squeezed_tcm(sd, p, x, d, k=5):
+    """SqueezedTCM.forward (:679-685), causal pad (k-1)*d."""
+    resi = x
+    x = nn.conv1d(x, sd[p + 'in_conv.weight'])
+
+    def branch(name):
+        y = nn.prelu(x, sd[p + name + '.0.weight'])
+        y = nn.instancenorm(y, sd[p + name + '.1.weight'], sd[p + name + '.1.bias'])
+        y = np.pad(y, ((0, 0), (0, 0), ((k - 1) * d, 0)))
+        return nn.conv1d(y, sd[p + name + '.3.weight'], dilation=d)
+    x = branch('left_conv') * nn.sigmoid(branch('right_conv'))
+    y = nn.instancenorm(nn.prelu(x, sd[p + 'out_conv.0.weight']), sd[p + 'out_conv.1.weight'], sd[p + 'out_conv.1.bias'])
+    return nn.conv1d(y, sd[p + 'out_conv.2.weight']) + resi
+
+
+def _tcms(sd, p, x, n=2, dils=(1, 2, 5, 9)):
+    for i in range(n):
+        for j, d in enumerate(dils):
+            x = _squeezed_tcm(sd, f'{p}tcms.{i}.tcm_list.{j}.', x, d)
+    return x
+
+
+def taylorsenet_forward(sd, inputs, order_num=3):
+    """TaylorSENet.forward (:66-94): [B,2,T,161] -> [B,2,T,161]."""
+    mag = np.sqrt(inputs[:, 0] ** 2 + inputs[:, 1] ** 2)
+    ph = np.arctan2(inputs[:, -1], inputs[:, 0])
+    # ZeroOrderBlock (:139-153)
+    en_x, ens = _u2net_encoder(sd, 'zeroorderblock.en.', inputs)
+    B, C, T, F = en_x.shape
+    x = _tcms(sd, 'zeroorderblock.', np.swapaxes(en_x, -2, -1).reshape(B, C * F, T))
+    gain = _u2net_decoder(sd, 'zeroorderblock.de.', np.swapaxes(x.reshape(B, C, F, T), -2, -1), ens)
+    zmag = gain * mag
+    zero = np.stack([zmag * np.cos(ph), zmag * np.sin(ph)], axis=1)          # :73-76
+    fh, _ = _u2net_encoder(sd, 'separate_en.', inputs)                       # :78-82
+    fh = np.swapaxes(fh, -2, -1).reshape(B, -1, T)
+    out, pre = zero, zero
+    fact = 1.0
+    for k in range(order_num):                                               # :84-93
+        p = f'highorderblock_list.{k}.'
+        x1 = np.swapaxes(pre, -2, -1).reshape(B, -1, T)                      # HighOrderBlock.forward :191-214
+        x = nn.conv1d(np.concatenate([fh, x1], axis=1), sd[p + 'in_conv.weight'], sd[p + 'in_conv.bias'])
+        x = _tcms(sd, p, x)
+        xr = np.swapaxes(nn.conv1d(x, sd[p + 'real_resi.weight'], sd[p + 'real_resi.bias']), -2, -1)
+        xi = np.swapaxes(nn.conv1d(x, sd[p + 'imag_resi.weight'], sd[p + 'imag_resi.bias']), -2, -1)
+        upd = np.stack([xr, xi], axis=1) + k * pre
+        pre = upd
+        fact *= (k + 1)
+        out = out + upd / fact
+    return out

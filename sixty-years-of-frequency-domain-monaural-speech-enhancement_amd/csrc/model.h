@@ -63,5 +63,6 @@ std::unique_ptr<Model> make_dpcrn(EngineCtx& ctx);
 std::unique_ptr<Model> make_fullsubnet(EngineCtx& ctx);
 std::unique_ptr<Model> make_gcrn(EngineCtx& ctx);
 std::unique_ptr<Model> make_ctsnet(EngineCtx& ctx);
+std::unique_ptr<Model> make_taylorsenet(EngineCtx& ctx);
 
 }  // namespace se

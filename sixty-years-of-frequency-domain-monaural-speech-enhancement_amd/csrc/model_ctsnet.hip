@@ -8,7 +8,7 @@
 // so batched results equal batch-1 results); the TCM blocks run on [B][256][1][T]: 1x1 convs are pointwise GEMMs,
 // PReLU + InstanceNorm1d + ShareSepConv is one row-resident kernel, the dilated k=5 convs are tap-table GEMMs with
 // the sigmoid / gate product / residual in their epilogues.
-#include "rnn.h"
+#include "blocks.h"
 
 namespace se {
 
@@ -16,83 +16,6 @@ namespace {
 
 constexpr int NFFT = 320, HOP = 160, NBIN = 161, NTCM = 18;
 constexpr int EF[5] = {79, 39, 19, 9, 4}, DF[5] = {9, 19, 39, 79, 161};
-
-struct NormAct {
-    float *g = nullptr, *b = nullptr, *s = nullptr;
-    void load(const TrackedSD& sd, const std::string& in_key, const std::string& prelu_key) {
-        g = to_device(sd.get(in_key + "weight").data);
-        b = to_device(sd.get(in_key + "bias").data);
-        s = to_device(sd.get(prelu_key + "weight").data);
-    }
-    void free() {
-        for (float* d : {g, b, s})
-            if (d) (void)hipFree(d);
-        g = b = s = nullptr;
-    }
-};
-
-struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:126-158)
-    GCPlan in_conv, convL, convR, out_conv;
-    NormAct nL, nR, nO;
-    float *firL = nullptr, *firR = nullptr;
-    int K = 0, d = 1;
-    void load(const TrackedSD& sd, const std::string& p, int dil, const std::string& left, const std::string& right) {
-        d = dil;
-        K = 2 * d - 1;
-        auto c1 = [&](const std::string& key, int co, int ci, int k) {
-            const HostTensor& w = sd.get(key, {co, ci, k});
-            HostTensor w4 = w;
-            w4.shape = {co, ci, 1, k};
-            return conv_weights(w4, nullptr, false);
-        };
-        in_conv = make_pointwise_plan(c1(p + "in_conv.weight", 64, 256, 1), ACT_NONE, {}, 401);
-        convR = make_conv_plan(c1(p + right + ".4.weight", 64, 64, 5), 1, 0, 4 * d, 1, d, ACT_SIGMOID, {}, EPI_ACT, 401);
-        convL = make_conv_plan(c1(p + left + ".4.weight", 64, 64, 5), 1, 0, 4 * d, 1, d, ACT_NONE, {}, EPI_MUL, 401);
-        out_conv = make_pointwise_plan(c1(p + "out_conv.2.weight", 256, 64, 1), ACT_NONE, {}, 401, EPI_ADD);
-        nL.load(sd, p + left + ".1.", p + left + ".0.");
-        nR.load(sd, p + right + ".1.", p + right + ".0.");
-        nO.load(sd, p + "out_conv.1.", p + "out_conv.0.");
-        firL = to_device(sd.get(p + left + ".2.weight", {1, 1, K}).data);
-        firR = to_device(sd.get(p + right + ".2.weight", {1, 1, K}).data);
-    }
-    void free() {
-        for (GCPlan* g : {&in_conv, &convL, &convR, &out_conv}) gc_free_plan(*g);
-        nL.free();
-        nR.free();
-        nO.free();
-        if (firL) (void)hipFree(firL);
-        if (firR) (void)hipFree(firR);
-    }
-};
-
-struct TcmScratch {
-    float *h, *a, *r, *m;     // [B][64][T] each
-};
-
-// x [B][256][T] -> y [B][256][T]
-void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratch& s, int B, int T, hipStream_t st, Profiler* pf) {
-    run_pointwise(k.in_conv, x, 256L * T, T, s.h, 64L * T, T, B, T, st, pf);
-    launch_tcm_head(s.h, s.a, k.nR.s, k.nR.g, k.nR.b, k.firR, k.K, B, 64, T, st);
-    run_conv(k.convR, act4(s.a, 64, 1, T), nullptr, s.r, 64, 1, B, T, T, st, pf);
-    launch_tcm_head(s.h, s.a, k.nL.s, k.nL.g, k.nL.b, k.firL, k.K, B, 64, T, st);
-    {
-        GCParams p = k.convL.p;
-        p.src0 = s.a; p.s0_b = 64L * T; p.s0_c = T; p.s0_f = T; p.src1 = nullptr;
-        p.Fin = 1; p.Tin = T; p.B = B; p.Q = 1; p.Tout = T;
-        p.dst = s.m; p.d_b = 64L * T; p.d_c = T; p.d_f = T;
-        p.aux = s.r; p.x_b = 64L * T; p.x_c = T; p.x_f = T;
-        gc_launch_prof(k.convL, p, st, pf);
-    }
-    launch_tcm_head(s.m, s.a, k.nO.s, k.nO.g, k.nO.b, nullptr, 0, B, 64, T, st);
-    {
-        GCParams p = k.out_conv.p;
-        p.src0 = s.a; p.s0_b = 64L * T; p.s0_c = T; p.s0_f = 0; p.src1 = nullptr;
-        p.Fin = 1; p.Tin = T; p.B = B; p.Q = 1; p.Tout = T;
-        p.dst = y; p.d_b = 256L * T; p.d_c = T; p.d_f = 0;
-        p.aux = x; p.x_b = 256L * T; p.x_c = T; p.x_f = 0;
-        gc_launch_prof(k.out_conv, p, st, pf);
-    }
-}
 
 struct GatedEncoder {
     GCPlan conv[5];
@@ -182,7 +105,7 @@ class CtsNet final : public Model {
             for (int k = 0; k < 3; ++k)
                 for (int i = 0; i < 6; ++i)
                     tcm1[k * 6 + i].load(sd, "step1.tcm" + std::to_string(k + 1) + ".tcm_list." + std::to_string(i) + ".", 1 << i,
-                                         "left_conv", "right_conv");
+                                         "left_conv", "right_conv", 4, 2 * (1 << i) - 1, 5);
         }
         if (has2) {
             en2.load(sd, "step2.en.en_module.", 4);
@@ -191,7 +114,7 @@ class CtsNet final : public Model {
             for (int r = 0; r < 3; ++r)
                 for (int i = 0; i < 6; ++i)
                     tcm2[r * 6 + i].load(sd, "step2.tcm_list." + std::to_string(r) + ".glu_list." + std::to_string(i) + ".", 1 << i,
-                                         "ori_conv", "att_ori");
+                                         "ori_conv", "att_ori", 4, 2 * (1 << i) - 1, 5);
         }
     }
 

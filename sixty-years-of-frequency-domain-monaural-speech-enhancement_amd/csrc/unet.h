@@ -1,0 +1,183 @@
+// U^2-Net style gated encoder / decoder shared by TaylorSENet and G2Net.
+//
+// Reference: TaylorSENet/TaylorSENet.py:336-603 (U2Net_Encoder, U2Net_Decoder, En_unet_module, Conv2dunit,
+// Deconv2dunit, GateConv2d, GateConvTranspose2d); G2Net_VB/gaf_net_320.py:277-486 has the same encoder.
+// Every (de)conv is a tap-table GEMM (gated ones as (value, gate) row pairs), InstanceNorm2d(affine) + PReLU(C) is one
+// plane-wise kernel, 'cat' skips are two-source K loops, 'add' skips / residuals are one elementwise kernel.
+#pragma once
+#include "blocks.h"
+
+namespace se {
+
+struct ConvIN {        // conv (plain or gated) -> InstanceNorm2d -> PReLU
+    GCPlan plan;
+    NormAct na;
+    int cout = 0, kf = 3;
+    void free() {
+        gc_free_plan(plan);
+        na.free();
+    }
+};
+struct DeconvIN {
+    DeconvPlan plan;
+    NormAct na;
+    int cout = 0, kf = 3;
+    void free() {
+        free_deconv_plan(plan);
+        na.free();
+    }
+};
+
+// GateConv2d / GateConvTranspose2d produce 2C channels [value ; gate] from ONE conv: interleave to (value, gate) pairs
+inline DenseW gate_pairs(DenseW w) {
+    const int C = w.M / 2;
+    std::vector<int> perm(w.M);
+    for (int j = 0; j < C; ++j) {
+        perm[2 * j] = j;
+        perm[2 * j + 1] = C + j;
+    }
+    permute_rows(w, perm);
+    return w;
+}
+
+inline ConvIN load_gate_conv_in(const TrackedSD& sd, const std::string& p, int cin, int cout, int kt, int kf, int c0 = -1) {
+    ConvIN c;
+    c.cout = cout;
+    c.kf = kf;
+    const std::string key = p + (kt > 1 ? "0.conv.1." : "0.conv.");
+    DenseW w = conv_weights(sd.get(key + "weight", {2 * cout, cin, kt, kf}), &sd.get(key + "bias", {2 * cout}), true);
+    c.plan = make_conv_plan(gate_pairs(w), 2, 0, kt - 1, 1, 1, ACT_NONE, {}, EPI_GLU, 401, c0);
+    c.na.load(sd, p + "1.", p + "2.");
+    return c;
+}
+inline DeconvIN load_gate_deconv_in(const TrackedSD& sd, const std::string& p, int cin, int cout, int kt, int kf, int c0) {
+    DeconvIN c;
+    c.cout = cout;
+    c.kf = kf;
+    const std::string key = p + (kt > 1 ? "0.conv.0." : "0.conv.");
+    DenseW w = deconv_weights(sd.get(key + "weight", {cin, 2 * cout, kt, kf}), &sd.get(key + "bias", {2 * cout}), true);
+    c.plan = make_deconv_plan(gate_pairs(w), 2, 0, 0, ACT_NONE, {}, 401, c0, nullptr, EPI_GLU);
+    c.na.load(sd, p + "1.", p + "2.");
+    return c;
+}
+
+struct UnetScratch {
+    float* lev[5] = {};     // encoder levels 1..4 of the nested U-Net
+    float* dec[5] = {};     // decoder outputs at levels 0..3
+    void alloc(Arena& a, size_t BT) {
+        const int F[5] = {79, 39, 19, 9, 4};
+        for (int i = 0; i < 5; ++i) {
+            lev[i] = a.alloc_f(BT * 64 * F[i]);
+            dec[i] = a.alloc_f(BT * 64 * F[i]);
+        }
+    }
+};
+
+struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
+    bool de = false;
+    int scale = 1, k1f = 3;
+    ConvIN in_c;
+    DeconvIN in_d;
+    ConvIN enco[4];
+    DeconvIN deco[4];
+
+    void load(const TrackedSD& sd, const std::string& p, int cin, int k1t, int k1f_, int scale_, bool de_, int c0) {
+        de = de_;
+        scale = scale_;
+        k1f = k1f_;
+        if (de) in_d = load_gate_deconv_in(sd, p + "in_conv.", cin, 64, k1t, k1f, c0);
+        else in_c = load_gate_conv_in(sd, p + "in_conv.", cin, 64, k1t, k1f, c0);
+        for (int i = 0; i < scale; ++i) {
+            const std::string q = p + "enco." + std::to_string(i) + ".conv.";     // Conv2dunit k2 = (2,3)
+            enco[i].cout = 64;
+            DenseW w = conv_weights(sd.get(q + "1.weight", {64, 64, 2, 3}), &sd.get(q + "1.bias", {64}), true);
+            enco[i].plan = make_conv_plan(w, 2, 0, 1, 1, 1, ACT_NONE, {}, EPI_ACT, 401);
+            enco[i].na.load(sd, q + "2.", q + "3.");
+            const std::string r = p + "deco." + std::to_string(i) + ".deconv.";   // Deconv2dunit ('add' for i = 0, else 'cat')
+            const int ci = i == 0 ? 64 : 128;
+            deco[i].cout = 64;
+            DenseW dw = deconv_weights(sd.get(r + "0.weight", {ci, 64, 2, 3}), &sd.get(r + "0.bias", {64}), true);
+            deco[i].plan = make_deconv_plan(dw, 2, 0, 0, ACT_NONE, {}, 401, i == 0 ? -1 : 64);
+            deco[i].na.load(sd, r + "2.", r + "3.");
+        }
+    }
+    void free() {
+        if (de) in_d.free();
+        else in_c.free();
+        for (int i = 0; i < scale; ++i) {
+            enco[i].free();
+            deco[i].free();
+        }
+    }
+    int out_F(int Fin) const { return de ? (Fin - 1) * 2 + k1f : (Fin - k1f) / 2 + 1; }
+
+    // in0 (+ optional in1 concatenated on channels), both with F = Fin  ->  out [B][64][out_F][T]
+    void run(const Act4& in0, const Act4* in1, float* out, const UnetScratch& s, int B, int T, hipStream_t st,
+             Profiler* pf) const {
+        const int F0 = out_F(in0.F);
+        if (de) {
+            run_deconv(in_d.plan, in0, in1, out, 64, F0, B, T, T, st, pf);
+            launch_instnorm_prelu(out, out, in_d.na.g, in_d.na.b, in_d.na.s, B, 64, F0 * T, st);
+        } else {
+            run_conv(in_c.plan, in0, in1, out, 64, F0, B, T, T, st, pf);
+            launch_instnorm_prelu(out, out, in_c.na.g, in_c.na.b, in_c.na.s, B, 64, F0 * T, st);
+        }
+        int Fs[6];
+        Fs[0] = F0;
+        float* xs[5];
+        xs[0] = out;
+        // which scratch level holds F: levels are sized {79,39,19,9,4}
+        auto lvl = [](int F) { return F >= 79 ? 0 : F >= 39 ? 1 : F >= 19 ? 2 : F >= 9 ? 3 : 4; };
+        for (int i = 0; i < scale; ++i) {
+            Fs[i + 1] = (Fs[i] - 3) / 2 + 1;
+            float* y = s.lev[lvl(Fs[i + 1])];
+            run_conv(enco[i].plan, act4(xs[i], 64, Fs[i], T), nullptr, y, 64, Fs[i + 1], B, T, T, st, pf);
+            launch_instnorm_prelu(y, y, enco[i].na.g, enco[i].na.b, enco[i].na.s, B, 64, Fs[i + 1] * T, st);
+            xs[i + 1] = y;
+        }
+        const float* x = xs[scale];
+        for (int i = 0; i < scale; ++i) {
+            const int Fi = Fs[scale - i], Fo = Fs[scale - i - 1];
+            float* y = s.dec[lvl(Fo)];
+            Act4 a0 = act4(x, 64, Fi, T);
+            if (i == 0) {
+                run_deconv(deco[i].plan, a0, nullptr, y, 64, Fo, B, T, T, st, pf);
+            } else {
+                Act4 a1 = act4(xs[scale - i], 64, Fi, T);          // x_list[-(i+1)]
+                run_deconv(deco[i].plan, a0, &a1, y, 64, Fo, B, T, T, st, pf);
+            }
+            launch_instnorm_prelu(y, y, deco[i].na.g, deco[i].na.b, deco[i].na.s, B, 64, Fo * T, st);
+            x = y;
+        }
+        launch_add(out, x, out, (long)B * 64 * F0 * T, st);         // x_resi + x
+    }
+};
+
+struct U2Encoder {      // U2Net_Encoder (TaylorSENet.py:336-370)
+    UnetModule m[4];
+    ConvIN last;
+    void load(const TrackedSD& sd, const std::string& p, int cin) {
+        m[0].load(sd, p + "meta_unet_list.0.", cin, 2, 5, 4, false, -1);
+        m[1].load(sd, p + "meta_unet_list.1.", 64, 1, 3, 3, false, -1);
+        m[2].load(sd, p + "meta_unet_list.2.", 64, 1, 3, 2, false, -1);
+        m[3].load(sd, p + "meta_unet_list.3.", 64, 1, 3, 1, false, -1);
+        last = load_gate_conv_in(sd, p + "last_conv.", 64, 64, 1, 3);
+    }
+    void free() {
+        for (auto& x : m) x.free();
+        last.free();
+    }
+    // in [B][cin][161][T] -> ens[0..4] with F = 79, 39, 19, 9, 4 (ens[4] is the bottleneck)
+    void run(const Act4& in, float* const ens[5], const UnetScratch& s, int B, int T, hipStream_t st, Profiler* pf) const {
+        Act4 x = in;
+        const int F[5] = {79, 39, 19, 9, 4};
+        for (int i = 0; i < 4; ++i) {
+            m[i].run(x, nullptr, ens[i], s, B, T, st, pf);
+            x = act4(ens[i], 64, F[i], T);
+        }
+        run_conv(last.plan, x, nullptr, ens[4], 64, 4, B, T, T, st, pf);
+        launch_instnorm_prelu(ens[4], ens[4], last.na.g, last.na.b, last.na.s, B, 64, 4 * T, st);
+    }
+};
+
+}  // namespace se

@@ -192,6 +192,26 @@ class CTSNet:
         return self.engine.enhance_batch(wav)
 
 
-MODEL_CLASSES = {'fullsubnet': Model, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
+class TaylorSENet(_EngineModule):
+    """TaylorSENet/TaylorSENet.py:8 as built at taylorsenet_decode_vb.py:11-13.  forward: RI [B,2,T,161] -> RI."""
+    _model = 'taylorsenet'
+
+    def __init__(self, cin=2, k1=(1, 3), k2=(2, 3), c=64, kd1=3, cd1=64, d_feat=256, dilations=(1, 2, 5, 9), p=2,
+                 fft_num=320, order_num=3, intra_connect='cat', inter_connect='add', is_causal=True, is_conformer=False,
+                 is_u2=True, is_param_share=False, is_encoder_share=False, **kw):
+        cfg = (cin, tuple(k1), tuple(k2), c, kd1, cd1, d_feat, tuple(dilations), p, fft_num, order_num, intra_connect,
+               inter_connect, is_causal, is_conformer, is_u2, is_param_share, is_encoder_share)
+        if cfg != (2, (1, 3), (2, 3), 64, 5, 64, 256, (1, 2, 5, 9), 2, 320, 3, 'cat', 'cat', True, False, True, False, False):
+            raise NotImplementedError("the engine builds the decode script's TaylorSENet configuration; got " + repr(cfg))
+        super().__init__(**kw)
+
+
+def _taylor(**kw):
+    return TaylorSENet(cin=2, k1=(1, 3), k2=(2, 3), c=64, kd1=5, cd1=64, d_feat=256, dilations=[1, 2, 5, 9], p=2,
+                       fft_num=320, order_num=3, intra_connect='cat', inter_connect='cat', is_causal=True,
+                       is_conformer=False, is_u2=True, is_param_share=False, is_encoder_share=False, **kw)
+
+
+MODEL_CLASSES = {'fullsubnet': Model, 'taylorsenet': _taylor, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
                  'dccrn': lambda **kw: DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
                                              kernel_num=[32, 64, 128, 256, 256, 256], **kw)}

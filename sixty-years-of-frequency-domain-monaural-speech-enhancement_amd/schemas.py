@@ -220,4 +220,19 @@ def cts_step2_schema(X=6, R=3):
     return d
 
 
-SCHEMAS = {'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
+def _from_data(name):
+    """Large schemas (hundreds of keys) ship as data: the (key, shape, dtype) list captured from the reference
+    module's state_dict() by oracle/gen_golden.py - names and shapes only, no weights."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'schema_data', name + '.json')
+    with open(path) as f:
+        return OrderedDict((k, (tuple(sh), d)) for k, sh, d in json.load(f))
+
+
+def taylorsenet_schema():
+    """TaylorSENet/TaylorSENet.py:8 as built at taylorsenet_decode_vb.py:11-13 (811 keys)."""
+    return _from_data('taylorsenet')
+
+
+SCHEMAS = {'taylorsenet': taylorsenet_schema, 'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}

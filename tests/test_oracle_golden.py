@@ -42,7 +42,7 @@ def _sd(name, seed):
 @pytest.mark.parametrize('name,seed,fwd', [
     ('lstm', 11, M.lstm_net_forward), ('crn', 12, M.crn_net_forward),
     ('dpcrn', 13, M.dpcrn_forward), ('dccrn', 14, M.dccrn_forward), ('fullsubnet', 15, M.fullsubnet_forward),
-    ('gcrn', 16, M.gcrn_forward)])
+    ('gcrn', 16, M.gcrn_forward), ('taylorsenet', 19, M.taylorsenet_forward)])
 def test_forward_matches_reference(name, seed, fwd):
     G = load_golden(name)
     sd = _sd(name, seed)
@@ -54,7 +54,7 @@ def test_forward_matches_reference(name, seed, fwd):
     assert rms(y64 - G['y']) < 2e-6 * max(scale, 1.0)
 
 
-@pytest.mark.parametrize('name,seed', [('lstm', 11), ('crn', 12), ('dpcrn', 13), ('dccrn', 14), ('fullsubnet', 15), ('gcrn', 16)])
+@pytest.mark.parametrize('name,seed', [('lstm', 11), ('crn', 12), ('dpcrn', 13), ('dccrn', 14), ('fullsubnet', 15), ('gcrn', 16), ('taylorsenet', 19)])
 def test_enhance_matches_reference(name, seed):
     G = load_golden(name)
     sd = _sd(name, seed)

@@ -162,3 +162,23 @@ def enhance_taylorsenet(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
 
 
 ENHANCE['taylorsenet'] = enhance_taylorsenet
+
+
+def enhance_g2net(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+    """G2Net_VB/com_decode.py:39-88: normalises with x / c, c = RMS (:43-44) and restores with * c (:88)."""
+    wav = np.asarray(wav, dtype=np.float64)
+    c = np.sqrt(np.sum(wav ** 2.0) / len(wav))
+    x = wav / c
+    spec = S.stft(x, 320, 160).T                                          # :49
+    mag, ph = np.abs(spec) ** p_in, np.angle(spec)                        # :53
+    feat = np.stack([(mag * np.cos(ph)).astype(net_dtype), (mag * np.sin(ph)).astype(net_dtype)], 0)   # :61
+    est = M.g2net_forward(sd, feat[None])[-1][0]                          # :66-69  [2,161,T]
+    est = np.transpose(est, (0, 2, 1))                                    # :74
+    emag = np.sqrt(est[0] ** 2 + est[1] ** 2) ** p_out                    # :76
+    eph = np.arctan2(est[1], est[0])
+    de = emag.astype(np.float64) * np.exp(1j * eph.astype(np.float64))
+    y = S.istft(de.T, 320, 160, length=len(x))                            # :86-87
+    return y * c
+
+
+ENHANCE['g2net'] = enhance_g2net

@@ -379,7 +379,39 @@ def gen_taylorsenet():
     save('taylorsenet', x=x, y=y, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
 
 
-GENS = {'stft': gen_stft, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+def gen_g2net():
+    install_stubs()
+    mod = import_ref('G2Net_VB', 'gaf_net_320')
+    model = mod.gaf_base(3, 64, 2, 4, 4, [1, 2, 5, 9], 256 + 161 * 2, 256, 256, (2, 3), (1, 3), 64, 'cat', 3,
+                         is_aux=False, encoder_type='U2Net', tcm_type='full-band')
+    schema, _ = load_synth(model, 20)
+    save_schema('g2net', schema)
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((2, 2, 30, 161)).astype(np.float32)
+    with torch.no_grad():
+        ys = model(torch.from_numpy(x))
+    y = ys[-1].numpy()
+    y0 = ys[0].numpy()
+
+    def enh(wav, p_in, p_out):
+        xw = np.asarray(wav, dtype=np.float64)
+        c = np.sqrt(np.sum(xw ** 2.0) / len(xw))
+        xt = torch.from_numpy(xw / c)
+        w = torch.hann_window(320, dtype=torch.float64)
+        spec = torch.stft(xt, 320, 160, 320, window=w, return_complex=True).T
+        mag, ph = spec.abs() ** p_in, spec.angle()
+        feat = torch.stack(((mag * torch.cos(ph)).float(), (mag * torch.sin(ph)).float()), dim=0)
+        with torch.no_grad():
+            e = model(feat[None])[-1][0].permute(0, 2, 1)
+        emag, eph = torch.norm(e, dim=0) ** p_out, torch.atan2(e[1], e[0])
+        de = (emag * torch.cos(eph)).double() + 1j * (emag * torch.sin(eph)).double()
+        yy = torch.istft(de.T, 320, 160, 320, window=w, length=len(xt))
+        return (yy * c).numpy()
+    wav = synth.synth_clip(11, 'speech', 6000)
+    save('g2net', x=x, y=y, y0=y0, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
+
+
+GENS = {'stft': gen_stft, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

@@ -518,3 +518,80 @@ def taylorsenet_forward(sd, inputs, order_num=3):
         fact *= (k + 1)
         out = out + upd / fact
     return out
+
+
+# ----------------------------------------------------------------------------
+# G2Net   (reference G2Net_VB/gaf_net_320.py:10-526) for the decode script's constructor (com_decode.py:23):
+# gaf_base(3, 64, 2, 4, 4, [1,2,5,9], 256+161*2, 256, 256, (2,3), (1,3), 64, 'cat', 3, is_aux=False,
+#          encoder_type='U2Net', tcm_type='full-band')
+# ----------------------------------------------------------------------------
+def _g2_gate_conv(sd, p, x):
+    """Gate_2dconv de_flag=False (gaf_net_320.py:465-486): two convs, top pad 1."""
+    x = np.pad(x, ((0, 0), (0, 0), (1, 0), (0, 0)))
+    a = nn.conv2d(x, sd[p + 'conv.1.weight'], sd[p + 'conv.1.bias'], stride=(1, 2))
+    g = nn.conv2d(x, sd[p + 'gate_conv.1.weight'], sd[p + 'gate_conv.1.bias'], stride=(1, 2))
+    return a * nn.sigmoid(g)
+
+
+def _g2_unet_module(sd, p, x, scale):
+    """En_unet_module.forward (:415-431), k2 = (1,3): inner (de)convs have no time extent."""
+    x_resi = _in_prelu(sd, p + 'in_conv.1.', p + 'in_conv.2.', _g2_gate_conv(sd, p + 'in_conv.0.', x))
+    x = x_resi
+    xs = []
+    for i in range(scale):
+        q = f'{p}enco.{i}.conv.'
+        x = _in_prelu(sd, q + '1.', q + '2.', nn.conv2d(x, sd[q + '0.weight'], sd[q + '0.bias'], stride=(1, 2)))
+        xs.append(x)
+    for i in range(scale):
+        q = f'{p}deco.{i}.deconv.'
+        if i > 0:
+            x = np.concatenate([x, xs[-(i + 1)]], axis=1)
+        x = _in_prelu(sd, q + '1.', q + '2.', nn.conv_transpose2d(x, sd[q + '0.weight'], sd[q + '0.bias'], stride=(1, 2)))
+    return x_resi + x
+
+
+def _g2_glu(sd, p, x, d):
+    """Glu (:245-274): single (un-gated) branch, k = 3, causal."""
+    resi = x
+    x = nn.conv1d(x, sd[p + 'in_conv.weight'])
+    y = nn.instancenorm(nn.prelu(x, sd[p + 'left_conv.0.weight']), sd[p + 'left_conv.1.weight'], sd[p + 'left_conv.1.bias'])
+    x = nn.conv1d(np.pad(y, ((0, 0), (0, 0), (2 * d, 0))), sd[p + 'left_conv.3.weight'], dilation=d)
+    y = nn.instancenorm(nn.prelu(x, sd[p + 'out_conv.0.weight']), sd[p + 'out_conv.1.weight'], sd[p + 'out_conv.1.bias'])
+    return nn.conv1d(y, sd[p + 'out_conv.2.weight']) + resi
+
+
+def _g2_tcm_seq(sd, p, x, n_out_idx=2, dils=(1, 2, 5, 9)):
+    """nn.Sequential(*[Tcm_list]*2, Conv1d(256,161,1)[, Sigmoid])."""
+    for i in range(2):
+        for j, d in enumerate(dils):
+            x = _g2_glu(sd, f'{p}{i}.tcm_list.{j}.', x, d)
+    return nn.conv1d(x, sd[f'{p}{n_out_idx}.weight'], sd[f'{p}{n_out_idx}.bias'])
+
+
+def g2net_forward(sd, inpt, stage_num=3):
+    """gaf_base.forward (:73-87): [B,2,T,161] -> list of stage outputs [B,2,161,T]."""
+    B, _, T, _ = inpt.shape
+    x = inpt
+    for i, scale in enumerate((4, 3, 2, 1)):                     # U2Net_Encoder (:277-304)
+        x = _g2_unet_module(sd, f'en.meta_unet_list.{i}.', x, scale)
+    x = _in_prelu(sd, 'en.last_conv.1.', 'en.last_conv.2.', _g2_gate_conv(sd, 'en.last_conv.0.', x))
+    feat = np.swapaxes(x, -2, -1).reshape(B, -1, T)
+    pre = np.swapaxes(inpt, -2, -1)                               # [B,2,161,T]
+    outs = []
+    for s in range(stage_num):                                    # GAF_module.forward (:104-115)
+        p = f'gafs.{s}.'
+        pmag = np.sqrt(pre[:, 0] ** 2 + pre[:, 1] ** 2)
+        pph = np.arctan2(pre[:, -1], pre[:, 0])
+        xin = np.concatenate([feat, pre.reshape(B, -1, T)], axis=1)
+
+        def gate_in(q):
+            a = nn.conv1d(xin, sd[q + 'in_conv_main.weight'], sd[q + 'in_conv_main.bias'])
+            g = nn.conv1d(xin, sd[q + 'in_conv_gate.0.weight'], sd[q + 'in_conv_gate.0.bias'])
+            return a * nn.sigmoid(g)
+        gain = nn.sigmoid(_g2_tcm_seq(sd, p + 'glance_branch.mstcm_filter.', gate_in(p + 'glance_branch.')))   # :142-146
+        xf = gate_in(p + 'focus_branch.')                                                                          # :179-183
+        resi = np.stack([_g2_tcm_seq(sd, p + 'focus_branch.mstcm_r.', xf), _g2_tcm_seq(sd, p + 'focus_branch.mstcm_i.', xf)], 1)
+        xm = pmag * gain
+        pre = np.stack([xm * np.cos(pph), xm * np.sin(pph)], 1) + resi
+        outs.append(pre)
+    return outs

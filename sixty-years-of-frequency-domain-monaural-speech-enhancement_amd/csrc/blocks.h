@@ -23,10 +23,12 @@ struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:
     NormAct nL, nR, nO;
     float *firL = nullptr, *firR = nullptr;
     int K = 0, d = 1;
+    bool gated = true;     // false: single branch (G2Net_VB/gaf_net_320.py:245-274 Glu has no gate)
     // conv_idx: index of the dilated Conv1d inside the branch Sequential; fir_k: ShareSepConv length (0 = none);
     // ks: kernel size of the dilated conv (causal pad (ks-1)*dil)
     void load(const TrackedSD& sd, const std::string& p, int dil, const std::string& left, const std::string& right,
-              int conv_idx, int fir_k, int ks) {
+              int conv_idx, int fir_k, int ks, bool gated_ = true) {
+        gated = gated_;
         d = dil;
         K = fir_k;
         const std::string ci = "." + std::to_string(conv_idx) + ".weight";
@@ -37,15 +39,15 @@ struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:
             return conv_weights(w4, nullptr, false);
         };
         in_conv = make_pointwise_plan(c1(p + "in_conv.weight", 64, 256, 1), ACT_NONE, {}, 401);
-        convR = make_conv_plan(c1(p + right + ci, 64, 64, ks), 1, 0, (ks - 1) * d, 1, d, ACT_SIGMOID, {}, EPI_ACT, 401);
-        convL = make_conv_plan(c1(p + left + ci, 64, 64, ks), 1, 0, (ks - 1) * d, 1, d, ACT_NONE, {}, EPI_MUL, 401);
+        if (gated) convR = make_conv_plan(c1(p + right + ci, 64, 64, ks), 1, 0, (ks - 1) * d, 1, d, ACT_SIGMOID, {}, EPI_ACT, 401);
+        convL = make_conv_plan(c1(p + left + ci, 64, 64, ks), 1, 0, (ks - 1) * d, 1, d, ACT_NONE, {}, gated ? EPI_MUL : EPI_ACT, 401);
         out_conv = make_pointwise_plan(c1(p + "out_conv.2.weight", 256, 64, 1), ACT_NONE, {}, 401, EPI_ADD);
         nL.load(sd, p + left + ".1.", p + left + ".0.");
-        nR.load(sd, p + right + ".1.", p + right + ".0.");
+        if (gated) nR.load(sd, p + right + ".1.", p + right + ".0.");
         nO.load(sd, p + "out_conv.1.", p + "out_conv.0.");
         if (K > 0) {
             firL = to_device(sd.get(p + left + ".2.weight", {1, 1, K}).data);
-            firR = to_device(sd.get(p + right + ".2.weight", {1, 1, K}).data);
+            if (gated) firR = to_device(sd.get(p + right + ".2.weight", {1, 1, K}).data);
         }
     }
     void free() {
@@ -65,8 +67,10 @@ struct TcmScratch {
 // x [B][256][T] -> y [B][256][T]
 inline void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratch& s, int B, int T, hipStream_t st, Profiler* pf) {
     run_pointwise(k.in_conv, x, 256L * T, T, s.h, 64L * T, T, B, T, st, pf);
-    launch_tcm_head(s.h, s.a, k.nR.s, k.nR.g, k.nR.b, k.firR, k.K, B, 64, T, st);
-    run_conv(k.convR, act4(s.a, 64, 1, T), nullptr, s.r, 64, 1, B, T, T, st, pf);
+    if (k.gated) {
+        launch_tcm_head(s.h, s.a, k.nR.s, k.nR.g, k.nR.b, k.firR, k.K, B, 64, T, st);
+        run_conv(k.convR, act4(s.a, 64, 1, T), nullptr, s.r, 64, 1, B, T, T, st, pf);
+    }
     launch_tcm_head(s.h, s.a, k.nL.s, k.nL.g, k.nL.b, k.firL, k.K, B, 64, T, st);
     {
         GCParams p = k.convL.p;

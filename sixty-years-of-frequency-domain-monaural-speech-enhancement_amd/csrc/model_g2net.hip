@@ -1,0 +1,206 @@
+// G2Net (glance-and-gaze) on the MI355X engine.
+//
+// Reference: G2Net_VB/gaf_net_320.py:10-526 for the decode script's constructor (G2Net_VB/com_decode.py:23:
+// gaf_base(3, 64, 2, 4, 4, [1,2,5,9], 256+161*2, 256, 256, (2,3), (1,3), 64, 'cat', 3, is_aux=False,
+// encoder_type='U2Net', tcm_type='full-band')); decode loop com_decode.py:39-88 (x / c with c = RMS, y * c).
+//
+// U^2-Net gated encoder -> 3 GAF stages; a stage fuses [feature(256) ; previous estimate (2x161)] with a gated 1x1
+// conv (one two-source GEMM over (value, gate) row pairs) in a glance branch (-> sigmoid gain per bin) and a focus
+// branch (-> complex residual), each followed by two stacks of un-gated dilated TCMs:
+//   x_{s+1} = gain * x_s + residual                                  (gaf_net_320.py:104-115, |x| e^{j angle x} = x)
+#include "unet.h"
+
+namespace se {
+
+namespace {
+
+constexpr int NFFT = 320, HOP = 160, NBIN = 161, NDIL = 4, NSTAGE = 3;
+constexpr int DIL[NDIL] = {1, 2, 5, 9};
+
+// x_next = gain * pre + resi ; gain [B][161][T], pre / resi / out [B][2][161][T]
+__global__ __launch_bounds__(256) void gaf_combine_kernel(const float* __restrict__ gain, const float* __restrict__ pre,
+                                                          const float* __restrict__ resi, float* __restrict__ out, long plane,
+                                                          long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / plane, r = i - b * plane;
+    const long o = b * 2 * plane + r;
+    const float g = gain[i];
+    out[o] = g * pre[o] + resi[o];
+    out[o + plane] = g * pre[o + plane] + resi[o + plane];
+}
+
+struct G2TcmSeq {      // nn.Sequential(Tcm_list, Tcm_list, Conv1d(256, 161, 1)[, Sigmoid])
+    TcmBlock blk[2 * NDIL];
+    GCPlan out;
+    void load(const TrackedSD& sd, const std::string& p, int act, DenseW* stack_with = nullptr) {
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NDIL; ++j)
+                blk[i * NDIL + j].load(sd, p + std::to_string(i) + ".tcm_list." + std::to_string(j) + ".", DIL[j], "left_conv",
+                                       "left_conv", 3, 0, 3, false);
+        HostTensor w4 = sd.get(p + "2.weight", {NBIN, 256, 1});
+        w4.shape = {NBIN, 256, 1, 1};
+        out = make_pointwise_plan(conv_weights(w4, &sd.get(p + "2.bias", {NBIN}), false), act, {}, 401);
+        (void)stack_with;
+    }
+    void free() {
+        for (auto& b : blk) b.free();
+        gc_free_plan(out);
+    }
+    // x [B][256][T] -> dst ([B] planes of 161 x T at stride dst_b)
+    void run(const float* x, float* const X[2], const TcmScratch& ts, float* dst, long dst_b, int B, int T, hipStream_t st,
+             Profiler* pf) const {
+        for (int n = 0; n < 2 * NDIL; ++n) {
+            float* y = X[n & 1];
+            run_tcm(blk[n], x, y, ts, B, T, st, pf);
+            x = y;
+        }
+        run_pointwise(out, x, 256L * T, T, dst, dst_b, T, B, T, st, pf);
+    }
+};
+
+struct GafStage {
+    GCPlan gin, fin;          // gated input convs of the glance / focus branch (two-source, (value, gate) pairs)
+    G2TcmSeq glance, fr, fi;
+    void load(const TrackedSD& sd, const std::string& p) {
+        auto gate_in = [&](const std::string& q) {
+            auto c1 = [&](const std::string& key) {
+                HostTensor w4 = sd.get(key + "weight", {256, 256 + 2 * NBIN, 1});
+                w4.shape = {256, 256 + 2 * NBIN, 1, 1};
+                return conv_weights(w4, &sd.get(key + "bias", {256}), false);
+            };
+            DenseW w = interleave_rows(c1(q + "in_conv_main."), c1(q + "in_conv_gate.0."));
+            return gc_make_plan(512, 256 + 2 * NBIN, one_tap(), w.w, w.bias, {}, ACT_NONE, EPI_GLU, 1, 1, 0, 401, 1, 256);
+        };
+        gin = gate_in(p + "glance_branch.");
+        fin = gate_in(p + "focus_branch.");
+        glance.load(sd, p + "glance_branch.mstcm_filter.", ACT_SIGMOID);
+        fr.load(sd, p + "focus_branch.mstcm_r.", ACT_NONE);
+        fi.load(sd, p + "focus_branch.mstcm_i.", ACT_NONE);
+    }
+    void free() {
+        gc_free_plan(gin);
+        gc_free_plan(fin);
+        glance.free();
+        fr.free();
+        fi.free();
+    }
+};
+
+class G2Net final : public Model {
+  public:
+    explicit G2Net(EngineCtx& c) : Model(c) {}
+    ~G2Net() override {
+        en.free();
+        for (auto& s : st_) s.free();
+    }
+    StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
+
+    void finalize(const TrackedSD& sd) override {
+        en.load(sd, "en.", 2, UNET_G2NET, 2);
+        for (int s = 0; s < NSTAGE; ++s) st_[s].load(sd, "gafs." + std::to_string(s) + ".");
+    }
+
+    void plan_buffers(int B, int T) override {
+        cur.B = 0;
+        bufs(B, T);
+    }
+
+    // forward returns the LAST stage output, [B,2,161,T] (the decode script takes esti_x_list[-1], com_decode.py:69)
+    void forward(const float* in, const int64_t* shape, int ndim, float* out, hipStream_t st) override {
+        SE_CHECK(ndim == 4 && shape[1] == 2 && shape[3] == NBIN, "G2Net forward expects [B,2,T,161]");
+        const int B = (int)shape[0], T = (int)shape[2];
+        Bufs& b = bufs(B, T);
+        launch_transpose_akt(in, b.spec, T, 2 * B, NBIN, NBIN, (long)T * NBIN, T, (long)NBIN * T, st);
+        const float* y = network(b, st);
+        SE_HIP(hipMemcpyAsync(out, y, (size_t)B * 2 * NBIN * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+
+    void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
+        const int T = 1 + L / HOP;
+        Bufs& b = bufs(B, T);
+        launch_rms_scale(wav, B, L, pitch, b.c, st);        // c_engine = 1 / RMS: x * c_engine == x / RMS (:43-44), y / c_engine == y * RMS (:88)
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, nullptr, T, T, st);      // :49-61
+        const float* y = network(b, st);                                                           // :66-69
+        launch_polar_pow(y, b.est, B, NBIN, T, ctx.p_out, st);                                     // :76-82
+        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :86-88
+    }
+
+  private:
+    struct Bufs {
+        int B = 0, T = 0;
+        float *c, *spec, *est, *frames, *ens[5], *pre[2], *gain, *resi, *hx, *X[2];
+        UnetScratch us;
+        TcmScratch ts;
+    } cur;
+    U2Encoder en;
+    GafStage st_[NSTAGE];
+
+    Bufs& bufs(int B, int T) {
+        if (cur.B == B && cur.T == T) return cur;
+        Arena& a = ctx.arena;
+        a.reset();
+        Bufs b;
+        b.B = B;
+        b.T = T;
+        const size_t BT = (size_t)B * T;
+        const int F[5] = {79, 39, 19, 9, 4};
+        b.c = a.alloc_f(B);
+        b.spec = a.alloc_f(BT * 2 * NBIN);
+        b.est = a.alloc_f(BT * 2 * NBIN);
+        b.pre[0] = a.alloc_f(BT * 2 * NBIN);
+        b.pre[1] = a.alloc_f(BT * 2 * NBIN);
+        b.resi = a.alloc_f(BT * 2 * NBIN);
+        b.gain = a.alloc_f(BT * NBIN);
+        b.frames = a.alloc_f(BT * NFFT);
+        for (int i = 0; i < 5; ++i) b.ens[i] = a.alloc_f(BT * 64 * F[i]);
+        b.hx = a.alloc_f(BT * 256);
+        b.X[0] = a.alloc_f(BT * 256);
+        b.X[1] = a.alloc_f(BT * 256);
+        b.us.alloc(a, BT);
+        b.ts.h = a.alloc_f(BT * 64);
+        b.ts.a = a.alloc_f(BT * 64);
+        b.ts.r = a.alloc_f(BT * 64);
+        b.ts.m = a.alloc_f(BT * 64);
+        cur = b;
+        return cur;
+    }
+
+    void gate_in(const GCPlan& pl, const float* feat, const float* pre, float* dst, int B, int T, hipStream_t st) {
+        GCParams p = pl.p;
+        p.src0 = feat; p.s0_b = 256L * T; p.s0_c = T; p.s0_f = 0; p.C0 = 256;
+        p.src1 = pre; p.s1_b = 2L * NBIN * T; p.s1_c = T; p.s1_f = 0; p.C1 = 2 * NBIN;
+        p.Fin = 1; p.Tin = T; p.B = B; p.Q = 1; p.Tout = T;
+        p.dst = dst; p.d_b = 256L * T; p.d_c = T; p.d_f = 0;
+        gc_launch_prof(pl, p, st, &ctx.prof);
+    }
+
+    // b.spec [B][2][161][T] -> pointer to the last stage output [B][2][161][T]
+    const float* network(Bufs& b, hipStream_t st) {
+        const int B = b.B, T = b.T;
+        Profiler* pf = &ctx.prof;
+        en.run(act4(b.spec, 2, NBIN, T), b.ens, b.us, B, T, st, pf);
+        const float* feat = b.ens[4];            // [B][256][T]
+        const float* pre = b.spec;               // inpt.transpose(-2,-1) is the engine layout already (:78)
+        const long plane = (long)NBIN * T, tot = plane * B;
+        for (int s = 0; s < NSTAGE; ++s) {
+            gate_in(st_[s].gin, feat, pre, b.hx, B, T, st);
+            st_[s].glance.run(b.hx, b.X, b.ts, b.gain, plane, B, T, st, pf);
+            gate_in(st_[s].fin, feat, pre, b.hx, B, T, st);
+            st_[s].fr.run(b.hx, b.X, b.ts, b.resi, 2 * plane, B, T, st, pf);
+            st_[s].fi.run(b.hx, b.X, b.ts, b.resi + plane, 2 * plane, B, T, st, pf);
+            float* nxt = b.pre[s & 1];
+            hipLaunchKernelGGL(gaf_combine_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b.gain, pre, b.resi, nxt,
+                               plane, tot);
+            pre = nxt;
+        }
+        SE_HIP(hipGetLastError());
+        return pre;
+    }
+};
+
+}  // namespace
+
+std::unique_ptr<Model> make_g2net(EngineCtx& ctx) { return std::unique_ptr<Model>(new G2Net(ctx)); }
+
+}  // namespace se

@@ -61,6 +61,26 @@ inline DeconvIN load_gate_deconv_in(const TrackedSD& sd, const std::string& p, i
     return c;
 }
 
+// Key / kernel conventions that differ between the two reference files that share this encoder.
+struct UnetStyle {
+    bool two_conv_gate;   // true: Gate_2dconv = two convs `conv` / `gate_conv` (G2Net); false: one conv to 2C (TaylorSENet)
+    int inner_kt;         // time extent of the nested (de)convs: 2 (TaylorSENet k2 = (2,3)) or 1 (G2Net k2 = (1,3))
+};
+constexpr UnetStyle UNET_TAYLOR{false, 2};
+constexpr UnetStyle UNET_G2NET{true, 1};
+
+// Gate_2dconv (G2Net_VB/gaf_net_320.py:465-486): value and gate are separate convs, always behind a ConstantPad2d
+inline ConvIN load_gate2_conv_in(const TrackedSD& sd, const std::string& p, int cin, int cout, int kt, int kf) {
+    ConvIN c;
+    c.cout = cout;
+    c.kf = kf;
+    DenseW a = conv_weights(sd.get(p + "0.conv.1.weight", {cout, cin, kt, kf}), &sd.get(p + "0.conv.1.bias", {cout}), true);
+    DenseW g = conv_weights(sd.get(p + "0.gate_conv.1.weight", {cout, cin, kt, kf}), &sd.get(p + "0.gate_conv.1.bias", {cout}), true);
+    c.plan = make_conv_plan(interleave_rows(a, g), 2, 0, kt - 1, 1, 1, ACT_NONE, {}, EPI_GLU, 401);
+    c.na.load(sd, p + "1.", p + "2.");
+    return c;
+}
+
 struct UnetScratch {
     float* lev[5] = {};     // encoder levels 1..4 of the nested U-Net
     float* dec[5] = {};     // decoder outputs at levels 0..3
@@ -81,24 +101,30 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
     ConvIN enco[4];
     DeconvIN deco[4];
 
-    void load(const TrackedSD& sd, const std::string& p, int cin, int k1t, int k1f_, int scale_, bool de_, int c0) {
+    void load(const TrackedSD& sd, const std::string& p, int cin, int k1t, int k1f_, int scale_, bool de_, int c0,
+              UnetStyle sty = UNET_TAYLOR) {
         de = de_;
         scale = scale_;
         k1f = k1f_;
         if (de) in_d = load_gate_deconv_in(sd, p + "in_conv.", cin, 64, k1t, k1f, c0);
+        else if (sty.two_conv_gate) in_c = load_gate2_conv_in(sd, p + "in_conv.", cin, 64, k1t, k1f);
         else in_c = load_gate_conv_in(sd, p + "in_conv.", cin, 64, k1t, k1f, c0);
+        const int kt = sty.inner_kt;
+        // Sequential indices: with a time pad / chomp the conv sits at 1 (enc) and the norm at 2; without, 0 and 1
+        const std::string ec = kt > 1 ? "1." : "0.", en = kt > 1 ? "2." : "1.", ep = kt > 1 ? "3." : "2.";
+        const std::string dn = kt > 1 ? "2." : "1.", dp = kt > 1 ? "3." : "2.";
         for (int i = 0; i < scale; ++i) {
             const std::string q = p + "enco." + std::to_string(i) + ".conv.";     // Conv2dunit k2 = (2,3)
             enco[i].cout = 64;
-            DenseW w = conv_weights(sd.get(q + "1.weight", {64, 64, 2, 3}), &sd.get(q + "1.bias", {64}), true);
-            enco[i].plan = make_conv_plan(w, 2, 0, 1, 1, 1, ACT_NONE, {}, EPI_ACT, 401);
-            enco[i].na.load(sd, q + "2.", q + "3.");
+            DenseW w = conv_weights(sd.get(q + ec + "weight", {64, 64, kt, 3}), &sd.get(q + ec + "bias", {64}), true);
+            enco[i].plan = make_conv_plan(w, 2, 0, kt - 1, 1, 1, ACT_NONE, {}, EPI_ACT, 401);
+            enco[i].na.load(sd, q + en, q + ep);
             const std::string r = p + "deco." + std::to_string(i) + ".deconv.";   // Deconv2dunit ('add' for i = 0, else 'cat')
             const int ci = i == 0 ? 64 : 128;
             deco[i].cout = 64;
-            DenseW dw = deconv_weights(sd.get(r + "0.weight", {ci, 64, 2, 3}), &sd.get(r + "0.bias", {64}), true);
+            DenseW dw = deconv_weights(sd.get(r + "0.weight", {ci, 64, kt, 3}), &sd.get(r + "0.bias", {64}), true);
             deco[i].plan = make_deconv_plan(dw, 2, 0, 0, ACT_NONE, {}, 401, i == 0 ? -1 : 64);
-            deco[i].na.load(sd, r + "2.", r + "3.");
+            deco[i].na.load(sd, r + dn, r + dp);
         }
     }
     void free() {
@@ -156,12 +182,14 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
 struct U2Encoder {      // U2Net_Encoder (TaylorSENet.py:336-370)
     UnetModule m[4];
     ConvIN last;
-    void load(const TrackedSD& sd, const std::string& p, int cin) {
-        m[0].load(sd, p + "meta_unet_list.0.", cin, 2, 5, 4, false, -1);
-        m[1].load(sd, p + "meta_unet_list.1.", 64, 1, 3, 3, false, -1);
-        m[2].load(sd, p + "meta_unet_list.2.", 64, 1, 3, 2, false, -1);
-        m[3].load(sd, p + "meta_unet_list.3.", 64, 1, 3, 1, false, -1);
-        last = load_gate_conv_in(sd, p + "last_conv.", 64, 64, 1, 3);
+    // k1t: time extent of the inter-module gated convs (TaylorSENet k1 = (1,3) -> 1; G2Net k1 = (2,3) -> 2)
+    void load(const TrackedSD& sd, const std::string& p, int cin, UnetStyle sty = UNET_TAYLOR, int k1t = 1) {
+        m[0].load(sd, p + "meta_unet_list.0.", cin, 2, 5, 4, false, -1, sty);
+        m[1].load(sd, p + "meta_unet_list.1.", 64, k1t, 3, 3, false, -1, sty);
+        m[2].load(sd, p + "meta_unet_list.2.", 64, k1t, 3, 2, false, -1, sty);
+        m[3].load(sd, p + "meta_unet_list.3.", 64, k1t, 3, 1, false, -1, sty);
+        last = sty.two_conv_gate ? load_gate2_conv_in(sd, p + "last_conv.", 64, 64, k1t, 3)
+                                 : load_gate_conv_in(sd, p + "last_conv.", 64, 64, k1t, 3);
     }
     void free() {
         for (auto& x : m) x.free();

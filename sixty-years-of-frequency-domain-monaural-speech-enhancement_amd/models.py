@@ -212,6 +212,30 @@ def _taylor(**kw):
                        is_conformer=False, is_u2=True, is_param_share=False, is_encoder_share=False, **kw)
 
 
-MODEL_CLASSES = {'fullsubnet': Model, 'taylorsenet': _taylor, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
+class gaf_base(_EngineModule):
+    """G2Net_VB/gaf_net_320.py:10 as built at com_decode.py:23.  forward: RI [B,2,T,161] -> list of stage outputs;
+    the engine returns the list with only the LAST stage ([B,2,161,T]) materialised - the decode script uses [-1]."""
+    _model = 'g2net'
+
+    def __init__(self, kd1=3, cd1=64, tcm_num=2, sub_g1=4, sub_g2=4, dilas=(1, 2, 5, 9), ci=256 + 161 * 2, co1=256,
+                 co2=256, k1=(2, 3), k2=(1, 3), c=64, intra_connect='cat', stage_num=3, is_causal=True, is_aux=True,
+                 encoder_type='U2Net', tcm_type='full-band', **kw):
+        cfg = (kd1, cd1, tcm_num, tuple(dilas), ci, co1, co2, tuple(k1), tuple(k2), c, intra_connect, stage_num,
+               is_causal, is_aux, encoder_type, tcm_type)
+        if cfg != (3, 64, 2, (1, 2, 5, 9), 578, 256, 256, (2, 3), (1, 3), 64, 'cat', 3, True, False, 'U2Net', 'full-band'):
+            raise NotImplementedError("the engine builds the decode script's gaf_base configuration; got " + repr(cfg))
+        super().__init__(**kw)
+
+    def forward(self, x):
+        B, _, T, F = x.shape
+        return [self.engine.forward(x.contiguous(), out_shape=(B, 2, F, T))]
+
+
+def _g2net(**kw):
+    return gaf_base(3, 64, 2, 4, 4, [1, 2, 5, 9], 256 + 161 * 2, 256, 256, (2, 3), (1, 3), 64, 'cat', 3, is_aux=False,
+                    encoder_type='U2Net', tcm_type='full-band', **kw)
+
+
+MODEL_CLASSES = {'fullsubnet': Model, 'g2net': _g2net, 'taylorsenet': _taylor, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
                  'dccrn': lambda **kw: DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
                                              kernel_num=[32, 64, 128, 256, 256, 256], **kw)}

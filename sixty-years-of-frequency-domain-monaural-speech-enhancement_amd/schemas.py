@@ -235,4 +235,9 @@ def taylorsenet_schema():
     return _from_data('taylorsenet')
 
 
-SCHEMAS = {'taylorsenet': taylorsenet_schema, 'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
+def g2net_schema():
+    """G2Net_VB/gaf_net_320.py:10 `gaf_base(...)` as built at com_decode.py:23 (stage_num = 3, 825 keys)."""
+    return _from_data('g2net')
+
+
+SCHEMAS = {'taylorsenet': taylorsenet_schema, 'g2net': g2net_schema, 'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}

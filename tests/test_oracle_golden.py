@@ -96,3 +96,13 @@ def test_ctsnet_matches_reference():
     assert rms(y2 - G['y2']) < 2e-6 * max(rms(G['y2']), 1.0)
     y = D.enhance_ctsnet(sd1, sd2, G['wav'])
     assert rms(y - G['enh']) < 1e-5 * max(rms(G['enh']), 1e-3)       # two chained fp32 networks (reference runs fp32)
+
+
+def test_g2net_matches_reference():
+    G = load_golden('g2net')
+    sd = synth.synth_state_dict(load_schema('g2net'), 20)
+    ys = M.g2net_forward(sd, G['x'])
+    assert rms(ys[-1] - G['y']) < 5e-6 * max(rms(G['y']), 1.0)
+    assert rms(ys[0] - G['y0']) < 5e-6 * max(rms(G['y0']), 1.0)
+    y = D.enhance_g2net(sd, G['wav'])
+    assert rms(y - G['enh']) < 1e-5 * max(rms(G['enh']), 1e-3)

@@ -182,3 +182,20 @@ def enhance_g2net(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
 
 
 ENHANCE['g2net'] = enhance_g2net
+
+
+def enhance_uformer(sd, wav, net_dtype=np.float32):
+    """Uformer/uformer_decode_vb.py:34-62 + the STFT/iSTFT inside Uformer.forward (uformer.py:178, 276):
+    torch.stft(n_fft=512, hop=160, win=400), istft without `length` -> 160*floor(L/160) samples."""
+    wav = np.asarray(wav, dtype=np.float64)
+    c = S.rms_scale(wav)
+    x = (wav * c).astype(net_dtype)                                      # :39 FloatTensor
+    spec = S.stft(x, 512, 160, 400)
+    re, im = spec.real.astype(net_dtype)[None], spec.imag.astype(net_dtype)[None]
+    er, ei = M.uformer_core(sd, re, im)
+    de = er[0].astype(np.float64) + 1j * ei[0].astype(np.float64)
+    y = S.istft(de, 512, 160, 400)
+    return y / c
+
+
+ENHANCE['uformer'] = enhance_uformer

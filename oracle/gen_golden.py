@@ -15,6 +15,7 @@ The decode-loop bodies (`enhance`) are re-stated around the imported model with
 torch.stft/istft (legacy real-output API shimmed) exactly as SURVEY 8(c) says.
 """
 import importlib
+from collections import OrderedDict
 import json
 import os
 import sys
@@ -411,7 +412,39 @@ def gen_g2net():
     save('g2net', x=x, y=y, y0=y0, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
 
 
-GENS = {'stft': gen_stft, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+def gen_uformer():
+    """Uformer.forward hard-codes .cuda() and the legacy real-output torch.stft/istft API: shimmed."""
+    install_stubs()
+    for m in ('uformer', 'dilated_dualpath_conformer', 'trans'):
+        sys.modules.pop(m, None)
+    mod = import_ref('Uformer', 'uformer')
+    model = mod.Uformer()
+    sd_full = model.state_dict()
+    keep = OrderedDict((k, v) for k, v in sd_full.items() if not (k.startswith('stft.') or k.startswith('istft.')))
+    schema = synth.schema_of(keep)
+    sdn = synth.synth_state_dict(schema, 21)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sdn.items()}, strict=False)
+    model.eval()
+    save_schema('uformer', schema)
+    o_stft, o_istft, o_cuda = torch.stft, torch.istft, torch.Tensor.cuda
+    torch.stft = lambda x, **k: torch.view_as_real(o_stft(x, return_complex=True, **k))
+    torch.istft = lambda x, **k: o_istft(torch.view_as_complex(x.contiguous()), **k)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        wav = synth.synth_clip(12, 'speech', 4000)
+        c = np.sqrt(len(wav) / np.sum(wav.astype(np.float64) ** 2.0))
+        xw = torch.FloatTensor(wav.astype(np.float64) * c)
+        with torch.no_grad():
+            out, _, cplx, _ = model(xw[None], xw[None])
+        enh = (out[0].numpy() / c)
+        # the spectral core alone on random spectra (B = 2)
+        rng = np.random.default_rng(14)
+        save('uformer', wav=wav, enh=enh, cplx=cplx.numpy())
+    finally:
+        torch.stft, torch.istft, torch.Tensor.cuda = o_stft, o_istft, o_cuda
+
+
+GENS = {'stft': gen_stft, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

@@ -595,3 +595,193 @@ def g2net_forward(sd, inpt, stage_num=3):
         pre = np.stack([xm * np.cos(pph), xm * np.sin(pph)], 1) + resi
         outs.append(pre)
     return outs
+
+
+# ----------------------------------------------------------------------------
+# Uformer   (reference Uformer/uformer.py:30-287 + conv2d_cplx.py, conv2d_real.py, fusion.py,
+# dilated_dualpath_conformer.py, ff_cplx.py, ff_real.py, linear_cplx.py, linear_real.py, t_att_cplx.py, f_att_cplx.py,
+# t_att_real.py, f_att_real.py, dsconv2d_cplx.py, dsconv2d_real.py).  Complex tensors are (real, imag) pairs of
+# [N,C,F,T] arrays (the reference stacks them on a trailing axis of size 2).
+# ----------------------------------------------------------------------------
+_UEPS = float(np.finfo(np.float32).eps)       # uformer.py:16 EPSILON
+
+
+def _u_ln(sd, p, x):
+    """nn.LayerNorm(C) applied over the channel axis of [N,C,F,T] (x.transpose(1,-1) in the reference)."""
+    mu = x.mean(axis=1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=1, keepdims=True)
+    w = sd[p + 'weight'].astype(x.dtype).reshape(1, -1, 1, 1)
+    b = sd[p + 'bias'].astype(x.dtype).reshape(1, -1, 1, 1)
+    return (x - mu) / np.sqrt(var + 1e-5) * w + b
+
+
+def _u_lin(w, b, x):
+    return np.einsum('oc,ncft->noft', w.astype(x.dtype), x, optimize=True) + b.astype(x.dtype).reshape(1, -1, 1, 1)
+
+
+def _u_rlin(sd, p, x):                         # Real_Linear (linear_real.py:11-24)
+    return _u_lin(sd[p + 'linear.weight'], sd[p + 'linear.bias'], x)
+
+
+def _u_clin(sd, p, r, i):                      # Complex_Linear (linear_cplx.py:11-27)
+    wr, br, wi, bi = sd[p + 'real_linear.weight'], sd[p + 'real_linear.bias'], sd[p + 'imag_linear.weight'], sd[p + 'imag_linear.bias']
+    return _u_lin(wr, br, r) - _u_lin(wi, bi, i), _u_lin(wr, br, i) + _u_lin(wi, bi, r)
+
+
+def _u_fusion(r, i, mag):                      # fusion.py:13-19
+    cm = np.sqrt(np.maximum(r ** 2 + i ** 2, _UEPS))
+    s = nn.sigmoid(mag)
+    return r + s, i + s, mag + nn.sigmoid(cm)
+
+
+def _u_att(q, k, v, axis):
+    """softmax(Q K^T / 4) V along `axis` (3 = time, 2 = frequency) of [N,16,F,T]."""
+    if axis == 3:
+        e = np.einsum('ndft,ndfs->nfts', q, k, optimize=True) / 4.0
+    else:
+        e = np.einsum('ndft,ndgt->ntfg', q, k, optimize=True) / 4.0
+    e = e - e.max(axis=-1, keepdims=True)
+    pr = np.exp(e)
+    pr = pr / pr.sum(axis=-1, keepdims=True)
+    if axis == 3:
+        return np.einsum('nfts,ndfs->ndft', pr, v, optimize=True)
+    return np.einsum('ntfg,ndgt->ndft', pr, v, optimize=True)
+
+
+def _u_catt(sd, p, r, i, axis, nm):
+    """Multihead_Attention_{T,F}_Branch (t_att_cplx.py:73-96 / f_att_cplx.py:65-88), one head."""
+    h = p + 'attn_heads.0.'
+    xr, xi = _u_ln(sd, h + 'layernorm1.', r), _u_ln(sd, h + 'layernorm1.', i)
+    src = {'r': xr, 'i': xi}
+    combos = ['rrr', 'rii', 'iri', 'iir', 'rri', 'rir', 'irr', 'iii']        # (q, k, v) sources of att1..att8
+    outs = []
+    for n, cmb in enumerate(combos):
+        a = f'{h}{nm}_att{n + 1}.'
+        outs.append(_u_att(_u_rlin(sd, a + 'query.', src[cmb[0]]), _u_rlin(sd, a + 'key.', src[cmb[1]]),
+                           _u_rlin(sd, a + 'value.', src[cmb[2]]), axis))
+    A, B, C, D, E, F_, G, H = outs
+    ar, ai = A - B - C - D, E + F_ + G - H
+    ar, ai = _u_ln(sd, h + 'layernorm2.', ar), _u_ln(sd, h + 'layernorm2.', ai)
+    tr, ti = _u_clin(sd, p + 'transform_linear.', ar, ai)
+    pw = sd[p + 'prelu.weight']
+    return nn.prelu(_u_ln(sd, p + 'layernorm3.', tr), pw) + r, nn.prelu(_u_ln(sd, p + 'layernorm3.', ti), pw) + i
+
+
+def _u_ratt(sd, p, x, axis, nm):
+    """Multihead_Attention_{T,F}_Branch_real (t_att_real.py:53-76)."""
+    h = p + 'attn_heads.0.'
+    y = _u_ln(sd, h + 'layernorm1.', x)
+    a = f'{h}{nm}_att.'
+    y = _u_att(_u_rlin(sd, a + 'query.', y), _u_rlin(sd, a + 'key.', y), _u_rlin(sd, a + 'value.', y), axis)
+    y = _u_ln(sd, h + 'layernorm2.', y)
+    y = _u_rlin(sd, p + 'transform_linear.', y)
+    return nn.prelu(_u_ln(sd, p + 'layernorm3.', y), sd[p + 'prelu.weight']) + x
+
+
+def _u_cconv(sd, p, r, i, stride, pad, dil, T, transposed=False, out_pad=(0, 0)):
+    """ComplexConv2d_Encoder / _Decoder (conv2d_cplx.py:11-68): two real (de)convs, output cut to the first T frames."""
+    wr, br, wi, bi = sd[p + 'real_conv.weight'], sd[p + 'real_conv.bias'], sd[p + 'imag_conv.weight'], sd[p + 'imag_conv.bias']
+    if transposed:
+        f = lambda a, w, b: nn.conv_transpose2d(a, w, b, stride=stride, padding=pad, output_padding=out_pad)
+    else:
+        f = lambda a, w, b: nn.conv2d(a, w, b, stride=stride, padding=pad, dilation=dil)
+    return (f(r, wr, br) - f(i, wi, bi))[..., :T], (f(i, wr, br) + f(r, wi, bi))[..., :T]
+
+
+def _u_rconv(sd, p, x, stride, pad, dil, T, transposed=False, out_pad=(0, 0)):
+    if transposed:
+        return nn.conv_transpose2d(x, sd[p + 'conv.weight'], sd[p + 'conv.bias'], stride=stride, padding=pad, output_padding=out_pad)[..., :T]
+    return nn.conv2d(x, sd[p + 'conv.weight'], sd[p + 'conv.bias'], stride=stride, padding=pad, dilation=dil)[..., :T]
+
+
+def _u_ff(sd, p, r, i=None):
+    """FF_Cplx (ff_cplx.py:10-33) / FF_Real (ff_real.py:11-33): LN -> Linear -> PReLU -> Linear, y*0.5 + x."""
+    pw = sd[p + 'prelu.weight']
+    if i is None:
+        y = _u_rlin(sd, p + 'linear1.', _u_ln(sd, p + 'layernorm_linear.', r))
+        return _u_rlin(sd, p + 'linear2.', nn.prelu(y, pw)) * 0.5 + r
+    yr, yi = _u_clin(sd, p + 'linear1.', _u_ln(sd, p + 'layernorm_linear.', r), _u_ln(sd, p + 'layernorm_linear.', i))
+    yr, yi = _u_clin(sd, p + 'linear2.', nn.prelu(yr, pw), nn.prelu(yi, pw))
+    return yr * 0.5 + r, yi * 0.5 + i
+
+
+def _u_dsconv(sd, p, d1, d2, r, i=None):
+    """DSConv2d (dsconv2d_cplx.py:44-60) / DSConv2d_Real (dsconv2d_real.py:44-60)."""
+    T = r.shape[-1]
+    pw = sd[p + 'prelu.weight']
+    if i is None:
+        y = nn.prelu(_u_rconv(sd, p + 'conv1x1.', _u_ln(sd, p + 'layernorm_conv1.', r), 1, 0, 1, T), pw)
+        y1 = _u_rconv(sd, p + 'dconv1.', y, 1, (1, d1), (1, d1), T)
+        y2 = _u_rconv(sd, p + 'dconv2.', y, 1, (1, d2), (1, d2), T)
+        y = _u_ln(sd, p + 'layernorm_conv2.', y1 * nn.sigmoid(y2))
+        return r + _u_rconv(sd, p + 'sconv.', y * nn.sigmoid(y), 1, 0, 1, T)
+    yr, yi = _u_cconv(sd, p + 'conv1x1.', _u_ln(sd, p + 'layernorm_conv1.', r), _u_ln(sd, p + 'layernorm_conv1.', i), 1, 0, 1, T)
+    yr, yi = nn.prelu(yr, pw), nn.prelu(yi, pw)
+    ar, ai = _u_cconv(sd, p + 'dconv1.', yr, yi, 1, (1, d1), (1, d1), T)
+    br, bi = _u_cconv(sd, p + 'dconv2.', yr, yi, 1, (1, d2), (1, d2), T)
+    yr, yi = _u_ln(sd, p + 'layernorm_conv2.', ar * nn.sigmoid(br)), _u_ln(sd, p + 'layernorm_conv2.', ai * nn.sigmoid(bi))
+    sr, si = _u_cconv(sd, p + 'sconv.', yr * nn.sigmoid(yr), yi * nn.sigmoid(yi), 1, 0, 1, T)
+    return r + sr, i + si
+
+
+def uformer_core(sd, re, im):
+    """Spectral part of Uformer.forward (uformer.py:197-262): noisy STFT (re, im) [N,257,T] ->
+    enhanced (real, imag) [N,257,T].  The STFT / iSTFT around it are in oracle/decode.py."""
+    T = re.shape[-1]
+    mag = np.sqrt(np.maximum(re ** 2 + im ** 2, _UEPS))                     # :197
+    phase = np.arctan2(im + _UEPS, re)
+    mag0 = mag[:, None]
+    r, i = (mag * np.cos(phase))[:, None, 1:], (mag * np.sin(phase))[:, None, 1:]   # :205-210
+    m = mag0[:, :, 1:]
+    enc, menc = [], []
+    for k in range(6):                                                      # :214-219
+        r, i = _u_cconv(sd, f'encoder.{k}.0.', r, i, (2, 1), (2, 1), 1, T)
+        bn = lambda a: nn.batchnorm(a, sd[f'encoder.{k}.1.weight'], sd[f'encoder.{k}.1.bias'],
+                                    sd[f'encoder.{k}.1.running_mean'], sd[f'encoder.{k}.1.running_var'])
+        r, i = nn.prelu(bn(r), sd[f'encoder.{k}.2.weight']), nn.prelu(bn(i), sd[f'encoder.{k}.2.weight'])
+        m = _u_rconv(sd, f'encoder_real.{k}.0.', m, (2, 1), (2, 1), 1, T)
+        m = nn.prelu(_bn(sd, f'encoder_real.{k}.1.', m), sd[f'encoder_real.{k}.2.weight'])
+        r, i, m = _u_fusion(r, i, m)
+        enc.append((r, i))
+        menc.append(m)
+    # Dilated_Dualpath_Conformer.forward (dilated_dualpath_conformer.py:53-78)
+    c = 'conformer.'
+    r, i = _u_ff(sd, c + 'ff1_cplx.', r, i)
+    m = _u_ff(sd, c + 'ff1_mag.', m)
+    r, i, m = _u_fusion(r, i, m)
+    r, i = _u_catt(sd, c + 'cplx_tatt.', r, i, 3, 'T')
+    m = _u_ratt(sd, c + 'mag_tatt.', m, 3, 'T')
+    r, i, m = _u_fusion(r, i, m)
+    r, i = _u_catt(sd, c + 'cplx_fatt.', r, i, 2, 'F')
+    m = _u_ratt(sd, c + 'mag_fatt.', m, 2, 'F')
+    r, i, m = _u_fusion(r, i, m)
+    dil = [1, 2, 4, 8, 16, 32, 64, 128]
+    for k in range(8):
+        r, i = _u_dsconv(sd, f'{c}dsconv_cplx.{k}.', dil[k], dil[7 - k], r, i)
+        m = _u_dsconv(sd, f'{c}dsconv_real.{k}.', dil[k], dil[7 - k], m)
+        r, i, m = _u_fusion(r, i, m)
+    r, i = _u_ff(sd, c + 'ff2_cplx.', r, i)
+    m = _u_ff(sd, c + 'ff2_mag.', m)
+    r, i, m = _u_fusion(r, i, m)
+    r, i, m = _u_ln(sd, c + 'ln_conformer_cplx.', r), _u_ln(sd, c + 'ln_conformer_cplx.', i), _u_ln(sd, c + 'ln_conformer_mag.', m)
+    for k in range(6):                                                      # :225-232
+        er, ei = enc[-1 - k]
+        r, i = _u_cconv(sd, f'decoder.{k}.0.', np.concatenate([er, r], 1), np.concatenate([ei, i], 1), (2, 1), (2, 0), 1, T,
+                        True, (1, 0))
+        m = _u_rconv(sd, f'decoder_real.{k}.0.', np.concatenate([menc[-1 - k], m], 1), (2, 1), (2, 0), 1, T, True, (1, 0))
+        if k < 5:
+            bn = lambda a: nn.batchnorm(a, sd[f'decoder.{k}.1.weight'], sd[f'decoder.{k}.1.bias'],
+                                        sd[f'decoder.{k}.1.running_mean'], sd[f'decoder.{k}.1.running_var'])
+            r, i = nn.prelu(bn(r), sd[f'decoder.{k}.2.weight']), nn.prelu(bn(i), sd[f'decoder.{k}.2.weight'])
+            m = nn.prelu(_bn(sd, f'decoder_real.{k}.1.', m), sd[f'decoder_real.{k}.2.weight'])
+        r, i, m = _u_fusion(r, i, m)
+    m = np.pad(nn.sigmoid(m), ((0, 0), (0, 0), (1, 0), (0, 0)))[:, 0] * mag0[:, 0]       # :236-239
+    mr, mi = r[:, 0], i[:, 0]
+    mm = np.sqrt(np.maximum(mr ** 2 + mi ** 2, _UEPS))                     # :244
+    rp, ip = mr / (mm + _UEPS), mi / (mm + _UEPS)
+    mph = np.arctan2(ip + _UEPS, rp)                                        # :248
+    mm = np.pad(np.tanh(mm + _UEPS), ((0, 0), (1, 0), (0, 0)))
+    mph = np.pad(mph, ((0, 0), (1, 0), (0, 0)))
+    est_m = (mm * mag0[:, 0] + m) * 0.5                                     # :254-262
+    est_p = phase + mph
+    return est_m * np.cos(est_p), est_m * np.sin(est_p)

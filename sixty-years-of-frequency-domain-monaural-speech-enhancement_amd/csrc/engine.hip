@@ -66,6 +66,7 @@ int se_engine_create(const se_config* cfg, se_engine** out) {
             case SE_MODEL_CTSNET: e->model = make_ctsnet(e->ctx); break;
             case SE_MODEL_TAYLORSENET: e->model = make_taylorsenet(e->ctx); break;
             case SE_MODEL_G2NET: e->model = make_g2net(e->ctx); break;
+            case SE_MODEL_UFORMER: e->model = make_uformer(e->ctx); break;
             case SE_MODEL_FULLSUBNET: e->model = make_fullsubnet(e->ctx); break;
             default: SE_CHECK(false, "model id " + std::to_string(cfg->model) + " is not built into this engine yet");
         }

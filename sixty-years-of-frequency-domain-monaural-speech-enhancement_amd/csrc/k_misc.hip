@@ -89,7 +89,8 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
 // ---- LayerNorm over (C, F) per (b, t) + residual ------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                            const float* __restrict__ w, const float* __restrict__ bb,
-                                                           float* __restrict__ out, int C, int F, int T, float eps) {
+                                                           float* __restrict__ out, int C, int F, int T, float eps, int post,
+                                                           const float* __restrict__ prelu_slope) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (t >= T) return;
@@ -108,13 +109,16 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
         for (int f = 0; f < F; ++f) {
             const long o = base + ((long)c * F + f) * T;
             float y = (x[o] - mu) * rs * w[f * C + c] + bb[f * C + c];
+            if (post == 1) y = y / (1.f + expf(-y));
+            if (prelu_slope) y = y >= 0.f ? y : prelu_slope[0] * y;
             if (res) y += res[o];
             out[o] = y;
         }
 }
 void launch_layernorm_cf(const float* x, const float* res, const float* w, const float* b, float* out, int B, int C,
-                         int F, int T, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_cf_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, res, w, b, out, C, F, T, eps);
+                         int F, int T, float eps, hipStream_t s, int post, const float* prelu_slope) {
+    hipLaunchKernelGGL(layernorm_cf_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, res, w, b, out, C, F, T, eps, post,
+                       prelu_slope);
     SE_HIP(hipGetLastError());
 }
 

@@ -65,8 +65,10 @@ void launch_polar_pow(const float* x, float* out, int B, int F, int T, float p_o
 // nn.LayerNorm([F, C]) over the (C, F) plane of every (b, t) column of a [B][C][F][T] tensor, affine weight/bias
 // indexed [f][c] (DPCRN/DPCRN.py:56-57 ln1/ln2), fused with the residual add that follows it (:74, :88):
 //   out = LN(x) * w + b + res
+// post: 0 none, 1 swish y*sigmoid(y) (Uformer/dsconv2d_cplx.py:56); prelu_slope: device scalar or null, applied after
+// the norm (Uformer attention branches, t_att_cplx.py:93); order: norm -> post -> prelu -> + res
 void launch_layernorm_cf(const float* x, const float* res, const float* w, const float* b, float* out, int B, int C,
-                         int F, int T, float eps, hipStream_t s);
+                         int F, int T, float eps, hipStream_t s, int post = 0, const float* prelu_slope = nullptr);
 
 // Complex ratio mask applied to the network input (DPCRN/DPCRN.py:33-42) + decode-script decompress
 // (dpcrn_decode_vb.py:48-57): est = (X * M); out = |est|^p_out * est / |est|.   All [B][2][F][T].

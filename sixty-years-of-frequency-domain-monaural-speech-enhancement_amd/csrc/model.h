@@ -65,5 +65,6 @@ std::unique_ptr<Model> make_gcrn(EngineCtx& ctx);
 std::unique_ptr<Model> make_ctsnet(EngineCtx& ctx);
 std::unique_ptr<Model> make_taylorsenet(EngineCtx& ctx);
 std::unique_ptr<Model> make_g2net(EngineCtx& ctx);
+std::unique_ptr<Model> make_uformer(EngineCtx& ctx);
 
 }  // namespace se

@@ -1,0 +1,620 @@
+// Uformer on the MI355X engine.
+//
+// Reference: Uformer/uformer.py:30-287 (Uformer.forward :172-287) with its blocks conv2d_cplx.py, conv2d_real.py,
+// fusion.py, dilated_dualpath_conformer.py:23-78, ff_cplx.py, ff_real.py, linear_cplx.py, linear_real.py,
+// t_att_cplx.py, f_att_cplx.py, t_att_real.py, f_att_real.py, dsconv2d_cplx.py, dsconv2d_real.py; decode loop
+// Uformer/uformer_decode_vb.py:34-62.  STFT (512/160, Hann 400) and iSTFT live INSIDE the model's forward.
+//
+// Engine mapping: a complex tensor [N,C,F,T,2] is stored as [B][2C][F][T] (real planes, then imaginary planes) so
+//   * complex convs / deconvs / linears are real tap-table GEMMs over a 2x2 block weight, BatchNorm3d folded, scalar
+//     PReLU in the epilogue, skip concatenations as two-source K loops;
+//   * LayerNorm over C is one kernel on the [2B][C][F*T] view (real and imaginary parts normalised separately, as
+//     `x.transpose(1,4)` does), with the following swish / PReLU / residual fused;
+//   * the 24 Q/K/V projections of a complex attention are ONE GEMM (rows read the real or the imaginary half through
+//     zero blocks), the 8 real attentions run in one kernel per branch with the A-B-C-D / E+F+G-H combination in
+//     registers (T-branch: 401 x 401 online softmax per (b, f) with K/V tiles in LDS; F-branch: 4 x 4 per (b, t));
+//   * the dilated 3x3 conv pairs use the sigmoid and gate-product epilogues, `fusion` is one elementwise kernel.
+#include "rnn.h"
+
+namespace se {
+
+namespace {
+
+constexpr int NFFT = 512, HOP = 160, WIN = 400, NBIN = 257, NL = 6, CC = 128, HD = 16, NDS = 8;
+constexpr int KN[NL + 1] = {1, 8, 16, 32, 64, 128, 128};
+constexpr float UEPS = 1.1920928955078125e-07f;       // torch.finfo(float32).eps (uformer.py:16)
+
+// ---- :187-210  mag = sqrt(clamp(re^2+im^2, EPS)) [**p_in], phase = atan2(im+EPS, re); network inputs drop the DC bin
+__global__ __launch_bounds__(256) void uf_prep_kernel(const float* __restrict__ spec, float* __restrict__ mag0,
+                                                      float* __restrict__ ph0, float* __restrict__ xc, float* __restrict__ xm,
+                                                      int T, float p_in) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long plane = (long)NBIN * T;
+    const long o = ((long)b * 2 * NBIN + k) * T + t;
+    const float re = spec[o], im = spec[o + plane];
+    float m = sqrtf(fmaxf(re * re + im * im, UEPS));
+    if (p_in != 1.f) m = powf(m, p_in);
+    const float ph = atan2f(im + UEPS, re);
+    mag0[((long)b * NBIN + k) * T + t] = m;
+    ph0[((long)b * NBIN + k) * T + t] = ph;
+    if (k > 0) {
+        const long q = ((long)b * 2 * (NBIN - 1) + (k - 1)) * T + t;
+        xc[q] = m * cosf(ph);
+        xc[q + (long)(NBIN - 1) * T] = m * sinf(ph);
+        xm[((long)b * (NBIN - 1) + (k - 1)) * T + t] = m;
+    }
+}
+
+// ---- fusion.py:13-19 on cplx [B][2C][P] / mag [B][C][P], in place
+__global__ __launch_bounds__(256) void uf_fusion_kernel(float* __restrict__ cplx, float* __restrict__ mag, long CP, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / CP, r = i - b * CP;
+    float* cr = cplx + b * 2 * CP + r;
+    const float re = cr[0], im = cr[CP], m = mag[i];
+    const float cm = sqrtf(fmaxf(re * re + im * im, UEPS));
+    const float s = 1.f / (1.f + expf(-m));
+    cr[0] = re + s;
+    cr[CP] = im + s;
+    mag[i] = m + 1.f / (1.f + expf(-cm));
+}
+
+// ---- attention along T (t_att_cplx.py:15-40, :58-67): pq [B][nh*48][F][T] rows (q,k,v) x 16 per head.
+// One block = 256 queries of one (b, f); per head K/V [16][T] go through LDS; online softmax; heads are combined with
+// signs into out [B][nout*16][F][T] (complex: heads 0-3 -> real (+,-,-,-), heads 4-7 -> imag (+,+,+,-); real: 1 head).
+__global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__ pq, float* __restrict__ out, int F, int T,
+                                                       int nh) {
+    extern __shared__ float kv[];          // K [16][T], V [16][T]
+    float* Ks = kv;
+    float* Vs = kv + HD * T;
+    const int f = blockIdx.x % F, b = blockIdx.x / F;
+    const int t = blockIdx.y * 256 + threadIdx.x;
+    const long P = (long)F * T;
+    const float* base = pq + (long)b * nh * 48 * P + (long)f * T;
+    float accr[HD], acci[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) accr[d] = acci[d] = 0.f;
+    for (int h = 0; h < nh; ++h) {
+        const float* hq = base + (long)h * 48 * P;
+        __syncthreads();
+        for (int i = threadIdx.x; i < HD * T; i += 256) {
+            const int d = i / T, s = i - d * T;
+            Ks[i] = hq[(long)(HD + d) * P + s];
+            Vs[i] = hq[(long)(2 * HD + d) * P + s];
+        }
+        __syncthreads();
+        if (t < T) {
+            float q[HD], o[HD];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                q[d] = hq[(long)d * P + t] * 0.25f;       // / hidden_channel ** 0.5
+                o[d] = 0.f;
+            }
+            float mx = -3.0e38f, l = 0.f;
+            for (int s = 0; s < T; ++s) {
+                float e = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) e += q[d] * Ks[d * T + s];
+                const float mn = fmaxf(mx, e);
+                const float corr = expf(mx - mn), pe = expf(e - mn);
+                l = l * corr + pe;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) o[d] = o[d] * corr + pe * Vs[d * T + s];
+                mx = mn;
+            }
+            const float inv = 1.f / l;
+            const float sg = (nh == 1) ? 1.f : ((h == 0 || (h >= 4 && h < 7)) ? 1.f : -1.f);
+            if (nh == 1 || h < 4) {
+#pragma unroll
+                for (int d = 0; d < HD; ++d) accr[d] += sg * o[d] * inv;
+            } else {
+#pragma unroll
+                for (int d = 0; d < HD; ++d) acci[d] += sg * o[d] * inv;
+            }
+        }
+    }
+    if (t < T) {
+        const int nout = nh == 1 ? 1 : 2;
+        float* ob = out + (long)b * nout * HD * P + (long)f * T + t;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            ob[(long)d * P] = accr[d];
+            if (nout == 2) ob[(long)(HD + d) * P] = acci[d];
+        }
+    }
+}
+
+// ---- attention along F (f_att_cplx.py:13-29): one thread per (b, f_q, t)
+__global__ __launch_bounds__(256) void uf_att_f_kernel(const float* __restrict__ pq, float* __restrict__ out, int F, int T,
+                                                       int nh) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int fq = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long P = (long)F * T;
+    const float* base = pq + (long)b * nh * 48 * P + t;
+    float accr[HD], acci[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) accr[d] = acci[d] = 0.f;
+    for (int h = 0; h < nh; ++h) {
+        const float* hq = base + (long)h * 48 * P;
+        float q[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) q[d] = hq[(long)d * P + (long)fq * T] * 0.25f;
+        float e[8];
+        float mx = -3.0e38f;
+        for (int g = 0; g < F; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s += q[d] * hq[(long)(HD + d) * P + (long)g * T];
+            e[g] = s;
+            mx = fmaxf(mx, s);
+        }
+        float l = 0.f;
+        for (int g = 0; g < F; ++g) {
+            e[g] = expf(e[g] - mx);
+            l += e[g];
+        }
+        const float inv = 1.f / l;
+        const float sg = (nh == 1) ? 1.f : ((h == 0 || (h >= 4 && h < 7)) ? 1.f : -1.f);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            float o = 0.f;
+            for (int g = 0; g < F; ++g) o += e[g] * hq[(long)(2 * HD + d) * P + (long)g * T];
+            if (nh == 1 || h < 4) accr[d] += sg * o * inv;
+            else acci[d] += sg * o * inv;
+        }
+    }
+    const int nout = nh == 1 ? 1 : 2;
+    float* ob = out + (long)b * nout * HD * P + (long)fq * T + t;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        ob[(long)d * P] = accr[d];
+        if (nout == 2) ob[(long)(HD + d) * P] = acci[d];
+    }
+}
+
+// ---- :236-262  sigmoid magnitude mask, tanh complex-magnitude mask + phase add, average, polar -> RI [B][2][257][T]
+__global__ __launch_bounds__(256) void uf_post_kernel(const float* __restrict__ dc, const float* __restrict__ dm,
+                                                      const float* __restrict__ mag0, const float* __restrict__ ph0,
+                                                      float* __restrict__ est, int T, float p_out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long i0 = ((long)b * NBIN + k) * T + t;
+    const float m0 = mag0[i0], p0 = ph0[i0];
+    float mmask = 0.f, cm = 0.f, cph = 0.f;
+    if (k > 0) {
+        const long q = ((long)b * 2 * (NBIN - 1) + (k - 1)) * T + t;
+        const float mr = dc[q], mi = dc[q + (long)(NBIN - 1) * T];
+        const float mg = dm[((long)b * (NBIN - 1) + (k - 1)) * T + t];
+        mmask = 1.f / (1.f + expf(-mg));
+        const float mm = sqrtf(fmaxf(mr * mr + mi * mi, UEPS));
+        const float rp = mr / (mm + UEPS), ip = mi / (mm + UEPS);
+        cm = tanhf(mm + UEPS);
+        cph = atan2f(ip + UEPS, rp);
+    }
+    float em = (cm * m0 + mmask * m0) * 0.5f;
+    if (p_out != 1.f) em = powf(em, p_out);
+    const float ep = p0 + cph;
+    const long o = ((long)b * 2 * NBIN + k) * T + t;
+    est[o] = em * cosf(ep);
+    est[o + (long)NBIN * T] = em * sinf(ep);
+}
+
+// ------------------------------------------------------------------------------------------------ weight helpers
+HostTensor dup2(const HostTensor& t) {         // BatchNorm3d(C) acts on the real and the imaginary planes alike
+    HostTensor o = t;
+    o.shape = {2 * t.numel()};
+    o.data.insert(o.data.end(), t.data.begin(), t.data.end());
+    return o;
+}
+DenseW clinear(const TrackedSD& sd, const std::string& p, int out, int in, float scale = 1.f) {   // Complex_Linear
+    DenseW w = complex_expand(linear_weights(sd.get(p + "real_linear.weight", {out, in}), &sd.get(p + "real_linear.bias", {out})),
+                              linear_weights(sd.get(p + "imag_linear.weight", {out, in}), &sd.get(p + "imag_linear.bias", {out})));
+    for (auto& v : w.w) v *= scale;
+    for (auto& v : w.bias) v *= scale;
+    return w;
+}
+DenseW rlinear(const TrackedSD& sd, const std::string& p, int out, int in, float scale = 1.f) {   // Real_Linear
+    DenseW w = linear_weights(sd.get(p + "linear.weight", {out, in}), &sd.get(p + "linear.bias", {out}));
+    for (auto& v : w.w) v *= scale;
+    for (auto& v : w.bias) v *= scale;
+    return w;
+}
+DenseW cconv(const TrackedSD& sd, const std::string& p, int co, int ci, int kf, int kt, bool deconv) {
+    std::vector<int64_t> sh = deconv ? std::vector<int64_t>{ci, co, kf, kt} : std::vector<int64_t>{co, ci, kf, kt};
+    auto one = [&](const std::string& n) {
+        return deconv ? deconv_weights(sd.get(p + n + ".weight", sh), &sd.get(p + n + ".bias", {co}), false)
+                      : conv_weights(sd.get(p + n + ".weight", sh), &sd.get(p + n + ".bias", {co}), false);
+    };
+    return complex_expand(one("real_conv"), one("imag_conv"));
+}
+struct LnW {
+    float *w = nullptr, *b = nullptr;
+    void load(const TrackedSD& sd, const std::string& p) {
+        w = to_device(sd.get(p + "weight").data);
+        b = to_device(sd.get(p + "bias").data);
+    }
+    void free() {
+        if (w) (void)hipFree(w);
+        if (b) (void)hipFree(b);
+    }
+};
+float* dev_scalar(const TrackedSD& sd, const std::string& key) { return to_device(sd.get(key, {1}).data); }
+
+struct FFBlock {          // FF_Cplx / FF_Real
+    LnW ln;
+    GCPlan l1, l2;
+    void load(const TrackedSD& sd, const std::string& p, bool cplx) {
+        ln.load(sd, p + "layernorm_linear.");
+        DenseW a = cplx ? clinear(sd, p + "linear1.", 64, CC) : rlinear(sd, p + "linear1.", 64, CC);
+        DenseW b = cplx ? clinear(sd, p + "linear2.", CC, 64, 0.5f) : rlinear(sd, p + "linear2.", CC, 64, 0.5f);   // y*0.5 + x
+        l1 = make_pointwise_plan(a, ACT_PRELU, prelu_slopes(sd.get(p + "prelu.weight"), a.M), 1604);
+        l2 = make_pointwise_plan(b, ACT_NONE, {}, 1604, EPI_ADD);
+    }
+    void free() {
+        ln.free();
+        gc_free_plan(l1);
+        gc_free_plan(l2);
+    }
+};
+
+struct AttBlock {         // Multihead_Attention_{T,F}_Branch[_real]
+    LnW ln1, ln2, ln3;
+    GCPlan proj, trans;
+    float* slope = nullptr;
+    int nh = 8;
+    void load(const TrackedSD& sd, const std::string& p, bool cplx, const char* nm) {
+        nh = cplx ? 8 : 1;
+        const std::string h = p + "attn_heads.0.";
+        ln1.load(sd, h + "layernorm1.");
+        ln2.load(sd, h + "layernorm2.");
+        ln3.load(sd, p + "layernorm3.");
+        slope = dev_scalar(sd, p + "prelu.weight");
+        const int K = cplx ? 2 * CC : CC;
+        DenseW w;
+        w.M = nh * 48;
+        w.Cin = K;
+        w.w.assign((size_t)w.M * K, 0.f);
+        w.bias.assign(w.M, 0.f);
+        const char* combos[8] = {"rrr", "rii", "iri", "iir", "rri", "rir", "irr", "iii"};   // (q,k,v) sources :58-65
+        const char* names[3] = {"query", "key", "value"};
+        for (int n = 0; n < nh; ++n) {
+            const std::string a = h + nm + (cplx ? "_att" + std::to_string(n + 1) : std::string("_att")) + ".";
+            for (int j = 0; j < 3; ++j) {
+                const HostTensor& lw = sd.get(a + names[j] + ".linear.weight", {HD, CC});
+                const HostTensor& lb = sd.get(a + names[j] + ".linear.bias", {HD});
+                const int off = (cplx && combos[n][j] == 'i') ? CC : 0;
+                for (int d = 0; d < HD; ++d) {
+                    const int row = n * 48 + j * HD + d;
+                    for (int c = 0; c < CC; ++c) w.w[(size_t)row * K + off + c] = lw.data[d * CC + c];
+                    w.bias[row] = lb.data[d];
+                }
+            }
+        }
+        proj = make_pointwise_plan(w, ACT_NONE, {}, 1604);
+        DenseW t = cplx ? clinear(sd, p + "transform_linear.", CC, HD) : rlinear(sd, p + "transform_linear.", CC, HD);
+        trans = make_pointwise_plan(t, ACT_NONE, {}, 1604);
+    }
+    void free() {
+        ln1.free(); ln2.free(); ln3.free();
+        gc_free_plan(proj);
+        gc_free_plan(trans);
+        if (slope) (void)hipFree(slope);
+    }
+};
+
+struct DsBlock {          // DSConv2d / DSConv2d_Real
+    LnW ln1, ln2;
+    GCPlan c1, d1, d2, sc;
+    void load(const TrackedSD& sd, const std::string& p, bool cplx, int dil1, int dil2) {
+        ln1.load(sd, p + "layernorm_conv1.");
+        ln2.load(sd, p + "layernorm_conv2.");
+        auto conv = [&](const std::string& n, int co, int ci, int k) {
+            if (cplx) return cconv(sd, p + n + ".", co, ci, k, k, false);
+            return conv_weights(sd.get(p + n + ".conv.weight", {co, ci, k, k}), &sd.get(p + n + ".conv.bias", {co}), false);
+        };
+        DenseW a = conv("conv1x1", 32, CC, 1);
+        c1 = make_conv_plan(a, 1, 0, 0, 1, 1, ACT_PRELU, prelu_slopes(sd.get(p + "prelu.weight"), a.M), EPI_ACT, 401);
+        d2 = make_conv_plan(conv("dconv2", 32, 32, 3), 1, 1, dil2, 1, dil2, ACT_SIGMOID, {}, EPI_ACT, 401);
+        d1 = make_conv_plan(conv("dconv1", 32, 32, 3), 1, 1, dil1, 1, dil1, ACT_NONE, {}, EPI_MUL, 401);
+        sc = make_conv_plan(conv("sconv", CC, 32, 1), 1, 0, 0, 1, 1, ACT_NONE, {}, EPI_ADD, 401);
+    }
+    void free() {
+        ln1.free(); ln2.free();
+        for (GCPlan* g : {&c1, &d1, &d2, &sc}) gc_free_plan(*g);
+    }
+};
+
+class Uformer final : public Model {
+  public:
+    explicit Uformer(EngineCtx& c) : Model(c) {}
+    ~Uformer() override {
+        for (int k = 0; k < NL; ++k) {
+            gc_free_plan(encC[k]);
+            gc_free_plan(encR[k]);
+            free_deconv_plan(decC[k]);
+            free_deconv_plan(decR[k]);
+        }
+        for (int j = 0; j < 2; ++j) {
+            ffC[j].free(); ffR[j].free(); attC[j].free(); attR[j].free();
+        }
+        for (int k = 0; k < NDS; ++k) {
+            dsC[k].free();
+            dsR[k].free();
+        }
+        lnC.free();
+        lnR.free();
+    }
+    StftGeom default_geom() const override { return StftGeom{NFFT, HOP, WIN}; }
+    int64_t output_samples(int L) const override { return (int64_t)HOP * (L / HOP); }   // istft without length (:276)
+
+    void finalize(const TrackedSD& sd) override {
+        for (int k = 0; k < NL; ++k) {        // :49-83  (5,2) stride (2,1) pad (2,1) then [..., :T]  -> causal in time
+            const std::string p = "encoder." + std::to_string(k) + ".";
+            DenseW w = cconv(sd, p + "0.", KN[k + 1], KN[k], 5, 2, false);
+            fold_bn(w, dup2(sd.get(p + "1.weight")), dup2(sd.get(p + "1.bias")), dup2(sd.get(p + "1.running_mean")),
+                    dup2(sd.get(p + "1.running_var")));
+            encC[k] = make_conv_plan(w, 2, 2, 1, 1, 1, ACT_PRELU, prelu_slopes(sd.get(p + "2.weight"), w.M), EPI_ACT, 401);
+            const std::string q = "encoder_real." + std::to_string(k) + ".";
+            DenseW r = conv_weights(sd.get(q + "0.conv.weight", {KN[k + 1], KN[k], 5, 2}), &sd.get(q + "0.conv.bias", {KN[k + 1]}), false);
+            fold_bn(r, sd.get(q + "1.weight"), sd.get(q + "1.bias"), sd.get(q + "1.running_mean"), sd.get(q + "1.running_var"));
+            encR[k] = make_conv_plan(r, 2, 2, 1, 1, 1, ACT_PRELU, prelu_slopes(sd.get(q + "2.weight"), r.M), EPI_ACT, 401);
+        }
+        for (int k = 0; k < NL; ++k) {        // :90-158  ConvTranspose2d (5,2) stride (2,1) pad (2,0) out_pad (1,0), [..., :T]
+            const int idx = NL - k, ci = KN[idx], co = KN[idx - 1];
+            const std::string p = "decoder." + std::to_string(k) + ".";
+            DenseW w = cconv(sd, p + "0.", co, 2 * ci, 5, 2, true);
+            // reference channel order of the cat([skip, out]) per part: [skip_r, out_r | skip_i, out_i];
+            // engine two-source order: [skip_r, skip_i | out_r, out_i]
+            std::vector<int> perm(4 * ci);
+            for (int c = 0; c < ci; ++c) {
+                perm[c] = c;
+                perm[ci + c] = 2 * ci + c;
+                perm[2 * ci + c] = ci + c;
+                perm[3 * ci + c] = 3 * ci + c;
+            }
+            permute_cin(w, perm);
+            const std::string q = "decoder_real." + std::to_string(k) + ".";
+            DenseW r = deconv_weights(sd.get(q + "0.conv.weight", {2 * ci, co, 5, 2}), &sd.get(q + "0.conv.bias", {co}), false);
+            std::vector<float> sc, sr;
+            int act = ACT_NONE;
+            if (k < NL - 1) {
+                fold_bn(w, dup2(sd.get(p + "1.weight")), dup2(sd.get(p + "1.bias")), dup2(sd.get(p + "1.running_mean")),
+                        dup2(sd.get(p + "1.running_var")));
+                fold_bn(r, sd.get(q + "1.weight"), sd.get(q + "1.bias"), sd.get(q + "1.running_mean"), sd.get(q + "1.running_var"));
+                sc = prelu_slopes(sd.get(p + "2.weight"), w.M);
+                sr = prelu_slopes(sd.get(q + "2.weight"), r.M);
+                act = ACT_PRELU;
+            }
+            decC[k] = make_deconv_plan(w, 2, 2, 0, act, sc, 401, 2 * ci);
+            decR[k] = make_deconv_plan(r, 2, 2, 0, act, sr, 401, ci);
+        }
+        const std::string c = "conformer.";
+        ffC[0].load(sd, c + "ff1_cplx.", true);
+        ffR[0].load(sd, c + "ff1_mag.", false);
+        ffC[1].load(sd, c + "ff2_cplx.", true);
+        ffR[1].load(sd, c + "ff2_mag.", false);
+        attC[0].load(sd, c + "cplx_tatt.", true, "T");
+        attR[0].load(sd, c + "mag_tatt.", false, "T");
+        attC[1].load(sd, c + "cplx_fatt.", true, "F");
+        attR[1].load(sd, c + "mag_fatt.", false, "F");
+        const int dil[NDS] = {1, 2, 4, 8, 16, 32, 64, 128};
+        for (int k = 0; k < NDS; ++k) {
+            dsC[k].load(sd, c + "dsconv_cplx." + std::to_string(k) + ".", true, dil[k], dil[NDS - 1 - k]);
+            dsR[k].load(sd, c + "dsconv_real." + std::to_string(k) + ".", false, dil[k], dil[NDS - 1 - k]);
+        }
+        lnC.load(sd, c + "ln_conformer_cplx.");
+        lnR.load(sd, c + "ln_conformer_mag.");
+    }
+
+    void plan_buffers(int B, int T) override {
+        cur.B = 0;
+        bufs(B, T);
+    }
+
+    // model(wav, wav)[0]: [B, L] waveform -> [B, 160*floor(L/160)]  (the STFT / iSTFT are inside the model)
+    void forward(const float* in, const int64_t* shape, int ndim, float* out, hipStream_t st) override {
+        SE_CHECK(ndim == 2, "Uformer forward expects waveforms [B, L]");
+        run(in, shape[1], (int)shape[0], (int)shape[1], out, (long)output_samples((int)shape[1]), false, st);
+    }
+    void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
+        run(wav, pitch, B, L, out, out_pitch, true, st);                  // uformer_decode_vb.py:35-36,62
+    }
+
+  private:
+    struct Bufs {
+        int B = 0, T = 0;
+        float *c, *spec, *est, *frames, *mag0, *ph0, *xc, *xm;
+        float *EC[NL], *ER[NL], *DC[NL], *DR[NL];
+        float *XC[2], *XR[2], *t1, *t2, *t3, *pq;
+    } cur;
+    GCPlan encC[NL], encR[NL];
+    DeconvPlan decC[NL], decR[NL];
+    FFBlock ffC[2], ffR[2];
+    AttBlock attC[2], attR[2];
+    DsBlock dsC[NDS], dsR[NDS];
+    LnW lnC, lnR;
+
+    Bufs& bufs(int B, int T) {
+        if (cur.B == B && cur.T == T) return cur;
+        Arena& a = ctx.arena;
+        a.reset();
+        Bufs b;
+        b.B = B;
+        b.T = T;
+        const size_t BT = (size_t)B * T;
+        b.c = a.alloc_f(B);
+        b.spec = a.alloc_f(BT * 2 * NBIN);
+        b.est = a.alloc_f(BT * 2 * NBIN);
+        b.frames = a.alloc_f(BT * NFFT);
+        b.mag0 = a.alloc_f(BT * NBIN);
+        b.ph0 = a.alloc_f(BT * NBIN);
+        b.xc = a.alloc_f(BT * 2 * 256);
+        b.xm = a.alloc_f(BT * 256);
+        int F = 256;
+        for (int k = 0; k < NL; ++k) {
+            F /= 2;
+            b.EC[k] = a.alloc_f(BT * 2 * KN[k + 1] * F);
+            b.ER[k] = a.alloc_f(BT * KN[k + 1] * F);
+        }
+        F = 4;
+        for (int k = 0; k < NL; ++k) {
+            F *= 2;
+            b.DC[k] = a.alloc_f(BT * 2 * KN[NL - k - 1] * F);
+            b.DR[k] = a.alloc_f(BT * KN[NL - k - 1] * F);
+        }
+        const size_t P = BT * 4;
+        for (int j = 0; j < 2; ++j) {
+            b.XC[j] = a.alloc_f(P * 2 * CC);
+            b.XR[j] = a.alloc_f(P * CC);
+        }
+        b.t1 = a.alloc_f(P * 2 * CC);
+        b.t2 = a.alloc_f(P * 2 * CC);
+        b.t3 = a.alloc_f(P * 2 * CC);
+        b.pq = a.alloc_f(P * 8 * 48);
+        cur = b;
+        return cur;
+    }
+
+    // pointwise GEMM on a [B][C][P] tensor
+    void pw(const GCPlan& pl, const float* x, int Cin, float* y, int Cout, const float* res, int B, long P, hipStream_t st) {
+        GCParams p = pl.p;
+        p.src0 = x; p.s0_b = Cin * P; p.s0_c = P; p.s0_f = 0; p.src1 = nullptr;
+        p.Fin = 1; p.Tin = (int)P; p.B = B; p.Q = 1; p.Tout = (int)P;
+        p.dst = y; p.d_b = Cout * P; p.d_c = P; p.d_f = 0;
+        if (res) { p.aux = res; p.x_b = Cout * P; p.x_c = P; p.x_f = 0; }
+        gc_launch_prof(pl, p, st, &ctx.prof);
+    }
+    void fusion(float* c, float* m, int B, long CP, hipStream_t st) {
+        const long tot = (long)B * CP;
+        hipLaunchKernelGGL(uf_fusion_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c, m, CP, tot);
+    }
+    // LayerNorm over C of a [Bv][C][P] view
+    void ln(const LnW& w, const float* x, float* y, int Bv, int C, long P, hipStream_t st, int post = 0, const float* slope = nullptr,
+            const float* res = nullptr) {
+        launch_layernorm_cf(x, res, w.w, w.b, y, Bv, C, 1, (int)P, 1e-5f, st, post, slope);
+    }
+
+    void ff(const FFBlock& f, bool cplx, const float* x, float* y, Bufs& b, long P, hipStream_t st) {
+        const int m = cplx ? 2 : 1;
+        ln(f.ln, x, b.t1, m * b.B, CC, P, st);
+        pw(f.l1, b.t1, m * CC, b.t2, m * 64, nullptr, b.B, P, st);
+        pw(f.l2, b.t2, m * 64, y, m * CC, x, b.B, P, st);
+    }
+    void att(const AttBlock& a, bool cplx, bool along_t, const float* x, float* y, Bufs& b, int F, int T, hipStream_t st) {
+        const int m = cplx ? 2 : 1, B = b.B;
+        const long P = (long)F * T;
+        ln(a.ln1, x, b.t1, m * B, CC, P, st);
+        pw(a.proj, b.t1, m * CC, b.pq, a.nh * 48, nullptr, B, P, st);
+        if (along_t) {
+            const size_t lds = (size_t)2 * HD * T * sizeof(float);
+            SE_CHECK(lds <= 64 * 1024, "utterance too long for the LDS-resident T-attention K/V tiles");
+            hipLaunchKernelGGL(uf_att_t_kernel, dim3(B * F, (T + 255) / 256), dim3(256), lds, st, b.pq, b.t2, F, T, a.nh);
+        } else {
+            SE_CHECK(F <= 8, "F-attention kernel is built for the 4-bin bottleneck");
+            hipLaunchKernelGGL(uf_att_f_kernel, dim3((T + 255) / 256, F, B), dim3(256), 0, st, b.pq, b.t2, F, T, a.nh);
+        }
+        ln(a.ln2, b.t2, b.t1, m * B, HD, P, st);
+        pw(a.trans, b.t1, m * HD, b.t3, m * CC, nullptr, B, P, st);
+        ln(a.ln3, b.t3, y, m * B, CC, P, st, 0, a.slope, x);
+    }
+    void ds(const DsBlock& d, bool cplx, const float* x, float* y, Bufs& b, int F, int T, hipStream_t st) {
+        const int m = cplx ? 2 : 1, B = b.B;
+        const long P = (long)F * T;
+        Profiler* pf = &ctx.prof;
+        ln(d.ln1, x, b.t1, m * B, CC, P, st);
+        run_conv(d.c1, act4(b.t1, m * CC, F, T), nullptr, b.t2, m * 32, F, B, T, T, st, pf);
+        run_conv(d.d2, act4(b.t2, m * 32, F, T), nullptr, b.t3, m * 32, F, B, T, T, st, pf);
+        {
+            GCParams p = d.d1.p;
+            Act4 a = act4(b.t2, m * 32, F, T);
+            p.src0 = a.p; p.s0_b = a.sb; p.s0_c = a.sc; p.s0_f = a.sf; p.src1 = nullptr;
+            p.Fin = F; p.Tin = T; p.B = B; p.Q = F; p.Tout = T;
+            p.dst = b.t1; p.d_b = (long)m * 32 * P; p.d_c = P; p.d_f = T;
+            p.aux = b.t3; p.x_b = (long)m * 32 * P; p.x_c = P; p.x_f = T;
+            gc_launch_prof(d.d1, p, st, pf);
+        }
+        ln(d.ln2, b.t1, b.t2, m * B, 32, P, st, 1);
+        {
+            GCParams p = d.sc.p;
+            Act4 a = act4(b.t2, m * 32, F, T);
+            p.src0 = a.p; p.s0_b = a.sb; p.s0_c = a.sc; p.s0_f = a.sf; p.src1 = nullptr;
+            p.Fin = F; p.Tin = T; p.B = B; p.Q = F; p.Tout = T;
+            p.dst = y; p.d_b = (long)m * CC * P; p.d_c = P; p.d_f = T;
+            p.aux = x; p.x_b = (long)m * CC * P; p.x_c = P; p.x_f = T;
+            gc_launch_prof(d.sc, p, st, pf);
+        }
+    }
+
+    void run(const float* wav, long pitch, int B, int L, float* out, long out_pitch, bool normalise, hipStream_t st) {
+        const int T = 1 + L / HOP;
+        Bufs& b = bufs(B, T);
+        Profiler* pf = &ctx.prof;
+        if (normalise) launch_rms_scale(wav, B, L, pitch, b.c, st);
+        const float* cs = normalise ? b.c : nullptr;
+        launch_stft(ctx.geom, wav, pitch, B, L, L, cs, 1.f, b.spec, nullptr, T, T, st);          // uformer.py:178
+        hipLaunchKernelGGL(uf_prep_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, b.spec, b.mag0, b.ph0, b.xc, b.xm, T,
+                           ctx.p_in);
+        // ---- encoder (:214-219)
+        Act4 xc = act4(b.xc, 2, 256, T), xm = act4(b.xm, 1, 256, T);
+        int F = 256;
+        for (int k = 0; k < NL; ++k) {
+            F /= 2;
+            run_conv(encC[k], xc, nullptr, b.EC[k], 2 * KN[k + 1], F, B, T, T, st, pf);
+            run_conv(encR[k], xm, nullptr, b.ER[k], KN[k + 1], F, B, T, T, st, pf);
+            fusion(b.EC[k], b.ER[k], B, (long)KN[k + 1] * F * T, st);
+            xc = act4(b.EC[k], 2 * KN[k + 1], F, T);
+            xm = act4(b.ER[k], KN[k + 1], F, T);
+        }
+        // ---- dilated dual-path conformer at [B][128][4][T] (dilated_dualpath_conformer.py:53-78)
+        const long P = 4L * T, CP = (long)CC * P;
+        const float *c = b.EC[NL - 1], *m = b.ER[NL - 1];
+        int pp = 0;
+        auto step = [&](auto&& fc, auto&& fr) {
+            fc(c, b.XC[pp]);
+            fr(m, b.XR[pp]);
+            fusion(b.XC[pp], b.XR[pp], B, CP, st);
+            c = b.XC[pp];
+            m = b.XR[pp];
+            pp ^= 1;
+        };
+        step([&](const float* x, float* y) { ff(ffC[0], true, x, y, b, P, st); }, [&](const float* x, float* y) { ff(ffR[0], false, x, y, b, P, st); });
+        step([&](const float* x, float* y) { att(attC[0], true, true, x, y, b, 4, T, st); },
+             [&](const float* x, float* y) { att(attR[0], false, true, x, y, b, 4, T, st); });
+        step([&](const float* x, float* y) { att(attC[1], true, false, x, y, b, 4, T, st); },
+             [&](const float* x, float* y) { att(attR[1], false, false, x, y, b, 4, T, st); });
+        for (int k = 0; k < NDS; ++k)
+            step([&](const float* x, float* y) { ds(dsC[k], true, x, y, b, 4, T, st); },
+                 [&](const float* x, float* y) { ds(dsR[k], false, x, y, b, 4, T, st); });
+        step([&](const float* x, float* y) { ff(ffC[1], true, x, y, b, P, st); }, [&](const float* x, float* y) { ff(ffR[1], false, x, y, b, P, st); });
+        ln(lnC, c, b.XC[pp], 2 * B, CC, P, st);
+        ln(lnR, m, b.XR[pp], B, CC, P, st);
+        c = b.XC[pp];
+        m = b.XR[pp];
+        // ---- decoder (:225-232): cat([skip, out]) two-source, fusion after every layer
+        F = 4;
+        for (int k = 0; k < NL; ++k) {
+            const int ci = KN[NL - k], co = KN[NL - k - 1];
+            Act4 s0 = act4(b.EC[NL - 1 - k], 2 * ci, F, T), s1 = act4(c, 2 * ci, F, T);
+            run_deconv(decC[k], s0, &s1, b.DC[k], 2 * co, 2 * F, B, T, T, st, pf);
+            Act4 r0 = act4(b.ER[NL - 1 - k], ci, F, T), r1 = act4(m, ci, F, T);
+            run_deconv(decR[k], r0, &r1, b.DR[k], co, 2 * F, B, T, T, st, pf);
+            F *= 2;
+            fusion(b.DC[k], b.DR[k], B, (long)co * F * T, st);
+            c = b.DC[k];
+            m = b.DR[k];
+        }
+        hipLaunchKernelGGL(uf_post_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, c, m, b.mag0, b.ph0, b.est, T, ctx.p_out);
+        SE_HIP(hipGetLastError());
+        launch_istft(ctx.geom, b.est, B, T, T, b.frames, cs, out, out_pitch, HOP * (T - 1), st);  // :276
+    }
+};
+
+}  // namespace
+
+std::unique_ptr<Model> make_uformer(EngineCtx& ctx) { return std::unique_ptr<Model>(new Uformer(ctx)); }
+
+}  // namespace se

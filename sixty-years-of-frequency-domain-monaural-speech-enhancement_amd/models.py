@@ -236,6 +236,30 @@ def _g2net(**kw):
                     encoder_type='U2Net', tcm_type='full-band', **kw)
 
 
-MODEL_CLASSES = {'fullsubnet': Model, 'g2net': _g2net, 'taylorsenet': _taylor, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
+class Uformer(_EngineModule):
+    """Uformer/uformer.py:30 `Uformer()`.  forward(inputs, src): waveforms [B, L] -> (enhanced waveform
+    [B, 160*floor(L/160)], src, None, None) - the STFT / iSTFT are inside the model (uformer.py:178, 276); the spectra the
+    reference also returns (training-only) are not materialised."""
+    _model = 'uformer'
+    _IGNORED = ('stft.K', 'stft.w', 'istft.K', 'istft.w')
+
+    def __init__(self, win_len=400, win_inc=160, fft_len=512, win_type='hanning', fid=None, **kw):
+        if (win_len, win_inc, fft_len) != (400, 160, 512):
+            raise NotImplementedError("the engine builds Uformer() with its default front end (400/160/512)")
+        super().__init__(**kw)
+
+    def load_state_dict(self, sd, strict=True):
+        return super().load_state_dict({k: v for k, v in sd.items() if k not in self._IGNORED}, strict)
+
+    def forward(self, inputs, src=None):
+        B, L = inputs.shape
+        out = self.engine.forward(inputs.contiguous(), out_shape=(B, self.engine.output_samples(L)))
+        return out, src, None, None
+
+    def __call__(self, inputs, src=None):
+        return self.forward(inputs, src)
+
+
+MODEL_CLASSES = {'fullsubnet': Model, 'uformer': Uformer, 'g2net': _g2net, 'taylorsenet': _taylor, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,
                  'dccrn': lambda **kw: DCCRN(rnn_units=256, masking_mode='E', use_clstm=True,
                                              kernel_num=[32, 64, 128, 256, 256, 256], **kw)}

@@ -240,4 +240,10 @@ def g2net_schema():
     return _from_data('g2net')
 
 
-SCHEMAS = {'taylorsenet': taylorsenet_schema, 'g2net': g2net_schema, 'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
+def uformer_schema():
+    """Uformer/uformer.py:30 `Uformer()` (664 keys).  The reference state dict also carries the frozen conv-STFT
+    kernels `stft.K, stft.w, istft.K, istft.w` that forward never uses: accepted and ignored."""
+    return _from_data('uformer')
+
+
+SCHEMAS = {'taylorsenet': taylorsenet_schema, 'uformer': uformer_schema, 'g2net': g2net_schema, 'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}

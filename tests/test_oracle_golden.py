@@ -106,3 +106,11 @@ def test_g2net_matches_reference():
     assert rms(ys[0] - G['y0']) < 5e-6 * max(rms(G['y0']), 1.0)
     y = D.enhance_g2net(sd, G['wav'])
     assert rms(y - G['enh']) < 1e-5 * max(rms(G['enh']), 1e-3)
+
+
+def test_uformer_matches_reference():
+    G = load_golden('uformer')
+    sd = synth.synth_state_dict(load_schema('uformer'), 21)
+    y = D.enhance_uformer(sd, G['wav'])
+    assert y.shape == G['enh'].shape
+    assert rms(y - G['enh']) < 1e-5 * max(rms(G['enh']), 1e-3)

@@ -5,7 +5,7 @@ from se_amd import schemas
 from conftest import load_schema
 
 
-@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'dccrn', 'fullsubnet', 'gcrn', 'cts_step1', 'cts_step2', 'taylorsenet', 'g2net'])
+@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'dccrn', 'fullsubnet', 'gcrn', 'cts_step1', 'cts_step2', 'taylorsenet', 'g2net', 'uformer'])
 def test_schema_matches_reference(name):
     ref = load_schema(name)
     mine = schemas.SCHEMAS[name]()

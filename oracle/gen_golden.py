@@ -310,13 +310,13 @@ def gen_gcrn():
     save('gcrn', x=x, y=y, wav=wav, enh=_enhance_librosa_family(model, wav, 'ri', 0.5, 2.0))
 
 
-def gen_ctsnet():
-    m1 = import_ref('CTSNet', 'Step1_network').Step1_net()
+def gen_ctsnet(ref_dir='CTSNet', tag=''):
+    m1 = import_ref(ref_dir, 'Step1_network').Step1_net()
     sch1, _ = load_synth(m1, 17)
-    m2 = import_ref('CTSNet', 'Step2_network').Step2_net(X=6, R=3)
+    m2 = import_ref(ref_dir, 'Step2_network').Step2_net(X=6, R=3)
     sch2, _ = load_synth(m2, 18)
-    save_schema('cts_step1', sch1)
-    save_schema('cts_step2', sch2)
+    save_schema('cts_step1' + tag, sch1)
+    save_schema('cts_step2' + tag, sch2)
     rng = np.random.default_rng(11)
     x1 = np.abs(rng.standard_normal((2, 40, 161))).astype(np.float32)
     x2 = rng.standard_normal((2, 4, 40, 161)).astype(np.float32)
@@ -345,16 +345,16 @@ def gen_ctsnet():
         y = torch.istft(de.T, 320, 160, 320, window=torch.hann_window(320, dtype=torch.float64))[:wav_len]
         return (y / c).numpy()
     wav = synth.synth_clip(9, 'speech', 8000)
-    save('ctsnet', x1=x1, y1=y1, x2=x2, y2=y2, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
+    save('ctsnet' + tag, x1=x1, y1=y1, x2=x2, y2=y2, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
 
 
-def gen_taylorsenet():
-    mod = import_ref('TaylorSENet', 'TaylorSENet')
+def gen_taylorsenet(ref_dir='TaylorSENet', tag=''):
+    mod = import_ref(ref_dir, 'TaylorSENet')
     model = mod.TaylorSENet(cin=2, k1=(1, 3), k2=(2, 3), c=64, kd1=5, cd1=64, d_feat=256, dilations=[1, 2, 5, 9], p=2,
                             fft_num=320, order_num=3, intra_connect='cat', inter_connect='cat', is_causal=True,
                             is_conformer=False, is_u2=True, is_param_share=False, is_encoder_share=False)
     schema, _ = load_synth(model, 19)
-    save_schema('taylorsenet', schema)
+    save_schema('taylorsenet' + tag, schema)
     rng = np.random.default_rng(12)
     x = rng.standard_normal((2, 2, 30, 161)).astype(np.float32)
     with torch.no_grad():
@@ -377,16 +377,16 @@ def gen_taylorsenet():
         y = torch.istft(de.T, 320, 160, 320, window=torch.hann_window(320, dtype=torch.float64), length=wav_len)
         return (y / c).numpy()
     wav = synth.synth_clip(10, 'speech', 6000)
-    save('taylorsenet', x=x, y=y, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
+    save('taylorsenet' + tag, x=x, y=y, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
 
 
-def gen_g2net():
+def gen_g2net(ref_dir='G2Net_VB', tag=''):
     install_stubs()
-    mod = import_ref('G2Net_VB', 'gaf_net_320')
+    mod = import_ref(ref_dir, 'gaf_net_320')
     model = mod.gaf_base(3, 64, 2, 4, 4, [1, 2, 5, 9], 256 + 161 * 2, 256, 256, (2, 3), (1, 3), 64, 'cat', 3,
                          is_aux=False, encoder_type='U2Net', tcm_type='full-band')
     schema, _ = load_synth(model, 20)
-    save_schema('g2net', schema)
+    save_schema('g2net' + tag, schema)
     rng = np.random.default_rng(13)
     x = rng.standard_normal((2, 2, 30, 161)).astype(np.float32)
     with torch.no_grad():
@@ -409,7 +409,7 @@ def gen_g2net():
         yy = torch.istft(de.T, 320, 160, 320, window=w, length=len(xt))
         return (yy * c).numpy()
     wav = synth.synth_clip(11, 'speech', 6000)
-    save('g2net', x=x, y=y, y0=y0, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
+    save('g2net' + tag, x=x, y=y, y0=y0, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
 
 
 def gen_uformer():
@@ -444,7 +444,20 @@ def gen_uformer():
         torch.stft, torch.istft, torch.Tensor.cuda = o_stft, o_istft, o_cuda
 
 
-GENS = {'stft': gen_stft, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+def gen_ctsnet_new():
+    """CTSNet_new: CTSNet with every InstanceNorm replaced by CumulativeLayerNorm (Step1_network.py:213-286)."""
+    gen_ctsnet('CTSNet_new', '_new')
+
+
+def gen_taylorsenet_new():
+    gen_taylorsenet('TaylorSENet_new', '_new')
+
+
+def gen_g2net_new():
+    gen_g2net('G2Net_new', '_new')
+
+
+GENS = {'stft': gen_stft, 'ctsnet_new': gen_ctsnet_new, 'taylorsenet_new': gen_taylorsenet_new, 'g2net_new': gen_g2net_new, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

@@ -305,8 +305,16 @@ def gcrn_forward(sd, x):
 # ----------------------------------------------------------------------------
 # CTSNet   (reference CTSNet/Step1_network.py:12-211, CTSNet/Step2_network.py:13-210)
 # ----------------------------------------------------------------------------
-def _in2d(sd, p, x):
+def _norm(sd, p, x):
+    """InstanceNorm{1,2}d(affine) of the base models, or the CumulativeLayerNorm of the `_new` variants (same position
+    in every nn.Sequential; parameters are `gain` / `bias` there) - selected by the keys present in the state dict."""
+    if p + 'gain' in sd:
+        return nn.cumulative_layernorm(x, sd[p + 'gain'], sd[p + 'bias'])
     return nn.instancenorm(x, sd[p + 'weight'], sd[p + 'bias'])
+
+
+def _in2d(sd, p, x):
+    return _norm(sd, p, x)
 
 
 def _cts_gate_conv(sd, p, x, stride=(1, 2)):
@@ -341,13 +349,13 @@ def _cts_glu(sd, p, x, d, left='left_conv', right='right_conv'):
 
     def branch(name):
         y = nn.prelu(x, sd[p + name + '.0.weight'])
-        y = nn.instancenorm(y, sd[p + name + '.1.weight'], sd[p + name + '.1.bias'])
+        y = _norm(sd, p + name + '.1.', y)
         y = _share_sep_conv(sd[p + name + '.2.weight'], y)
         y = np.pad(y, ((0, 0), (0, 0), (4 * d, 0)))
         return nn.conv1d(y, sd[p + name + '.4.weight'], dilation=d)
     x = branch(left) * nn.sigmoid(branch(right))
     y = nn.prelu(x, sd[p + 'out_conv.0.weight'])
-    y = nn.instancenorm(y, sd[p + 'out_conv.1.weight'], sd[p + 'out_conv.1.bias'])
+    y = _norm(sd, p + 'out_conv.1.', y)
     return nn.conv1d(y, sd[p + 'out_conv.2.weight']) + resi
 
 
@@ -405,7 +413,7 @@ def cts_step2_forward(sd, inpt, R=3, X=6):
 # order_num=3, intra/inter 'cat', causal, no conformer, U2 encoder, no sharing.
 # ----------------------------------------------------------------------------
 def _in_prelu(sd, p_in, p_pr, x):
-    return nn.prelu(nn.instancenorm(x, sd[p_in + 'weight'], sd[p_in + 'bias']), sd[p_pr + 'weight'])
+    return nn.prelu(_norm(sd, p_in, x), sd[p_pr + 'weight'])
 
 
 def _gate_conv2d(sd, p, x, kt):
@@ -476,11 +484,11 @@ def _squeezed_tcm(sd, p, x, d, k=5):
 
     def branch(name):
         y = nn.prelu(x, sd[p + name + '.0.weight'])
-        y = nn.instancenorm(y, sd[p + name + '.1.weight'], sd[p + name + '.1.bias'])
+        y = _norm(sd, p + name + '.1.', y)
         y = np.pad(y, ((0, 0), (0, 0), ((k - 1) * d, 0)))
         return nn.conv1d(y, sd[p + name + '.3.weight'], dilation=d)
     x = branch('left_conv') * nn.sigmoid(branch('right_conv'))
-    y = nn.instancenorm(nn.prelu(x, sd[p + 'out_conv.0.weight']), sd[p + 'out_conv.1.weight'], sd[p + 'out_conv.1.bias'])
+    y = _norm(sd, p + 'out_conv.1.', nn.prelu(x, sd[p + 'out_conv.0.weight']))
     return nn.conv1d(y, sd[p + 'out_conv.2.weight']) + resi
 
 
@@ -554,9 +562,9 @@ def _g2_glu(sd, p, x, d):
     """Glu (:245-274): single (un-gated) branch, k = 3, causal."""
     resi = x
     x = nn.conv1d(x, sd[p + 'in_conv.weight'])
-    y = nn.instancenorm(nn.prelu(x, sd[p + 'left_conv.0.weight']), sd[p + 'left_conv.1.weight'], sd[p + 'left_conv.1.bias'])
+    y = _norm(sd, p + 'left_conv.1.', nn.prelu(x, sd[p + 'left_conv.0.weight']))
     x = nn.conv1d(np.pad(y, ((0, 0), (0, 0), (2 * d, 0))), sd[p + 'left_conv.3.weight'], dilation=d)
-    y = nn.instancenorm(nn.prelu(x, sd[p + 'out_conv.0.weight']), sd[p + 'out_conv.1.weight'], sd[p + 'out_conv.1.bias'])
+    y = _norm(sd, p + 'out_conv.1.', nn.prelu(x, sd[p + 'out_conv.0.weight']))
     return nn.conv1d(y, sd[p + 'out_conv.2.weight']) + resi
 
 

@@ -82,6 +82,22 @@ def instancenorm(x, weight, bias, eps=1e-5):
     return y
 
 
+def cumulative_layernorm(x, gain, bias, eps=1e-5):
+    """CumulativeLayerNorm2d / 1d of the `_new` variants (CTSNet_new/Step1_network.py:213-286): at frame t the statistics
+    run over all channels (and frequencies) of frames <= t.  x [B,C,T,F] or [B,C,T]; gain / bias [1,C,1(,1)].
+    Variance uses the reference's formula (sum x^2 - 2 mu sum x) / n + mu^2."""
+    axes = (1, 3) if x.ndim == 4 else (1,)
+    per = x.shape[1] * (x.shape[3] if x.ndim == 4 else 1)
+    step = x.sum(axis=axes, keepdims=True)
+    step2 = (x ** 2).sum(axis=axes, keepdims=True)
+    cs, cp = np.cumsum(step, axis=2), np.cumsum(step2, axis=2)
+    cnt = (per * np.arange(1, x.shape[2] + 1)).astype(x.dtype)
+    cnt = cnt.reshape((1, 1, -1, 1) if x.ndim == 4 else (1, 1, -1))
+    mu = cs / cnt
+    var = (cp - 2 * mu * cs) / cnt + mu ** 2
+    return (x - mu) / np.sqrt(var + eps) * gain.astype(x.dtype) + bias.astype(x.dtype)
+
+
 # ----------------------------------------------------------------------------
 # linear / conv
 # ----------------------------------------------------------------------------

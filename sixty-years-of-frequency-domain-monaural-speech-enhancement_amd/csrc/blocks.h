@@ -6,8 +6,10 @@ namespace se {
 
 struct NormAct {
     float *g = nullptr, *b = nullptr, *s = nullptr;
+    bool cum = false;      // CumulativeLayerNorm (`_new` variants: parameters `gain` / `bias`) instead of InstanceNorm
     void load(const TrackedSD& sd, const std::string& in_key, const std::string& prelu_key) {
-        g = to_device(sd.get(in_key + "weight").data);
+        cum = sd.has(in_key + "gain");
+        g = to_device(sd.get(in_key + (cum ? "gain" : "weight")).data);
         b = to_device(sd.get(in_key + "bias").data);
         s = to_device(sd.get(prelu_key + "weight").data);
     }
@@ -17,6 +19,17 @@ struct NormAct {
         g = b = s = nullptr;
     }
 };
+
+// norm -> PReLU on x [B][C][F][T] (in place allowed)
+inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int C, int F, int T, hipStream_t st) {
+    if (n.cum) launch_cln(x, y, n.g, n.b, nullptr, n.s, nullptr, 0, B, C, F, T, st);
+    else launch_instnorm_prelu(x, y, n.g, n.b, n.s, B, C, F * T, st);
+}
+// PReLU -> norm -> shared FIR on x [B][C][T]
+inline void tcm_head(const NormAct& n, const float* fir, int K, const float* x, float* y, int B, int C, int T, hipStream_t st) {
+    if (n.cum) launch_cln(x, y, n.g, n.b, n.s, nullptr, fir, K, B, C, 1, T, st);
+    else launch_tcm_head(x, y, n.s, n.g, n.b, fir, K, B, C, T, st);
+}
 
 struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:126-158)
     GCPlan in_conv, convL, convR, out_conv;
@@ -68,10 +81,10 @@ struct TcmScratch {
 inline void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratch& s, int B, int T, hipStream_t st, Profiler* pf) {
     run_pointwise(k.in_conv, x, 256L * T, T, s.h, 64L * T, T, B, T, st, pf);
     if (k.gated) {
-        launch_tcm_head(s.h, s.a, k.nR.s, k.nR.g, k.nR.b, k.firR, k.K, B, 64, T, st);
+        tcm_head(k.nR, k.firR, k.K, s.h, s.a, B, 64, T, st);
         run_conv(k.convR, act4(s.a, 64, 1, T), nullptr, s.r, 64, 1, B, T, T, st, pf);
     }
-    launch_tcm_head(s.h, s.a, k.nL.s, k.nL.g, k.nL.b, k.firL, k.K, B, 64, T, st);
+    tcm_head(k.nL, k.firL, k.K, s.h, s.a, B, 64, T, st);
     {
         GCParams p = k.convL.p;
         p.src0 = s.a; p.s0_b = 64L * T; p.s0_c = T; p.s0_f = T; p.src1 = nullptr;
@@ -80,7 +93,7 @@ inline void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratc
         p.aux = s.r; p.x_b = 64L * T; p.x_c = T; p.x_f = T;
         gc_launch_prof(k.convL, p, st, pf);
     }
-    launch_tcm_head(s.m, s.a, k.nO.s, k.nO.g, k.nO.b, nullptr, 0, B, 64, T, st);
+    tcm_head(k.nO, nullptr, 0, s.m, s.a, B, 64, T, st);
     {
         GCParams p = k.out_conv.p;
         p.src0 = s.a; p.s0_b = 64L * T; p.s0_c = T; p.s0_f = 0; p.src1 = nullptr;

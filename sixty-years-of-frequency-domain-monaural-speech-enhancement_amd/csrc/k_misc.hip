@@ -288,6 +288,123 @@ void launch_tcm_head(const float* x, float* y, const float* slope, const float* 
     SE_HIP(hipGetLastError());
 }
 
+// ---- CumulativeLayerNorm (the `_new` variants) ----------------------------------------------------------------
+// Frame t is normalised with the mean / variance of ALL rows of frames 0..t (CTSNet_new/Step1_network.py:213-286).
+// x [B][R][T] with R = C * F rows (F = 1 for the 1-D flavour); three passes: per-frame sums over the rows, an
+// in-LDS prefix scan per utterance, then normalise + affine (+ PReLU before / after, + the TCM branch FIR).
+__global__ __launch_bounds__(256) void cln_stats_kernel(const float* __restrict__ x, const float* __restrict__ pre_slope,
+                                                        double* __restrict__ sum, double* __restrict__ sq, int R, int F,
+                                                        int T) {
+    __shared__ double sh[2][4][64];
+    const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6, t = blockIdx.x * 64 + tl, b = blockIdx.y;
+    double s = 0.0, q = 0.0;
+    if (t < T) {
+        const float* xp = x + (long)b * R * T + t;
+        for (int r = rg; r < R; r += 4) {
+            float v = xp[(long)r * T];
+            if (pre_slope) v = v >= 0.f ? v : pre_slope[r / F] * v;
+            s += v;
+            q += (double)v * v;
+        }
+    }
+    sh[0][rg][tl] = s;
+    sh[1][rg][tl] = q;
+    __syncthreads();
+    if (rg == 0 && t < T) {
+        sum[(long)b * T + t] = sh[0][0][tl] + sh[0][1][tl] + sh[0][2][tl] + sh[0][3][tl];
+        sq[(long)b * T + t] = sh[1][0][tl] + sh[1][1][tl] + sh[1][2][tl] + sh[1][3][tl];
+    }
+}
+
+__global__ __launch_bounds__(256) void cln_scan_kernel(const double* __restrict__ sum, const double* __restrict__ sq,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int R, int T) {
+    extern __shared__ double sc[];       // [2][T]
+    const int b = blockIdx.x;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        sc[t] = sum[(long)b * T + t];
+        sc[T + t] = sq[(long)b * T + t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, q = 0.0;
+        for (int t = 0; t < T; ++t) {
+            a += sc[t];
+            q += sc[T + t];
+            sc[t] = a;
+            sc[T + t] = q;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const double cnt = (double)R * (t + 1), mu = sc[t] / cnt;
+        const double var = (sc[T + t] - 2.0 * mu * sc[t]) / cnt + mu * mu;
+        mean[(long)b * T + t] = (float)mu;
+        rstd[(long)b * T + t] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+__global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gain, const float* __restrict__ bias,
+                                                        const float* __restrict__ pre_slope,
+                                                        const float* __restrict__ post_slope, const float* __restrict__ fir,
+                                                        int K, int R, int F, int T) {
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
+    if (t >= T) return;
+    const float* mu = mean + (long)b * T;
+    const float* rs = rstd + (long)b * T;
+    for (int r = blockIdx.y * 8; r < min(R, blockIdx.y * 8 + 8); ++r) {
+        const int c = r / F;
+        const float* xp = x + ((long)b * R + r) * T;
+        const float g = gain[c], bt = bias[c], ps = pre_slope ? pre_slope[c] : 1.f;
+        auto nrm = [&](int ti) {
+            float v = xp[ti];
+            v = v >= 0.f ? v : ps * v;
+            return (v - mu[ti]) * rs[ti] * g + bt;
+        };
+        float o;
+        if (K <= 0) {
+            o = nrm(t);
+            if (post_slope) o = o >= 0.f ? o : post_slope[c] * o;
+        } else {
+            o = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const int ti = t - (K - 1) + k;
+                if (ti >= 0) o += fir[k] * nrm(ti);
+            }
+        }
+        y[((long)b * R + r) * T + t] = o;
+    }
+}
+
+void launch_cln(const float* x, float* y, const float* gain, const float* bias, const float* pre_slope,
+                const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s) {
+    // per-(b, t) statistics live in a small engine-lifetime buffer (grown on first use, never on the steady-state path)
+    static thread_local char* stat = nullptr;
+    static thread_local size_t cap = 0;
+    const size_t need = (size_t)B * T * (2 * sizeof(double) + 2 * sizeof(float));
+    if (need > cap) {
+        if (stat) {
+            SE_HIP(hipStreamSynchronize(s));
+            SE_HIP(hipFree(stat));
+        }
+        SE_HIP(hipMalloc(&stat, need));
+        cap = need;
+    }
+    SE_CHECK(K <= 0 || x != y, "cLN + FIR cannot run in place");
+    SE_CHECK((size_t)T * 16 <= 60000, "utterance too long for the LDS-resident cLN scan");
+    double* sum = (double*)stat;
+    double* sq = sum + (size_t)B * T;
+    float* mean = (float*)(sq + (size_t)B * T);
+    float* rstd = mean + (size_t)B * T;
+    const int R = C * F;
+    hipLaunchKernelGGL(cln_stats_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T);
+    hipLaunchKernelGGL(cln_scan_kernel, dim3(B), dim3(256), (size_t)T * 16, s, sum, sq, mean, rstd, R, T);
+    hipLaunchKernelGGL(cln_apply_kernel, dim3((T + 255) / 256, (R + 7) / 8, B), dim3(256), 0, s, x, y, mean, rstd, gain,
+                       bias, pre_slope, post_slope, fir, K, R, F, T);
+    SE_HIP(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ y, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

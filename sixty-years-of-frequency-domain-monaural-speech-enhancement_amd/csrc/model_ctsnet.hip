@@ -38,7 +38,7 @@ struct GatedEncoder {
         Act4 x = in0;
         for (int i = 0; i < 5; ++i) {
             run_conv(conv[i], x, i == 0 ? in1 : nullptr, E[i], 64, EF[i], B, T, T, st, pf);
-            launch_instnorm_prelu(E[i], E[i], na[i].g, na[i].b, na[i].s, B, 64, EF[i] * T, st);
+            norm2d_prelu(na[i], E[i], E[i], B, 64, EF[i], T, st);
             x = act4(E[i], 64, EF[i], T);
         }
     }
@@ -73,7 +73,7 @@ struct GatedDecoder {
             const int co = i == 4 ? 1 : 64;
             Act4 a1 = act4(E[4 - i], 64, a0.F, T);
             run_deconv(dc[i], a0, &a1, D[i], co, DF[i], B, T, T, st, pf);
-            launch_instnorm_prelu(D[i], D[i], na[i].g, na[i].b, na[i].s, B, co, DF[i] * T, st);
+            norm2d_prelu(na[i], D[i], D[i], B, co, DF[i], T, st);
             a0 = act4(D[i], co, DF[i], T);
         }
         GCParams p = fc.p;    // Linear(161,161) over F

@@ -199,7 +199,7 @@ class TaylorSENet final : public Model {
         {
             Act4 a1 = act4(b.ens[0], 64, 79, T);
             run_deconv(zlast.plan, a0, &a1, b.dlast, 16, NBIN, B, T, T, st, pf);
-            launch_instnorm_prelu(b.dlast, b.dlast, zlast.na.g, zlast.na.b, zlast.na.s, B, 16, NBIN * T, st);
+            norm2d_prelu(zlast.na, b.dlast, b.dlast, B, 16, NBIN, T, st);
             run_conv(zgain, act4(b.dlast, 16, NBIN, T), nullptr, b.gain, 1, NBIN, B, T, T, st, pf);
         }
         const long plane = (long)NBIN * T, tot = plane * B;

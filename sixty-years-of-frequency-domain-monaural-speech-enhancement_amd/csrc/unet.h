@@ -143,10 +143,10 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
         const int F0 = out_F(in0.F);
         if (de) {
             run_deconv(in_d.plan, in0, in1, out, 64, F0, B, T, T, st, pf);
-            launch_instnorm_prelu(out, out, in_d.na.g, in_d.na.b, in_d.na.s, B, 64, F0 * T, st);
+            norm2d_prelu(in_d.na, out, out, B, 64, F0, T, st);
         } else {
             run_conv(in_c.plan, in0, in1, out, 64, F0, B, T, T, st, pf);
-            launch_instnorm_prelu(out, out, in_c.na.g, in_c.na.b, in_c.na.s, B, 64, F0 * T, st);
+            norm2d_prelu(in_c.na, out, out, B, 64, F0, T, st);
         }
         int Fs[6];
         Fs[0] = F0;
@@ -158,7 +158,7 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
             Fs[i + 1] = (Fs[i] - 3) / 2 + 1;
             float* y = s.lev[lvl(Fs[i + 1])];
             run_conv(enco[i].plan, act4(xs[i], 64, Fs[i], T), nullptr, y, 64, Fs[i + 1], B, T, T, st, pf);
-            launch_instnorm_prelu(y, y, enco[i].na.g, enco[i].na.b, enco[i].na.s, B, 64, Fs[i + 1] * T, st);
+            norm2d_prelu(enco[i].na, y, y, B, 64, Fs[i + 1], T, st);
             xs[i + 1] = y;
         }
         const float* x = xs[scale];
@@ -172,7 +172,7 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
                 Act4 a1 = act4(xs[scale - i], 64, Fi, T);          // x_list[-(i+1)]
                 run_deconv(deco[i].plan, a0, &a1, y, 64, Fo, B, T, T, st, pf);
             }
-            launch_instnorm_prelu(y, y, deco[i].na.g, deco[i].na.b, deco[i].na.s, B, 64, Fo * T, st);
+            norm2d_prelu(deco[i].na, y, y, B, 64, Fo, T, st);
             x = y;
         }
         launch_add(out, x, out, (long)B * 64 * F0 * T, st);         // x_resi + x
@@ -204,7 +204,7 @@ struct U2Encoder {      // U2Net_Encoder (TaylorSENet.py:336-370)
             x = act4(ens[i], 64, F[i], T);
         }
         run_conv(last.plan, x, nullptr, ens[4], 64, 4, B, T, T, st, pf);
-        launch_instnorm_prelu(ens[4], ens[4], last.na.g, last.na.b, last.na.s, B, 64, 4 * T, st);
+        norm2d_prelu(last.na, ens[4], ens[4], B, 64, 4, T, st);
     }
 };
 

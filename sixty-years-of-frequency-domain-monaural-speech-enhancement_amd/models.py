@@ -12,7 +12,8 @@ from .engine import Engine
 
 class _EngineModule:
     """Common plumbing: lazy engine creation, strict state-dict load, torch-like call surface."""
-    _model = None          # key into _lib.MODEL_IDS / schemas.SCHEMAS
+    _model = None          # key into _lib.MODEL_IDS
+    _schema = None         # key into schemas.SCHEMAS (defaults to _model)
     p_in = 1.0             # magnitude exponents the decode script applies around the network
     p_out = 1.0
 
@@ -29,7 +30,7 @@ class _EngineModule:
     # -- reference-compatible surface -------------------------------------------------------------
     @classmethod
     def state_dict_schema(cls):
-        return schemas.SCHEMAS[cls._model]()
+        return schemas.SCHEMAS[cls._schema or cls._model]()
 
     def load_state_dict(self, sd, strict=True):
         assert strict, "the engine only supports strict loads (as every reference decode script does)"
@@ -129,11 +130,6 @@ class _CtsStage(_EngineModule):
     """One CTSNet stage; the engine model `ctsnet` holds both stages under the key prefixes step1. / step2."""
     _model = 'ctsnet'
     _prefix = ''
-    _schema = ''
-
-    @classmethod
-    def state_dict_schema(cls):
-        return schemas.SCHEMAS[cls._schema]()
 
     def load_state_dict(self, sd, strict=True):
         want = self.state_dict_schema()
@@ -171,6 +167,8 @@ class Step2_net(_CtsStage):
 class CTSNet:
     """The two chained stages of CTSNet/two_stage_com_decode_vb.py:13-16,78-84 in one engine (decode path)."""
 
+    _stages = (Step1_net, Step2_net)
+
     def __init__(self, **kw):
         self._kw = kw
         self.engine = None
@@ -185,8 +183,8 @@ class CTSNet:
         return self
 
     def load_synthetic(self, seed1=17, seed2=18):
-        return self.load_state_dicts(synth.synth_state_dict(schemas.cts_step1_schema(), seed1),
-                                     synth.synth_state_dict(schemas.cts_step2_schema(), seed2))
+        return self.load_state_dicts(synth.synth_state_dict(self._stages[0].state_dict_schema(), seed1),
+                                     synth.synth_state_dict(self._stages[1].state_dict_schema(), seed2))
 
     def enhance_batch(self, wav):
         return self.engine.enhance_batch(wav)

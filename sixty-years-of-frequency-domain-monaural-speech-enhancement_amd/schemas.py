@@ -246,4 +246,23 @@ def uformer_schema():
     return _from_data('uformer')
 
 
+def cln_variant(schema):
+    """The `*_new` flavour of a schema: every InstanceNorm (a 1-D `weight` with a sibling 1-D `bias`) becomes a
+    CumulativeLayerNorm with `gain` / `bias` of shape [1,C,1,1] (2-D) or [1,C,1] (inside a TCM), same position
+    (CTSNet_new/Step1_network.py:213-286)."""
+    out = OrderedDict()
+    for k, (shape, dt) in schema.items():
+        stem, leaf = k.rsplit('.', 1)
+        is_norm = (len(shape) == 1 and len(schema.get(stem + '.weight', ((), ''))[0]) == 1 and stem + '.bias' in schema
+                   and len(schema[stem + '.bias'][0]) == 1 and leaf in ('weight', 'bias'))
+        if not is_norm:
+            out[k] = (shape, dt)
+            continue
+        one_d = 'tcm' in stem or 'glu_list' in stem
+        new_shape = (1, shape[0], 1) if one_d else (1, shape[0], 1, 1)
+        out[stem + ('.gain' if leaf == 'weight' else '.bias')] = (new_shape, dt)
+    return out
+
+
 SCHEMAS = {'taylorsenet': taylorsenet_schema, 'uformer': uformer_schema, 'g2net': g2net_schema, 'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
+SCHEMAS.update({n + '_new': (lambda n=n: cln_variant(SCHEMAS[n]())) for n in ('cts_step1', 'cts_step2', 'taylorsenet', 'g2net')})

@@ -28,8 +28,10 @@ def synth_state_dict(schema, seed=0):
         elif len(shape) <= 1 and leaf.startswith('weight'):
             # norm gains; scalar / per-channel PReLU slopes
             v = rng.uniform(0.1, 0.4, shape) if shape in ((1,), ()) else rng.uniform(0.5, 1.5, shape)
-        elif len(shape) <= 1:
-            v = rng.uniform(-0.1, 0.1, shape)                 # biases
+        elif leaf == 'gain':
+            v = rng.uniform(0.5, 1.5, shape)                  # CumulativeLayerNorm gain [1,C,1(,1)]
+        elif len(shape) <= 1 or (leaf == 'bias' and shape[0] == 1):
+            v = rng.uniform(-0.1, 0.1, shape)                 # biases (cLN bias is [1,C,1(,1)])
         else:
             fan_in = int(np.prod(shape[1:]))
             bound = 1.0 / np.sqrt(fan_in)

@@ -114,3 +114,46 @@ def test_uformer_matches_reference():
     y = D.enhance_uformer(sd, G['wav'])
     assert y.shape == G['enh'].shape
     assert rms(y - G['enh']) < 1e-5 * max(rms(G['enh']), 1e-3)
+
+
+# ---- the `*_new` directories: same networks with CumulativeLayerNorm, decoded with the 0.5 / 2.0 exponents ----------
+def test_cumulative_layernorm_against_definition():
+    """cLN statistics at frame t == plain mean / biased variance over everything up to t."""
+    from oracle import nnops
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 7, 5))
+    g, b = rng.uniform(0.5, 1.5, (1, 3, 1, 1)), rng.uniform(-0.1, 0.1, (1, 3, 1, 1))
+    y = nnops.cumulative_layernorm(x, g, b)
+    for t in range(7):
+        seg = x[:, :, :t + 1, :]
+        mu = seg.mean(axis=(1, 2, 3), keepdims=True)
+        var = seg.var(axis=(1, 2, 3), keepdims=True)
+        want = (x[:, :, t:t + 1] - mu) / np.sqrt(var + 1e-5) * g + b
+        assert np.allclose(y[:, :, t:t + 1], want, atol=1e-10)
+
+
+def test_taylorsenet_new_matches_reference():
+    G = load_golden('taylorsenet_new')
+    sd = _sd('taylorsenet_new', 19)
+    y = M.taylorsenet_forward(sd, G['x'])
+    assert rms(y - G['y']) < 5e-6 * max(rms(G['y']), 1.0), rms(y - G['y'])
+    e = D.enhance_taylorsenet(sd, G['wav'], 0.5, 2.0)
+    assert rms(e - G['enh_cprs']) < 1e-5 * max(rms(G['enh_cprs']), 1e-3)
+
+
+def test_g2net_new_matches_reference():
+    G = load_golden('g2net_new')
+    sd = _sd('g2net_new', 20)
+    ys = M.g2net_forward(sd, G['x'])
+    assert rms(ys[-1] - G['y']) < 5e-6 * max(rms(G['y']), 1.0)
+    e = D.enhance_g2net(sd, G['wav'], 0.5, 2.0)
+    assert rms(e - G['enh_cprs']) < 1e-5 * max(rms(G['enh_cprs']), 1e-3)
+
+
+def test_ctsnet_new_matches_reference():
+    G = load_golden('ctsnet_new')
+    sd1, sd2 = _sd('cts_step1_new', 17), _sd('cts_step2_new', 18)
+    assert rms(M.cts_step1_forward(sd1, G['x1']) - G['y1']) < 5e-6 * max(rms(G['y1']), 1.0)
+    assert rms(M.cts_step2_forward(sd2, G['x2']) - G['y2']) < 5e-6 * max(rms(G['y2']), 1.0)
+    e = D.enhance_ctsnet(sd1, sd2, G['wav'], 0.5, 2.0)
+    assert rms(e - G['enh_cprs']) < 1e-5 * max(rms(G['enh_cprs']), 1e-3)

@@ -1,0 +1,220 @@
+// Weight-stationary LSTM recurrence for LARGE hidden sizes (H = 512 / 1024): ONE cooperative launch walks all time
+// steps with W_hh spread over the register files of the whole chip.
+//
+// Reference: the nn.LSTM layers of LSTM/LSTM.py:18-20 (3 x 1024), CRN/CRN.py:19 (2 x 1024), GCRN's GLSTM
+// (GCRN/GCRN_noncprs.py:5-39, 2 groups x 512 per layer) and FullSubNet's full-band model (sequence_model.py:66-84,
+// 2 x 512).  W_hh is 4H x H fp32 = 16 MB at H = 1024: it fits neither LDS nor one CU, and streaming it from L2 /
+// Infinity Cache once per time step (the per-step GEMM launch this replaces) is what bounded those models.
+//
+// MI355X mapping: a workgroup owns 16 hidden units (64 gate rows); wave w keeps the 16 rows of its 4 units as
+// v_mfma_f32_16x16x4_f32 A-fragments in H/4 VGPRs for the whole utterance.  H/16 workgroups ("unit slices") cover
+// one LSTM; the remaining CUs are filled by slicing the sequences (SS "sequence slices", weights replicated).  Per
+// step a workgroup stages h_{t-1} of 16 sequences ([16][H], coalesced 16 B loads) into LDS, every wave multiplies
+// its rows against it, the cell update is lane-local (gate-interleaved rows) and h_t is published to a
+// double-buffered exchange tensor hx[2][S][H]; unit slices of the same sequence slice then meet at a release /
+// acquire counter barrier in global memory (cross-XCD: agent-scope fences).  The K order is permuted
+// (k = l4*H/4 + kg) identically on both operands so that a lane's B values are contiguous (ds_read_b128).
+#include "kernels.h"
+#include "common.h"
+#include <type_traits>
+
+namespace se {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for_c(F&& f) {
+    if constexpr (N > 0) {
+        static_for_c<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_fast(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a) {
+    constexpr int KQ = H / 4;          // k values per MFMA k-slot (l4)
+    constexpr int LDW = H + 4;         // LDS row stride: 16 lanes x 16 B land in 64 distinct banks
+    constexpr int US = H / 16;         // unit slices per LSTM
+    extern __shared__ float hs[];      // [16][LDW]  h_{t-1} of the current 16 sequences
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int us = blockIdx.x % US, ss = (blockIdx.x / US) % a.SS, z = blockIdx.x / (US * a.SS);
+    const bool rev = (a.reverse >> z) & 1;
+    const int NT = (a.S + 15) >> 4;
+
+    // ---- W_hh rows of this wave's 4 units -> registers
+    const int r0 = us * 64 + wave * 16;                           // first gate row (rows are 4u+g)
+    floatx4 wa[KQ / 4];
+    {
+        const floatx4* __restrict__ W =
+            reinterpret_cast<const floatx4*>(a.whh + (long)z * a.whh_z + (long)(r0 + l15) * H + l4 * KQ);
+        static_for_c<KQ / 4>([&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            wa[j] = W[j];
+        });
+    }
+    const int u = us * 16 + wave * 4 + l4;                        // hidden unit of this lane's accumulator
+    const float* __restrict__ gx = a.gx + (long)z * a.gx_z + (long)(4 * u) * a.gx_row;
+    float* __restrict__ out = a.out + (long)z * a.out_z + (long)u * a.out_row;
+    float* __restrict__ cell = a.cell + ((long)z * H + u) * a.S;
+    float* __restrict__ hx = a.hx + (long)z * 2 * a.S * H;
+    unsigned* bar = a.bar + z * a.SS + ss;
+
+    // gate pre-activations of this lane's (unit, sequence) for the block's first tile of a step (prefetched before
+    // the exchange barrier of the previous step - they do not depend on h)
+    auto load_g = [&](int step, int nt, float (&g)[4]) {
+        const int t = rev ? a.T - 1 - step : step;
+        const int n = min(nt * 16 + l15, a.S - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = gx[(long)t * a.gx_t + q * a.gx_row + n];
+    };
+    float gfirst[4], cfirst = 0.f;
+    load_g(0, ss, gfirst);
+
+    for (int step = 0; step < a.T; ++step) {
+        const int t = rev ? a.T - 1 - step : step;
+        const float* hprev = hx + (long)(step & 1) * a.S * H;
+        float* hnext = hx + (long)((step + 1) & 1) * a.S * H;
+        for (int nt = ss; nt < NT; nt += a.SS) {
+            const int n = nt * 16 + l15;
+            const bool col_ok = n < a.S;
+            float g[4];
+            if (nt == ss) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = gfirst[q];
+            } else {
+                load_g(step, nt, g);
+            }
+            // cell state: a register for the block's first tile (the only one unless S > 16 * SS), global scratch otherwise
+            const float cprev = step == 0 ? 0.f : (nt == ss ? cfirst : cell[min(n, a.S - 1)]);
+            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+            if (step > 0) {
+                // stage h_{t-1} of the tile's 16 sequences: [16][H] fp32 through agent-coherent (sc1) 8 B loads - they
+                // bypass this XCD's possibly stale L2 lines, so the exchange needs no cache invalidate; all in flight
+                constexpr int NLD = 16 * (H / 2) / 256;
+                unsigned long long v[NLD];
+                if (!(a.dbg & 1)) {
+                    static_for_c<NLD>([&](auto I_) {
+                        constexpr int i = decltype(I_)::value;
+                        const int e = tid + 256 * i, row = e / (H / 2), c2 = e % (H / 2);
+                        const int nn = min(nt * 16 + row, a.S - 1);
+                        v[i] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(hprev + (long)nn * H + 2 * c2),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    });
+                }
+                if (nt != ss) __syncthreads();                     // previous tile's readers are done with hs
+                if (!(a.dbg & 1)) {
+                    static_for_c<NLD>([&](auto I_) {
+                        constexpr int i = decltype(I_)::value;
+                        const int e = tid + 256 * i, row = e / (H / 2), c2 = e % (H / 2);
+                        *reinterpret_cast<unsigned long long*>(hs + row * LDW + 2 * c2) = v[i];
+                    });
+                }
+                __syncthreads();
+                if (!(a.dbg & 2)) {
+                    const floatx4* hb = reinterpret_cast<const floatx4*>(hs + l15 * LDW + l4 * KQ);
+                    static_for_c<KQ / 4>([&](auto J_) {
+                        constexpr int j = decltype(J_)::value;
+                        const floatx4 b = hb[j];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][0], b[0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][1], b[1], acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][2], b[2], acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][3], b[3], acc3, 0, 0, 0);
+                    });
+                }
+            }
+            const floatx4 acc = (acc0 + acc1) + (acc2 + acc3);
+            const float cn = sigm(acc[1] + g[1]) * cprev + sigm(acc[0] + g[0]) * tanhf_fast(acc[2] + g[2]);
+            const float h = sigm(acc[3] + g[3]) * tanhf_fast(cn);
+            if (nt == ss) cfirst = cn;
+            else if (col_ok) cell[n] = cn;
+            if (col_ok) {
+                out[(long)t * a.out_t + n] = h;
+                __hip_atomic_store(hnext + (long)n * H + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (step + 1 < a.T) {
+            // unit slices of this (z, sequence slice) exchange h_t: release our writes, wait for the others'
+            __syncthreads();                                       // (also: every wave is done reading hs)
+            // h_t went out as agent-coherent (sc1) stores and the workgroup barrier above waited for their completion,
+            // so a relaxed arrival is enough: no L2 write-back / invalidate per step
+            if (tid == 0 && !(a.dbg & 4)) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            load_g(step + 1, ss, gfirst);
+            if (tid == 0 && !(a.dbg & 4)) {
+                const unsigned want = (unsigned)US * (unsigned)(step + 1);
+                const unsigned long long t0 = wall_clock64();
+                // relaxed polling: an acquire load would invalidate the caches on every iteration
+                while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    if (a.dbg & 8) __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+char* coop_scratch(size_t need, hipStream_t s) {
+    static thread_local char* buf = nullptr;
+    static thread_local size_t cap = 0;
+    if (need > cap) {
+        if (buf) {
+            SE_HIP(hipStreamSynchronize(s));
+            SE_HIP(hipFree(buf));
+        }
+        SE_HIP(hipMalloc(&buf, need));
+        cap = need;
+    }
+    return buf;
+}
+
+template <int H>
+void launch_t(LstmCoopArgs a, int n_cu, hipStream_t s) {
+    constexpr int US = H / 16;
+    const int NT = (a.S + 15) / 16;
+    SE_CHECK(US * a.Z <= n_cu, "cooperative LSTM: more unit slices than CUs");
+    a.SS = std::max(1, std::min(NT, n_cu / (US * a.Z)));
+    static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
+    a.dbg = dbg;
+    // exchange tensor hx [Z][2][S][H] + one arrival counter per (z, sequence slice)
+    const size_t hx_bytes = (size_t)a.Z * 2 * a.S * H * sizeof(float);
+    char* sc = coop_scratch(hx_bytes + 256 * sizeof(unsigned), s);
+    a.hx = reinterpret_cast<float*>(sc);
+    a.bar = reinterpret_cast<unsigned*>(sc + hx_bytes);
+    SE_HIP(hipMemsetAsync(a.bar, 0, 256 * sizeof(unsigned), s));
+    const size_t shmem = (size_t)16 * (H + 4) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop_kernel<H>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    void* params[] = {&a};
+    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop_kernel<H>), dim3(US * a.SS * a.Z), dim3(256),
+                                      params, (unsigned)shmem, s));
+}
+
+}  // namespace
+
+bool lstm_coop_supported(int H, int S, int Z) { return (H == 512 || H == 1024) && (H / 16) * Z <= 256 && S <= 4096; }
+
+void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        SE_HIP(hipGetDevice(&dev));
+        SE_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    SE_CHECK(a.Z * std::max(1, std::min((a.S + 15) / 16, n_cu / ((a.H / 16) * a.Z))) <= 256, "cooperative LSTM: too many slices");
+    if (a.H == 1024) launch_t<1024>(a, n_cu, s);
+    else if (a.H == 512) launch_t<512>(a, n_cu, s);
+    else SE_CHECK(false, "cooperative LSTM kernel is built for H = 512 / 1024");
+}
+
+}  // namespace se

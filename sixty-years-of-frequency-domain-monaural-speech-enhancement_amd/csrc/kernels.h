@@ -100,4 +100,21 @@ struct LstmPersistArgs {
 };
 void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s);
 
+
+// Weight-stationary cooperative LSTM recurrence for H = 512 / 1024 (k_lstm_coop.hip): W_hh spread over the register
+// files of all CUs, one launch for all T steps.  Same tensor conventions as LstmPersistArgs (O = 1):
+//   gx   : element (z, t, row, n) at gx + z*gx_z + t*gx_t + row*gx_row + n   (rows gate-interleaved, bias included)
+//   out  : h_t element (z, t, u, n) at out + z*out_z + t*out_t + u*out_row + n
+//   cell : scratch [Z][H][S];  hx / bar / SS are filled in by the launcher
+struct LstmCoopArgs {
+    const float* gx; const float* whh; float* out; float* cell;
+    long gx_z, gx_t, gx_row;
+    long whh_z;
+    long out_z, out_t, out_row;
+    int H, T, S, Z, reverse;
+    float* hx; unsigned* bar; int SS, dbg;
+};
+bool lstm_coop_supported(int H, int S, int Z);
+void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s);
+
 }  // namespace se

@@ -69,16 +69,27 @@ inline void run_pointwise(const GCPlan& pl, const float* src, long s_o, long s_c
 // as one GEMM over all steps, then one fused GEMM + LSTM-cell launch per step (weights stream from L2 / Infinity Cache).
 struct LstmBig {
     GCPlan gin, step;
+    float* whh_dev = nullptr;     // row-major [4H][H] (gate-interleaved rows) for the weight-stationary cooperative kernel
     int I = 0, H = 0;
     void build(const LstmW& w, int s_hint) {
         I = w.I;
         H = w.H;
         gin = make_pointwise_plan(w.wih, ACT_NONE, {}, s_hint);
         step = gc_make_plan(4 * H, H, one_tap(), w.whh.w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, s_hint);
+        if (H == 512 || H == 1024) whh_dev = to_device(w.whh.w);
     }
     void free() {
         gc_free_plan(gin);
         gc_free_plan(step);
+        if (whh_dev) (void)hipFree(whh_dev);
+        whh_dev = nullptr;
+    }
+    static bool coop_enabled() {
+        static const int on = [] {
+            const char* e = getenv("SE_LSTM_COOP");
+            return e ? atoi(e) : 1;
+        }();
+        return on != 0;
     }
     // x [T][I][S] -> out [T][H][S];  G scratch [T][4H][S];  cell scratch [H][S]
     void run(const float* x, float* G, float* cell, float* out, int T, int S, hipStream_t st, Profiler* prof) const {
@@ -89,6 +100,19 @@ struct LstmBig {
     void run_strided(const float* x, long x_t, float* G, float* cell, float* out, long out_t, int out_rs, int T, int S,
                      hipStream_t st, Profiler* prof) const {
         run_pointwise(gin, x, x_t, S, G, 4L * H * S, S, T, S, st, prof);
+        if (whh_dev && coop_enabled() && lstm_coop_supported(H, S, 1)) {
+            LstmCoopArgs a{};
+            a.gx = G; a.whh = whh_dev; a.out = out; a.cell = cell;
+            a.gx_z = 0; a.gx_t = 4L * H * S; a.gx_row = S;
+            a.whh_z = 0;
+            a.out_z = 0; a.out_t = out_t; a.out_row = (long)out_rs * S;
+            a.H = H; a.T = T; a.S = S; a.Z = 1; a.reverse = 0;
+            const bool timed = prof && prof->on;
+            if (timed) prof->begin(st);
+            launch_lstm_coop(a, st);
+            if (timed) prof->end(st, 2.0 * 4 * H * (double)H * S * (T - 1));
+            return;
+        }
         for (int t = 0; t < T; ++t) {
             GCParams p = step.p;
             p.first_step = (t == 0);

@@ -84,3 +84,24 @@ def test_strict_load_errors():
     bad['lstm.weight_hh_l1'] = bad['lstm.weight_hh_l1'][:, :100]
     with pytest.raises(EngineError):
         crn_net().load_state_dict(bad)
+
+
+@pytest.mark.parametrize('name,B', [('crn', 72), ('lstm', 70), ('gcrn', 136), ('fullsubnet', 130)])
+def test_large_batch_matches_small_batch(name, B):
+    """The weight-stationary cooperative LSTM kernel (k_lstm_coop.hip) slices sequences over workgroups and loops over
+    16-sequence tiles when S > 16 * slices (ragged last tile, cell state in global scratch): a big ragged batch must
+    reproduce, clip for clip, what the fixture-pinned B = 2 configuration gives."""
+    torch = _torch()
+    from se_amd.models import MODEL_CLASSES
+    L = 4000
+    clips = np.stack([synth.synth_clip(300 + i, 'speech' if i % 3 else 'white', L) for i in range(6)])
+    wav = torch.from_numpy(clips[np.arange(B) % 6].copy()).cuda()
+    big = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(SEEDS[name])
+    yb = big.enhance_batch(wav).cpu().numpy()
+    small = MODEL_CLASSES[name](max_batch=2, max_samples=L).load_synthetic(SEEDS[name])
+    for i in (0, 2, 4):
+        ys = small.enhance_batch(torch.from_numpy(clips[i:i + 2].copy()).cuda()).cpu().numpy()
+        for j in (0, 1):
+            for k in range(i + j, B, 6):
+                e = rms(yb[k] - ys[j])
+                assert e < 1e-5 * max(rms(ys[j]), 1e-4), (name, k, e, rms(ys[j]))     # fp32 tile shapes differ with the batch

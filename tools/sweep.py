@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Throughput survey over every model the engine builds (not the headline bench): whole decode path on 4 s clips.
+
+  python tools/sweep.py [--batch 64] [--steps 3] [--models dccrn,crn,...]
+Prints one JSON line per model: utt/s, ms/step, share of the step spent in the tap-table GEMM family.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+GFLOP = {'lstm': 17.5, 'crn': 17.3, 'gcrn': 13.2, 'dpcrn': 4.8, 'dccrn': 53.4, 'fullsubnet': 238.5, 'ctsnet': 25.6,
+         'g2net': 10.7, 'taylorsenet': 31.3, 'uformer': 27.5}      # SURVEY 8(d), per 4 s utterance
+
+
+def build(name, B):
+    import se_amd  # noqa: F401
+    from se_amd import models, models_new
+    kw = dict(max_batch=B, max_samples=64000)
+    if name == 'ctsnet':
+        return models.CTSNet(**kw).load_synthetic(17, 18)
+    if name == 'ctsnet_new':
+        return models_new.CTSNet(**kw).load_synthetic(17, 18)
+    return models.MODEL_CLASSES[name](**kw).load_synthetic(1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--models', type=str, default='lstm,crn,gcrn,dpcrn,dccrn,fullsubnet,ctsnet,g2net,taylorsenet,uformer')
+    args = ap.parse_args()
+    import torch
+    from se_amd import synth
+    B = args.batch
+    base = synth.synth_batch(8, 'speech', 64000, seed0=100)
+    wav = torch.from_numpy(np.tile(base, ((B + 7) // 8, 1))[:B].copy()).cuda()
+    for name in args.models.split(','):
+        m = build(name, B)
+        eng = m.engine
+        out = torch.empty((B, eng.output_samples(64000)), dtype=torch.float32, device='cuda')
+        eng.enhance_batch(wav, out)
+        torch.cuda.synchronize()
+        eng.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.enhance_batch(wav, out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        prof = eng.get_profile()
+        eng.set_profiling(False)
+        assert bool(torch.isfinite(out).all()), name
+        ups = B / dt
+        g = GFLOP.get(name.replace('_new', ''), 0.0)
+        print(json.dumps({'model': name, 'batch': B, 'utt_per_s': round(ups, 1), 'ms_per_step': round(dt * 1e3, 2),
+                          'x_realtime': round(ups * 4, 0), 'algo_tflops': round(ups * g / 1e3, 2),
+                          'gemm_ms': round(prof['gemm_ms'], 2), 'gemm_launches': prof['gemm_launches'],
+                          'gemm_tflops': round(prof['gemm_flops'] / max(prof['gemm_ms'], 1e-9) / 1e9, 2)}), flush=True)
+        del m, eng
+
+
+if __name__ == '__main__':
+    main()

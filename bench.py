@@ -30,6 +30,30 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32 MFMA peak (MI355X_MICROARCH.md,
 DCCRN_GFLOP_PER_UTT = 53.4    # algorithmic 2*MAC per 4 s utterance (T = 501)
 
 
+def dccrn_conv_bytes(B, T=501):
+    """Algorithmic HBM bytes of the 21 tap-table GEMM launches of one DCCRN step (DESIGN.md 'Measurement'): every
+    launch reads its input activations once and writes its output once (fp32; weights are < 0.1 %).  Encoder: 6 convs;
+    decoder: 6 transposed convs = 2 frequency-parity launches each, both reading the (previous, skip) pair; LSTM input /
+    output projections: 3 launches.  Channels are real counts (complex = 2 x)."""
+    ch = [2, 32, 64, 128, 256, 256, 256]
+    F = [257, 129, 65, 33, 17, 9, 5]
+    act = [ch[i] * F[i] * T for i in range(7)]                 # floats per utterance at each encoder level
+    rd = sum(act[0:6]) + 2 * sum(2 * act[i] for i in range(1, 7))
+    wr = sum(act[1:7]) + sum(act[0:6])
+    lstm = 2 * (256 * 5 * T) + 2 * (4 * 256 * T) * 2 + 2 * (256 * 5 * T)    # in-proj, 2 x (gates), out-proj
+    return 4.0 * B * (rd + lstm), 4.0 * B * (wr + lstm)
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the gc_kernel family from the committed rocprofv3 --pmc passes of this same command
+    (tools/pmc_summary.py -> profiles/r01_pmc_dccrn.json); None when the summary is absent."""
+    p = os.path.join(ROOT, 'profiles', 'r01_pmc_dccrn.json')
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return json.load(f)['gc_family']
+
+
 def cpu_baseline(seed, p_in, p_out):
     """The numpy oracle (a port of the reference decode loop) on the host cores: bounded sample of the same
     workload (whole-path decode of 4 s clips, one at a time like the reference's batch-1 loop)."""
@@ -134,10 +158,16 @@ def main():
         }
         if prof and prof['gemm_ms'] > 0:
             ach = prof['gemm_flops'] / (prof['gemm_ms'] * 1e-3) / 1e12
+            pmc = pmc_traffic()
+            rd_b, wr_b = dccrn_conv_bytes(B)
             res["roofline"] = {
                 "bound": "mfma", "kernel": "se::gc_kernel<BM,BN,..> (f32-MFMA tap-table implicit-GEMM conv)",
                 "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": pmc['traffic_GB_per_launch'] if pmc and B == 256 else None,
+                "traffic_unit": "GB of HBM traffic per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 "
+                                "--pmc passes of this command at batch 256: profiles/r01_pmc_dccrn.md)",
+                "algorithmic_GB_per_launch": round((rd_b + wr_b) / 1e9 / max(prof['gemm_launches'], 1), 3),
                 "launches_per_step": prof['gemm_launches'],
                 "algorithmic_gflop_per_step": round(prof['gemm_flops'] / 1e9, 1),
                 "kernel_ms_per_step": round(prof['gemm_ms'], 3),

@@ -39,6 +39,7 @@ enum Epi : int {
 
 struct GCParams {
     const float* A;          // packed weights [nchunks][KCp][Mp]
+    const float* Ws;         // direct small-M path (M <= 4): plain weights [z][ci][tap][MM]; nullptr -> MFMA path
     const float* bias;       // [M] or nullptr
     const float* slope;      // [M] PReLU slopes or nullptr
     const float* post_scale; // EPI_GLU: per output channel scale / shift applied after the gate product (eval BatchNorm)
@@ -74,6 +75,7 @@ struct GCPlan {
     GCParams p{};            // static part (taps, chunking, weights); pointers for activations filled per launch
     int BM = 128, BN = 128;  // tile config
     float* dA = nullptr;     // device copies owned by the plan
+    float* dWs = nullptr;
     float* dBias = nullptr;
     float* dSlope = nullptr;
     int* dTab = nullptr;

@@ -343,6 +343,81 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
 }
 
 // ------------------------------------------------------------------------------------------------
+// Direct (VALU) path for layers with at most 4 output channels - the final (de)convs back to one spectrum plane or
+// an RI pair (DCCRN decoder layer 5: 64 -> 2, DCCRN_cprs.py:108-132; CRN/DPCRN/GCRN/CTSNet last layers alike).  On
+// the MFMA path their M pads to 32 rows (16x wasted matrix work and a full LDS staging per 2 useful rows); here a
+// thread owns one (q, t) output position, walks the same tap table with coalesced loads straight from L1/L2 (every
+// input element is re-read by ~ntaps neighbouring positions: cache hits), and the weights are wave-uniform scalar
+// loads.  The layer is then bound by reading its input once from HBM.
+// ------------------------------------------------------------------------------------------------
+template <int MM, int EPI>
+__global__ __launch_bounds__(256) void gc_small_kernel(const GCParams p) {
+    __shared__ int s_df[GC_MAX_TAPS], s_dt[GC_MAX_TAPS];
+    if (threadIdx.x < p.ntaps) {
+        s_df[threadIdx.x] = p.tab[p.tab[GC_MAX_ROWS + threadIdx.x]];
+        s_dt[threadIdx.x] = p.tab[GC_MAX_ROWS + GC_MAX_TAPS + threadIdx.x];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int q = blockIdx.y;
+    const int b = blockIdx.z % p.B, z = blockIdx.z / p.B;
+    const int tc = min(t, p.Tout - 1);
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    const float* __restrict__ W = p.Ws + (long)z * (p.C0 + p.C1) * p.ntaps * MM;
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+        const int C = seg ? p.C1 : p.C0;
+        if (C == 0) continue;
+        const float* __restrict__ src = seg ? p.src1 + (long)z * p.src1_z + (long)b * p.s1_b
+                                            : p.src0 + (long)z * p.src0_z + (long)b * p.s0_b;
+        const long s_c = seg ? p.s1_c : p.s0_c, s_f = seg ? p.s1_f : p.s0_f;
+        const float* __restrict__ Wc = W + (long)(seg ? p.C0 : 0) * p.ntaps * MM;
+        for (int j = 0; j < p.ntaps; ++j) {
+            const int fi = q * p.si + s_df[j], ti = tc + s_dt[j];
+            const bool ok = fi >= 0 && fi < p.Fin && ti >= 0 && ti < p.Tin;
+            const float* __restrict__ xp = src + (long)min(max(fi, 0), p.Fin - 1) * s_f + min(max(ti, 0), p.Tin - 1);
+            const float keep = ok ? 1.f : 0.f;
+#pragma unroll 8
+            for (int c = 0; c < C; ++c) {
+                const float x = xp[(long)c * s_c] * keep;
+                const float* __restrict__ w = Wc + ((long)c * p.ntaps + j) * MM;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) acc[m] = fmaf(w[m], x, acc[m]);
+            }
+        }
+    }
+    if (t >= p.Tout) return;
+    const int fo = q * p.so + p.po;
+    const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
+    float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
+    const float* __restrict__ res = (EPI != EPI_ACT) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        if (m < p.M) {
+            float v = acc[m] + (bias ? bias[m] : 0.f);
+            v = act_apply(v, p.act, p.slope ? p.slope[m] : 0.f);
+            if (EPI == EPI_ADD) v += res[(long)m * p.x_c + t];
+            if (EPI == EPI_MUL) v *= res[(long)m * p.x_c + t];
+            dst[(long)m * p.d_c + t] = v;
+        }
+    }
+}
+
+template <int MM>
+static void gc_small_launch(const GCParams& p, hipStream_t stream) {
+    dim3 grid((p.Tout + 255) / 256, p.Q, p.B * p.Z);
+    switch (p.epi) {
+        case EPI_ACT: hipLaunchKernelGGL((gc_small_kernel<MM, EPI_ACT>), grid, dim3(256), 0, stream, p); break;
+        case EPI_ADD: hipLaunchKernelGGL((gc_small_kernel<MM, EPI_ADD>), grid, dim3(256), 0, stream, p); break;
+        case EPI_MUL: hipLaunchKernelGGL((gc_small_kernel<MM, EPI_MUL>), grid, dim3(256), 0, stream, p); break;
+        default: SE_CHECK(false, "direct small-M path: unsupported epilogue");
+    }
+    SE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM) {
@@ -427,6 +502,19 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.A_z = (long)per_z;
     pl.dA = to_device(packed);
     p.A = pl.dA;
+    // direct path (gc_small_kernel): plain weights [z][ci][tap][MM] for layers with <= 4 output channels
+    static const int small_env = getenv("SE_GC_SMALL") ? atoi(getenv("SE_GC_SMALL")) : 1;
+    if (small_env && M <= 4 && (epi == EPI_ACT || epi == EPI_ADD || epi == EPI_MUL)) {
+        const int MM = M <= 1 ? 1 : (M <= 2 ? 2 : 4);
+        std::vector<float> ws((size_t)Z * Cin * taps.ntaps * MM, 0.f);
+        for (int z = 0; z < Z; ++z)
+            for (int m = 0; m < M; ++m)
+                for (int ci = 0; ci < Cin; ++ci)
+                    for (int j = 0; j < taps.ntaps; ++j)
+                        ws[(((size_t)z * Cin + ci) * taps.ntaps + j) * MM + m] = w[(((size_t)z * M + m) * Cin + ci) * taps.ntaps + j];
+        pl.dWs = to_device(ws);
+        p.Ws = pl.dWs;
+    }
     if (!bias.empty()) {
         SE_CHECK((long)bias.size() == (long)Z * M, "bias size");
         pl.dBias = to_device(bias);
@@ -443,6 +531,8 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
 
 void gc_free_plan(GCPlan& pl) {
     if (pl.dA) (void)hipFree(pl.dA);
+    if (pl.dWs) (void)hipFree(pl.dWs);
+    pl.dWs = nullptr;
     if (pl.dBias) (void)hipFree(pl.dBias);
     if (pl.dSlope) (void)hipFree(pl.dSlope);
     if (pl.dTab) (void)hipFree(pl.dTab);
@@ -488,6 +578,12 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     p.dbg = dbg_env;
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
     if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;
+    if (p.Ws) {
+        if (p.M <= 1) gc_small_launch<1>(p, stream);
+        else if (p.M <= 2) gc_small_launch<2>(p, stream);
+        else gc_small_launch<4>(p, stream);
+        return;
+    }
     if (pl.BM == 128 && pl.BN == 128) gc_launch_t<128, 128, 2, 2>(p, stream);
     else if (pl.BM == 64 && pl.BN == 128) gc_launch_t<64, 128, 2, 2>(p, stream);
     else if (pl.BM == 32 && pl.BN == 128) gc_launch_t<32, 128, 1, 4>(p, stream);

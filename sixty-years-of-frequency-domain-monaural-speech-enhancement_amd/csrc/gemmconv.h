@@ -21,6 +21,7 @@ namespace se {
 constexpr int GC_MAX_TAPS = 16;
 constexpr int GC_MAX_ROWS = 8;
 constexpr int GC_MAX_KCP = 48;
+constexpr int GC_TAB_KOFF = GC_MAX_ROWS + 2 * GC_MAX_TAPS;   // start of the per-K-row patch offsets in GCParams::tab
 // K rows of one staged chunk and patch elements staged per thread, by output-channel tile
 constexpr int gc_kcp_max(int BM) { return 48; }
 constexpr int gc_bld_max(int BM) { return 13; }
@@ -67,7 +68,7 @@ struct GCParams {
     int dbuf;                // 1: double-buffered LDS staging, 0: single buffer (more blocks per CU)
     int dbg;                 // ablation switches for tuning (0 in production): 1 no global loads, 2 no LDS restage, 4 no MFMA
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
-    const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS]
+    const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]
 };
 
 // Host-side description of one dense layer, built once at finalize.

@@ -42,6 +42,18 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// 16 B per lane global -> LDS copy without a register round trip (global_load_lds_dwordx4: lane l lands at
+// lds_base + 16*l, lds_base wave-uniform in M0).  Issued from inline asm on purpose: through the builtin the compiler
+// has to assume that the DMA write may alias the LDS reads of the MFMA loop and parks an s_waitcnt vmcnt(0) right
+// behind the issue, i.e. a full memory round trip per K chunk.  The kernel's own ordering makes that wait unnecessary:
+// vmcnt retires in order and the activation-patch loads of the same chunk are consumed behind an s_waitcnt vmcnt(0)
+// (the compiler's wait for its newest load drains every older or younger VMEM op) before the __syncthreads() that
+// publishes the buffer.
+__device__ __forceinline__ void gc_dma16(const float* g, float* lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+}
+
 // Per-thread staging descriptors are chunk-invariant: element e = (row rr = wave + 4*i, column w = lane + 64*j)
 // of the activation patch reads  base_chunk[boff[e]]  (always an in-bounds address) and is zeroed when its validity
 // bit is clear, so the per-chunk staging code is one load + one select per element with a uniform 64-bit base.
@@ -101,27 +113,17 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     constexpr int NPAIR = KCP_MAX / 2;
     constexpr bool KOFF_REGS = (BM >= 128);      // small-M tiles keep the table in LDS: registers buy occupancy there
     int koffv[KOFF_REGS ? NPAIR : 1];
-    int* koff_lds = reinterpret_cast<int*>(Bs + nbuf * Bs_sz);
+    // the whole device table (frequency rows, taps, per-K-row patch offsets) is staged once into LDS: every later
+    // lookup is a short LDS read instead of a dependent global load in the block prologue
+    int* tabl = reinterpret_cast<int*>(Bs + nbuf * Bs_sz);
+    int* koff_lds = tabl + GC_TAB_KOFF;
+    if (tid < GC_TAB_KOFF + KCP_MAX + 8) tabl[tid] = p.tab[tid];
+    __syncthreads();
     if constexpr (KOFF_REGS) {
         static_for<NPAIR>([&](auto KP) {
             constexpr int kp = decltype(KP)::value;
-            const int k = 2 * kp + hi;
-            int off = 0;
-            if (k < p.KC) {
-                const int cil = k / p.ntaps, j = k - cil * p.ntaps;
-                off = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
-            }
-            koffv[kp] = off;
+            koffv[kp] = koff_lds[2 * kp + hi];
         });
-    } else {
-        for (int k = tid; k < KCP_MAX + 4; k += 256) {
-            int off = 0;
-            if (k < p.KC) {
-                const int cil = k / p.ntaps, j = k - cil * p.ntaps;
-                off = cil * (p.nrows * p.Wp) + p.tab[GC_MAX_ROWS + j] * p.Wp + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + j] - p.dtmin);
-            }
-            koff_lds[k] = off;
-        }
     }
 
     // ---- chunk-invariant staging descriptors (all staging loops have uniform bounds: no exec masking)
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         aoff[i] = (unsigned)((idx / (BM / 4)) * p.Mp + (idx % (BM / 4)) * 4);
     });
     unsigned boff[NB];
-    bool vok[NB];            // element lies inside the tensor (else it is a zero of the padding)
+    unsigned vmask[NB];      // all-ones when the element lies inside the tensor, 0 for a zero of the padding
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -160,29 +162,29 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             const int rr = fe / p.Wp, w = fe - rr * p.Wp;                                          \
             const int cil = rr / p.nrows, r = rr - cil * p.nrows;                                  \
             const bool staged = fe < npatch;                                                       \
-            const int f = q * p.si + p.tab[staged ? r : 0];                                        \
+            const int f = q * p.si + tabl[staged ? r : 0];                                         \
             const int t = t0 + p.dtmin + w;                                                        \
             const int fc = f < 0 ? 0 : (f >= p.Fin ? p.Fin - 1 : f);                               \
             const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
             boff[e] = staged ? (unsigned)((long)cc * s_c + (long)fc * s_f + tc) : 0u;              \
-            vok[e] = staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin); \
+            vmask[e] = (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? 0xffffffffu : 0u; \
         });                                                                                        \
     }
 #define GC_LOAD_CHUNK(CH, BUF)                                                                     \
     {                                                                                              \
-        const float* __restrict__ Ac = Ag + (long)(gchunk + (CH)) * p.KCp * p.Mp;                  \
-        float* Adw = As + (BUF) * As_sz + wave * 256;   /* wave-uniform LDS base of this wave's 1 KB slice */ \
-        static_for<A_IT>([&](auto I) {                                                             \
-            constexpr int i = decltype(I)::value;                                                  \
-            if (i < ait)                                                                           \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ac + aoff[i]), \
-                                                 (__attribute__((address_space(3))) void*)(Adw + i * 1024), 16, 0, 0); \
-        });                                                                                        \
+        /* activation patch first (HBM latency), weights second: the DMA issues are invisible to the compiler's */ \
+        /* vmcnt bookkeeping, and behind the patch loads they never make one of its waits block early           */ \
         const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
         static_for<NB>([&](auto E) {                                                               \
             constexpr int e = decltype(E)::value;                                                  \
             preB[e] = Bc[boff[e]];                                                                 \
+        });                                                                                        \
+        const float* __restrict__ Ac = Ag + (long)(gchunk + (CH)) * p.KCp * p.Mp;                  \
+        float* Adw = As + (BUF) * As_sz + wave * 256;   /* wave-uniform LDS base of this wave's 1 KB slice */ \
+        static_for<A_IT>([&](auto I) {                                                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            if (i < ait) gc_dma16(Ac + aoff[i], Adw + i * 1024);                                   \
         });                                                                                        \
     }
 #define GC_STORE_CHUNK(BUF)                                                                        \
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         float* Bd = Bs + (BUF) * Bs_sz + tid;                                                      \
         static_for<NB>([&](auto E) {                                                               \
             constexpr int e = decltype(E)::value;                                                  \
-            if (e < bit) Bd[256 * e] = vok[e] ? preB[e] : 0.f;                                     \
+            if (e < bit) Bd[256 * e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, preB[e]) & vmask[e]); \
         });                                                                                        \
     }
 
@@ -422,7 +424,7 @@ static void gc_small_launch(const GCParams& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
-    return (p.dbuf ? 2 : 1) * (as + bs) * 4 + (GC_MAX_KCP + 8) * 4 + 64;
+    return (p.dbuf ? 2 : 1) * (as + bs) * 4 + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + 64;
 }
 
 GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w, const std::vector<float>& bias,
@@ -450,17 +452,6 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.dtmin = dtmin;
     p.Wp = (pl.BN + (dtmax - dtmin) + 3) & ~3;             // LDS row stride of the patch
     SE_CHECK(p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256, "tap span too wide for one staged patch");
-    {
-        std::vector<int> tab(GC_MAX_ROWS + 2 * GC_MAX_TAPS, 0);
-        for (int r = 0; r < p.nrows; ++r) tab[r] = rows[r];
-        for (int j = 0; j < taps.ntaps; ++j) {
-            tab[GC_MAX_ROWS + j] = (int)(std::find(rows.begin(), rows.end(), taps.df[j]) - rows.begin());
-            tab[GC_MAX_ROWS + GC_MAX_TAPS + j] = taps.dt[j];
-        }
-        SE_HIP(hipMalloc(&pl.dTab, tab.size() * sizeof(int)));
-        SE_HIP(hipMemcpy(pl.dTab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-        p.tab = pl.dTab;
-    }
     // chunking: largest CI_C within the staging budgets (SE_GC_KCP / SE_GC_DBUF: tuning overrides)
     static const int kcp_cap = getenv("SE_GC_KCP") ? atoi(getenv("SE_GC_KCP")) : GC_MAX_KCP;
     static const int dbuf_env = getenv("SE_GC_DBUF") ? atoi(getenv("SE_GC_DBUF")) : 1;
@@ -474,6 +465,22 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.KC = cic * taps.ntaps;
     p.KCp = (p.KC + 3) & ~3;
     SE_CHECK(p.KCp <= gc_kcp_max(pl.BM), "single-channel chunk exceeds K budget");
+    {
+        // device table: frequency rows, tap -> row / dt, and the patch offset of every K row of a chunk (k = cil*ntaps + j)
+        std::vector<int> tab(GC_TAB_KOFF + GC_MAX_KCP + 8, 0);
+        for (int r = 0; r < p.nrows; ++r) tab[r] = rows[r];
+        for (int j = 0; j < taps.ntaps; ++j) {
+            tab[GC_MAX_ROWS + j] = (int)(std::find(rows.begin(), rows.end(), taps.df[j]) - rows.begin());
+            tab[GC_MAX_ROWS + GC_MAX_TAPS + j] = taps.dt[j];
+        }
+        for (int k = 0; k < p.KC; ++k) {
+            const int cil = k / taps.ntaps, j = k - cil * taps.ntaps;
+            tab[GC_TAB_KOFF + k] = cil * (p.nrows * p.Wp) + tab[GC_MAX_ROWS + j] * p.Wp + (taps.dt[j] - dtmin);
+        }
+        SE_HIP(hipMalloc(&pl.dTab, tab.size() * sizeof(int)));
+        SE_HIP(hipMemcpy(pl.dTab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        p.tab = pl.dTab;
+    }
     const int nch0 = (C0 + cic - 1) / cic, nch1 = (Cin - C0 + cic - 1) / cic;
     p.nchunks = nch0 + nch1;
     p.M = M;

@@ -51,7 +51,27 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // publishes the buffer.
 __device__ __forceinline__ void gc_dma16(const float* g, float* lds_wave_base) {
     const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory");
+}
+// 4 B per lane, only for the lanes whose `pred` is non-zero (EXEC is narrowed inside the asm block and restored):
+// lane l lands at lds_base + 4*l, masked lanes leave their LDS word untouched (the patch buffers are zeroed once per
+// block, so a never-written word IS the zero of the padding).
+__device__ __forceinline__ void gc_dma4_masked(const float* g, unsigned lds_wave_base, unsigned pred) {
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %1\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %3, off\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(saved)
+        : "v"(pred), "s"(lds_wave_base), "v"(g)
+        : "memory", "vcc");
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
 }
 
 // Per-thread staging descriptors are chunk-invariant: element e = (row rr = wave + 4*i, column w = lane + 64*j)
@@ -76,7 +96,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     const int ait = (nA4 + 255) >> 8;                // float4 groups of the weight chunk per thread (uniform)
     const int As_sz = ait * 1024;                    // padded so that every thread stores unconditionally
     const int Bs_sz = bit * 256;                     // padded: every thread stores unconditionally
-    const int nbuf = p.dbuf ? 2 : 1;
+    constexpr int nbuf = 2;                          // double-buffered staging
     float* As = smem;
     float* Bs = smem + nbuf * As_sz;
 
@@ -135,7 +155,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         aoff[i] = (unsigned)((idx / (BM / 4)) * p.Mp + (idx % (BM / 4)) * 4);
     });
     unsigned boff[NB];
-    unsigned vmask[NB];      // all-ones when the element lies inside the tensor, 0 for a zero of the padding
+    unsigned vbits = 0;      // bit e set when patch element e lies inside the tensor (else it is a zero of the padding)
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -149,13 +169,13 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     const int am = wm * (TM * 32) + l31;      // A column base inside the tile
     const int bn = wn * (TN * 32) + l31;      // B column base inside the tile
 
-    float preB[NB];
     int gchunk = 0;          // global chunk counter (weights are packed segment after segment)
     int buf = 0;
 
 #define GC_MAKE_DESC(LIM)                                                                          \
     {                                                                                              \
         const int lim_ = (LIM);                                                                    \
+        vbits = 0;                                                                                 \
         static_for<NB>([&](auto E) {                                                               \
             constexpr int e = decltype(E)::value;                                                  \
             const int fe = tid + 256 * e;                 /* flat patch index = LDS slot */        \
@@ -168,17 +188,18 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
             boff[e] = staged ? (unsigned)((long)cc * s_c + (long)fc * s_f + tc) : 0u;              \
-            vmask[e] = (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? 0xffffffffu : 0u; \
+            vbits |= (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? (1u << e) : 0u; \
         });                                                                                        \
     }
 #define GC_LOAD_CHUNK(CH, BUF)                                                                     \
     {                                                                                              \
-        /* activation patch first (HBM latency), weights second: the DMA issues are invisible to the compiler's */ \
-        /* vmcnt bookkeeping, and behind the patch loads they never make one of its waits block early           */ \
+        /* both operands go global -> LDS by DMA: no staging registers, no ds_write phase; the activation patch first */ \
+        /* (HBM latency), the weights (L2-resident) behind it                                                        */ \
         const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
+        const unsigned bl = __builtin_amdgcn_readfirstlane(lds_addr(Bs + (BUF) * Bs_sz + wave * 64)); \
         static_for<NB>([&](auto E) {                                                               \
             constexpr int e = decltype(E)::value;                                                  \
-            preB[e] = Bc[boff[e]];                                                                 \
+            if (e < bit) gc_dma4_masked(Bc + boff[e], bl + 1024u * e, vbits & (1u << e));          \
         });                                                                                        \
         const float* __restrict__ Ac = Ag + (long)(gchunk + (CH)) * p.KCp * p.Mp;                  \
         float* Adw = As + (BUF) * As_sz + wave * 256;   /* wave-uniform LDS base of this wave's 1 KB slice */ \
@@ -187,14 +208,12 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             if (i < ait) gc_dma16(Ac + aoff[i], Adw + i * 1024);                                   \
         });                                                                                        \
     }
-#define GC_STORE_CHUNK(BUF)                                                                        \
-    {                                                                                              \
-        float* Bd = Bs + (BUF) * Bs_sz + tid;                                                      \
-        static_for<NB>([&](auto E) {                                                               \
-            constexpr int e = decltype(E)::value;                                                  \
-            if (e < bit) Bd[256 * e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, preB[e]) & vmask[e]); \
-        });                                                                                        \
-    }
+// the DMA writes are invisible to the compiler: drain them by hand before the barrier that publishes the buffer
+#define GC_WAIT_CHUNK() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+    // zeros of the padding: the patch buffers are cleared once, masked DMA lanes never touch them again
+    for (int i = tid; i < 2 * Bs_sz; i += 256) Bs[i] = 0.f;
+    __syncthreads();
 
     for (int seg = 0; seg < 2; ++seg) {
         const int Cseg = seg ? p.C1 : p.C0;
@@ -206,15 +225,14 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         const int tail = Cseg - (nch - 1) * p.CI_C;       // channels in the last chunk
 
         GC_MAKE_DESC(nch > 1 ? p.CI_C : tail);
-        GC_LOAD_CHUNK(0, buf);
-        __syncthreads();                 // previous segment's readers are done with `buf`
-        GC_STORE_CHUNK(buf);
+        GC_LOAD_CHUNK(0, buf);           // `buf` is free: the previous segment's last chunk was read from buf ^ 1
+        GC_WAIT_CHUNK();
         __syncthreads();
 
         for (int c = 0; c < nch; ++c) {
             if (c + 1 < nch && !(p.dbg & 1)) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
-                GC_LOAD_CHUNK(c + 1, p.dbuf ? (buf ^ 1) : 0);
+                GC_LOAD_CHUNK(c + 1, buf ^ 1);
             }
             // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
             const float* Ab = As + buf * As_sz + hi * BM + am;
@@ -254,22 +272,15 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             }
 #undef GC_FETCH
 #undef GC_MMA
-            if (p.dbg & 2) {
-            } else if (p.dbuf) {
-                if (c + 1 < nch) GC_STORE_CHUNK(buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
-            } else {
-                __syncthreads();
-                if (c + 1 < nch) GC_STORE_CHUNK(0);
-                __syncthreads();
-            }
+            GC_WAIT_CHUNK();
+            __syncthreads();
+            buf ^= 1;
         }
         gchunk += nch;
     }
 #undef GC_MAKE_DESC
 #undef GC_LOAD_CHUNK
-#undef GC_STORE_CHUNK
+#undef GC_WAIT_CHUNK
 
     // ---------------------------------------------------------------- epilogue
     if (p.dbg & 8) return;
@@ -424,7 +435,7 @@ static void gc_small_launch(const GCParams& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
-    return (p.dbuf ? 2 : 1) * (as + bs) * 4 + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + 64;
+    return 2 * (as + bs) * 4 + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + 64;
 }
 
 GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w, const std::vector<float>& bias,

@@ -68,6 +68,7 @@ struct GCParams {
     int dbuf;                // 1: double-buffered LDS staging, 0: single buffer (more blocks per CU)
     int dbg;                 // ablation switches for tuning (0 in production): 1 no global loads, 2 no LDS restage, 4 no MFMA
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
+    unsigned long long* timing;   // tuning builds (-DGC_TIMING): per-phase s_memtime accumulators, else unused
     const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]
 };
 

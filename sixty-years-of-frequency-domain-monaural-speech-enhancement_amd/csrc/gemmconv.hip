@@ -77,8 +77,25 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 // Per-thread staging descriptors are chunk-invariant: element e = (row rr = wave + 4*i, column w = lane + 64*j)
 // of the activation patch reads  base_chunk[boff[e]]  (always an in-bounds address) and is zeroed when its validity
 // bit is clear, so the per-chunk staging code is one load + one select per element with a uniform 64-bit base.
+// Phase timing for tuning builds (make gcbench_timing: -DGC_TIMING): wave 0 of every block accumulates s_memtime
+// deltas per phase into p.timing[0..5] (prologue, load issue, mfma, vmcnt wait, barrier, epilogue), [6] = blocks.
+#ifdef GC_TIMING
+#define GC_T(SLOT)                                                               \
+    {                                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+        if (tid == 0) tacc[SLOT] += now_ - tlast;                                \
+        tlast = __builtin_amdgcn_s_memtime();                                    \
+    }
+#else
+#define GC_T(SLOT)
+#endif
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {
+#ifdef GC_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     // small-M tiles do little MFMA work per staged K row, so they stage twice the K depth per barrier to keep the
@@ -225,15 +242,20 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         const int tail = Cseg - (nch - 1) * p.CI_C;       // channels in the last chunk
 
         GC_MAKE_DESC(nch > 1 ? p.CI_C : tail);
+        GC_T(0);
         GC_LOAD_CHUNK(0, buf);           // `buf` is free: the previous segment's last chunk was read from buf ^ 1
+        GC_T(1);
         GC_WAIT_CHUNK();
+        GC_T(3);
         __syncthreads();
+        GC_T(4);
 
         for (int c = 0; c < nch; ++c) {
             if (c + 1 < nch && !(p.dbg & 1)) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
                 GC_LOAD_CHUNK(c + 1, buf ^ 1);
             }
+            GC_T(1);
             // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
             const float* Ab = As + buf * As_sz + hi * BM + am;
             const float* Bb = Bs + buf * Bs_sz + bn;
@@ -272,8 +294,11 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             }
 #undef GC_FETCH
 #undef GC_MMA
+            GC_T(2);
             GC_WAIT_CHUNK();
+            GC_T(3);
             __syncthreads();
+            GC_T(4);
             buf ^= 1;
         }
         gchunk += nch;
@@ -284,49 +309,94 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
 
     // ---------------------------------------------------------------- epilogue
     if (p.dbg & 8) return;
+    GC_T(0);
     const int fo = q * p.so + p.po;
     const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
     float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
 
-    if (EPI == EPI_ACT || EPI == EPI_ADD || EPI == EPI_MUL) {
-        const float* __restrict__ res =
-            (EPI != EPI_ACT) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int t = t0 + wn * (TN * 32) + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (m < p.M && t < p.Tout) {
-                        float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
-                        v = act_apply(v, p.act, p.slope ? p.slope[m] : 0.f);
-                        if (EPI == EPI_ADD) v += res[(long)m * p.x_c + t];
-                        if (EPI == EPI_MUL) v *= res[(long)m * p.x_c + t];
-                        dst[(long)m * p.d_c + t] = v;
-                    }
-                }
+    // per-row epilogue parameters go through LDS once per block (the K loop's last barrier has retired every reader
+    // of the staging buffers): no dependent global load sits in front of a store.  The activated tile is then
+    // transposed through LDS inside each wave so that a lane stores 16 B runs along t (4x fewer, 4x wider stores
+    // than the MFMA accumulator layout gives).
+    float* ep = smem;
+    constexpr int OROWS = (EPI == EPI_GLU) ? TM * 16 : TM * 32;   // output rows of one wave's strip
+    constexpr int OST = TN * 32 + 4;                               // LDS row stride of the strip
+    float* strip = smem + 4 * BM + wave * (TM * 32 * OST);
+    if (EPI == EPI_ACT || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_GLU) {
+        if (tid < BM) {
+            const int m = min(m0 + tid, p.M - 1);
+            ep[tid] = bias ? bias[m] : 0.f;
+            if (EPI != EPI_GLU) {
+                ep[BM + tid] = p.slope ? p.slope[m] : 0.f;
+            } else if (tid < BM / 2) {
+                const int oc = min((m0 >> 1) + tid, (p.M >> 1) - 1);
+                ep[BM + tid] = p.slope ? p.slope[oc] : 0.f;
+                ep[2 * BM + tid] = p.post_scale ? p.post_scale[oc] : 1.f;
+                ep[3 * BM + tid] = p.post_scale ? p.post_shift[oc] : 0.f;
             }
-    } else if (EPI == EPI_GLU) {
+        }
+        __syncthreads();
+        const int mw = wm * (TM * 32) + 4 * hi;                 // first tile row of this lane
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int t = t0 + wn * (TN * 32) + j * 32 + l31;
+                if (EPI != EPI_GLU) {
 #pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) {
-                    const int r = 2 * r2;
-                    const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;   // even row
-                    if (m + 1 < p.M && t < p.Tout) {
-                        const float a = acc[i][j][r] + (bias ? bias[m] : 0.f);
-                        const float g = acc[i][j][r + 1] + (bias ? bias[m + 1] : 0.f);
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][j][r] + ep[mw + dm];
+                        v = act_apply(v, p.act, ep[BM + mw + dm]);
+                        strip[(4 * hi + dm) * OST + j * 32 + l31] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) {
+                        const int r = 2 * r2;
+                        const int dm = i * 32 + (r & 3) + 8 * (r >> 2);      // even row (value), dm + 1 = its gate
+                        const float a = acc[i][j][r] + ep[mw + dm];
+                        const float g = acc[i][j][r + 1] + ep[mw + dm + 1];
+                        const int ol = (mw + dm) >> 1;
                         float v = a * sigmoidf_(g);
-                        if (p.post_scale) v = v * p.post_scale[m >> 1] + p.post_shift[m >> 1];
-                        dst[(long)(m >> 1) * p.d_c + t] = act_apply(v, p.act, p.slope ? p.slope[m >> 1] : 0.f);
+                        v = v * ep[2 * BM + ol] + ep[3 * BM + ol];
+                        strip[((4 * hi + dm) >> 1) * OST + j * 32 + l31] = act_apply(v, p.act, ep[BM + ol]);
                     }
                 }
             }
+        __syncthreads();
+        // read back as rows: lane -> (row, 4 consecutive t)
+        constexpr int L4 = TN * 8;                               // float4 groups per strip row
+        constexpr int RPI = 64 / L4;                             // rows per wave instruction
+        const int lr = lane / L4, lc = (lane % L4) * 4;
+        const int mo0 = (EPI == EPI_GLU ? (m0 >> 1) : m0) + wm * OROWS;      // first output row of the strip
+        const int Mo = (EPI == EPI_GLU) ? (p.M >> 1) : p.M;
+        const int tg = t0 + wn * (TN * 32) + lc;
+        const float* __restrict__ res =
+            (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+#pragma unroll
+        for (int it = 0; it < OROWS / RPI; ++it) {
+            const int row = it * RPI + lr, m = mo0 + row;
+            floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * OST + lc);
+            if (m < Mo) {
+                float* __restrict__ dp = dst + (long)m * p.d_c + tg;
+                if (tg + 3 < p.Tout) {
+                    if (EPI == EPI_ADD || EPI == EPI_MUL) {
+                        const floatx4 rv = *reinterpret_cast<const floatx4*>(res + (long)m * p.x_c + tg);
+                        v = (EPI == EPI_ADD) ? v + rv : v * rv;
+                    }
+                    *reinterpret_cast<floatx4*>(dp) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (tg + k < p.Tout) {
+                            float o = v[k];
+                            if (EPI == EPI_ADD) o += res[(long)m * p.x_c + tg + k];
+                            if (EPI == EPI_MUL) o *= res[(long)m * p.x_c + tg + k];
+                            dp[k] = o;
+                        }
+                }
+            }
+        }
     } else {   // EPI_LSTM
         const float* __restrict__ gx = p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f;
         float* __restrict__ cell = p.cell + (long)z * p.cell_z + (long)b * p.d_b + (long)fo * p.d_f;
@@ -353,6 +423,13 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
                 }
             }
     }
+#ifdef GC_TIMING
+    GC_T(5);
+    if (tid == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(p.timing + i, tacc[i]);
+        atomicAdd(p.timing + 6, 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -433,9 +510,10 @@ static void gc_small_launch(const GCParams& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static size_t gc_lds_bytes(const GCParams& p, int BM) {
+static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
-    return 2 * (as + bs) * 4 + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + 64;
+    const size_t staging = 2 * (as + bs) * 4 + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + 64;
+    return std::max(staging, epi_bytes);
 }
 
 GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w, const std::vector<float>& bias,
@@ -565,7 +643,9 @@ void gc_free_plan(GCPlan& pl) {
 
 template <int BM, int BN, int WM, int WN, int EPI>
 static void gc_launch_e(const GCParams& p, hipStream_t stream) {
-    const size_t lds = gc_lds_bytes(p, BM);
+    // epilogue: 4*BM row parameters + one transposition strip per wave (rows x (cols + 4))
+    const size_t epi = (size_t)(4 * BM + 4 * (BM / WM) * (BN / WN + 4)) * sizeof(float);
+    const size_t lds = gc_lds_bytes(p, BM, epi);
     static bool attr_set = false;
     if (!attr_set) {
         SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI>),

@@ -24,6 +24,12 @@ int main(int argc, char** argv) {
     SE_HIP(hipMalloc(&din, nin * 4 + 4096));
     SE_HIP(hipMalloc(&dout, nout * 4));
     SE_HIP(hipMemcpy(din, hin.data(), nin * 4, hipMemcpyHostToDevice));
+#ifdef GC_TIMING
+    unsigned long long* dt;
+    SE_HIP(hipMalloc(&dt, 64));
+    SE_HIP(hipMemset(dt, 0, 64));
+    pl.p.timing = dt;
+#endif
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     Act4 a = act4(din, Cin, Fin, T);
@@ -36,6 +42,21 @@ int main(int argc, char** argv) {
     SE_HIP(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     double fl = 2.0 * Cout * Cin * 10.0 * B * Fout * T;
+#ifdef GC_TIMING
+    {
+        SE_HIP(hipMemset(dt, 0, 64));
+        run_conv(pl, a, nullptr, dout, Cout, Fout, B, T, T, 0);
+        SE_HIP(hipDeviceSynchronize());
+        unsigned long long h[8];
+        SE_HIP(hipMemcpy(h, dt, 64, hipMemcpyDeviceToHost));
+        const char* nm[6] = {"prologue/desc", "load issue", "mfma", "vmcnt wait", "barrier", "epilogue"};
+        double tot = 0;
+        for (int i = 0; i < 6; ++i) tot += (double)h[i];
+        printf("blocks=%llu  per-block s_memtime ticks (wave 0):", h[6]);
+        for (int i = 0; i < 6; ++i) printf("  %s %.0f (%.1f%%)", nm[i], (double)h[i] / h[6], 100.0 * h[i] / tot);
+        printf("  total %.0f\n", tot / h[6]);
+    }
+#endif
     printf("Cin=%d Cout=%d Fin=%d B=%d T=%d BM=%d BN=%d CI_C=%d KCp=%d: %.3f ms  %.1f TFLOP/s\n", Cin, Cout, Fin, B, T, pl.BM, pl.BN,
            pl.p.CI_C, pl.p.KCp, ms, fl / ms / 1e9);
     return 0;

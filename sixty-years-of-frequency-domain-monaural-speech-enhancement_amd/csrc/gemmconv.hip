@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     // than the MFMA accumulator layout gives).
     float* ep = smem;
     constexpr int OROWS = (EPI == EPI_GLU) ? TM * 16 : TM * 32;   // output rows of one wave's strip
-    constexpr int OST = TN * 32 + 4;                               // LDS row stride of the strip
+    constexpr int OST = 32 + 4;                                    // LDS row stride of the strip (one 32-column MFMA tile wide)
     float* strip = smem + 4 * BM + wave * (TM * 32 * OST);
     if (EPI == EPI_ACT || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_GLU) {
         if (tid < BM) {
@@ -337,17 +337,23 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         }
         __syncthreads();
         const int mw = wm * (TM * 32) + 4 * hi;                 // first tile row of this lane
+        const int lr = lane >> 3, lc = (lane & 7) * 4;           // read-back role: (row within 8, 4 consecutive t)
+        const int mo0 = (EPI == EPI_GLU ? (m0 >> 1) : m0) + wm * OROWS;      // first output row of the strip
+        const int Mo = (EPI == EPI_GLU) ? (p.M >> 1) : p.M;
+        const float* __restrict__ res =
+            (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+            if (j > 0) __syncthreads();                          // the previous column tile has been read back
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+            for (int i = 0; i < TM; ++i) {
                 if (EPI != EPI_GLU) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
                         float v = acc[i][j][r] + ep[mw + dm];
                         v = act_apply(v, p.act, ep[BM + mw + dm]);
-                        strip[(4 * hi + dm) * OST + j * 32 + l31] = v;
+                        strip[(4 * hi + dm) * OST + l31] = v;
                     }
                 } else {
 #pragma unroll
@@ -359,41 +365,35 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
                         const int ol = (mw + dm) >> 1;
                         float v = a * sigmoidf_(g);
                         v = v * ep[2 * BM + ol] + ep[3 * BM + ol];
-                        strip[((4 * hi + dm) >> 1) * OST + j * 32 + l31] = act_apply(v, p.act, ep[BM + ol]);
+                        strip[((4 * hi + dm) >> 1) * OST + l31] = act_apply(v, p.act, ep[BM + ol]);
                     }
                 }
             }
-        __syncthreads();
-        // read back as rows: lane -> (row, 4 consecutive t)
-        constexpr int L4 = TN * 8;                               // float4 groups per strip row
-        constexpr int RPI = 64 / L4;                             // rows per wave instruction
-        const int lr = lane / L4, lc = (lane % L4) * 4;
-        const int mo0 = (EPI == EPI_GLU ? (m0 >> 1) : m0) + wm * OROWS;      // first output row of the strip
-        const int Mo = (EPI == EPI_GLU) ? (p.M >> 1) : p.M;
-        const int tg = t0 + wn * (TN * 32) + lc;
-        const float* __restrict__ res =
-            (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+            __syncthreads();
+            // read back as rows: 8 lanes x 16 B cover the 32 columns of one row, 8 rows per wave instruction
+            const int tg = t0 + wn * (TN * 32) + j * 32 + lc;
 #pragma unroll
-        for (int it = 0; it < OROWS / RPI; ++it) {
-            const int row = it * RPI + lr, m = mo0 + row;
-            floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * OST + lc);
-            if (m < Mo) {
-                float* __restrict__ dp = dst + (long)m * p.d_c + tg;
-                if (tg + 3 < p.Tout) {
-                    if (EPI == EPI_ADD || EPI == EPI_MUL) {
-                        const floatx4 rv = *reinterpret_cast<const floatx4*>(res + (long)m * p.x_c + tg);
-                        v = (EPI == EPI_ADD) ? v + rv : v * rv;
-                    }
-                    *reinterpret_cast<floatx4*>(dp) = v;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (tg + k < p.Tout) {
-                            float o = v[k];
-                            if (EPI == EPI_ADD) o += res[(long)m * p.x_c + tg + k];
-                            if (EPI == EPI_MUL) o *= res[(long)m * p.x_c + tg + k];
-                            dp[k] = o;
+            for (int it = 0; it < OROWS / 8; ++it) {
+                const int row = it * 8 + lr, m = mo0 + row;
+                floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * OST + lc);
+                if (m < Mo) {
+                    float* __restrict__ dp = dst + (long)m * p.d_c + tg;
+                    if (tg + 3 < p.Tout) {
+                        if (EPI == EPI_ADD || EPI == EPI_MUL) {
+                            const floatx4 rv = *reinterpret_cast<const floatx4*>(res + (long)m * p.x_c + tg);
+                            v = (EPI == EPI_ADD) ? v + rv : v * rv;
                         }
+                        *reinterpret_cast<floatx4*>(dp) = v;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (tg + k < p.Tout) {
+                                float o = v[k];
+                                if (EPI == EPI_ADD) o += res[(long)m * p.x_c + tg + k];
+                                if (EPI == EPI_MUL) o *= res[(long)m * p.x_c + tg + k];
+                                dp[k] = o;
+                            }
+                    }
                 }
             }
         }
@@ -644,7 +644,7 @@ void gc_free_plan(GCPlan& pl) {
 template <int BM, int BN, int WM, int WN, int EPI>
 static void gc_launch_e(const GCParams& p, hipStream_t stream) {
     // epilogue: 4*BM row parameters + one transposition strip per wave (rows x (cols + 4))
-    const size_t epi = (size_t)(4 * BM + 4 * (BM / WM) * (BN / WN + 4)) * sizeof(float);
+    const size_t epi = (size_t)(4 * BM + 4 * (BM / WM) * 36) * sizeof(float);
     const size_t lds = gc_lds_bytes(p, BM, epi);
     static bool attr_set = false;
     if (!attr_set) {

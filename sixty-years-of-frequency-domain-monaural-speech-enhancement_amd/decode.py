@@ -13,13 +13,25 @@ import numpy as np
 from . import wavio
 from .models import MODEL_CLASSES
 
-# checkpoint name checked in at each reference decode script
+# checkpoint name(s) checked in at each reference decode script
 DEFAULT_CKPT = {
-    'lstm': './BEST_MODEL/vb_lstm_noncprs_model.pth',       # LSTM/lstm_decode_vb.py:19
-    'crn': './BEST_MODEL/vb_crn_noncprs_model.pth',         # CRN/crn_decode_vb.py:19
-    'dpcrn': './BEST_MODEL/vb_dpcrn_noncprs_model.pth',     # DPCRN/dpcrn_decode_vb.py:20
-    'dccrn': './BEST_MODEL/vb_dccrn_noncprs_model.pth',     # DCCRN/dccrn_decode_vb.py:12
+    'lstm': './BEST_MODEL/vb_lstm_noncprs_model.pth',                       # LSTM/lstm_decode_vb.py:19
+    'crn': './BEST_MODEL/vb_crn_noncprs_model.pth',                         # CRN/crn_decode_vb.py:19
+    'gcrn': './BEST_MODEL/vb_gcrn_cprs_model.pth',                          # GCRN/gcrn_decode_vb.py:20
+    'dpcrn': './BEST_MODEL/vb_dpcrn_noncprs_model.pth',                     # DPCRN/dpcrn_decode_vb.py:20
+    'dccrn': './BEST_MODEL/vb_dccrn_noncprs_model.pth',                     # DCCRN/dccrn_decode_vb.py:12
+    'fullsubnet': './BEST_MODEL/vb_fullsubnet_noncprs_model_512_256.pth',   # FullSubNet/fullsubnet_sa_decode_vb.py:25
+    'ctsnet': ('./BEST_MODEL/step1_vb_cts_noncprs_model_final.pth',         # CTSNet/two_stage_com_decode_vb.py:15-16
+               './BEST_MODEL/step2_vb_cts_noncprs_model.pth'),
+    'g2net': './BEST_MODEL/vb_gaf_noncprs_model.pth',                       # G2Net_VB/com_decode.py:103 (--Model_path)
+    'taylorsenet': './BEST_MODEL/vb_taylor_noncprs_model.pth',              # TaylorSENet/taylorsenet_decode_vb.py:14
+    'uformer': './BEST_MODEL/vb_uformer_cprs_model.pth',                    # Uformer/uformer_decode_vb.py:20
+    'ctsnet_new': ('./BEST_MODEL/step1_vb_cts_cprs_model_final.pth',        # CTSNet_new/two_stage_com_decode_vb.py:15-16
+                   './BEST_MODEL/step2_vb_cts_cprs_model.pth'),
+    'taylorsenet_new': './BEST_MODEL/vb_taylor_cprs_model.pth',             # TaylorSENet_new/taylorsenet_decode_vb.py:14
+    'g2net_new': './BEST_MODEL/vb_gaf_cprs_model.pth',                      # G2Net_new/com_decode.py:104
 }
+MODELS = sorted(DEFAULT_CKPT)
 
 
 def load_checkpoint(path):
@@ -30,9 +42,29 @@ def load_checkpoint(path):
     return torch.load(path, map_location='cpu')
 
 
-def enhance(args, model='dccrn', checkpoint=None, p_in=1.0, p_out=1.0, max_batch=64, state_dict=None):
+def _build(model, checkpoint, state_dict, **kw):
+    """Construct the host class of `model` and load its weights (CTSNet: two files / two state dicts)."""
+    from . import models, models_new
+    if model in ('ctsnet', 'ctsnet_new'):
+        net = (models_new if model.endswith('_new') else models).CTSNet(**kw)
+        sds = state_dict if state_dict is not None else [load_checkpoint(c) for c in (checkpoint or DEFAULT_CKPT[model])]
+        return net.load_state_dicts(*sds)
+    net = MODEL_CLASSES[model](**kw)
+    sd = state_dict if state_dict is not None else load_checkpoint(checkpoint or DEFAULT_CKPT[model])
+    if isinstance(sd, dict) and 'model_state_dict' in sd:        # TaylorSENet/taylorsenet_decode_vb.py:14-15 wraps it
+        sd = sd['model_state_dict']
+    net.load_state_dict(sd)
+    return net
+
+
+def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_batch=64, state_dict=None):
+    """p_in / p_out None -> the exponents checked in at the model's decode script (host class defaults)."""
     import torch
     mix, out_dir = args.mix_file_path, getattr(args, 'esti_clean_file_path', None) or args.esti_file_path
+    if getattr(args, 'noise_type', None):
+        # WSJ0-SI84 grid drivers (`*_decode.py`, e.g. CRN/crn_decode.py:28-32): one (noise, seen/unseen, SNR) cell
+        mix = os.path.join(mix, args.noise_type, args.seen, str(args.snr))
+        out_dir = os.path.join(out_dir, args.noise_type, args.seen, str(args.snr))
     os.makedirs(out_dir, exist_ok=True)
     files = os.listdir(mix)
     clips = {}
@@ -43,9 +75,7 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=1.0, p_out=1.0, max_batch
                                       'SURVEY 8(f) rank 1: next)')
         clips.setdefault(len(x), []).append((name, x.astype(np.float32)))
     max_len = max(clips) if clips else 0
-    net = MODEL_CLASSES[model](max_batch=max_batch, max_samples=max(max_len, 512), p_in=p_in, p_out=p_out)
-    net.load_state_dict(state_dict if state_dict is not None else load_checkpoint(checkpoint or DEFAULT_CKPT[model]))
-    net.eval()
+    net = _build(model, checkpoint, state_dict, max_batch=max_batch, max_samples=max(max_len, 512), p_in=p_in, p_out=p_out)
     cnt = 0
     for length, items in clips.items():
         for i in range(0, len(items), max_batch):
@@ -64,12 +94,20 @@ def main():
     parser.add_argument('--mix_file_path', type=str, required=True)
     parser.add_argument('--esti_clean_file_path', '--esti_file_path', dest='esti_clean_file_path', type=str, required=True)
     parser.add_argument('--fs', type=int, default=16000)
-    parser.add_argument('--model', type=str, default='dccrn', choices=sorted(MODEL_CLASSES))
-    parser.add_argument('--checkpoint', type=str, default=None)
+    parser.add_argument('--model', type=str, default='dccrn', choices=MODELS)
+    parser.add_argument('--checkpoint', type=str, nargs='+', default=None, help='state dict file (two for ctsnet)')
     parser.add_argument('--cprs', action='store_true', help='compressed-spectrum variant: exponents 0.5 / 2.0')
+    parser.add_argument('--noncprs', action='store_true', help='uncompressed variant: exponents 1.0 / 1.0')
+    # WSJ0-SI84 grid drivers (`*_decode.py`): decode <mix>/<noise_type>/<seen>/<snr>/
+    parser.add_argument('--noise_type', type=str, default=None)
+    parser.add_argument('--seen', type=str, default='unseen')
+    parser.add_argument('--snr', type=str, default='-5')
     args = parser.parse_args()
-    p_in, p_out = (0.5, 2.0) if args.cprs else (1.0, 1.0)
-    enhance(args, args.model, args.checkpoint, p_in, p_out)
+    p_in, p_out = (0.5, 2.0) if args.cprs else ((1.0, 1.0) if args.noncprs else (None, None))
+    ck = args.checkpoint
+    if ck is not None and not args.model.startswith('ctsnet'):
+        ck = ck[0]
+    enhance(args, args.model, ck, p_in, p_out)
 
 
 if __name__ == '__main__':

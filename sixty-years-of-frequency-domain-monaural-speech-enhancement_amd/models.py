@@ -170,7 +170,7 @@ class CTSNet:
     _stages = (Step1_net, Step2_net)
 
     def __init__(self, **kw):
-        self._kw = kw
+        self._kw = {k: v for k, v in kw.items() if v is not None}
         self.engine = None
 
     def load_state_dicts(self, sd1, sd2):

@@ -26,6 +26,7 @@ class CTSNet(_base.CTSNet):
     _stages = (Step1_net, Step2_net)
 
     def __init__(self, **kw):
+        kw = {k: v for k, v in kw.items() if v is not None}
         kw.setdefault('p_in', 0.5)
         kw.setdefault('p_out', 2.0)
         super().__init__(**kw)

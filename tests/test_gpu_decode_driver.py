@@ -1,0 +1,75 @@
+"""GPU: the file-level `enhance(args)` driver (se_amd/decode.py) against the numpy oracle - directory in, PCM_16 WAV
+files out, same file names, both flavours of the reference drivers (`*_decode_vb.py` and the WSJ grid `*_decode.py`)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+import se_amd
+from se_amd import synth, schemas, wavio, decode
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_clips(d, lengths, seed0):
+    os.makedirs(d, exist_ok=True)
+    clips = {}
+    for i, L in enumerate(lengths):
+        x = synth.synth_clip(seed0 + i, 'speech', L)
+        name = f'p{232 + i}_{i:03d}.wav'
+        wavio.write_wav_pcm16(os.path.join(d, name), x, 16000)
+        clips[name] = wavio.read_wav(os.path.join(d, name))[0]        # what the driver will read back (PCM_16 rounded)
+    return clips
+
+
+def _pcm16(y):
+    return np.clip(np.round(np.asarray(y, dtype=np.float64) * 32768.0), -32768, 32767).astype(np.int64)
+
+
+def test_vb_driver_matches_oracle_and_pcm16(tmp_path):
+    import torch
+    assert torch.cuda.is_available()
+    from oracle import decode as D
+    mix, out = str(tmp_path / 'noisy'), str(tmp_path / 'enh')
+    clips = _write_clips(mix, [4000, 6000, 4000], 40)
+    sd = synth.synth_state_dict(schemas.crn_schema(), 12)
+    args = types.SimpleNamespace(mix_file_path=mix, esti_clean_file_path=out, fs=16000)
+    n = decode.enhance(args, 'crn', state_dict=sd, max_batch=2)
+    assert n == 3 and sorted(os.listdir(out)) == sorted(clips)
+    for name, x in clips.items():
+        y, fs = wavio.read_wav(os.path.join(out, name))
+        ref = D.enhance_crn(sd, x.astype(np.float64))
+        assert fs == 16000 and len(y) == len(ref)
+        # the files are PCM_16 (soundfile's default subtype): the engine and the reference path must quantise to the
+        # same integers up to ties at the rounding boundary -> identical PESQ / STOI by construction
+        diff = np.abs(_pcm16(ref) - np.round(y * 32768.0).astype(np.int64))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-3, (name, diff.max(), (diff != 0).mean())
+        assert rms(y - ref) < 1e-4
+
+
+def test_wsj_grid_driver_paths(tmp_path):
+    """CRN/crn_decode.py:28-32: <mix>/<noise_type>/<seen>/<snr>/ in, same sub-tree out."""
+    mix, out = tmp_path / 'mix', tmp_path / 'esti'
+    cell = os.path.join('cafe', 'unseen', '-5')
+    clips = _write_clips(str(mix / cell), [3200, 3200], 50)
+    sd = synth.synth_state_dict(schemas.lstm_schema(), 11)
+    args = types.SimpleNamespace(mix_file_path=str(mix), esti_clean_file_path=str(out), fs=16000, noise_type='cafe',
+                                 seen='unseen', snr='-5')
+    assert decode.enhance(args, 'lstm', state_dict=sd, max_batch=4) == 2
+    assert sorted(os.listdir(str(out / cell))) == sorted(clips)
+
+
+def test_ctsnet_driver_two_state_dicts(tmp_path):
+    from oracle import decode as D
+    mix, out = str(tmp_path / 'noisy'), str(tmp_path / 'enh')
+    clips = _write_clips(mix, [4000], 60)
+    sd1 = synth.synth_state_dict(schemas.SCHEMAS['cts_step1_new'](), 17)
+    sd2 = synth.synth_state_dict(schemas.SCHEMAS['cts_step2_new'](), 18)
+    args = types.SimpleNamespace(mix_file_path=mix, esti_file_path=out, fs=16000)
+    assert decode.enhance(args, 'ctsnet_new', state_dict=(sd1, sd2), max_batch=1) == 1     # exponents default to 0.5 / 2.0
+    (name, x), = clips.items()
+    y, _ = wavio.read_wav(os.path.join(out, name))
+    ref = D.enhance_ctsnet(sd1, sd2, x.astype(np.float64), 0.5, 2.0)
+    assert rms(y - ref) < 1e-4 and np.abs(_pcm16(ref) - np.round(y * 32768.0).astype(np.int64)).max() <= 1

@@ -11,14 +11,16 @@
 //
 // Kernel shape: one 64-lane wave transforms one frame with a Stockham autosort FFT in LDS (radix 4/4/4/4/2 for
 // n_fft=512, 4/4/4/5 for n_fft=320 - the radix-5 and radix-2 tail stages need no twiddles), twiddles and the
-// window staged once per block in LDS.  A block owns 8 consecutive frames so that the [F][T]-major spectrogram
-// is written / read in 32-byte runs along T, and the waveform is read in coalesced rows.
+// window staged once per block in LDS.  A block owns 16 consecutive frames, transformed in pairs as 8 complex FFTs
+// (two-for-one real FFT), so that the [F][T]-major spectrogram is written / read in 64-byte runs along T and the
+// waveform is read in coalesced rows.
 #include "kernels.h"
 #include "common.h"
 
 namespace se {
 
-constexpr int FPB = 8;   // frames per block
+constexpr int FPB = 16;  // frames per block
+constexpr int PPB = 8;   // complex transforms per block: frames are transformed in pairs (two-for-one real FFT)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -122,45 +124,51 @@ struct StftArgs {
     float* spec; float* mag; int T, Tp, hop, win;
 };
 
+// two-for-one: a block owns 16 consecutive frames as 8 complex transforms z = x_{2p} + i x_{2p+1}
+//   X_{2p}[k] = (Z[k] + conj Z[N-k]) / 2,   X_{2p+1}[k] = (Z[k] - conj Z[N-k]) / (2i)
 template <int N>
 __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
     constexpr int F = N / 2 + 1;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float2* tw = reinterpret_cast<float2*>(smem_f);
-    float2* bufs = tw + N;                                  // [FPB][2][N]
-    float* win = reinterpret_cast<float*>(bufs + FPB * 2 * N);
+    float2* bufs = tw + N;                                  // [PPB][2][N]
+    float* win = reinterpret_cast<float*>(bufs + PPB * 2 * N);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, t0 = blockIdx.x * FPB;
     init_tables<N>(tw, win, a.win, tid);
     __syncthreads();
     const float c = a.c_scale ? a.c_scale[b] : 1.f;
     const float* x = a.wav + (long)b * a.pitch;
+    auto sample = [&](int t, int n) {
+        float v = 0.f;
+        if (t < a.T) {
+            int idx = t * a.hop + n - N / 2;
+            if (idx < 0) idx = -idx;
+            if (idx >= a.Lpad) idx = 2 * (a.Lpad - 1) - idx;
+            if (idx >= 0 && idx < a.L) v = x[idx] * c * win[n];
+        }
+        return v;
+    };
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
-        const int fi = wave + 4 * rep, t = t0 + fi;
-        float2* b0 = bufs + (fi * 2) * N;
+        const int pi = wave + 4 * rep, t = t0 + 2 * pi;
+        float2* b0 = bufs + (pi * 2) * N;
         float2* b1 = b0 + N;
-        for (int n = lane; n < N; n += 64) {
-            float v = 0.f;
-            if (t < a.T) {
-                int idx = t * a.hop + n - N / 2;
-                if (idx < 0) idx = -idx;
-                if (idx >= a.Lpad) idx = 2 * (a.Lpad - 1) - idx;
-                if (idx >= 0 && idx < a.L) v = x[idx] * c * win[n];
-            }
-            b0[n] = make_float2(v, 0.f);
-        }
+        for (int n = lane; n < N; n += 64) b0[n] = make_float2(sample(t, n), sample(t + 1, n));
         __syncthreads();
         fft_frame<N, false>(b0, b1, tw, lane);
     }
-    // write [F][T]-major: 8 consecutive frames of one bin are 32 contiguous bytes
+    // write [F][T]-major: the 16 frames of one bin are 64 contiguous bytes
     for (int idx = tid; idx < F * FPB; idx += 256) {
-        const int fi = idx & (FPB - 1), k = idx >> 3;
+        const int fi = idx & (FPB - 1), k = idx >> 4;
         const int t = t0 + fi;
         if (t >= a.T) continue;
         // natural-order result sits in buf1 after 5 stages (512) / buf0 after 4 stages (320)
-        const float2* src = bufs + (fi * 2) * N + ((N == 512) ? N : 0);
-        float2 v = src[k];
+        const float2* src = bufs + ((fi >> 1) * 2) * N + ((N == 512) ? N : 0);
+        const float2 zk = src[k], zc = src[k == 0 ? 0 : N - k];       // Z[k], Z[(N - k) mod N]
+        float2 v;
+        if (fi & 1) v = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));      // (Z[k] - conj Z[N-k]) / (2i)
+        else v = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));              // (Z[k] + conj Z[N-k]) / 2
         const float m = sqrtf(v.x * v.x + v.y * v.y);
         float mp = m;
         if (a.p_in != 1.f) {
@@ -181,38 +189,39 @@ struct IstftArgs {
     const float* spec; int B, T, Tp; float* frames; int win;
 };
 
+// inverse two-for-one: Z = X_{2p} + i X_{2p+1} on the Hermitian-extended spectra -> z = x_{2p} + i x_{2p+1}
 template <int N>
 __global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
     constexpr int F = N / 2 + 1;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float2* tw = reinterpret_cast<float2*>(smem_f);
     float2* bufs = tw + N;
-    float* win = reinterpret_cast<float*>(bufs + FPB * 2 * N);
+    float* win = reinterpret_cast<float*>(bufs + PPB * 2 * N);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, t0 = blockIdx.x * FPB;
     init_tables<N>(tw, win, a.win, tid);
-    // Hermitian-extended spectrum of 8 frames into buf0 of each frame
-    for (int idx = tid; idx < F * FPB; idx += 256) {
-        const int fi = idx & (FPB - 1), k = idx >> 3;
-        const int t = t0 + fi;
-        float2 v = make_float2(0.f, 0.f);
-        if (t < a.T) {
-            v.x = a.spec[(((long)b * 2 + 0) * F + k) * a.Tp + t];
-            v.y = a.spec[(((long)b * 2 + 1) * F + k) * a.Tp + t];
-        }
-        float2* b0 = bufs + (fi * 2) * N;
+    // 8 lanes x 2 frames = 16 consecutive frames of one bin (64 contiguous bytes per plane)
+    for (int idx = tid; idx < F * PPB; idx += 256) {
+        const int pi = idx & (PPB - 1), k = idx >> 3;
+        const int t = t0 + 2 * pi;
+        float2 xa = make_float2(0.f, 0.f), xb = make_float2(0.f, 0.f);
+        const float* re = a.spec + (((long)b * 2 + 0) * F + k) * a.Tp;
+        const float* im = a.spec + (((long)b * 2 + 1) * F + k) * a.Tp;
+        if (t < a.T) xa = make_float2(re[t], im[t]);
+        if (t + 1 < a.T) xb = make_float2(re[t + 1], im[t + 1]);
+        float2* b0 = bufs + (pi * 2) * N;
         if (k == 0 || k == N / 2) {
-            b0[k] = make_float2(v.x, 0.f);          // C2R ignores the imaginary part of DC / Nyquist
+            b0[k] = make_float2(xa.x, xb.x);                // C2R ignores the imaginary part of DC / Nyquist
         } else {
-            b0[k] = v;
-            b0[N - k] = make_float2(v.x, -v.y);
+            b0[k] = make_float2(xa.x - xb.y, xa.y + xb.x);              // X_a[k] + i X_b[k]
+            b0[N - k] = make_float2(xa.x + xb.y, xb.x - xa.y);          // conj X_a[k] + i conj X_b[k]
         }
     }
     __syncthreads();
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
-        const int fi = wave + 4 * rep;
-        float2* b0 = bufs + (fi * 2) * N;
+        const int pi = wave + 4 * rep;
+        float2* b0 = bufs + (pi * 2) * N;
         fft_frame<N, true>(b0, b0 + N, tw, lane);
     }
     const float invN = 1.f / N;
@@ -220,8 +229,8 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
         const int fi = idx / N, n = idx - fi * N;
         const int t = t0 + fi;
         if (t >= a.T) continue;
-        const float2* src = bufs + (fi * 2) * N + ((N == 512) ? N : 0);
-        a.frames[((long)b * a.T + t) * N + n] = src[n].x * invN * win[n];
+        const float2 z = (bufs + ((fi >> 1) * 2) * N + ((N == 512) ? N : 0))[n];
+        a.frames[((long)b * a.T + t) * N + n] = ((fi & 1) ? z.y : z.x) * invN * win[n];
     }
 }
 
@@ -277,7 +286,7 @@ void launch_rms_scale(const float* wav, int B, int L, long pitch, float* c_out, 
 }
 
 template <int N>
-static size_t fft_lds_bytes() { return (size_t)N * 8 + (size_t)FPB * 2 * N * 8 + (size_t)N * 4; }
+static size_t fft_lds_bytes() { return (size_t)N * 8 + (size_t)PPB * 2 * N * 8 + (size_t)N * 4; }
 
 template <typename K>
 static void set_lds_attr(K kernel, size_t bytes) {

@@ -69,6 +69,7 @@ struct GCParams {
     int dbg;                 // ablation switches for tuning (0 in production): 1 no global loads, 2 no LDS restage, 4 no MFMA
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
     unsigned long long* timing;   // tuning builds (-DGC_TIMING): per-phase s_memtime accumulators, else unused
+    const unsigned* desc;    // host-built patch-slot descriptors [NB][256]: w | r << 12 | cil << 16 | staged << 31
     const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]
 };
 
@@ -78,6 +79,7 @@ struct GCPlan {
     int BM = 128, BN = 128;  // tile config
     float* dA = nullptr;     // device copies owned by the plan
     float* dWs = nullptr;
+    unsigned* dDesc = nullptr;
     float* dBias = nullptr;
     float* dSlope = nullptr;
     int* dTab = nullptr;

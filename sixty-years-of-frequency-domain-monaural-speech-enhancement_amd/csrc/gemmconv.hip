@@ -195,10 +195,10 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         vbits = 0;                                                                                 \
         static_for<NB>([&](auto E) {                                                               \
             constexpr int e = decltype(E)::value;                                                  \
-            const int fe = tid + 256 * e;                 /* flat patch index = LDS slot */        \
-            const int rr = fe / p.Wp, w = fe - rr * p.Wp;                                          \
-            const int cil = rr / p.nrows, r = rr - cil * p.nrows;                                  \
-            const bool staged = fe < npatch;                                                       \
+            /* host-built descriptor of flat patch slot fe = tid + 256 e: w | r << 12 | cil << 16 | staged << 31 */ \
+            const unsigned d_ = p.desc[256 * e + tid];                                             \
+            const int w = d_ & 0xfff, r = (d_ >> 12) & 0xf, cil = (d_ >> 16) & 0x7fff;             \
+            const bool staged = (d_ >> 31) != 0;                                                   \
             const int f = q * p.si + tabl[staged ? r : 0];                                         \
             const int t = t0 + p.dtmin + w;                                                        \
             const int fc = f < 0 ? 0 : (f >= p.Fin ? p.Fin - 1 : f);                               \
@@ -570,6 +570,22 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
         SE_HIP(hipMemcpy(pl.dTab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
         p.tab = pl.dTab;
     }
+    {
+        // per-(thread, element) patch descriptors: slot fe = tid + 256 e -> (row rr = fe / Wp, column w), rr -> (cil, r)
+        const int NB = gc_bld_max(pl.BM), npatch = cic * p.nrows * p.Wp;
+        std::vector<unsigned> desc((size_t)NB * 256, 0u);
+        for (int e = 0; e < NB; ++e)
+            for (int t = 0; t < 256; ++t) {
+                const int fe = t + 256 * e;
+                if (fe >= npatch) continue;
+                const int rr = fe / p.Wp, w = fe - rr * p.Wp, cil = rr / p.nrows, r = rr - cil * p.nrows;
+                desc[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)r << 12) | ((unsigned)cil << 16) | 0x80000000u;
+            }
+        SE_CHECK(p.Wp < 4096 && p.nrows <= 16 && cic < 32768, "patch descriptor field overflow");
+        SE_HIP(hipMalloc(&pl.dDesc, desc.size() * sizeof(unsigned)));
+        SE_HIP(hipMemcpy(pl.dDesc, desc.data(), desc.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        p.desc = pl.dDesc;
+    }
     const int nch0 = (C0 + cic - 1) / cic, nch1 = (Cin - C0 + cic - 1) / cic;
     p.nchunks = nch0 + nch1;
     p.M = M;
@@ -628,7 +644,9 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
 void gc_free_plan(GCPlan& pl) {
     if (pl.dA) (void)hipFree(pl.dA);
     if (pl.dWs) (void)hipFree(pl.dWs);
+    if (pl.dDesc) (void)hipFree(pl.dDesc);
     pl.dWs = nullptr;
+    pl.dDesc = nullptr;
     if (pl.dBias) (void)hipFree(pl.dBias);
     if (pl.dSlope) (void)hipFree(pl.dSlope);
     if (pl.dTab) (void)hipFree(pl.dTab);

@@ -70,6 +70,7 @@ class Arena {
         return static_cast<char*>(base_) + a;
     }
     size_t used() const { return off_; }
+    const void* base() const { return base_; }
     size_t capacity() const { return cap_; }
 
   private:

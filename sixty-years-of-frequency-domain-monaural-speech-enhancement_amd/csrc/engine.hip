@@ -88,6 +88,7 @@ int se_engine_destroy(se_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     if (e->frames_scratch) (void)hipFree(e->frames_scratch);
+    if (e->ctx.arena.base()) gc_unregister_overread_range(e->ctx.arena.base());
     delete e;
     return 0;
 }
@@ -130,6 +131,7 @@ int se_engine_finalize(se_engine* e) {
         e->model->plan_buffers(e->ctx.max_batch, T);
         const size_t need = e->ctx.arena.measure_end();
         e->ctx.arena.reserve(need + (1 << 20));
+        gc_register_overread_range(e->ctx.arena.base(), e->ctx.arena.capacity());
         e->model->plan_buffers(e->ctx.max_batch, T);
         e->sd.clear();
         SE_HIP(hipDeviceSynchronize());

@@ -69,6 +69,8 @@ struct GCParams {
     int dbg;                 // ablation switches for tuning (0 in production): 1 no global loads, 2 no LDS restage, 4 no MFMA
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
     unsigned long long* timing;   // tuning builds (-DGC_TIMING): per-phase s_memtime accumulators, else unused
+    const unsigned* desc4;   // pointwise layers: descriptors of 16 B groups (w | cil << 16 | staged << 31), else nullptr
+    int pw4;                 // per launch: 1 -> stage the patch in 16 B groups (pointwise layer and Tin % 4 == 0)
     const unsigned* desc;    // host-built patch-slot descriptors [NB][256]: w | r << 12 | cil << 16 | staged << 31
     const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]
 };
@@ -80,6 +82,7 @@ struct GCPlan {
     float* dA = nullptr;     // device copies owned by the plan
     float* dWs = nullptr;
     unsigned* dDesc = nullptr;
+    unsigned* dDesc4 = nullptr;
     float* dBias = nullptr;
     float* dSlope = nullptr;
     int* dTab = nullptr;
@@ -100,6 +103,10 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
                     const std::vector<float>& bias, const std::vector<float>& slope, int act, int epi,
                     int si, int so, int po, int tout_hint, int z = 1, int C0split = -1);
 void gc_free_plan(GCPlan& pl);
+
+// Device ranges (the engine arenas) whose tensors may be over-read by <= 12 B past their end (pointwise 16 B staging).
+void gc_register_overread_range(const void* lo, size_t bytes);
+void gc_unregister_overread_range(const void* lo);
 
 // Launch: p must have src/dst pointers, strides, B/Q/Tout/Fin/Tin/C0/C1 filled in.
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream);

@@ -67,7 +67,22 @@ __device__ __forceinline__ void gc_dma4_masked(const float* g, unsigned lds_wave
         "global_load_lds_dword %3, off\n\t"
         "s_mov_b64 exec, %0"
         : "=&s"(saved)
-        : "v"(pred), "s"(lds_wave_base), "v"(g)
+        : "v"(pred), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)), "v"(g)
+        : "memory", "vcc");
+}
+// 16 B per lane variant (pointwise layers: a lane's 4 consecutive frames are one aligned group of the patch row)
+__device__ __forceinline__ void gc_dma16_masked(const float* g, unsigned lds_wave_base, unsigned pred) {
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %1\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(saved)
+        : "v"(pred), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)), "v"(g)
         : "memory", "vcc");
 }
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
@@ -109,6 +124,8 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     const int rows = p.CI_C * p.nrows;
     const int npatch = rows * p.Wp;                  // floats of one staged activation patch
     const int bit = (npatch + 255) >> 8;             // patch elements per thread (uniform)
+    const bool pw4 = p.pw4 != 0;                     // pointwise layer, Tin % 4 == 0: the patch is staged in 16 B groups
+    const int bit4 = (npatch / 4 + 255) >> 8;
     const int nA4 = p.KCp * (BM / 4);
     const int ait = (nA4 + 255) >> 8;                // float4 groups of the weight chunk per thread (uniform)
     const int As_sz = ait * 1024;                    // padded so that every thread stores unconditionally
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         static_for<NB>([&](auto E) {                                                               \
             constexpr int e = decltype(E)::value;                                                  \
             /* host-built descriptor of flat patch slot fe = tid + 256 e: w | r << 12 | cil << 16 | staged << 31 */ \
-            const unsigned d_ = p.desc[256 * e + tid];                                             \
+            const unsigned d_ = (pw4 ? p.desc4 : p.desc)[256 * e + tid];                           \
             const int w = d_ & 0xfff, r = (d_ >> 12) & 0xf, cil = (d_ >> 16) & 0x7fff;             \
             const bool staged = (d_ >> 31) != 0;                                                   \
             const int f = q * p.si + tabl[staged ? r : 0];                                         \
@@ -205,6 +222,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
             boff[e] = staged ? (unsigned)((long)cc * s_c + (long)fc * s_f + tc) : 0u;              \
+            /* pw4: the slot is a group of 4 frames, wholly inside or wholly outside the row (Tin % 4 == 0) */ \
             vbits |= (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? (1u << e) : 0u; \
         });                                                                                        \
     }
@@ -213,11 +231,19 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         /* both operands go global -> LDS by DMA: no staging registers, no ds_write phase; the activation patch first */ \
         /* (HBM latency), the weights (L2-resident) behind it                                                        */ \
         const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
-        const unsigned bl = __builtin_amdgcn_readfirstlane(lds_addr(Bs + (BUF) * Bs_sz + wave * 64)); \
-        static_for<NB>([&](auto E) {                                                               \
-            constexpr int e = decltype(E)::value;                                                  \
-            if (e < bit) gc_dma4_masked(Bc + boff[e], bl + 1024u * e, vbits & (1u << e));          \
-        });                                                                                        \
+        const unsigned bb = __builtin_amdgcn_readfirstlane(lds_addr(Bs + (BUF) * Bs_sz));          \
+        const unsigned bl = bb + 256u * wave, bl4 = bb + 1024u * wave;                             \
+        if (pw4) {                                                                                 \
+            static_for<NB>([&](auto E) {                                                           \
+                constexpr int e = decltype(E)::value;                                              \
+                if (e < bit4) gc_dma16_masked(Bc + boff[e], bl4 + 4096u * e, vbits & (1u << e)); \
+            });                                                                                    \
+        } else {                                                                                   \
+            static_for<NB>([&](auto E) {                                                           \
+                constexpr int e = decltype(E)::value;                                              \
+                if (e < bit) gc_dma4_masked(Bc + boff[e], bl + 1024u * e, vbits & (1u << e));      \
+            });                                                                                    \
+        }                                                                                          \
         const float* __restrict__ Ac = Ag + (long)(gchunk + (CH)) * p.KCp * p.Mp;                  \
         float* Adw = As + (BUF) * As_sz + wave * 256;   /* wave-uniform LDS base of this wave's 1 KB slice */ \
         static_for<A_IT>([&](auto I) {                                                             \
@@ -398,6 +424,8 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             }
         }
     } else {   // EPI_LSTM
+        // a lane's 16 accumulators of one MFMA tile are the i,f,g,o gates of 4 cells: all 16 gate pre-activations and
+        // the 4 cell states are fetched by unconditional (clamped) loads in one batch, then the cells update
         const float* __restrict__ gx = p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f;
         float* __restrict__ cell = p.cell + (long)z * p.cell_z + (long)b * p.d_b + (long)fo * p.d_f;
 #pragma unroll
@@ -405,20 +433,30 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int t = t0 + wn * (TN * 32) + j * 32 + l31;
+                const int tc = min(t, p.Tout - 1);
+                const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * hi;      // gate-i row of this lane's first cell
+                float g[16], cp[4];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int m = m0 + wm * (TM * 32) + i * 32 + 8 * g4 + 4 * hi;   // row of gate i of unit m/4
+                    const int m = min(mb + 8 * g4, p.M - 4);
+                    const float* gp = gx + (long)m * p.x_c + tc;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[4 * g4 + k] = gp[(long)k * p.x_c];
+                    cp[g4] = p.first_step ? 0.f : cell[(long)(m >> 2) * p.d_c + tc];
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int m = mb + 8 * g4;
+                    const float gi = acc[i][j][4 * g4 + 0] + g[4 * g4 + 0];
+                    const float gf = acc[i][j][4 * g4 + 1] + g[4 * g4 + 1];
+                    const float gg = acc[i][j][4 * g4 + 2] + g[4 * g4 + 2];
+                    const float go = acc[i][j][4 * g4 + 3] + g[4 * g4 + 3];
+                    const float cn = sigmoidf_(gf) * cp[g4] + sigmoidf_(gi) * tanhf(gg);
+                    const float hn = sigmoidf_(go) * tanhf(cn);
                     if (m + 3 < p.M && t < p.Tout) {
-                        const float* gp = gx + (long)m * p.x_c + t;
-                        const float gi = acc[i][j][4 * g4 + 0] + gp[0];
-                        const float gf = acc[i][j][4 * g4 + 1] + gp[p.x_c];
-                        const float gg = acc[i][j][4 * g4 + 2] + gp[2 * p.x_c];
-                        const float go = acc[i][j][4 * g4 + 3] + gp[3 * p.x_c];
                         const long oi = (long)(m >> 2) * p.d_c + t;
-                        const float cprev = p.first_step ? 0.f : cell[oi];
-                        const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
                         cell[oi] = cn;
-                        dst[oi] = sigmoidf_(go) * tanhf(cn);
+                        dst[oi] = hn;
                     }
                 }
             }
@@ -545,10 +583,15 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     static const int kcp_cap = getenv("SE_GC_KCP") ? atoi(getenv("SE_GC_KCP")) : GC_MAX_KCP;
     static const int dbuf_env = getenv("SE_GC_DBUF") ? atoi(getenv("SE_GC_DBUF")) : 1;
     p.dbuf = dbuf_env;
+    static const bool pw_chunks = !(getenv("SE_GC_PW4") && atoi(getenv("SE_GC_PW4")) == 0);
     int cic = 1;
     for (int c = 1; c <= std::max(std::max(C0, Cin - C0), 1); ++c) {
         int kcp = (c * taps.ntaps + 3) & ~3;
-        if (kcp <= std::min(gc_kcp_max(pl.BM), kcp_cap) && c * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256) cic = c;
+        // pointwise layers stage 16 B groups (4x the slots) and size the chunk by the LDS budget of 3 blocks per CU
+        const bool pw = taps.ntaps == 1 && pw_chunks;
+        const int kmax = pw ? (pl.BM >= 128 ? 24 : (pl.BM >= 64 ? 32 : 40)) : gc_kcp_max(pl.BM);
+        const int cap = gc_bld_max(pl.BM) * 256 * (pw ? 4 : 1);
+        if (kcp <= std::min(kmax, kcp_cap) && c * p.nrows * p.Wp <= cap) cic = c;
     }
     p.CI_C = cic;
     p.KC = cic * taps.ntaps;
@@ -581,6 +624,21 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
                 const int rr = fe / p.Wp, w = fe - rr * p.Wp, cil = rr / p.nrows, r = rr - cil * p.nrows;
                 desc[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)r << 12) | ((unsigned)cil << 16) | 0x80000000u;
             }
+        if (taps.ntaps == 1) {
+            // pointwise layers: the same patch seen as groups of 4 consecutive frames (slot fg = tid + 256 e <-> LDS float 4 fg)
+            std::vector<unsigned> d4((size_t)NB * 256, 0u);
+            const int gpr = p.Wp / 4;
+            for (int e = 0; e < NB; ++e)
+                for (int t = 0; t < 256; ++t) {
+                    const int fg = t + 256 * e;
+                    if (4 * fg >= npatch) continue;
+                    const int rr = fg / gpr, w = 4 * (fg - rr * gpr);
+                    d4[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)rr << 16) | 0x80000000u;     // nrows = 1: rr = cil, r = 0
+                }
+            SE_HIP(hipMalloc(&pl.dDesc4, d4.size() * sizeof(unsigned)));
+            SE_HIP(hipMemcpy(pl.dDesc4, d4.data(), d4.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+            p.desc4 = pl.dDesc4;
+        }
         SE_CHECK(p.Wp < 4096 && p.nrows <= 16 && cic < 32768, "patch descriptor field overflow");
         SE_HIP(hipMalloc(&pl.dDesc, desc.size() * sizeof(unsigned)));
         SE_HIP(hipMemcpy(pl.dDesc, desc.data(), desc.size() * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -641,10 +699,38 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     return pl;
 }
 
+// Device ranges whose tensors may be over-read by up to 12 B past their last element (the engine arenas: every
+// allocation is followed by more arena or by the arena's tail slack).  Pointwise layers stage their patch in 16 B groups;
+// a group that straddles the end of a row only feeds output columns that are never stored, so the only requirement on
+// the over-read is that it stays inside mapped memory.
+static std::vector<std::pair<const char*, const char*>>& gc_safe_ranges() {
+    static std::vector<std::pair<const char*, const char*>> r;
+    return r;
+}
+void gc_register_overread_range(const void* lo, size_t bytes) {
+    gc_safe_ranges().emplace_back(static_cast<const char*>(lo), static_cast<const char*>(lo) + bytes);
+}
+void gc_unregister_overread_range(const void* lo) {
+    auto& r = gc_safe_ranges();
+    for (size_t i = 0; i < r.size(); ++i)
+        if (r[i].first == lo) {
+            r.erase(r.begin() + i);
+            return;
+        }
+}
+static bool gc_overread_ok(const void* ptr) {
+    if (!ptr) return true;
+    for (const auto& r : gc_safe_ranges())
+        if (ptr >= r.first && static_cast<const char*>(ptr) + 16 <= r.second) return true;
+    return false;
+}
+
 void gc_free_plan(GCPlan& pl) {
     if (pl.dA) (void)hipFree(pl.dA);
     if (pl.dWs) (void)hipFree(pl.dWs);
     if (pl.dDesc) (void)hipFree(pl.dDesc);
+    if (pl.dDesc4) (void)hipFree(pl.dDesc4);
+    pl.dDesc4 = nullptr;
     pl.dWs = nullptr;
     pl.dDesc = nullptr;
     if (pl.dBias) (void)hipFree(pl.dBias);
@@ -694,6 +780,10 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     p.dbg = dbg_env;
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
     if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;
+    static const int pw4_env = getenv("SE_GC_PW4") ? atoi(getenv("SE_GC_PW4")) : 1;
+    p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || (gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
+    SE_CHECK(p.pw4 || p.CI_C * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256,
+             "pointwise layer with a row length that is not a multiple of 4 needs its sources inside the engine arena");
     if (p.Ws) {
         if (p.M <= 1) gc_small_launch<1>(p, stream);
         else if (p.M <= 2) gc_small_launch<2>(p, stream);

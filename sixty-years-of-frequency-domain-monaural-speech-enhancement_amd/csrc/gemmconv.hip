@@ -41,6 +41,8 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float fsig_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 // 16 B per lane global -> LDS copy without a register round trip (global_load_lds_dwordx4: lane l lands at
 // lds_base + 16*l, lds_base wave-uniform in M0).  Issued from inline asm on purpose: through the builtin the compiler
@@ -451,8 +453,10 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
                     const float gf = acc[i][j][4 * g4 + 1] + g[4 * g4 + 1];
                     const float gg = acc[i][j][4 * g4 + 2] + g[4 * g4 + 2];
                     const float go = acc[i][j][4 * g4 + 3] + g[4 * g4 + 3];
-                    const float cn = sigmoidf_(gf) * cp[g4] + sigmoidf_(gi) * tanhf(gg);
-                    const float hn = sigmoidf_(go) * tanhf(cn);
+                    // fast exp / reciprocal as in the persistent LSTM kernels (5 transcendentals per cell, 16 cells per lane
+                    // and tile: libm's tanhf / expf made this the longest phase of a step block)
+                    const float cn = fsig_(gf) * cp[g4] + fsig_(gi) * ftanh_(gg);
+                    const float hn = fsig_(go) * ftanh_(cn);
                     if (m + 3 < p.M && t < p.Tout) {
                         const long oi = (long)(m >> 2) * p.d_c + t;
                         cell[oi] = cn;

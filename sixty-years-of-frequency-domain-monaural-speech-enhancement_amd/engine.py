@@ -90,8 +90,11 @@ class Engine:
         n_out = self.output_samples(L)
         if out is None:
             out = torch.empty((B, n_out), dtype=torch.float32, device=wav.device)
-        self._check(self._lib.se_enhance_batch(self._h, C.c_void_p(wav.data_ptr()), wav.stride(0), B, L,
-                                               C.c_void_p(out.data_ptr()), out.stride(0), self._stream()))
+        # the stride of a size-1 dimension is arbitrary in torch / numpy: a single row has pitch L
+        in_pitch = wav.stride(0) if B > 1 else L
+        out_pitch = out.stride(0) if B > 1 else n_out
+        self._check(self._lib.se_enhance_batch(self._h, C.c_void_p(wav.data_ptr()), in_pitch, B, L,
+                                               C.c_void_p(out.data_ptr()), out_pitch, self._stream()))
         return out
 
     # ------------------------------------------------------------------ stage hooks

@@ -69,8 +69,9 @@ struct GCParams {
     int dbg;                 // ablation switches for tuning (0 in production): 1 no global loads, 2 no LDS restage, 4 no MFMA
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
     unsigned long long* timing;   // tuning builds (-DGC_TIMING): per-phase s_memtime accumulators, else unused
-    const unsigned* desc4;   // pointwise layers: descriptors of 16 B groups (w | cil << 16 | staged << 31), else nullptr
-    int pw4;                 // per launch: 1 -> stage the patch in 16 B groups (pointwise layer and Tin % 4 == 0)
+    const unsigned* desc4;   // descriptors of the patch seen as 16 B groups (same packing as desc, w = first frame)
+    int pw4;                 // per launch: 1 -> stage the patch in 16 B groups
+    int causal;              // no tap looks ahead in time (dt <= 0 for every tap)
     const unsigned* desc;    // host-built patch-slot descriptors [NB][256]: w | r << 12 | cil << 16 | staged << 31
     const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]
 };

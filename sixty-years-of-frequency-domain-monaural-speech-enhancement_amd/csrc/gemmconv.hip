@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     const int rows = p.CI_C * p.nrows;
     const int npatch = rows * p.Wp;                  // floats of one staged activation patch
     const int bit = (npatch + 255) >> 8;             // patch elements per thread (uniform)
-    const bool pw4 = p.pw4 != 0;                     // pointwise layer, Tin % 4 == 0: the patch is staged in 16 B groups
+    const bool pw4 = p.pw4 != 0;                     // the patch is staged in 16 B groups (decided per launch, gc_launch)
     const int bit4 = (npatch / 4 + 255) >> 8;
     const int nA4 = p.KCp * (BM / 4);
     const int ait = (nA4 + 255) >> 8;                // float4 groups of the weight chunk per thread (uniform)
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
             boff[e] = staged ? (unsigned)((long)cc * s_c + (long)fc * s_f + tc) : 0u;              \
-            /* pw4: the slot is a group of 4 frames, wholly inside or wholly outside the row (Tin % 4 == 0) */ \
+            /* pw4: the slot is a group of 4 frames; never straddles frame 0, may straddle Tin (see gc_launch)   */ \
             vbits |= (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? (1u << e) : 0u; \
         });                                                                                        \
     }
@@ -580,8 +580,13 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     SE_CHECK((int)rows.size() <= GC_MAX_ROWS, "too many distinct frequency rows");
     p.ntaps = taps.ntaps;
     p.nrows = (int)rows.size();
+    // patch geometry: the staged time window starts a multiple of 4 frames before the tile (origin t0 - pad4) so that it
+    // decomposes into 16 B groups that never straddle frame 0 (t0 is a multiple of BN): LDS column w <-> frame t0 + dtmin + w
+    p.causal = dtmax <= 0;
+    dtmin = -((std::max(-dtmin, 0) + 3) & ~3);
+    dtmax = (std::max(dtmax, 0) + 3) & ~3;
     p.dtmin = dtmin;
-    p.Wp = (pl.BN + (dtmax - dtmin) + 3) & ~3;             // LDS row stride of the patch
+    p.Wp = pl.BN + (dtmax - dtmin);                         // LDS row stride of the patch (multiple of 4)
     SE_CHECK(p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256, "tap span too wide for one staged patch");
     // chunking: largest CI_C within the staging budgets (SE_GC_KCP / SE_GC_DBUF: tuning overrides)
     static const int kcp_cap = getenv("SE_GC_KCP") ? atoi(getenv("SE_GC_KCP")) : GC_MAX_KCP;
@@ -628,16 +633,16 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
                 const int rr = fe / p.Wp, w = fe - rr * p.Wp, cil = rr / p.nrows, r = rr - cil * p.nrows;
                 desc[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)r << 12) | ((unsigned)cil << 16) | 0x80000000u;
             }
-        if (taps.ntaps == 1) {
-            // pointwise layers: the same patch seen as groups of 4 consecutive frames (slot fg = tid + 256 e <-> LDS float 4 fg)
+        {
+            // the same patch seen as groups of 4 consecutive frames (slot fg = tid + 256 e <-> LDS floats 4 fg .. 4 fg + 3)
             std::vector<unsigned> d4((size_t)NB * 256, 0u);
             const int gpr = p.Wp / 4;
             for (int e = 0; e < NB; ++e)
                 for (int t = 0; t < 256; ++t) {
                     const int fg = t + 256 * e;
                     if (4 * fg >= npatch) continue;
-                    const int rr = fg / gpr, w = 4 * (fg - rr * gpr);
-                    d4[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)rr << 16) | 0x80000000u;     // nrows = 1: rr = cil, r = 0
+                    const int rr = fg / gpr, w = 4 * (fg - rr * gpr), cil = rr / p.nrows, r = rr - cil * p.nrows;
+                    d4[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)r << 12) | ((unsigned)cil << 16) | 0x80000000u;
                 }
             SE_HIP(hipMalloc(&pl.dDesc4, d4.size() * sizeof(unsigned)));
             SE_HIP(hipMemcpy(pl.dDesc4, d4.data(), d4.size() * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -785,7 +790,9 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
     if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;
     static const int pw4_env = getenv("SE_GC_PW4") ? atoi(getenv("SE_GC_PW4")) : 1;
-    p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || (gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
+    // 16 B staging groups: exact when no group straddles the end of a row (Tin % 4 == 0); for causal tap sets a straddling
+    // group only feeds output frames >= Tin, which are never stored - then it merely has to stay inside mapped memory
+    p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || (p.causal && gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
     SE_CHECK(p.pw4 || p.CI_C * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256,
              "pointwise layer with a row length that is not a multiple of 4 needs its sources inside the engine arena");
     if (p.Ws) {

@@ -490,9 +490,21 @@ __global__ __launch_bounds__(256) void gc_small_kernel(const GCParams p) {
         s_dt[threadIdx.x] = p.tab[GC_MAX_ROWS + GC_MAX_TAPS + threadIdx.x];
     }
     __syncthreads();
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int q = blockIdx.y;
-    const int b = blockIdx.z % p.B, z = blockIdx.z / p.B;
+    // XCD-aware block order (block id i runs on XCD i % 8): neighbouring frequency rows q of one (b, t-tile) read the
+    // same input rows through their taps, so they are made neighbours inside one XCD's L2
+    int lid;
+    {
+        const int nblk = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3, q8 = nblk >> 3, r8 = nblk & 7;
+        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int q = lid % p.Q;
+    int rest = lid / p.Q;
+    const int nt = (p.Tout + 255) >> 8;
+    const int tt = rest % nt;
+    rest /= nt;
+    const int b = rest % p.B, z = rest / p.B;
+    const int t = tt * 256 + threadIdx.x;
     const int tc = min(t, p.Tout - 1);
     float acc[MM];
 #pragma unroll
@@ -539,7 +551,9 @@ __global__ __launch_bounds__(256) void gc_small_kernel(const GCParams p) {
 
 template <int MM>
 static void gc_small_launch(const GCParams& p, hipStream_t stream) {
-    dim3 grid((p.Tout + 255) / 256, p.Q, p.B * p.Z);
+    const long nblk = (long)((p.Tout + 255) / 256) * p.Q * p.B * p.Z;
+    SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
+    dim3 grid((unsigned)nblk);
     switch (p.epi) {
         case EPI_ACT: hipLaunchKernelGGL((gc_small_kernel<MM, EPI_ACT>), grid, dim3(256), 0, stream, p); break;
         case EPI_ADD: hipLaunchKernelGGL((gc_small_kernel<MM, EPI_ADD>), grid, dim3(256), 0, stream, p); break;

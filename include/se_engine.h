@@ -105,6 +105,14 @@ int32_t se_num_bins(const se_engine* e);
 int se_set_profiling(se_engine* e, int32_t on);
 int se_get_profile(se_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
 
+/* Sample-rate conversion in front of the path: librosa.resample(y, sr_in, sr_out, fix=True, scale=False) as called at
+ * DCCRN/dccrn_decode_vb.py:26 and LSTM/lstm_decode_vb.py:34 (VoiceBank+DEMAND ships at 48 kHz; the models run at 16 kHz).
+ * Stateless (no engine handle; errors through se_last_error(NULL)).  Device pointers; `n_in` samples per row in,
+ * se_resample_samples(n_in, sr_in, sr_out) = ceil(n_in * sr_out / sr_in) samples per row out. */
+int64_t se_resample_samples(int32_t n_in, int32_t sr_in, int32_t sr_out);
+int se_resample(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n_in, int32_t sr_in, int32_t sr_out,
+                float* out_dev, int64_t out_pitch, void* stream);
+
 /* ABI version of this header. */
 int32_t se_abi_version(void);
 

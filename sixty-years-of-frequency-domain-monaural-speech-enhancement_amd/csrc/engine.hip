@@ -34,6 +34,20 @@ static int guard(se_engine* e, F&& f) {
 
 extern "C" {
 
+int64_t se_resample_samples(int32_t n_in, int32_t sr_in, int32_t sr_out) {
+    if (n_in <= 0 || sr_in <= 0 || sr_out <= 0) return -1;
+    return se::resample_out_samples(n_in, sr_in, sr_out);
+}
+
+int se_resample(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n_in, int32_t sr_in, int32_t sr_out,
+                float* out_dev, int64_t out_pitch, void* stream) {
+    return guard(nullptr, [&] {         // errors are reported through se_last_error(NULL)
+        SE_CHECK(in_dev && out_dev, "null argument");
+        SE_CHECK(in_pitch >= n_in && out_pitch >= se::resample_out_samples(n_in, sr_in, sr_out), "row pitch too small");
+        se::launch_resample(in_dev, in_pitch, batch, n_in, sr_in, sr_out, out_dev, out_pitch, static_cast<hipStream_t>(stream));
+    });
+}
+
 int32_t se_abi_version(void) { return 1; }
 
 const char* se_last_error(const se_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }

@@ -101,6 +101,12 @@ struct LstmPersistArgs {
 void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s);
 
 
+// librosa.resample(y, sr_in, sr_out, fix=True, scale=False) (resampy 'kaiser_best'), k_resample.hip; x [batch][n_in] ->
+// y [batch][resample_out_samples(n_in, sr_in, sr_out)]
+long resample_out_samples(int n_in, int sr_in, int sr_out);
+void launch_resample(const float* x, long in_pitch, int batch, int n_in, int sr_in, int sr_out, float* y, long out_pitch,
+                     hipStream_t s);
+
 // Weight-stationary cooperative LSTM recurrence for H = 512 / 1024 (k_lstm_coop.hip): W_hh spread over the register
 // files of all CUs, one launch for all T steps.  Same tensor conventions as LstmPersistArgs (O = 1):
 //   gx   : element (z, t, row, n) at gx + z*gx_z + t*gx_t + row*gx_row + n   (rows gate-interleaved, bias included)

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from . import wavio
+from . import wavio, resample
 from .models import MODEL_CLASSES
 
 # checkpoint name(s) checked in at each reference decode script
@@ -71,8 +71,8 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_bat
     for name in files:
         x, fs = wavio.read_wav(os.path.join(mix, name))
         if fs != 16000:
-            raise NotImplementedError(f'{name}: {fs} Hz input needs the resampler (librosa.resample in the reference, '
-                                      'SURVEY 8(f) rank 1: next)')
+            # librosa.resample(feat_wav, orig_fs, 16000, fix=True, scale=False), e.g. DCCRN/dccrn_decode_vb.py:26
+            x = resample.resample(torch.from_numpy(x.astype(np.float32)).cuda(), fs, 16000).cpu().numpy()
         clips.setdefault(len(x), []).append((name, x.astype(np.float32)))
     max_len = max(clips) if clips else 0
     net = _build(model, checkpoint, state_dict, max_batch=max_batch, max_samples=max(max_len, 512), p_in=p_in, p_out=p_out)

@@ -79,6 +79,36 @@ class Arena {
     bool measuring_ = false;
 };
 
+// true the first time it is called for (flag storage, current device): kernel attributes are per device
+inline bool first_on_device(bool (&seen)[64]) {
+    int dev = 0;
+    SE_HIP(hipGetDevice(&dev));
+    SE_CHECK(dev >= 0 && dev < 64, "device ordinal");
+    if (seen[dev]) return false;
+    seen[dev] = true;
+    return true;
+}
+
+// Engine-lifetime scratch that grows on first use, one slot per (purpose, device): handles of different devices may
+// live in one process and be driven from one host thread.  Growth synchronises the stream (never on the steady path).
+inline char* device_scratch(int purpose, size_t need, hipStream_t s) {
+    struct Slot { char* p = nullptr; size_t cap = 0; };
+    static Slot slots[4][64];
+    int dev = 0;
+    SE_HIP(hipGetDevice(&dev));
+    SE_CHECK(purpose >= 0 && purpose < 4 && dev >= 0 && dev < 64, "device_scratch: bad slot");
+    Slot& sl = slots[purpose][dev];
+    if (need > sl.cap) {
+        if (sl.p) {
+            SE_HIP(hipStreamSynchronize(s));
+            SE_HIP(hipFree(sl.p));
+        }
+        SE_HIP(hipMalloc(&sl.p, need));
+        sl.cap = need;
+    }
+    return sl.p;
+}
+
 // A host copy of one state-dict entry (fp32; int64 buffers are accepted and dropped).
 struct HostTensor {
     std::vector<int64_t> shape;

@@ -773,11 +773,10 @@ static void gc_launch_e(const GCParams& p, hipStream_t stream) {
     // epilogue: 4*BM row parameters + one transposition strip per wave (rows x (cols + 4))
     const size_t epi = (size_t)(4 * BM + 4 * (BM / WM) * 36) * sizeof(float);
     const size_t lds = gc_lds_bytes(p, BM, epi);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (first_on_device(attr_set)) {
         SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");

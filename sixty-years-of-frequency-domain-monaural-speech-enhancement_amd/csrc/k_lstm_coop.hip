@@ -160,19 +160,7 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
     }
 }
 
-char* coop_scratch(size_t need, hipStream_t s) {
-    static thread_local char* buf = nullptr;
-    static thread_local size_t cap = 0;
-    if (need > cap) {
-        if (buf) {
-            SE_HIP(hipStreamSynchronize(s));
-            SE_HIP(hipFree(buf));
-        }
-        SE_HIP(hipMalloc(&buf, need));
-        cap = need;
-    }
-    return buf;
-}
+char* coop_scratch(size_t need, hipStream_t s) { return device_scratch(0, need, s); }
 
 template <int H>
 void launch_t(LstmCoopArgs a, int n_cu, hipStream_t s) {
@@ -189,11 +177,10 @@ void launch_t(LstmCoopArgs a, int n_cu, hipStream_t s) {
     a.bar = reinterpret_cast<unsigned*>(sc + hx_bytes);
     SE_HIP(hipMemsetAsync(a.bar, 0, 256 * sizeof(unsigned), s));
     const size_t shmem = (size_t)16 * (H + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (first_on_device(attr_set)) {
         SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop_kernel<H>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
     }
     void* params[] = {&a};
     SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop_kernel<H>), dim3(US * a.SS * a.Z), dim3(256),

@@ -380,17 +380,8 @@ __global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict_
 void launch_cln(const float* x, float* y, const float* gain, const float* bias, const float* pre_slope,
                 const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s) {
     // per-(b, t) statistics live in a small engine-lifetime buffer (grown on first use, never on the steady-state path)
-    static thread_local char* stat = nullptr;
-    static thread_local size_t cap = 0;
     const size_t need = (size_t)B * T * (2 * sizeof(double) + 2 * sizeof(float));
-    if (need > cap) {
-        if (stat) {
-            SE_HIP(hipStreamSynchronize(s));
-            SE_HIP(hipFree(stat));
-        }
-        SE_HIP(hipMalloc(&stat, need));
-        cap = need;
-    }
+    char* stat = device_scratch(1, need, s);
     SE_CHECK(K <= 0 || x != y, "cLN + FIR cannot run in place");
     SE_CHECK((size_t)T * 16 <= 60000, "utterance too long for the LDS-resident cLN scan");
     double* sum = (double*)stat;

@@ -103,8 +103,11 @@ struct Tables {
     size_t treg_cap = 0;
 };
 Tables& tables() {
-    static thread_local Tables t;     // per host thread = per device context in this engine
-    return t;
+    static Tables t[64];              // one set of tables per device
+    int dev = 0;
+    SE_HIP(hipGetDevice(&dev));
+    SE_CHECK(dev >= 0 && dev < 64, "device ordinal");
+    return t[dev];
 }
 
 }  // namespace

@@ -299,12 +299,12 @@ void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, 
     StftArgs a{wav, pitch, B, L, Lpad, c_scale, p_in, spec_ri, mag, T, Tp, g.hop, g.win};
     dim3 grid((T + FPB - 1) / FPB, B);
     if (g.n_fft == 512) {
-        static bool once = (set_lds_attr(stft_kernel<512>, fft_lds_bytes<512>()), true);
-        (void)once;
+        static bool seen[64] = {};
+        if (first_on_device(seen)) set_lds_attr(stft_kernel<512>, fft_lds_bytes<512>());
         hipLaunchKernelGGL(stft_kernel<512>, grid, dim3(256), fft_lds_bytes<512>(), s, a);
     } else if (g.n_fft == 320) {
-        static bool once = (set_lds_attr(stft_kernel<320>, fft_lds_bytes<320>()), true);
-        (void)once;
+        static bool seen[64] = {};
+        if (first_on_device(seen)) set_lds_attr(stft_kernel<320>, fft_lds_bytes<320>());
         hipLaunchKernelGGL(stft_kernel<320>, grid, dim3(256), fft_lds_bytes<320>(), s, a);
     } else {
         SE_CHECK(false, "unsupported n_fft (320 and 512 are the reference geometries)");
@@ -317,12 +317,12 @@ void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp,
     IstftArgs a{spec_ri, B, T, Tp, frames, g.win};
     dim3 grid((T + FPB - 1) / FPB, B);
     if (g.n_fft == 512) {
-        static bool once = (set_lds_attr(istft_frames_kernel<512>, fft_lds_bytes<512>()), true);
-        (void)once;
+        static bool seen[64] = {};
+        if (first_on_device(seen)) set_lds_attr(istft_frames_kernel<512>, fft_lds_bytes<512>());
         hipLaunchKernelGGL(istft_frames_kernel<512>, grid, dim3(256), fft_lds_bytes<512>(), s, a);
     } else if (g.n_fft == 320) {
-        static bool once = (set_lds_attr(istft_frames_kernel<320>, fft_lds_bytes<320>()), true);
-        (void)once;
+        static bool seen[64] = {};
+        if (first_on_device(seen)) set_lds_attr(istft_frames_kernel<320>, fft_lds_bytes<320>());
         hipLaunchKernelGGL(istft_frames_kernel<320>, grid, dim3(256), fft_lds_bytes<320>(), s, a);
     } else {
         SE_CHECK(false, "unsupported n_fft");

@@ -87,37 +87,47 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
 }
 
 // ---- LayerNorm over (C, F) per (b, t) + residual ------------------------------------------------------------
+// block = 64 frames x 4 row groups: the C*F rows of a frame are split over 4 waves (partial sums meet in LDS), so a
+// launch has 4x the blocks and a quarter of the serial row walk of a thread-per-frame layout
 __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                            const float* __restrict__ w, const float* __restrict__ bb,
                                                            float* __restrict__ out, int C, int F, int T, float eps, int post,
                                                            const float* __restrict__ prelu_slope) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (t >= T) return;
-    const long base = (long)b * C * F * T + t;
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl, b = blockIdx.y;
+    const bool ok = t < T;
+    const long base = (long)b * C * F * T + (ok ? t : T - 1);
     const int n = C * F;
     float s = 0.f;
-    for (int i = 0; i < n; ++i) s += x[base + (long)i * T];
-    const float mu = s / n;
+    for (int i = rg; i < n; i += 4) s += x[base + (long)i * T];
+    red[rg][tl] = s;
+    __syncthreads();
+    const float mu = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / n;
+    __syncthreads();
     float v = 0.f;
-    for (int i = 0; i < n; ++i) {
+    for (int i = rg; i < n; i += 4) {
         const float d = x[base + (long)i * T] - mu;
         v += d * d;
     }
-    const float rs = rsqrtf(v / n + eps);
-    for (int c = 0; c < C; ++c)
-        for (int f = 0; f < F; ++f) {
-            const long o = base + ((long)c * F + f) * T;
-            float y = (x[o] - mu) * rs * w[f * C + c] + bb[f * C + c];
-            if (post == 1) y = y / (1.f + expf(-y));
-            if (prelu_slope) y = y >= 0.f ? y : prelu_slope[0] * y;
-            if (res) y += res[o];
-            out[o] = y;
-        }
+    red[rg][tl] = v;
+    __syncthreads();
+    const float rs = rsqrtf((red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / n + eps);
+    if (!ok) return;
+    const float slope = prelu_slope ? prelu_slope[0] : 1.f;
+    for (int i = rg; i < n; i += 4) {
+        const int c = i / F, f = i - c * F;
+        const long o = base + (long)i * T;
+        float y = (x[o] - mu) * rs * w[f * C + c] + bb[f * C + c];
+        if (post == 1) y = y / (1.f + expf(-y));
+        if (prelu_slope) y = y >= 0.f ? y : slope * y;
+        if (res) y += res[o];
+        out[o] = y;
+    }
 }
 void launch_layernorm_cf(const float* x, const float* res, const float* w, const float* b, float* out, int B, int C,
                          int F, int T, float eps, hipStream_t s, int post, const float* prelu_slope) {
-    hipLaunchKernelGGL(layernorm_cf_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, x, res, w, b, out, C, F, T, eps, post,
+    hipLaunchKernelGGL(layernorm_cf_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, res, w, b, out, C, F, T, eps, post,
                        prelu_slope);
     SE_HIP(hipGetLastError());
 }

@@ -14,6 +14,27 @@ struct EngineCtx {
     StftGeom geom{0, 0, 0};
     Arena arena;
     Profiler prof;
+    // second stream for independent sub-problems of one call (fork / join through events around the caller's stream)
+    static constexpr int MAX_AUX = 3;
+    hipStream_t aux[MAX_AUX] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_AUX] = {};
+    hipStream_t aux_stream(int i) {
+        SE_CHECK(i >= 0 && i < MAX_AUX, "aux stream index");
+        if (!ev_fork) SE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        if (!aux[i]) {
+            SE_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+            SE_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        }
+        return aux[i];
+    }
+    ~EngineCtx() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (int i = 0; i < MAX_AUX; ++i)
+            if (aux[i]) {
+                (void)hipStreamDestroy(aux[i]);
+                (void)hipEventDestroy(ev_join[i]);
+            }
+    }
 };
 
 // State dict with use tracking, so finalize can reject unexpected keys like a strict load_state_dict.

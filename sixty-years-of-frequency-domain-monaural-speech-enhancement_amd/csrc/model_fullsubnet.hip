@@ -222,9 +222,34 @@ class FullSubNet final : public Model {
         hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, st, b.sb, b.sb, nsb, B, b.mu2);
         SE_HIP(hipGetLastError());
         // ---- sub-band model (:106-114): LSTM(32->384)x2 over 257*B sequences, Linear(384->2)
-        sbl[0].run(b.sb, b.G, b.cell + 512 * (size_t)B, b.h[0], Tp, S, st, pf);
-        sbl[1].run(b.h[0], b.G, b.cell + 512 * (size_t)B, b.h[1], Tp, S, st, pf);
-        run_pointwise(sb_fc, b.h[1], 384L * S, S, b.maskT, 2L * S, S, Tp, S, st, pf);
+        // The 257 * B sequences are independent: two column halves run on two streams, so that the short per-step
+        // launches of one half (2 block rounds, every block in the same phase) overlap the other half's instead of
+        // leaving the matrix pipes idle during everybody's prologue / epilogue.
+        float* cell = b.cell + 512 * (size_t)B;
+        static const int parts_env = getenv("SE_FSN_SPLIT") ? atoi(getenv("SE_FSN_SPLIT")) : 2;
+        const int parts = std::max(1, std::min({parts_env, 1 + EngineCtx::MAX_AUX, S / 256}));
+        const int Sp = ((S + parts - 1) / parts + 127) / 128 * 128;           // columns per part (tile aligned)
+        auto part = [&](int c0, int Sn, hipStream_t s, Profiler* p) {
+            sbl[0].run_cols(b.sb, (long)SBW * S, b.G, cell, b.h[0], 384L * S, 1, Tp, S, c0, Sn, s, p);
+            sbl[1].run_cols(b.h[0], 384L * S, b.G, cell, b.h[1], 384L * S, 1, Tp, S, c0, Sn, s, p);
+            run_pointwise(sb_fc, b.h[1] + c0, 384L * S, S, b.maskT + c0, 2L * S, S, Tp, Sn, s, p);
+        };
+        if (parts > 1) {
+            for (int i = 1; i < parts; ++i) (void)ctx.aux_stream(i - 1);
+            SE_HIP(hipEventRecord(ctx.ev_fork, st));
+            for (int i = 1; i < parts; ++i) {
+                const int c0 = i * Sp, Sn = std::min(Sp, S - c0);
+                if (Sn <= 0) break;
+                SE_HIP(hipStreamWaitEvent(ctx.aux[i - 1], ctx.ev_fork, 0));
+                part(c0, Sn, ctx.aux[i - 1], nullptr);
+                SE_HIP(hipEventRecord(ctx.ev_join[i - 1], ctx.aux[i - 1]));
+            }
+            part(0, std::min(Sp, S), st, pf);
+            for (int i = 1; i < parts; ++i)
+                if (i * Sp < S) SE_HIP(hipStreamWaitEvent(st, ctx.ev_join[i - 1], 0));
+        } else {
+            part(0, S, st, pf);
+        }
         // [Tp][2][S] -> [S][2][Tp]
         launch_transpose_akt(b.maskT, b.maskBT, Tp, 2, S, 2L * S, S, 2L * Tp, Tp, st);
     }

@@ -65,6 +65,12 @@ inline void run_pointwise(const GCPlan& pl, const float* src, long s_o, long s_c
     gc_launch_prof(pl, p, st, prof);
 }
 
+// the same with the row length N decoupled from the row pitches (a column range of wider rows)
+inline void run_pointwise_cols(const GCPlan& pl, const float* src, long s_o, long s_c, float* dst, long d_o, long d_c, int O,
+                               int N, hipStream_t st, Profiler* prof) {
+    run_pointwise(pl, src, s_o, s_c, dst, d_o, d_c, O, N, st, prof);
+}
+
 // LSTM layer with a hidden size too large for register-resident weights (H = 1024 in LSTM/CRN): input projection
 // as one GEMM over all steps, then one fused GEMM + LSTM-cell launch per step (weights stream from L2 / Infinity Cache).
 struct LstmBig {
@@ -99,8 +105,14 @@ struct LstmBig {
     // j * out_rs of a tensor with per-step stride out_t (out_rs = 2 interleaves two groups, GCRN_noncprs.py:28-29)
     void run_strided(const float* x, long x_t, float* G, float* cell, float* out, long out_t, int out_rs, int T, int S,
                      hipStream_t st, Profiler* prof) const {
-        run_pointwise(gin, x, x_t, S, G, 4L * H * S, S, T, S, st, prof);
-        if (whh_dev && coop_enabled() && lstm_coop_supported(H, S, 1)) {
+        run_cols(x, x_t, G, cell, out, out_t, out_rs, T, S, 0, S, st, prof);
+    }
+    // the same on the sequence columns [c0, c0 + Sn) of tensors whose rows hold S sequences: sequences are independent,
+    // so disjoint column ranges can run concurrently on different streams (FullSubNet's 257 * B sub-band sequences)
+    void run_cols(const float* x, long x_t, float* G, float* cell, float* out, long out_t, int out_rs, int T, int S, int c0,
+                  int Sn, hipStream_t st, Profiler* prof) const {
+        run_pointwise_cols(gin, x + c0, x_t, S, G + c0, 4L * H * S, S, T, Sn, st, prof);
+        if (c0 == 0 && Sn == S && whh_dev && coop_enabled() && lstm_coop_supported(H, S, 1)) {
             LstmCoopArgs a{};
             a.gx = G; a.whh = whh_dev; a.out = out; a.cell = cell;
             a.gx_z = 0; a.gx_t = 4L * H * S; a.gx_row = S;
@@ -116,25 +128,25 @@ struct LstmBig {
         for (int t = 0; t < T; ++t) {
             GCParams p = step.p;
             p.first_step = (t == 0);
-            p.src0 = t > 0 ? out + (size_t)(t - 1) * out_t : out;
+            p.src0 = (t > 0 ? out + (size_t)(t - 1) * out_t : out) + c0;
             p.s0_b = 0;
             p.s0_c = (long)out_rs * S;
             p.s0_f = 0;
             p.src1 = nullptr;
             p.Fin = 1;
-            p.Tin = S;
+            p.Tin = Sn;
             p.B = 1;
             p.Q = 1;
-            p.Tout = S;
-            p.aux = G + (size_t)t * 4 * H * S;
+            p.Tout = Sn;
+            p.aux = G + (size_t)t * 4 * H * S + c0;
             p.x_b = 0;
             p.x_c = S;
             p.x_f = 0;
-            p.dst = out + (size_t)t * out_t;
+            p.dst = out + (size_t)t * out_t + c0;
             p.d_b = 0;
             p.d_c = (long)out_rs * S;
             p.d_f = 0;
-            p.cell = cell;
+            p.cell = cell + c0;
             gc_launch_prof(step, p, st, prof);
         }
     }

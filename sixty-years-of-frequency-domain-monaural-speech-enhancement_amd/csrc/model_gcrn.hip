@@ -26,6 +26,10 @@ class Gcrn final : public Model {
             for (auto& p : br) free_deconv_plan(p);
         for (auto& l : l1) l.free();
         for (auto& l : l2) l.free();
+        for (float*& w : whh_pair) {
+            if (w) (void)hipFree(w);
+            w = nullptr;
+        }
         gc_free_plan(fc[0]);
         gc_free_plan(fc[1]);
         for (float* d : {ln_w[0], ln_b[0], ln_w[1], ln_b[1]})
@@ -55,6 +59,14 @@ class Gcrn final : public Model {
             const std::string n = i == 0 ? "glstm.ln1." : "glstm.ln2.";
             ln_w[i] = to_device(sd.get(n + "weight", {1024}).data);
             ln_b[i] = to_device(sd.get(n + "bias", {1024}).data);
+        }
+        for (int L = 0; L < 2; ++L) {   // both groups' recurrent matrices back to back for the paired cooperative launch
+            const LstmBig* pr = L == 0 ? l1 : l2;
+            if (!pr[0].whh_dev || !pr[1].whh_dev) continue;
+            const size_t n = (size_t)4 * 512 * 512;
+            SE_HIP(hipMalloc(&whh_pair[L], 2 * n * sizeof(float)));
+            SE_HIP(hipMemcpy(whh_pair[L], pr[0].whh_dev, n * sizeof(float), hipMemcpyDeviceToDevice));
+            SE_HIP(hipMemcpy(whh_pair[L] + n, pr[1].whh_dev, n * sizeof(float), hipMemcpyDeviceToDevice));
         }
         const int DCI[5] = {512, 256, 128, 64, 32}, DCO[5] = {128, 64, 32, 16, 1};
         for (int br = 0; br < 2; ++br) {
@@ -106,6 +118,7 @@ class Gcrn final : public Model {
     GCPlan enc[5], fc[2];
     DeconvPlan dec[2][5];
     LstmBig l1[2], l2[2];
+    float* whh_pair[2] = {nullptr, nullptr};      // [2][2048][512]: both groups' W_hh of a layer, for the paired launch
     float *ln_w[2] = {nullptr, nullptr}, *ln_b[2] = {nullptr, nullptr};
 
     // kernel (1,3), stride 2 in F, no padding; conv2_t has output_padding 1 (an extra bias-only top row, handled by Fout)
@@ -154,7 +167,7 @@ class Gcrn final : public Model {
         b.Y = a.alloc_f(BT * 1024);
         b.Z = a.alloc_f(BT * 1024);
         b.L0 = a.alloc_f(BT * 1024);
-        b.G = a.alloc_f(BT * 2048);
+        b.G = a.alloc_f(BT * 2048 * 2);             // gate pre-activations of both groups
         b.cell = a.alloc_f((size_t)1024 * B);
         cur = b;
         return cur;
@@ -173,11 +186,12 @@ class Gcrn final : public Model {
         // ---- GLSTM, time-major [T][1024][B]
         const long S = B;
         launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, 1024L * S, S, st);
-        for (int i = 0; i < 2; ++i)     // group i reads features [512i, 512i+512); outputs interleaved (row 2j+i) :26-29
-            l1[i].run_strided(b.X + 512L * i * S, 1024L * S, b.G, b.cell, b.Y + (long)i * S, 1024L * S, 2, T, (int)S, st, pf);
+        // group i reads features [512i, 512i+512); outputs interleaved (row 2j+i) :26-29; both groups in one launch
+        run_lstm_pair(l1[0], l1[1], whh_pair[0], b.X, b.X + 512L * S, 1024L * S, b.G, b.cell, b.Y, S, 1024L * S, 2, T, (int)S,
+                      st, pf);
         launch_layernorm_cf(b.Y, nullptr, ln_w[0], ln_b[0], b.Z, T, 1024, 1, (int)S, 1e-5f, st);
-        for (int i = 0; i < 2; ++i)     // :32-33 (cat)
-            l2[i].run_strided(b.Z + 512L * i * S, 1024L * S, b.G, b.cell, b.Y + 512L * i * S, 1024L * S, 1, T, (int)S, st, pf);
+        run_lstm_pair(l2[0], l2[1], whh_pair[1], b.Z, b.Z + 512L * S, 1024L * S, b.G, b.cell, b.Y, 512L * S, 1024L * S, 1, T,
+                      (int)S, st, pf);                                                             // :32-33 (cat)
         launch_layernorm_cf(b.Y, nullptr, ln_w[1], ln_b[1], b.Z, T, 1024, 1, (int)S, 1e-5f, st);
         launch_transpose_akt(b.Z, b.L0, T, 1024, B, 1024L * S, S, 1024L * T, T, st);
         // ---- two decoders

@@ -152,4 +152,31 @@ struct LstmBig {
     }
 };
 
+// Two independent LSTM layers of equal shape (GCRN's grouped LSTM, GCRN/GCRN_noncprs.py:5-39) as ONE cooperative launch
+// (Z = 2): each alone covers H/16 x SS workgroups of the chip, together they fill it.  whh2 = [2][4H][H] device copy of
+// both recurrent matrices; G / cell hold both groups back to back.  Falls back to two sequential layers.
+inline void run_lstm_pair(const LstmBig& l0, const LstmBig& l1, const float* whh2, const float* x0, const float* x1, long x_t,
+                          float* G, float* cell, float* out0, long out_z, long out_t, int out_rs, int T, int S,
+                          hipStream_t st, Profiler* prof) {
+    const int H = l0.H;
+    const long gz = (long)T * 4 * H * S;
+    if (!(whh2 && LstmBig::coop_enabled() && lstm_coop_supported(H, S, 2))) {
+        l0.run_strided(x0, x_t, G, cell, out0, out_t, out_rs, T, S, st, prof);
+        l1.run_strided(x1, x_t, G, cell, out0 + out_z, out_t, out_rs, T, S, st, prof);
+        return;
+    }
+    run_pointwise(l0.gin, x0, x_t, S, G, 4L * H * S, S, T, S, st, prof);
+    run_pointwise(l1.gin, x1, x_t, S, G + gz, 4L * H * S, S, T, S, st, prof);
+    LstmCoopArgs a{};
+    a.gx = G; a.whh = whh2; a.out = out0; a.cell = cell;
+    a.gx_z = gz; a.gx_t = 4L * H * S; a.gx_row = S;
+    a.whh_z = 4L * H * H;
+    a.out_z = out_z; a.out_t = out_t; a.out_row = (long)out_rs * S;
+    a.H = H; a.T = T; a.S = S; a.Z = 2; a.reverse = 0;
+    const bool timed = prof && prof->on;
+    if (timed) prof->begin(st);
+    launch_lstm_coop(a, st);
+    if (timed) prof->end(st, 2.0 * 2 * 4 * H * (double)H * S * (T - 1));
+}
+
 }  // namespace se

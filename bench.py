@@ -66,9 +66,19 @@ def cpu_baseline(seed, p_in, p_out):
         D.enhance_dccrn(sd, synth.synth_clip(n, 'speech', CLIP_SAMPLES), p_in, p_out)
         n += 1
     dt = time.time() - t0
-    return {"value": round(n / dt, 4), "unit": "utt/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} x 4 s clips, batch-1 loop, numpy oracle (oracle/decode.py:enhance_dccrn), "
-                      f"{os.cpu_count()} BLAS threads, {dt:.1f} s"}
+    res = {"value": round(n / dt, 4), "unit": "utt/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n} x 4 s clips, batch-1 loop, numpy oracle (oracle/decode.py:enhance_dccrn), "
+                     f"{os.cpu_count()} BLAS threads, {dt:.1f} s"}
+    # the same loop pinned to one thread (what a single reference worker process gets), bounded to one clip
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            t1 = time.time()
+            D.enhance_dccrn(sd, synth.synth_clip(0, 'speech', CLIP_SAMPLES), p_in, p_out)
+            res["value_1_thread"] = round(1.0 / (time.time() - t1), 4)
+    except Exception:       # threadpoolctl missing: the all-core figure stands alone
+        pass
+    return res
 
 
 def main():

@@ -41,6 +41,12 @@ enum se_model_id {
  * (e.g. DCCRN/config.py:5-8 win_size/fft_num/win_shift; `** 1.0` vs `** 0.5 / ** 2.0` at
  * DCCRN/dccrn_decode_vb.py:40,48 and DCCRN/dccrn_decode.py:44,52).  n_fft/hop/win = 0 selects the
  * model's own front end. */
+/* se_config.flags: replay se_enhance_batch as a hipGraph per (batch, n_samples) shape - captured on the second call of
+ * a shape, caller buffers staged through engine-owned rows.  Results are bit-identical to the eager path.  Off by default:
+ * measured on MI355X the replay does not shorten a batch-1 decode (the path is bound by its chain of dependent small
+ * kernels, not by launch submission); models that fork onto auxiliary streams (FullSubNet) always run eagerly. */
+#define SE_CFG_GRAPHS 1
+
 typedef struct se_config {
     int32_t model;        /* enum se_model_id */
     int32_t device;       /* HIP device ordinal */
@@ -49,7 +55,7 @@ typedef struct se_config {
     float p_in;           /* magnitude exponent applied before the network (1.0 noncprs, 0.5 cprs) */
     float p_out;          /* magnitude exponent applied after the network  (1.0 noncprs, 2.0 cprs) */
     int32_t n_fft, hop, win;
-    int32_t flags;        /* reserved, 0 */
+    int32_t flags;        /* SE_CFG_* bits, 0 = defaults */
 } se_config;
 
 /* Model construction: `model = <Class>(...)` + `.cuda()`. */

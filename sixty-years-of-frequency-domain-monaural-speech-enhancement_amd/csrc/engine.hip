@@ -1,6 +1,7 @@
 // C ABI of the engine (include/se_engine.h): handle, strict state-dict load, stage hooks.
 #include "../../include/se_engine.h"
 #include "model.h"
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -15,6 +16,17 @@ struct se_engine {
     std::string err;
     float* frames_scratch = nullptr;     // for the se_istft stage hook
     size_t frames_scratch_n = 0;
+    // hipGraph replay of se_enhance_batch (SE_CFG_GRAPHS): one instantiated graph per (batch, samples) shape, captured
+    // on the second call of a shape (the first, eager call sets kernel attributes and grows the lazy scratch buffers);
+    // caller buffers are decoupled from the graph by engine-owned staging rows
+    struct GraphEntry {
+        int batch, samples;
+        hipGraphExec_t exec;     // nullptr: this shape could not be captured, stay eager
+    };
+    std::vector<GraphEntry> graphs;
+    std::vector<std::pair<int, int>> warmed;
+    float *stage_in = nullptr, *stage_out = nullptr;
+    hipStream_t cap_stream = nullptr;
 };
 
 static std::string g_create_err;
@@ -102,6 +114,11 @@ int se_engine_destroy(se_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     if (e->frames_scratch) (void)hipFree(e->frames_scratch);
+    for (auto& g : e->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->stage_in) (void)hipFree(e->stage_in);
+    if (e->stage_out) (void)hipFree(e->stage_out);
     if (e->ctx.arena.base()) gc_unregister_overread_range(e->ctx.arena.base());
     delete e;
     return 0;
@@ -175,8 +192,58 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
                  "n_samples outside [n_fft, max_samples]");
         SE_CHECK(in_pitch >= n_samples && out_pitch >= e->model->output_samples(n_samples), "row pitch too small");
         e->ctx.prof.reset();
-        e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch,
-                          static_cast<hipStream_t>(stream));
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        static const int graphs_env = getenv("SE_GRAPH") ? atoi(getenv("SE_GRAPH")) : -1;
+        const bool want_graph = (graphs_env >= 0 ? graphs_env != 0 : (e->cfg.flags & SE_CFG_GRAPHS) != 0) && !e->ctx.prof.on &&
+                                e->model->graph_capturable();
+        if (!want_graph) {
+            e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch, st);
+            return;
+        }
+        const int64_t n_out = e->model->output_samples(n_samples);
+        se_engine::GraphEntry* ge = nullptr;
+        for (auto& g : e->graphs)
+            if (g.batch == batch && g.samples == n_samples) ge = &g;
+        if (!ge) {
+            const std::pair<int, int> key(batch, n_samples);
+            if (std::find(e->warmed.begin(), e->warmed.end(), key) == e->warmed.end()) {
+                e->warmed.push_back(key);                       // first call of a shape: eager
+                e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch, st);
+                return;
+            }
+            if (!e->stage_in) {
+                const int64_t max_out = e->model->output_samples(e->ctx.max_samples);
+                SE_HIP(hipMalloc(&e->stage_in, (size_t)e->ctx.max_batch * e->ctx.max_samples * sizeof(float)));
+                SE_HIP(hipMalloc(&e->stage_out, (size_t)e->ctx.max_batch * max_out * sizeof(float)));
+            }
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            // capture on an engine-owned stream: the caller's stream may be the legacy default stream, which cannot capture
+            if (!e->cap_stream) SE_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+            hipStream_t cs = e->cap_stream;
+            SE_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            bool ok = true;
+            try {
+                e->model->enhance(e->stage_in, n_samples, batch, n_samples, e->stage_out, n_out, cs);
+            } catch (const std::exception&) {
+                ok = false;
+            }
+            if (hipStreamEndCapture(cs, &graph) != hipSuccess || !graph) ok = false;
+            if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            e->graphs.push_back({batch, n_samples, ok ? exec : nullptr});
+            ge = &e->graphs.back();
+        }
+        if (!ge->exec) {
+            e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch, st);
+            return;
+        }
+        SE_HIP(hipMemcpy2DAsync(e->stage_in, (size_t)n_samples * sizeof(float), wav_in_dev, (size_t)in_pitch * sizeof(float),
+                                (size_t)n_samples * sizeof(float), batch, hipMemcpyDeviceToDevice, st));
+        SE_HIP(hipGraphLaunch(ge->exec, st));
+        SE_HIP(hipMemcpy2DAsync(wav_out_dev, (size_t)out_pitch * sizeof(float), e->stage_out, (size_t)n_out * sizeof(float),
+                                (size_t)n_out * sizeof(float), batch, hipMemcpyDeviceToDevice, st));
     });
 }
 

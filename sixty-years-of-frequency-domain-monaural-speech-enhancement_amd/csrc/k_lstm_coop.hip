@@ -175,7 +175,9 @@ void launch_t(LstmCoopArgs a, int n_cu, hipStream_t s) {
     char* sc = coop_scratch(hx_bytes + 256 * sizeof(unsigned), s);
     a.hx = reinterpret_cast<float*>(sc);
     a.bar = reinterpret_cast<unsigned*>(sc + hx_bytes);
-    SE_HIP(hipMemsetAsync(a.bar, 0, 256 * sizeof(unsigned), s));
+    // zeroed by a kernel, not a memset node: under hipGraph replay the memset was observed not to be ordered before the
+    // cooperative kernel (stale arrival counts let every barrier fall through)
+    launch_fill(reinterpret_cast<float*>(a.bar), 256, 0.f, s);
     const size_t shmem = (size_t)16 * (H + 4) * sizeof(float);
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {

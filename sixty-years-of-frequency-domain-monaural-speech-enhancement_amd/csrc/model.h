@@ -72,6 +72,8 @@ class Model {
     // samples the STFT sees (decode scripts that tail-pad to a hop multiple)
     virtual int padded_samples(int L) const { return L; }
     int num_frames(int L) const { return 1 + padded_samples(L) / ctx.geom.hop; }
+    // false: enhance() forks onto auxiliary streams and is not replayed from a captured hipGraph (SE_CFG_GRAPHS)
+    virtual bool graph_capturable() const { return true; }
 
   protected:
     EngineCtx& ctx;

@@ -198,13 +198,15 @@ class FullSubNet final : public Model {
         return cur;
     }
 
+    bool graph_capturable() const override { return false; }     // sub-band halves run on two streams
+
     // mag [B][257][T] -> maskBT [n*B+b][2][T+2]
     void network(Bufs& b, const float* mag, hipStream_t st) {
         const int B = b.B, T = b.T, Tp = T + LA, S = NBIN * B;
         Profiler* pf = &ctx.prof;
         // ---- full-band model (model.py:84-85): utterance-mean normalisation, LSTM(257->512)x2, Linear + ReLU
         hipLaunchKernelGGL(fsn_mean_kernel, dim3(B), dim3(256), 0, st, mag, NBIN * T, (float)NBIN * Tp, b.mu);
-        SE_HIP(hipMemsetAsync(b.magT + (size_t)T * S, 0, (size_t)LA * S * sizeof(float), st));     // look-ahead pad :79
+        launch_fill(b.magT + (size_t)T * S, (long)LA * S, 0.f, st);                                // look-ahead pad :79 (a kernel, not a memset node: graph-replay safe)
         launch_transpose_akt(mag, b.magT, B, NBIN, T, (long)NBIN * T, T, (long)NBIN * B, B, st);
         const long nfb = (long)Tp * S;
         hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nfb + 255) / 256)), dim3(256), 0, st, b.magT, b.xfb, nfb, B, b.mu);
@@ -213,7 +215,7 @@ class FullSubNet final : public Model {
         run_pointwise(fb_fc, b.h[1], 512L * B, B, b.fbo, (long)NBIN * B, B, Tp, B, st, pf);
         // ---- sub-band input (:88-97): unfold(noisy, 15) ++ unfold(fb_out, 0), normalised by its utterance mean
         hipLaunchKernelGGL(fsn_build_sb_kernel, dim3((S + 255) / 256, SBW, Tp), dim3(256), 0, st, b.magT, b.fbo, b.sb, B);
-        SE_HIP(hipMemsetAsync(b.mu2, 0, B * sizeof(float), st));
+        launch_fill(b.mu2, B, 0.f, st);
         const long rows = (long)Tp * SBW * NBIN;
         SE_CHECK(B <= 256, "FullSubNet batch per call is limited to 256 utterances");
         hipLaunchKernelGGL(fsn_colsum_kernel, dim3(1024), dim3(256), 0, st, b.sb, rows, B, b.mu2);

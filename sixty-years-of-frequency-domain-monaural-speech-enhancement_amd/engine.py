@@ -14,11 +14,12 @@ class Engine:
     """One engine handle = one model replica on one GPU (one per rank)."""
 
     def __init__(self, model, device=0, max_batch=1, max_samples=64000, p_in=1.0, p_out=1.0,
-                 n_fft=0, hop=0, win=0):
+                 n_fft=0, hop=0, win=0, graphs=False):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.model = model
-        cfg = _lib.SeConfig(_lib.MODEL_IDS[model], device, max_batch, max_samples, p_in, p_out, n_fft, hop, win, 0)
+        cfg = _lib.SeConfig(_lib.MODEL_IDS[model], device, max_batch, max_samples, p_in, p_out, n_fft, hop, win,
+                            1 if graphs else 0)        # SE_CFG_GRAPHS
         if self._lib.se_engine_create(C.byref(cfg), C.byref(self._h)):
             raise EngineError(self._lib.se_last_error(None).decode())
         self.device = device

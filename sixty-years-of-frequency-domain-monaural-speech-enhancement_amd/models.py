@@ -17,7 +17,8 @@ class _EngineModule:
     p_in = 1.0             # magnitude exponents the decode script applies around the network
     p_out = 1.0
 
-    def __init__(self, device=0, max_batch=1, max_samples=64000, p_in=None, p_out=None):
+    def __init__(self, device=0, max_batch=1, max_samples=64000, p_in=None, p_out=None, graphs=False):
+        self._graphs = graphs          # replay enhance_batch as a hipGraph per shape (small, launch-bound batches)
         self._device = device
         self._max_batch = max_batch
         self._max_samples = max_samples
@@ -39,7 +40,8 @@ class _EngineModule:
         unexpected = [k for k in sd if k not in want]
         if missing or unexpected:
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
-        self.engine = Engine(self._model, self._device, self._max_batch, self._max_samples, self.p_in, self.p_out)
+        self.engine = Engine(self._model, self._device, self._max_batch, self._max_samples, self.p_in, self.p_out,
+                             graphs=self._graphs)
         self.engine.load_state_dict(sd)
         return self
 
@@ -138,7 +140,8 @@ class _CtsStage(_EngineModule):
         if missing or unexpected:
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
         self._sd = {self._prefix + k: v for k, v in sd.items()}
-        self.engine = Engine('ctsnet', self._device, self._max_batch, self._max_samples, self.p_in, self.p_out)
+        self.engine = Engine('ctsnet', self._device, self._max_batch, self._max_samples, self.p_in, self.p_out,
+                             graphs=self._graphs)
         self.engine.load_state_dict(self._sd)
         return self
 
@@ -178,7 +181,7 @@ class CTSNet:
         sd = {'step1.' + k: v for k, v in sd1.items()}
         sd.update({'step2.' + k: v for k, v in sd2.items()})
         self.engine = Engine('ctsnet', kw.get('device', 0), kw.get('max_batch', 1), kw.get('max_samples', 64000),
-                             kw.get('p_in', 1.0), kw.get('p_out', 1.0))
+                             kw.get('p_in', 1.0), kw.get('p_out', 1.0), graphs=kw.get('graphs', False))
         self.engine.load_state_dict(sd)
         return self
 

@@ -66,3 +66,20 @@ def test_workspace_bounds_are_enforced():
     # the engine is still usable after a refused call
     y = m.enhance_batch(torch.from_numpy(synth.synth_clip(1, 'speech', 2000)[None]).cuda())
     assert bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize('name', ['crn', 'dccrn', 'g2net', 'fullsubnet'])
+def test_graph_replay_matches_eager(name):
+    """SE_CFG_GRAPHS: the third call of a shape replays a captured hipGraph (first eager, second captures) and must
+    reproduce the eager result bit for bit, on fresh caller tensors, for two interleaved shapes."""
+    torch = _torch()
+    from se_amd.models import MODEL_CLASSES
+    seeds = dict(SEEDS, dccrn=14, fullsubnet=15)
+    eager = MODEL_CLASSES[name](max_batch=2, max_samples=4000).load_synthetic(seeds[name])
+    graph = MODEL_CLASSES[name](max_batch=2, max_samples=4000, graphs=True).load_synthetic(seeds[name])
+    for rep in range(3):
+        for B, L in ((2, 4000), (1, 3200)):
+            x = np.stack([synth.synth_clip(90 + 7 * rep + b, 'speech', L) for b in range(B)])
+            ye = eager.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+            yg = graph.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+            assert np.array_equal(ye, yg), (name, rep, B, L, np.abs(ye - yg).max())

@@ -63,21 +63,33 @@ __global__ __launch_bounds__(256) void fsn_build_sb_kernel(const float* __restri
     sb[((long)t * SBW + k) * S + s] = v;
 }
 
-// column sums of a [rows][B] matrix (utterance = innermost index) -> mu[b] = sum / rows
+// column sums of a [rows][B] matrix (utterance = innermost index) -> mu[b] = sum / rows; two deterministic stages
+// (per-block partials in a fixed order, then a fixed-order fp64 sum) - no float atomics, so repeated decodes are
+// bit-identical
+constexpr int FSN_SUM_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void fsn_colsum_kernel(const float* __restrict__ x, long rows, int B,
-                                                         float* __restrict__ acc) {
-    // thread handles column (tid % B) of rows tid / B + k * (256 / B)  (B divides 256 or is handled by the guard)
+                                                         float* __restrict__ part) {
+    __shared__ float sh[256];
+    // thread handles column (tid % B) of rows tid / B + k * (256 / B)
     const int per = 256 / B;
-    if (per == 0) return;
     const int b = threadIdx.x % B, r0 = threadIdx.x / B;
-    if (r0 >= per) return;
     float s = 0.f;
-    for (long r = (long)blockIdx.x * per + r0; r < rows; r += (long)gridDim.x * per) s += x[r * B + b];
-    atomicAdd(&acc[b], s);
+    if (per > 0 && r0 < per)
+        for (long r = (long)blockIdx.x * per + r0; r < rows; r += (long)gridDim.x * per) s += x[r * B + b];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (per > 0 && r0 == 0) {
+        float t = 0.f;
+        for (int k = 0; k < per; ++k) t += sh[k * B + b];
+        part[(long)blockIdx.x * B + b] = t;
+    }
 }
-__global__ void fsn_finish_mean_kernel(float* acc, float denom, int B) {
+__global__ void fsn_finish_mean_kernel(const float* __restrict__ part, float* __restrict__ mu, float denom, int B) {
     const int b = threadIdx.x;
-    if (b < B) acc[b] = acc[b] / denom;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int k = 0; k < FSN_SUM_BLOCKS; ++k) s += part[(long)k * B + b];
+    mu[b] = (float)(s / denom);
 }
 
 // out[b][c][n][t] = mask[(n*B + b)][c][t + LA]                       (forward hook), or
@@ -163,7 +175,7 @@ class FullSubNet final : public Model {
   private:
     struct Bufs {
         int B = 0, T = 0;
-        float *c, *spec, *mag, *est, *frames, *mu, *mu2;
+        float *c, *spec, *mag, *est, *frames, *mu, *mu2, *part;
         float *magT, *xfb, *G, *h[2], *cell, *fbo, *sb, *maskT, *maskBT;
     } cur;
     LstmBig fb[2], sbl[2];
@@ -180,6 +192,7 @@ class FullSubNet final : public Model {
         b.c = a.alloc_f(B);
         b.mu = a.alloc_f(B);
         b.mu2 = a.alloc_f(B);
+        b.part = a.alloc_f((size_t)FSN_SUM_BLOCKS * B);
         b.spec = a.alloc_f(BT * 2 * NBIN);
         b.mag = a.alloc_f(BT * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
@@ -215,11 +228,10 @@ class FullSubNet final : public Model {
         run_pointwise(fb_fc, b.h[1], 512L * B, B, b.fbo, (long)NBIN * B, B, Tp, B, st, pf);
         // ---- sub-band input (:88-97): unfold(noisy, 15) ++ unfold(fb_out, 0), normalised by its utterance mean
         hipLaunchKernelGGL(fsn_build_sb_kernel, dim3((S + 255) / 256, SBW, Tp), dim3(256), 0, st, b.magT, b.fbo, b.sb, B);
-        launch_fill(b.mu2, B, 0.f, st);
         const long rows = (long)Tp * SBW * NBIN;
         SE_CHECK(B <= 256, "FullSubNet batch per call is limited to 256 utterances");
-        hipLaunchKernelGGL(fsn_colsum_kernel, dim3(1024), dim3(256), 0, st, b.sb, rows, B, b.mu2);
-        hipLaunchKernelGGL(fsn_finish_mean_kernel, dim3(1), dim3(256), 0, st, b.mu2, (float)rows, B);
+        hipLaunchKernelGGL(fsn_colsum_kernel, dim3(FSN_SUM_BLOCKS), dim3(256), 0, st, b.sb, rows, B, b.part);
+        hipLaunchKernelGGL(fsn_finish_mean_kernel, dim3(1), dim3(256), 0, st, b.part, b.mu2, (float)rows, B);
         const long nsb = rows * B;
         hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, st, b.sb, b.sb, nsb, B, b.mu2);
         SE_HIP(hipGetLastError());

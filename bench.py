@@ -117,14 +117,17 @@ def main():
     base = synth.synth_batch(16, 'speech', CLIP_SAMPLES, seed0=100 + 16 * rank)
     wav = torch.from_numpy(np.tile(base, ((B + 15) // 16, 1))[:B].copy()).cuda()
     n_out = eng.output_samples(CLIP_SAMPLES)
-    out = torch.empty((B, n_out), dtype=torch.float32, device='cuda')
     from se_amd import shard
+    # enhanced waveforms of every rank end up device-resident on rank 0: asynchronous RCCL gather, double-buffered so
+    # that the gather of step k overlaps the compute of step k + 1 (se_amd/shard.py:GatherPipe); N = 1: no collective
+    pipe = shard.GatherPipe(B, n_out, torch.device('cuda', local_rank), dst=0)
+    out = None
 
     def step():
+        nonlocal out
+        out = pipe.slot()
         eng.enhance_batch(wav, out)
-        if world > 1:       # RCCL gather of this rank's enhanced waveforms to rank 0 (se_amd/shard.py)
-            return shard.gather_waveforms(out, B * world, dst=0)
-        return out
+        pipe.submit()
 
     def fence():
         if world > 1:
@@ -133,12 +136,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    pipe.finish()
     fence()
     if not args.no_profile:
         eng.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    pipe.finish()           # every gather of the timed steps has landed on rank 0
     fence()
     dt = time.perf_counter() - t0
     prof = eng.get_profile() if not args.no_profile else None

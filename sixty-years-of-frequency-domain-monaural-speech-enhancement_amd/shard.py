@@ -41,6 +41,53 @@ def gather_waveforms(local, n_items, dst=0, group=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
 
 
+class GatherPipe:
+    """Steady-state gather for a decode loop: preallocated receive rows on rank `dst`, asynchronous collective, two send
+    slots - so the gather of batch k travels over xGMI while batch k+1 is being enhanced (equal shards only).
+
+        pipe = GatherPipe(n_local, n_samples, device)
+        for k in ...:
+            out = pipe.slot()                  # [n_local, n_samples] buffer to enhance into (waits for its last gather)
+            engine.enhance_batch(wav, out)
+            pipe.submit()                      # async gather of that slot
+        rows = pipe.finish()                   # rank dst: list of `world` tensors of the LAST batch, else None
+    """
+
+    def __init__(self, n_local, n_samples, device, dst=0, group=None, dtype=torch.float32):
+        self.group, self.dst = group, dst
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.send = [torch.empty((n_local, n_samples), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [[torch.empty((n_local, n_samples), dtype=dtype, device=device) for _ in range(self.world)]
+                     for _ in range(2)] if (self.on and self.rank == dst) else [None, None]
+        self.work = [None, None]
+        self.k = 0
+
+    def slot(self):
+        i = self.k & 1
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        return self.send[i]
+
+    def submit(self):
+        i = self.k & 1
+        if self.on:
+            self.work[i] = dist.gather(self.send[i], self.recv[i], dst=self.dst, group=self.group, async_op=True)
+        self.k += 1
+
+    def finish(self):
+        for i in (0, 1):
+            if self.work[i] is not None:
+                self.work[i].wait()
+                self.work[i] = None
+        last = (self.k - 1) & 1
+        if not self.on:
+            return [self.send[last]]
+        return self.recv[last] if self.rank == self.dst else None
+
+
 def run_sharded(enhance_fn, wav, dst=0, group=None):
     """wav: [N, L] batch of equal-length clips, identical on every rank (or only meaningful rows of the local
     shard).  Each rank enhances its shard with `enhance_fn([n_local, L]) -> [n_local, L_out]`; rank dst gets all N."""

@@ -77,3 +77,32 @@ def test_sharded_decode_gather_gloo(tmp_path, n_items):
     out = torch.load(os.path.join(str(tmp_path), 'out.pt'))
     ref = torch.arange(n_items * 5, dtype=torch.float32).reshape(n_items, 5) * 2.0 + 1.0
     assert torch.equal(out, ref)
+
+
+def _pipe_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    pipe = shard.GatherPipe(3, 4, torch.device('cpu'))
+    for k in range(5):                                   # 5 batches through 2 send slots: slot reuse + async overlap
+        out = pipe.slot()
+        out.copy_(torch.full((3, 4), float(100 * k + rank)))
+        pipe.submit()
+    rows = pipe.finish()
+    if rank == 0:
+        torch.save(torch.stack(rows), os.path.join(tmp, 'pipe.pt'))
+    else:
+        assert rows is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_pipe_gloo(tmp_path):
+    """bench.py's steady-state gather (double-buffered, asynchronous): rank 0 holds every rank's rows of the last batch."""
+    import torch.multiprocessing as mp
+    port = 30500 + (os.getpid() % 1000)
+    mp.spawn(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rows = torch.load(os.path.join(str(tmp_path), 'pipe.pt'))
+    assert rows.shape == (2, 3, 4)
+    assert torch.equal(rows[0], torch.full((3, 4), 400.0)) and torch.equal(rows[1], torch.full((3, 4), 401.0))

@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     const int wm = wave / WN, wn = wave % WN;
     const int am = wm * (TM * 32) + l31;      // A column base inside the tile
     const int bn = wn * (TN * 32) + l31;      // B column base inside the tile
+    // 32-column sub-tiles of this wave with a frame below Tout (wave-uniform)
+    const int jact = max(0, min(TN, (p.Tout - t0 - wn * (TN * 32) + 31) >> 5));
 
     int gchunk = 0;          // global chunk counter (weights are packed segment after segment)
     int buf = 0;
@@ -297,28 +299,37 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         if constexpr (KOFF_REGS) o_ = koffv[(KP) < NPAIR ? (KP) : NPAIR - 1];                      \
         else o_ = koff_lds[2 * (KP) + hi];                                                         \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) AR[i] = Ab[(2 * (KP)) * BM + i * 32];       \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) BR[j] = Bb[o_ + j * 32];                    \
+        _Pragma("unroll") for (int j = 0; j < JN; ++j) BR[j] = Bb[o_ + j * 32];                    \
     }
 #define GC_MMA(AR, BR)                                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+        _Pragma("unroll") for (int j = 0; j < JN; ++j)                                             \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AR[i], BR[j], acc[i][j], 0, 0, 0);
-            if (!(p.dbg & 4)) {
-                float ax[TM], bx[TN], ay[TM], by[TN];
+            // JN = 32-column sub-tiles of this wave that hold at least one frame < Tout: in the last time tile of a row
+            // (e.g. 17 of 128 columns at T = 401) most waves own only padding and skip the matrix work altogether
+            auto mma_chunk = [&](auto JN_) {
+                constexpr int JN = decltype(JN_)::value;
+                float ax[TM], bx[JN], ay[TM], by[JN];
                 GC_FETCH(0, ax, bx);
                 static_for<NPAIR / 2>([&](auto KP2) {
                     constexpr int kp = 2 * decltype(KP2)::value;
                     if (kp < npair) {
                         GC_FETCH(kp + 1, ay, by);
-                        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
                         GC_MMA(ax, bx);
-                        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TM * JN, 0);
                         GC_FETCH(kp + 2, ax, bx);
-                        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (TN + 1) / 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
                         GC_MMA(ay, by);
-                        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TM * JN, 0);
                     }
                 });
+            };
+            if (!(p.dbg & 4)) {
+                if (jact == TN) mma_chunk(std::integral_constant<int, TN>{});
+                else if constexpr (TN > 1) {
+                    if (jact == 1) mma_chunk(std::integral_constant<int, 1>{});
+                }
             }
 #undef GC_FETCH
 #undef GC_MMA

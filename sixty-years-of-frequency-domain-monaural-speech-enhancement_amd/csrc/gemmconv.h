@@ -70,10 +70,23 @@ struct GCParams {
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
     unsigned long long* timing;   // tuning builds (-DGC_TIMING): per-phase s_memtime accumulators, else unused
     const unsigned* desc4;   // descriptors of the patch seen as 16 B groups (same packing as desc, w = first frame)
+    int t_base;              // first frame of time tile 0 of this launch (tail launches start at the last tile)
     int pw4;                 // per launch: 1 -> stage the patch in 16 B groups
     int causal;              // no tap looks ahead in time (dt <= 0 for every tap)
     const unsigned* desc;    // host-built patch-slot descriptors [NB][256]: w | r << 12 | cil << 16 | staged << 31
     const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]
+};
+
+// Device tables of one patch geometry (owned by the plan)
+struct GCGeom {
+    int* tab = nullptr;
+    unsigned* desc = nullptr;
+    unsigned* desc4 = nullptr;
+};
+// Narrow geometry for the last time tile of a row (BN = 0: unused)
+struct GCTail {
+    int BN = 0, Wp = 0;
+    GCGeom g;
 };
 
 // Host-side description of one dense layer, built once at finalize.
@@ -84,6 +97,7 @@ struct GCPlan {
     float* dWs = nullptr;
     unsigned* dDesc = nullptr;
     unsigned* dDesc4 = nullptr;
+    GCTail tail[2];          // 32- and 64-column geometries for a mostly empty last time tile
     float* dBias = nullptr;
     float* dSlope = nullptr;
     int* dTab = nullptr;

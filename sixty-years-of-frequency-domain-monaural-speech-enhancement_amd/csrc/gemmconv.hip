@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     rest /= p.Q;
     const int b = rest % p.B;
     const int z = rest / p.B;
-    const int t0 = ttile * BN;
+    const int t0 = p.t_base + ttile * BN;
     const int m0 = mt * BM;
 
     const float* __restrict__ Ag = p.A + (long)z * p.A_z + m0;
@@ -583,6 +583,45 @@ static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes) {
     return std::max(staging, epi_bytes);
 }
 
+// Device tables of one patch geometry (row stride Wp): frequency rows / tap table / K-row patch offsets, and the
+// per-(thread, slot) descriptors of the patch seen as single frames and as 16 B groups of 4 frames.
+GCGeom gc_build_geom(const TapSpec& taps, const std::vector<int>& rows, int dtmin, int nrows, int Wp, int cic, int KC, int NB) {
+    GCGeom g;
+    std::vector<int> tab(GC_TAB_KOFF + GC_MAX_KCP + 8, 0);
+    for (int r = 0; r < nrows; ++r) tab[r] = rows[r];
+    for (int j = 0; j < taps.ntaps; ++j) {
+        tab[GC_MAX_ROWS + j] = (int)(std::find(rows.begin(), rows.end(), taps.df[j]) - rows.begin());
+        tab[GC_MAX_ROWS + GC_MAX_TAPS + j] = taps.dt[j];
+    }
+    for (int k = 0; k < KC; ++k) {       // k = cil * ntaps + j
+        const int cil = k / taps.ntaps, j = k - cil * taps.ntaps;
+        tab[GC_TAB_KOFF + k] = cil * (nrows * Wp) + tab[GC_MAX_ROWS + j] * Wp + (taps.dt[j] - dtmin);
+    }
+    SE_HIP(hipMalloc(&g.tab, tab.size() * sizeof(int)));
+    SE_HIP(hipMemcpy(g.tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    // slot fe = tid + 256 e -> (row rr = fe / Wp, column w), rr -> (cil, r); groups: slot fg <-> LDS floats 4 fg .. 4 fg + 3
+    const int npatch = cic * nrows * Wp, gpr = Wp / 4;
+    SE_CHECK(Wp % 4 == 0 && Wp < 4096 && nrows <= 16 && cic < 32768, "patch descriptor field overflow");
+    std::vector<unsigned> desc((size_t)NB * 256, 0u), d4((size_t)NB * 256, 0u);
+    for (int e = 0; e < NB; ++e)
+        for (int t = 0; t < 256; ++t) {
+            const int fe = t + 256 * e;
+            if (fe < npatch) {
+                const int rr = fe / Wp, w = fe - rr * Wp, cil = rr / nrows, r = rr - cil * nrows;
+                desc[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)r << 12) | ((unsigned)cil << 16) | 0x80000000u;
+            }
+            if (4 * fe < npatch) {
+                const int rr = fe / gpr, w = 4 * (fe - rr * gpr), cil = rr / nrows, r = rr - cil * nrows;
+                d4[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)r << 12) | ((unsigned)cil << 16) | 0x80000000u;
+            }
+        }
+    SE_HIP(hipMalloc(&g.desc, desc.size() * sizeof(unsigned)));
+    SE_HIP(hipMemcpy(g.desc, desc.data(), desc.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    SE_HIP(hipMalloc(&g.desc4, d4.size() * sizeof(unsigned)));
+    SE_HIP(hipMemcpy(g.desc4, d4.data(), d4.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    return g;
+}
+
 GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float>& w, const std::vector<float>& bias,
                     const std::vector<float>& slope, int act, int epi, int si, int so, int po, int tout_hint, int Z,
                     int C0split) {
@@ -632,51 +671,26 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.KCp = (p.KC + 3) & ~3;
     SE_CHECK(p.KCp <= gc_kcp_max(pl.BM), "single-channel chunk exceeds K budget");
     {
-        // device table: frequency rows, tap -> row / dt, and the patch offset of every K row of a chunk (k = cil*ntaps + j)
-        std::vector<int> tab(GC_TAB_KOFF + GC_MAX_KCP + 8, 0);
-        for (int r = 0; r < p.nrows; ++r) tab[r] = rows[r];
-        for (int j = 0; j < taps.ntaps; ++j) {
-            tab[GC_MAX_ROWS + j] = (int)(std::find(rows.begin(), rows.end(), taps.df[j]) - rows.begin());
-            tab[GC_MAX_ROWS + GC_MAX_TAPS + j] = taps.dt[j];
-        }
-        for (int k = 0; k < p.KC; ++k) {
-            const int cil = k / taps.ntaps, j = k - cil * taps.ntaps;
-            tab[GC_TAB_KOFF + k] = cil * (p.nrows * p.Wp) + tab[GC_MAX_ROWS + j] * p.Wp + (taps.dt[j] - dtmin);
-        }
-        SE_HIP(hipMalloc(&pl.dTab, tab.size() * sizeof(int)));
-        SE_HIP(hipMemcpy(pl.dTab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-        p.tab = pl.dTab;
-    }
-    {
-        // per-(thread, element) patch descriptors: slot fe = tid + 256 e -> (row rr = fe / Wp, column w), rr -> (cil, r)
-        const int NB = gc_bld_max(pl.BM), npatch = cic * p.nrows * p.Wp;
-        std::vector<unsigned> desc((size_t)NB * 256, 0u);
-        for (int e = 0; e < NB; ++e)
-            for (int t = 0; t < 256; ++t) {
-                const int fe = t + 256 * e;
-                if (fe >= npatch) continue;
-                const int rr = fe / p.Wp, w = fe - rr * p.Wp, cil = rr / p.nrows, r = rr - cil * p.nrows;
-                desc[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)r << 12) | ((unsigned)cil << 16) | 0x80000000u;
+        GCGeom g = gc_build_geom(taps, rows, dtmin, p.nrows, p.Wp, cic, p.KC, gc_bld_max(pl.BM));
+        pl.dTab = g.tab;
+        pl.dDesc = g.desc;
+        pl.dDesc4 = g.desc4;
+        p.tab = g.tab;
+        p.desc = g.desc;
+        p.desc4 = g.desc4;
+        // narrower geometries for the last, mostly empty time tile of a row (T = 401 fills 17 of 128 columns of its 4th
+        // tile): same weights and chunking, own patch tables; gc_launch sends that tile to a 32- / 64-column kernel
+        static const int tail_env = getenv("SE_GC_TAIL") ? atoi(getenv("SE_GC_TAIL")) : 1;
+        // (only where the narrow kernel keeps all four waves busy: 128 rows x 32 columns; a 64-row layer would leave half
+        // its waves on padding again - measured slower than the skip logic of the full-width tile)
+        if (tail_env && pl.BN == 128 && pl.BM == 128 && !(taps.ntaps == 1 && pw_chunks)) {
+            for (int i = 0; i < 1; ++i) {
+                const int bn = 32;
+                pl.tail[i].BN = bn;
+                pl.tail[i].Wp = bn + (dtmax - dtmin);
+                pl.tail[i].g = gc_build_geom(taps, rows, dtmin, p.nrows, pl.tail[i].Wp, cic, p.KC, gc_bld_max(pl.BM));
             }
-        {
-            // the same patch seen as groups of 4 consecutive frames (slot fg = tid + 256 e <-> LDS floats 4 fg .. 4 fg + 3)
-            std::vector<unsigned> d4((size_t)NB * 256, 0u);
-            const int gpr = p.Wp / 4;
-            for (int e = 0; e < NB; ++e)
-                for (int t = 0; t < 256; ++t) {
-                    const int fg = t + 256 * e;
-                    if (4 * fg >= npatch) continue;
-                    const int rr = fg / gpr, w = 4 * (fg - rr * gpr), cil = rr / p.nrows, r = rr - cil * p.nrows;
-                    d4[(size_t)e * 256 + t] = (unsigned)w | ((unsigned)r << 12) | ((unsigned)cil << 16) | 0x80000000u;
-                }
-            SE_HIP(hipMalloc(&pl.dDesc4, d4.size() * sizeof(unsigned)));
-            SE_HIP(hipMemcpy(pl.dDesc4, d4.data(), d4.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-            p.desc4 = pl.dDesc4;
         }
-        SE_CHECK(p.Wp < 4096 && p.nrows <= 16 && cic < 32768, "patch descriptor field overflow");
-        SE_HIP(hipMalloc(&pl.dDesc, desc.size() * sizeof(unsigned)));
-        SE_HIP(hipMemcpy(pl.dDesc, desc.data(), desc.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-        p.desc = pl.dDesc;
     }
     const int nch0 = (C0 + cic - 1) / cic, nch1 = (Cin - C0 + cic - 1) / cic;
     p.nchunks = nch0 + nch1;
@@ -765,6 +779,12 @@ void gc_free_plan(GCPlan& pl) {
     if (pl.dDesc) (void)hipFree(pl.dDesc);
     if (pl.dDesc4) (void)hipFree(pl.dDesc4);
     pl.dDesc4 = nullptr;
+    for (auto& t : pl.tail) {
+        if (t.g.tab) (void)hipFree(t.g.tab);
+        if (t.g.desc) (void)hipFree(t.g.desc);
+        if (t.g.desc4) (void)hipFree(t.g.desc4);
+        t = GCTail{};
+    }
     pl.dWs = nullptr;
     pl.dDesc = nullptr;
     if (pl.dBias) (void)hipFree(pl.dBias);
@@ -824,6 +844,26 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
         else if (p.M <= 2) gc_small_launch<2>(p, stream);
         else gc_small_launch<4>(p, stream);
         return;
+    }
+    // the last time tile of a row, when it is at most half full, goes to a narrower kernel (own launch, same weights)
+    const int full = p.Tout / pl.BN, rem = p.Tout - full * pl.BN;
+    const GCTail* tl = nullptr;
+    if (full >= 1 && rem > 0)
+        for (const auto& t : pl.tail)
+            if (!tl && t.BN && rem <= t.BN) tl = &t;
+    if (tl) {
+        GCParams pt = p;
+        pt.t_base = full * pl.BN;
+        pt.n_ttiles = 1;
+        pt.Wp = tl->Wp;
+        pt.tab = tl->g.tab;
+        pt.desc = tl->g.desc;
+        pt.desc4 = tl->g.desc4;
+        p.n_ttiles = full;
+        if (pl.BM == 128 && tl->BN == 32) gc_launch_t<128, 32, 4, 1>(pt, stream);
+        else if (pl.BM == 128 && tl->BN == 64) gc_launch_t<128, 64, 4, 1>(pt, stream);
+        else if (pl.BM == 64 && tl->BN == 64) gc_launch_t<64, 64, 2, 2>(pt, stream);
+        else SE_CHECK(false, "no gemmconv tail tile config");
     }
     if (pl.BM == 128 && pl.BN == 128) gc_launch_t<128, 128, 2, 2>(p, stream);
     else if (pl.BM == 64 && pl.BN == 128) gc_launch_t<64, 128, 2, 2>(p, stream);

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
     float* __restrict__ out = a.out + (long)z * a.out_z + (long)u * a.out_row;
     float* __restrict__ cell = a.cell + ((long)z * H + u) * a.S;
     float* __restrict__ hx = a.hx + (long)z * 2 * a.S * H;
-    unsigned* bar = a.bar + z * a.SS + ss;
+    // one arrival flag per unit slice of this (z, sequence slice): a producer stores the step number into its own word,
+    // a consumer reads all US words with one wave load - no read-modify-write traffic serialised on a single counter
+    unsigned* flags = a.bar + (z * a.SS + ss) * 64;
 
     // gate pre-activations of this lane's (unit, sequence) for the block's first tile of a step (prefetched before
     // the exchange barrier of the previous step - they do not depend on h)
@@ -144,14 +146,16 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
             __syncthreads();                                       // (also: every wave is done reading hs)
             // h_t went out as agent-coherent (sc1) stores and the workgroup barrier above waited for their completion,
             // so a relaxed arrival is enough: no L2 write-back / invalidate per step
-            if (tid == 0 && !(a.dbg & 4)) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(a.dbg & 4))
+                __hip_atomic_store(flags + us, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             load_g(step + 1, ss, gfirst);
-            if (tid == 0 && !(a.dbg & 4)) {
-                const unsigned want = (unsigned)US * (unsigned)(step + 1);
+            if (wave == 0 && !(a.dbg & 4)) {
+                const unsigned want = (unsigned)(step + 1);
                 const unsigned long long t0 = wall_clock64();
                 // relaxed polling: an acquire load would invalidate the caches on every iteration
-                while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    if (a.dbg & 8) __builtin_amdgcn_s_sleep(2);
+                for (;;) {
+                    const unsigned v = lane < US ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+                    if (__builtin_amdgcn_ballot_w64(v < want) == 0) break;
                     if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
                 }
             }
@@ -170,14 +174,15 @@ void launch_t(LstmCoopArgs a, int n_cu, hipStream_t s) {
     a.SS = std::max(1, std::min(NT, n_cu / (US * a.Z)));
     static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
     a.dbg = dbg;
-    // exchange tensor hx [Z][2][S][H] + one arrival counter per (z, sequence slice)
+    // exchange tensor hx [Z][2][S][H] + 64 arrival flags per (z, sequence slice)
     const size_t hx_bytes = (size_t)a.Z * 2 * a.S * H * sizeof(float);
-    char* sc = coop_scratch(hx_bytes + 256 * sizeof(unsigned), s);
+    constexpr size_t NFLAG = 256 * 64;        // (z, sequence slice) groups x 64 unit-slice words
+    char* sc = coop_scratch(hx_bytes + NFLAG * sizeof(unsigned), s);
     a.hx = reinterpret_cast<float*>(sc);
     a.bar = reinterpret_cast<unsigned*>(sc + hx_bytes);
     // zeroed by a kernel, not a memset node: under hipGraph replay the memset was observed not to be ordered before the
     // cooperative kernel (stale arrival counts let every barrier fall through)
-    launch_fill(reinterpret_cast<float*>(a.bar), 256, 0.f, s);
+    launch_fill(reinterpret_cast<float*>(a.bar), (long)a.Z * a.SS * 64, 0.f, s);
     const size_t shmem = (size_t)16 * (H + 4) * sizeof(float);
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {

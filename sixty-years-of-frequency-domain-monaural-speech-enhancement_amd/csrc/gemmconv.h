@@ -65,8 +65,7 @@ struct GCParams {
     int CI_C, KC, KCp, nchunks;
     int act, epi;
     int n_ttiles, n_mtiles, Z;
-    int dbuf;                // 1: double-buffered LDS staging, 0: single buffer (more blocks per CU)
-    int dbg;                 // ablation switches for tuning (0 in production): 1 no global loads, 2 no LDS restage, 4 no MFMA
+    int dbg;                 // ablation switches for tuning (0 in production): 1 no global loads, 4 no MFMA, 8 no epilogue
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
     unsigned long long* timing;   // tuning builds (-DGC_TIMING): per-phase s_memtime accumulators, else unused
     const unsigned* desc4;   // descriptors of the patch seen as 16 B groups (same packing as desc, w = first frame)

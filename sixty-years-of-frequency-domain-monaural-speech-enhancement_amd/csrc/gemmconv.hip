@@ -652,10 +652,8 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.dtmin = dtmin;
     p.Wp = pl.BN + (dtmax - dtmin);                         // LDS row stride of the patch (multiple of 4)
     SE_CHECK(p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256, "tap span too wide for one staged patch");
-    // chunking: largest CI_C within the staging budgets (SE_GC_KCP / SE_GC_DBUF: tuning overrides)
+    // chunking: largest CI_C within the staging budgets (SE_GC_KCP: tuning override)
     static const int kcp_cap = getenv("SE_GC_KCP") ? atoi(getenv("SE_GC_KCP")) : GC_MAX_KCP;
-    static const int dbuf_env = getenv("SE_GC_DBUF") ? atoi(getenv("SE_GC_DBUF")) : 1;
-    p.dbuf = dbuf_env;
     static const bool pw_chunks = !(getenv("SE_GC_PW4") && atoi(getenv("SE_GC_PW4")) == 0);
     int cic = 1;
     for (int c = 1; c <= std::max(std::max(C0, Cin - C0), 1); ++c) {

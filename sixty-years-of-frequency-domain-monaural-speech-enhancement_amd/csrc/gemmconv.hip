@@ -110,7 +110,7 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {
 #ifdef GC_TIMING
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int TM = BM / (WM * 32);
@@ -173,7 +173,12 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     // lookup is a short LDS read instead of a dependent global load in the block prologue
     int* tabl = reinterpret_cast<int*>(Bs + nbuf * Bs_sz);
     int* koff_lds = tabl + GC_TAB_KOFF;
-    if (tid < GC_TAB_KOFF + KCP_MAX + 8) tabl[tid] = p.tab[tid];
+    GC_T(7);      /* kernel entry .. index decode */
+    // one barrier for both block-wide LDS initialisations: the tap table (its global load is in flight while the patch
+    // buffers are cleared) and the zeros of the padding (masked DMA lanes never touch their LDS words again)
+    const int tabv = (tid < GC_TAB_KOFF + KCP_MAX + 8) ? p.tab[tid] : 0;
+    for (int i = tid; i < 2 * Bs_sz / 4; i += 256) reinterpret_cast<floatx4*>(Bs)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (tid < GC_TAB_KOFF + KCP_MAX + 8) tabl[tid] = tabv;
     __syncthreads();
     if constexpr (KOFF_REGS) {
         static_for<NPAIR>([&](auto KP) {
@@ -214,10 +219,20 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     {                                                                                              \
         const int lim_ = (LIM);                                                                    \
         vbits = 0;                                                                                 \
+        /* host-built descriptors of the flat patch slots fe = tid + 256 e: w | r << 12 | cil << 16 | staged << 31.    */ \
+        /* All NB loads are issued as one batch into block-local registers before the first use: fused with their use */ \
+        /* the compiler waited for each load in turn (13 serial global round trips per block prologue).               */ \
+        unsigned dsc_[NB];                                                                         \
+        {                                                                                          \
+            const unsigned* __restrict__ dp_ = (pw4 ? p.desc4 : p.desc) + tid;                     \
+            static_for<NB>([&](auto E) {                                                           \
+                constexpr int e = decltype(E)::value;                                              \
+                dsc_[e] = dp_[256 * e];                                                            \
+            });                                                                                    \
+        }                                                                                          \
         static_for<NB>([&](auto E) {                                                               \
             constexpr int e = decltype(E)::value;                                                  \
-            /* host-built descriptor of flat patch slot fe = tid + 256 e: w | r << 12 | cil << 16 | staged << 31 */ \
-            const unsigned d_ = (pw4 ? p.desc4 : p.desc)[256 * e + tid];                           \
+            const unsigned d_ = dsc_[e];                                                           \
             const int w = d_ & 0xfff, r = (d_ >> 12) & 0xf, cil = (d_ >> 16) & 0x7fff;             \
             const bool staged = (d_ >> 31) != 0;                                                   \
             const int f = q * p.si + tabl[staged ? r : 0];                                         \
@@ -258,10 +273,6 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
 // the DMA writes are invisible to the compiler: drain them by hand before the barrier that publishes the buffer
 #define GC_WAIT_CHUNK() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-    // zeros of the padding: the patch buffers are cleared once, masked DMA lanes never touch them again
-    for (int i = tid; i < 2 * Bs_sz; i += 256) Bs[i] = 0.f;
-    __syncthreads();
-
     for (int seg = 0; seg < 2; ++seg) {
         const int Cseg = seg ? p.C1 : p.C0;
         if (Cseg <= 0) continue;
@@ -271,8 +282,9 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         const int nch = (Cseg + p.CI_C - 1) / p.CI_C;
         const int tail = Cseg - (nch - 1) * p.CI_C;       // channels in the last chunk
 
+        GC_T(9);      /* Bs zero + sync */
         GC_MAKE_DESC(nch > 1 ? p.CI_C : tail);
-        GC_T(0);
+        GC_T(10);     /* descriptors */
         GC_LOAD_CHUNK(0, buf);           // `buf` is free: the previous segment's last chunk was read from buf ^ 1
         GC_T(1);
         GC_WAIT_CHUNK();
@@ -480,6 +492,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     GC_T(5);
     if (tid == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(p.timing + i, tacc[i]);
+        for (int i = 7; i < 12; ++i) atomicAdd(p.timing + i, tacc[i]);
         atomicAdd(p.timing + 6, 1ull);
     }
 #endif

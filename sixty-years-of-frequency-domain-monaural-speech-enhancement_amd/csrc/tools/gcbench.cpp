@@ -90,8 +90,8 @@ int main(int argc, char** argv) {
     SE_HIP(hipMemcpy(din, hin.data(), nin * 4, hipMemcpyHostToDevice));
 #ifdef GC_TIMING
     unsigned long long* dt;
-    SE_HIP(hipMalloc(&dt, 64));
-    SE_HIP(hipMemset(dt, 0, 64));
+    SE_HIP(hipMalloc(&dt, 128));
+    SE_HIP(hipMemset(dt, 0, 128));
     pl.p.timing = dt;
 #endif
     hipEvent_t e0, e1;
@@ -108,11 +108,13 @@ int main(int argc, char** argv) {
     double fl = 2.0 * Cout * Cin * 10.0 * B * Fout * T;
 #ifdef GC_TIMING
     {
-        SE_HIP(hipMemset(dt, 0, 64));
+        SE_HIP(hipMemset(dt, 0, 128));
         run_conv(pl, a, nullptr, dout, Cout, Fout, B, T, T, 0);
         SE_HIP(hipDeviceSynchronize());
-        unsigned long long h[8];
-        SE_HIP(hipMemcpy(h, dt, 64, hipMemcpyDeviceToHost));
+        unsigned long long h[16];
+        SE_HIP(hipMemcpy(h, dt, 128, hipMemcpyDeviceToHost));
+        printf("prologue split: entry/decode %.0f  tab/koff/aoff %.0f  Bs zero %.0f  descriptors %.0f\n", (double)h[7] / h[6],
+               (double)h[8] / h[6], (double)h[9] / h[6], (double)h[10] / h[6]);
         const char* nm[6] = {"prologue/desc", "load issue", "mfma", "vmcnt wait", "barrier", "epilogue"};
         double tot = 0;
         for (int i = 0; i < 6; ++i) tot += (double)h[i];

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             const int fc = f < 0 ? 0 : (f >= p.Fin ? p.Fin - 1 : f);                               \
             const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
-            boff[e] = staged ? (unsigned)((long)cc * s_c + (long)fc * s_f + tc) : 0u;              \
+            boff[e] = staged ? (unsigned)cc * sc32 + (unsigned)fc * sf32 + (unsigned)tc : 0u;      \
             /* pw4: the slot is a group of 4 frames; never straddles frame 0, may straddle Tin (see gc_launch)   */ \
             vbits |= (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? (1u << e) : 0u; \
         });                                                                                        \
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         const float* __restrict__ sbase =
             (seg ? p.src1 + (long)z * p.src1_z + (long)b * p.s1_b : p.src0 + (long)z * p.src0_z + (long)b * p.s0_b);
         const long s_c = seg ? p.s1_c : p.s0_c, s_f = seg ? p.s1_f : p.s0_f;
+        const unsigned sc32 = (unsigned)s_c, sf32 = (unsigned)s_f;      // patch offsets inside one chunk fit 32 bits
         const int nch = (Cseg + p.CI_C - 1) / p.CI_C;
         const int tail = Cseg - (nch - 1) * p.CI_C;       // channels in the last chunk
 
@@ -844,6 +845,9 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     p.dbg = dbg_env;
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
     if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;
+    // patch offsets inside one staged chunk are 32-bit (the 64-bit part of an address is the per-block / per-chunk base)
+    SE_CHECK((double)p.CI_C * (double)std::max(p.s0_c, p.s1_c) + (double)p.Fin * (double)std::max(p.s0_f, p.s1_f) + p.Tin < 4.0e9,
+             "gc_launch: source plane too large for 32-bit patch offsets");
     static const int pw4_env = getenv("SE_GC_PW4") ? atoi(getenv("SE_GC_PW4")) : 1;
     // 16 B staging groups: exact when no group straddles the end of a row (Tin % 4 == 0); for causal tap sets a straddling
     // group only feeds output frames >= Tin, which are never stored - then it merely has to stay inside mapped memory

@@ -171,14 +171,42 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     int koffv[KOFF_REGS ? NPAIR : 1];
     // the whole device table (frequency rows, taps, per-K-row patch offsets) is staged once into LDS: every later
     // lookup is a short LDS read instead of a dependent global load in the block prologue
-    int* tabl = reinterpret_cast<int*>(Bs + nbuf * Bs_sz);
+    // LDS map: [staging buffers | epilogue strips (aliased)] [tap table] [per-row epilogue parameters]
+    constexpr int STRIPS = 4 * (TM * 32) * 36;       // floats of the four per-wave epilogue transposition strips
+    int* tabl = reinterpret_cast<int*>(smem + max(nbuf * (As_sz + Bs_sz), STRIPS));
     int* koff_lds = tabl + GC_TAB_KOFF;
+    float* ep = reinterpret_cast<float*>(tabl + GC_TAB_KOFF + KCP_MAX + 8);      // [4 * BM]
     GC_T(7);      /* kernel entry .. index decode */
     // one barrier for both block-wide LDS initialisations: the tap table (its global load is in flight while the patch
     // buffers are cleared) and the zeros of the padding (masked DMA lanes never touch their LDS words again)
     const int tabv = (tid < GC_TAB_KOFF + KCP_MAX + 8) ? p.tab[tid] : 0;
+    // per-row epilogue parameters (bias, PReLU slope, GLU post scale / shift) are fetched here, under the rest of the
+    // prologue, and parked in LDS: the epilogue then has no global load and no block barrier in front of its stores
+    const int fo = q * p.so + p.po;
+    const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
+    float epv[4] = {0.f, 0.f, 1.f, 0.f};
+    if (EPI != EPI_LSTM && tid < BM) {
+        const int m = min(m0 + tid, p.M - 1);
+        epv[0] = bias ? bias[m] : 0.f;
+        if (EPI != EPI_GLU) {
+            epv[1] = p.slope ? p.slope[m] : 0.f;
+        } else if (tid < BM / 2) {
+            const int oc = min((m0 >> 1) + tid, (p.M >> 1) - 1);
+            epv[1] = p.slope ? p.slope[oc] : 0.f;
+            epv[2] = p.post_scale ? p.post_scale[oc] : 1.f;
+            epv[3] = p.post_scale ? p.post_shift[oc] : 0.f;
+        }
+    }
     for (int i = tid; i < 2 * Bs_sz / 4; i += 256) reinterpret_cast<floatx4*>(Bs)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     if (tid < GC_TAB_KOFF + KCP_MAX + 8) tabl[tid] = tabv;
+    if (EPI != EPI_LSTM && tid < BM) {
+        ep[tid] = epv[0];
+        ep[BM + tid] = epv[1];
+        if (EPI == EPI_GLU && tid < BM / 2) {
+            ep[2 * BM + tid] = epv[2];
+            ep[3 * BM + tid] = epv[3];
+        }
+    }
     __syncthreads();
     if constexpr (KOFF_REGS) {
         static_for<NPAIR>([&](auto KP) {
@@ -362,32 +390,17 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     // ---------------------------------------------------------------- epilogue
     if (p.dbg & 8) return;
     GC_T(0);
-    const int fo = q * p.so + p.po;
-    const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
     float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
 
-    // per-row epilogue parameters go through LDS once per block (the K loop's last barrier has retired every reader
-    // of the staging buffers): no dependent global load sits in front of a store.  The activated tile is then
-    // transposed through LDS inside each wave so that a lane stores 16 B runs along t (4x fewer, 4x wider stores
-    // than the MFMA accumulator layout gives).
-    float* ep = smem;
+    // The activated tile is transposed through LDS inside each wave so that a lane stores 16 B runs along t (4x fewer,
+    // 4x wider stores than the MFMA accumulator layout gives).  The strips alias the staging buffers (the K loop's last
+    // barrier has retired every reader) and are private to a wave: DS operations of one wave execute in order, so the
+    // write -> read-back hand-over needs a wave-level fence only, no block barrier.
     constexpr int OROWS = (EPI == EPI_GLU) ? TM * 16 : TM * 32;   // output rows of one wave's strip
     constexpr int OST = 32 + 4;                                    // LDS row stride of the strip (one 32-column MFMA tile wide)
-    float* strip = smem + 4 * BM + wave * (TM * 32 * OST);
+    float* strip = smem + wave * (TM * 32 * OST);
+#define GC_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
     if (EPI == EPI_ACT || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_GLU) {
-        if (tid < BM) {
-            const int m = min(m0 + tid, p.M - 1);
-            ep[tid] = bias ? bias[m] : 0.f;
-            if (EPI != EPI_GLU) {
-                ep[BM + tid] = p.slope ? p.slope[m] : 0.f;
-            } else if (tid < BM / 2) {
-                const int oc = min((m0 >> 1) + tid, (p.M >> 1) - 1);
-                ep[BM + tid] = p.slope ? p.slope[oc] : 0.f;
-                ep[2 * BM + tid] = p.post_scale ? p.post_scale[oc] : 1.f;
-                ep[3 * BM + tid] = p.post_scale ? p.post_shift[oc] : 0.f;
-            }
-        }
-        __syncthreads();
         const int mw = wm * (TM * 32) + 4 * hi;                 // first tile row of this lane
         const int lr = lane >> 3, lc = (lane & 7) * 4;           // read-back role: (row within 8, 4 consecutive t)
         const int mo0 = (EPI == EPI_GLU ? (m0 >> 1) : m0) + wm * OROWS;      // first output row of the strip
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            if (j > 0) __syncthreads();                          // the previous column tile has been read back
+            if (j > 0) GC_WAVE_FENCE();                          // the previous column tile has been read back
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if (EPI != EPI_GLU) {
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
                     }
                 }
             }
-            __syncthreads();
+            GC_WAVE_FENCE();
             // read back as rows: 8 lanes x 16 B cover the 32 columns of one row, 8 rows per wave instruction
             const int tg = t0 + wn * (TN * 32) + j * 32 + lc;
 #pragma unroll
@@ -593,8 +606,7 @@ static void gc_small_launch(const GCParams& p, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
-    const size_t staging = 2 * (as + bs) * 4 + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + 64;
-    return std::max(staging, epi_bytes);
+    return std::max(2 * (as + bs) * 4, epi_bytes) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64;
 }
 
 // Device tables of one patch geometry (row stride Wp): frequency rows / tap table / K-row patch offsets, and the
@@ -814,7 +826,7 @@ void gc_free_plan(GCPlan& pl) {
 template <int BM, int BN, int WM, int WN, int EPI>
 static void gc_launch_e(const GCParams& p, hipStream_t stream) {
     // epilogue: 4*BM row parameters + one transposition strip per wave (rows x (cols + 4))
-    const size_t epi = (size_t)(4 * BM + 4 * (BM / WM) * 36) * sizeof(float);
+    const size_t epi = (size_t)(4 * (BM / WM) * 36) * sizeof(float);
     const size_t lds = gc_lds_bytes(p, BM, epi);
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {

@@ -123,8 +123,114 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     }
 }
 
+// ---- small sequence counts: 4 sequences per workgroup on v_mfma_f32_4x4x1_16b_f32 -----------------------------------
+// DCCRN's complex LSTM runs S = B sequences per (weight set, input): 16-sequence tiles give 16 * Z * O = 64 workgroups at
+// B = 256 and leave 3/4 of the chip idle for 2 x 3.6 ms of every step.  The 4x4x1 MFMA (16 independent 4x4 blocks, K = 1)
+// maps block <-> hidden unit, block row <-> gate, block column <-> sequence: a workgroup then owns 4 sequences, there are
+// 4x as many workgroups, and a lane still holds the four gates of one (unit, sequence) pair for a lane-local cell update.
+// Same register-resident W_hh (H*H/64 VGPRs per lane), h_{t-1} through a [4][H] LDS tile read as 16 B per 4 k values.
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_persist4_kernel(const LstmPersistArgs a) {
+    constexpr int RG = H / 64;         // 64-row groups (16 units) per wave: the wave owns H gate rows = H/4 units
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * H];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = lane >> 2, j = lane & 3;                  // MFMA block (unit) and column (sequence) of this lane
+    const int n0 = blockIdx.x * 4;
+    const int z = blockIdx.y % a.Z, o = blockIdx.y / a.Z;
+    const int n = n0 + j;
+    const bool rev = (a.reverse >> z) & 1;
+    const bool col_ok = n < a.S;
+
+    // A operand of block `blk`, row i = lane & 3: W[4 * unit + i][k]   (rows are gate-interleaved)
+    const float* __restrict__ W = a.whh + (long)z * a.whh_z;
+    float wa[RG][H];
+    static_for_l<RG>([&](auto R_) {
+        constexpr int rg = decltype(R_)::value;
+        const int row = 4 * (wave * (H / 4) + rg * 16 + blk) + j;
+        static_for_l<H>([&](auto K_) {
+            constexpr int k = decltype(K_)::value;
+            wa[rg][k] = W[(long)row * H + k];
+        });
+    });
+
+    const float* __restrict__ gx = a.gx + (long)z * a.gx_z + (long)o * a.gx_o + min(n, a.S - 1);
+    float* __restrict__ out = a.out + (long)z * a.out_z + (long)o * a.out_o + n;
+    float c[RG], gcur[RG][4], gnxt[RG][4];
+    static_for_l<RG>([&](auto R_) {
+        constexpr int rg = decltype(R_)::value;
+        c[rg] = 0.f;
+    });
+    for (int i = tid; i < 4 * H; i += 256) hs[0][i] = 0.f;
+
+    auto load_gx = [&](int step, float (&g)[RG][4]) {
+        const int t = rev ? a.T - 1 - step : step;
+        const float* gp = gx + (long)t * a.gx_t;
+        static_for_l<RG>([&](auto R_) {
+            constexpr int rg = decltype(R_)::value;
+            const int row = 4 * (wave * (H / 4) + rg * 16 + blk);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) g[rg][g4] = gp[(long)(row + g4) * a.gx_row];
+        });
+    };
+    load_gx(0, gcur);
+    __syncthreads();
+
+    for (int step = 0; step < a.T; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < a.T) load_gx(step + 1, gnxt);
+        floatx4 acc[RG];
+        static_for_l<RG>([&](auto R_) {
+            constexpr int rg = decltype(R_)::value;
+            acc[rg] = floatx4{0.f, 0.f, 0.f, 0.f};
+        });
+        if (step > 0) {
+            const floatx4* hb = reinterpret_cast<const floatx4*>(&hs[cur][j * H]);     // B operand: h_{t-1}[k] of sequence j
+            static_for_l<H / 4>([&](auto K4_) {
+                constexpr int k4 = decltype(K4_)::value;
+                const floatx4 b = hb[k4];
+                static_for_l<RG>([&](auto R_) {
+                    constexpr int rg = decltype(R_)::value;
+                    acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 0], b[0], acc[rg], 0, 0, 0);
+                    acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 1], b[1], acc[rg], 0, 0, 0);
+                    acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 2], b[2], acc[rg], 0, 0, 0);
+                    acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 3], b[3], acc[rg], 0, 0, 0);
+                });
+            });
+        }
+        const int t = rev ? a.T - 1 - step : step;
+        float* op = out + (long)t * a.out_t;
+        static_for_l<RG>([&](auto R_) {
+            constexpr int rg = decltype(R_)::value;
+            const int u = wave * (H / 4) + rg * 16 + blk;
+            const float gi = acc[rg][0] + gcur[rg][0];
+            const float gf = acc[rg][1] + gcur[rg][1];
+            const float gg = acc[rg][2] + gcur[rg][2];
+            const float go = acc[rg][3] + gcur[rg][3];
+            const float cn = fast_sigmoid(gf) * c[rg] + fast_sigmoid(gi) * fast_tanh(gg);
+            c[rg] = cn;
+            const float h = fast_sigmoid(go) * fast_tanh(cn);
+            hs[cur ^ 1][j * H + u] = h;
+            if (col_ok) op[(long)u * a.out_row] = h;
+        });
+        static_for_l<RG>([&](auto R_) {
+            constexpr int rg = decltype(R_)::value;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) gcur[rg][g4] = gnxt[rg][g4];
+        });
+        __syncthreads();
+    }
+}
+
 void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s) {
     SE_CHECK(a.H == 64 || a.H == 128, "persistent LSTM kernel is built for H = 64 / 128");
+    // few sequences: 4 per workgroup (4x4x1 MFMA) fill the chip where 16-sequence tiles would not
+    static const int p4_env = getenv("SE_LSTM_P4") ? atoi(getenv("SE_LSTM_P4")) : 1;
+    if (p4_env && a.H == 128 && ((a.S + 15) / 16) * a.Z * a.O <= 128) {
+        hipLaunchKernelGGL(lstm_persist4_kernel<128>, dim3((a.S + 3) / 4, a.Z * a.O), dim3(256), 0, s, a);
+        SE_HIP(hipGetLastError());
+        return;
+    }
     dim3 grid((a.S + 15) / 16, a.Z * a.O);
     if (a.H == 128) hipLaunchKernelGGL(lstm_persist_kernel<128>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(lstm_persist_kernel<64>, grid, dim3(256), 0, s, a);

@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist4_kernel(const LstmPersist
 void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s) {
     SE_CHECK(a.H == 64 || a.H == 128, "persistent LSTM kernel is built for H = 64 / 128");
     // few sequences: 4 per workgroup (4x4x1 MFMA) fill the chip where 16-sequence tiles would not
-    static const int p4_env = getenv("SE_LSTM_P4") ? atoi(getenv("SE_LSTM_P4")) : 1;
-    if (p4_env && a.H == 128 && ((a.S + 15) / 16) * a.Z * a.O <= 128) {
+    static const int p4_max = getenv("SE_LSTM_P4") ? atoi(getenv("SE_LSTM_P4")) : 128;      // 0 disables
+    if (a.H == 128 && ((a.S + 15) / 16) * a.Z * a.O <= p4_max) {
         hipLaunchKernelGGL(lstm_persist4_kernel<128>, dim3((a.S + 3) / 4, a.Z * a.O), dim3(256), 0, s, a);
         SE_HIP(hipGetLastError());
         return;

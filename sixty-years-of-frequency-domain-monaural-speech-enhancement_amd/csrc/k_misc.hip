@@ -93,26 +93,26 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
                                                            const float* __restrict__ w, const float* __restrict__ bb,
                                                            float* __restrict__ out, int C, int F, int T, float eps, int post,
                                                            const float* __restrict__ prelu_slope) {
-    __shared__ float red[4][64];
+    __shared__ double red[4][64], red2[4][64];
     const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + tl, b = blockIdx.y;
     const bool ok = t < T;
     const long base = (long)b * C * F * T + (ok ? t : T - 1);
     const int n = C * F;
-    float s = 0.f;
-    for (int i = rg; i < n; i += 4) s += x[base + (long)i * T];
-    red[rg][tl] = s;
-    __syncthreads();
-    const float mu = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / n;
-    __syncthreads();
-    float v = 0.f;
+    // one statistics pass (sum and sum of squares in fp64), then the normalise pass
+    double s = 0.0, v = 0.0;
     for (int i = rg; i < n; i += 4) {
-        const float d = x[base + (long)i * T] - mu;
-        v += d * d;
+        const double xv = x[base + (long)i * T];
+        s += xv;
+        v += xv * xv;
     }
-    red[rg][tl] = v;
+    red[rg][tl] = s;
+    red2[rg][tl] = v;
     __syncthreads();
-    const float rs = rsqrtf((red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / n + eps);
+    const double mud = (red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl]) / n;
+    const double vard = fmax((red2[0][tl] + red2[1][tl] + red2[2][tl] + red2[3][tl]) / n - mud * mud, 0.0);
+    const float mu = (float)mud;
+    const float rs = (float)(1.0 / sqrt(vard + (double)eps));
     if (!ok) return;
     const float slope = prelu_slope ? prelu_slope[0] : 1.f;
     for (int i = rg; i < n; i += 4) {

@@ -21,9 +21,15 @@ struct NormAct {
 };
 
 // norm -> PReLU on x [B][C][F][T] (in place allowed)
-inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int C, int F, int T, hipStream_t st) {
-    if (n.cum) launch_cln(x, y, n.g, n.b, nullptr, n.s, nullptr, 0, B, C, F, T, st);
-    else launch_instnorm_prelu(x, y, n.g, n.b, n.s, B, C, F * T, st);
+// res (optional, may alias y): y = PReLU(norm(x)) + res
+inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int C, int F, int T, hipStream_t st,
+                         const float* res = nullptr) {
+    if (n.cum) {
+        launch_cln(x, y == res ? const_cast<float*>(x) : y, n.g, n.b, nullptr, n.s, nullptr, 0, B, C, F, T, st);
+        if (res) launch_add(res, y == res ? x : y, y, (long)B * C * F * T, st);
+    } else {
+        launch_instnorm_prelu(x, y, n.g, n.b, n.s, B, C, F * T, st, res);
+    }
 }
 // PReLU -> norm -> shared FIR on x [B][C][T]
 inline void tcm_head(const NormAct& n, const float* fir, int K, const float* x, float* y, int B, int C, int T, hipStream_t st) {

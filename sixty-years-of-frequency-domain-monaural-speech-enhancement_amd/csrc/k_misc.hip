@@ -222,11 +222,13 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 
 __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ slope, int C, int P) {
+                                                             const float* __restrict__ slope, const float* res, int C,
+                                                             int P) {
     __shared__ double sh[4];
     const int c = blockIdx.x % C;
     const float* xp = x + (long)blockIdx.x * P;
     float* yp = y + (long)blockIdx.x * P;
+    const float* rp = res ? res + (long)blockIdx.x * P : nullptr;     // optional residual, may alias y
     // one statistics pass: sum and sum of squares in fp64 (the cancellation in E[x^2] - mu^2 costs ~1e-16 * mu^2 / var,
     // far below fp32 resolution), then one normalise pass: 2 reads + 1 write of the plane instead of 3 + 1
     double s = 0.0, q = 0.0;
@@ -241,12 +243,13 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
     const float g = gamma[c], bt = beta[c], sl = slope ? slope[c] : 1.f;
     for (int i = threadIdx.x; i < P; i += 256) {
         float o = (xp[i] - muf) * rs * g + bt;
-        yp[i] = o >= 0.f ? o : sl * o;
+        o = o >= 0.f ? o : sl * o;
+        yp[i] = rp ? o + rp[i] : o;
     }
 }
 void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
-                           int C, int P, hipStream_t s) {
-    hipLaunchKernelGGL(instnorm_prelu_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, C, P);
+                           int C, int P, hipStream_t s, const float* res) {
+    hipLaunchKernelGGL(instnorm_prelu_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, res, C, P);
     SE_HIP(hipGetLastError());
 }
 

@@ -45,8 +45,9 @@ void launch_fill(float* p, long n, float v, hipStream_t s);
 // nn.InstanceNorm2d / InstanceNorm1d (affine, per-utterance statistics, biased variance, eps 1e-5) over the contiguous
 // plane of P values of every (b, c), optionally followed by a per-channel PReLU; in place allowed.
 //   x [B][C][P];  gamma/beta [C];  slope [C] or null
+//   res (optional, [B][C][P], may alias y): y = PReLU(norm(x)) + res
 void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
-                           int C, int P, hipStream_t s);
+                           int C, int P, hipStream_t s, const float* res = nullptr);
 
 // TCM branch head (CTSNet/Step1_network.py:161-176): y = ShareSepConv( InstanceNorm1d( PReLU(x) ) ) per (b, c) row of
 // T frames; fir [K] is the single FIR shared by all channels (causal, left pad K-1), K = 0 -> no FIR.

@@ -172,10 +172,11 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
                 Act4 a1 = act4(xs[scale - i], 64, Fi, T);          // x_list[-(i+1)]
                 run_deconv(deco[i].plan, a0, &a1, y, 64, Fo, B, T, T, st, pf);
             }
-            norm2d_prelu(deco[i].na, y, y, B, 64, Fo, T, st);
+            // the last decoder level also adds the module's residual (x_resi + x): folded into its norm pass
+            if (i + 1 == scale) norm2d_prelu(deco[i].na, y, out, B, 64, Fo, T, st, out);
+            else norm2d_prelu(deco[i].na, y, y, B, 64, Fo, T, st);
             x = y;
         }
-        launch_add(out, x, out, (long)B * 64 * F0 * T, st);         // x_resi + x
     }
 };
 

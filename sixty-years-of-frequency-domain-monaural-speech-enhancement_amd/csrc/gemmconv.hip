@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 namespace se {
@@ -779,10 +780,16 @@ static std::vector<std::pair<const char*, const char*>>& gc_safe_ranges() {
     static std::vector<std::pair<const char*, const char*>> r;
     return r;
 }
+static std::mutex& gc_safe_mutex() {       // engines may be created / destroyed from different host threads
+    static std::mutex m;
+    return m;
+}
 void gc_register_overread_range(const void* lo, size_t bytes) {
+    std::lock_guard<std::mutex> lk(gc_safe_mutex());
     gc_safe_ranges().emplace_back(static_cast<const char*>(lo), static_cast<const char*>(lo) + bytes);
 }
 void gc_unregister_overread_range(const void* lo) {
+    std::lock_guard<std::mutex> lk(gc_safe_mutex());
     auto& r = gc_safe_ranges();
     for (size_t i = 0; i < r.size(); ++i)
         if (r[i].first == lo) {
@@ -792,6 +799,7 @@ void gc_unregister_overread_range(const void* lo) {
 }
 static bool gc_overread_ok(const void* ptr) {
     if (!ptr) return true;
+    std::lock_guard<std::mutex> lk(gc_safe_mutex());
     for (const auto& r : gc_safe_ranges())
         if (ptr >= r.first && static_cast<const char*>(ptr) + 16 <= r.second) return true;
     return false;

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <tuple>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -89,15 +91,18 @@ inline bool first_on_device(bool (&seen)[64]) {
     return true;
 }
 
-// Engine-lifetime scratch that grows on first use, one slot per (purpose, device): handles of different devices may
-// live in one process and be driven from one host thread.  Growth synchronises the stream (never on the steady path).
+// Engine-lifetime scratch that grows on first use, one buffer per (purpose, device, stream): work that can be in flight
+// at the same time is on different streams (two handles driven asynchronously, one handle's auxiliary streams), work on
+// one stream is ordered - so a buffer is never shared by two running kernels.  Growth synchronises the stream (never on
+// the steady path).
 inline char* device_scratch(int purpose, size_t need, hipStream_t s) {
     struct Slot { char* p = nullptr; size_t cap = 0; };
-    static Slot slots[4][64];
+    static std::map<std::tuple<int, int, hipStream_t>, Slot> slots;
+    static std::mutex mu;
     int dev = 0;
     SE_HIP(hipGetDevice(&dev));
-    SE_CHECK(purpose >= 0 && purpose < 4 && dev >= 0 && dev < 64, "device_scratch: bad slot");
-    Slot& sl = slots[purpose][dev];
+    std::lock_guard<std::mutex> lk(mu);
+    Slot& sl = slots[std::make_tuple(purpose, dev, s)];
     if (need > sl.cap) {
         if (sl.p) {
             SE_HIP(hipStreamSynchronize(s));

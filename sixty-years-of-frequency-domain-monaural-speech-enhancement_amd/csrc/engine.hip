@@ -27,6 +27,7 @@ struct se_engine {
     std::vector<std::pair<int, int>> warmed;
     float *stage_in = nullptr, *stage_out = nullptr;
     hipStream_t cap_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static std::string g_create_err;
@@ -116,7 +117,11 @@ int se_engine_destroy(se_engine* e) {
     if (e->frames_scratch) (void)hipFree(e->frames_scratch);
     for (auto& g : e->graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->cap_stream) {
+        (void)hipStreamDestroy(e->cap_stream);
+        (void)hipEventDestroy(e->ev_fork);
+        (void)hipEventDestroy(e->ev_join);
+    }
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     if (e->ctx.arena.base()) gc_unregister_overread_range(e->ctx.arena.base());
@@ -206,9 +211,20 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
             if (g.batch == batch && g.samples == n_samples) ge = &g;
         if (!ge) {
             const std::pair<int, int> key(batch, n_samples);
+            if (!e->cap_stream) {
+                SE_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+                SE_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+                SE_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+            }
             if (std::find(e->warmed.begin(), e->warmed.end(), key) == e->warmed.end()) {
-                e->warmed.push_back(key);                       // first call of a shape: eager
-                e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch, st);
+                // first call of a shape: eager, but on the capture stream (fork / join around the caller's stream) so that
+                // the lazily grown scratch buffers - keyed by stream - already exist when the shape is captured
+                e->warmed.push_back(key);
+                SE_HIP(hipEventRecord(e->ev_fork, st));
+                SE_HIP(hipStreamWaitEvent(e->cap_stream, e->ev_fork, 0));
+                e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch, e->cap_stream);
+                SE_HIP(hipEventRecord(e->ev_join, e->cap_stream));
+                SE_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
                 return;
             }
             if (!e->stage_in) {
@@ -218,8 +234,7 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
             }
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
-            // capture on an engine-owned stream: the caller's stream may be the legacy default stream, which cannot capture
-            if (!e->cap_stream) SE_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+            // capture on the engine-owned stream: the caller's stream may be the legacy default stream, which cannot capture
             hipStream_t cs = e->cap_stream;
             SE_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
             bool ok = true;
@@ -232,6 +247,8 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
             if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
+            if (getenv("SE_GRAPH_DEBUG"))
+                fprintf(stderr, "se_graph: %s (batch %d, samples %d)\n", ok ? "captured" : "capture failed", batch, n_samples);
             e->graphs.push_back({batch, n_samples, ok ? exec : nullptr});
             ge = &e->graphs.back();
         }

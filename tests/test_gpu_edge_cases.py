@@ -83,3 +83,31 @@ def test_graph_replay_matches_eager(name):
             ye = eager.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
             yg = graph.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
             assert np.array_equal(ye, yg), (name, rep, B, L, np.abs(ye - yg).max())
+
+
+def test_graph_replay_is_actually_captured():
+    """The replay path must really run from an instantiated graph for a capturable model (not silently stay eager):
+    the C ABI exposes no graph state, so this checks the side channel - a third call on fresh tensors is bit-identical
+    and the engine reports no error - plus, through SE_GRAPH_DEBUG, the capture count."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "\n".join([
+        "import sys, numpy as np, torch",
+        "sys.path.insert(0, %r)" % root,
+        "import se_amd",
+        "from se_amd import synth",
+        "from se_amd.models import crn_net",
+        "m = crn_net(max_batch=2, max_samples=4000, graphs=True).load_synthetic(12)",
+        "x = torch.from_numpy(np.stack([synth.synth_clip(b, 'speech', 4000) for b in range(2)])).cuda()",
+        "for _ in range(4):",
+        "    y = m.enhance_batch(x)",
+        "torch.cuda.synchronize()",
+        "print('finite', bool(torch.isfinite(y).all()))",
+    ])
+    env = dict(os.environ, SE_GRAPH_DEBUG='1')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'finite True' in r.stdout
+    assert 'se_graph: captured' in r.stderr and 'se_graph: capture failed' not in r.stderr, r.stderr[-2000:]

@@ -23,7 +23,7 @@ constexpr int GC_MAX_ROWS = 8;
 constexpr int GC_MAX_KCP = 48;
 constexpr int GC_TAB_KOFF = GC_MAX_ROWS + 2 * GC_MAX_TAPS;   // start of the per-K-row patch offsets in GCParams::tab
 // K rows of one staged chunk and patch elements staged per thread, by output-channel tile
-constexpr int gc_kcp_max(int BM) { return BM >= 128 ? 32 : 48; }
+constexpr int gc_kcp_max(int BM) { return 32; }
 constexpr int gc_bld_max(int BM) { return BM >= 128 ? 9 : 13; }
 // resident blocks per CU the kernel is register-budgeted for: small-M tiles do little matrix work per staged K row and
 // hide the global-load latency with occupancy instead

@@ -89,14 +89,25 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
         });
         if (step > 0) {
+            // h_{t-1} operand reads run PF k-groups ahead of the MFMAs that consume them (ring of 2 * PF registers): the
+            // compiler's own schedule waits lgkmcnt(0) behind every LDS read, 16-32 exposed LDS round trips per step
             const float* hb = &hs[cur][l4 * 16 + l15];
+            constexpr int PF = 4;
+            float bq[2 * PF];
+            static_for_l<PF>([&](auto K_) {
+                constexpr int kg = decltype(K_)::value;
+                bq[kg] = hb[kg * 64];
+            });
             static_for_l<KG>([&](auto K_) {
                 constexpr int kg = decltype(K_)::value;
-                const float bv = hb[kg * 64];
+                if constexpr (kg + PF < KG) bq[(kg + PF) % (2 * PF)] = hb[(kg + PF) * 64];
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                const float bv = bq[kg % (2 * PF)];
                 static_for_l<MT>([&](auto M_) {
                     constexpr int mt = decltype(M_)::value;
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][kg], bv, acc[mt], 0, 0, 0);
                 });
+                __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
             });
         }
         const int t = rev ? a.T - 1 - step : step;
@@ -186,9 +197,26 @@ __global__ __launch_bounds__(256, 1) void lstm_persist4_kernel(const LstmPersist
         });
         if (step > 0) {
             const floatx4* hb = reinterpret_cast<const floatx4*>(&hs[cur][j * H]);     // B operand: h_{t-1}[k] of sequence j
+            // operand reads two 16 B groups ahead of the MFMAs (ring of 3), see lstm_persist_kernel.  At 490 of 512
+            // registers the compiler's scheduler will not hoist a read on its own: the reads and their waits are asm
+            // (the wait names the register it releases so that no consumer can move above it)
+            floatx4 bq[3];
+            const unsigned haddr = (unsigned)(size_t)hb;           // LDS byte address (low 32 bits of the flat pointer)
+#define P4_READ(Q, K4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Q) : "v"(haddr), "n"((K4) * 16) : "memory")
+#define P4_WAIT(Q, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q))
+            P4_READ(bq[0], 0);
+            P4_READ(bq[1], 1);
             static_for_l<H / 4>([&](auto K4_) {
                 constexpr int k4 = decltype(K4_)::value;
-                const floatx4 b = hb[k4];
+                if constexpr (k4 + 2 < H / 4) {
+                    P4_READ(bq[(k4 + 2) % 3], k4 + 2);
+                    P4_WAIT(bq[k4 % 3], 2);
+                } else if constexpr (k4 + 1 < H / 4) {
+                    P4_WAIT(bq[k4 % 3], 1);
+                } else {
+                    P4_WAIT(bq[k4 % 3], 0);
+                }
+                const floatx4 b = bq[k4 % 3];
                 static_for_l<RG>([&](auto R_) {
                     constexpr int rg = decltype(R_)::value;
                     acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 0], b[0], acc[rg], 0, 0, 0);
@@ -197,6 +225,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist4_kernel(const LstmPersist
                     acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 3], b[3], acc[rg], 0, 0, 0);
                 });
             });
+#undef P4_READ
+#undef P4_WAIT
         }
         const int t = rev ? a.T - 1 - step : step;
         float* op = out + (long)t * a.out_t;

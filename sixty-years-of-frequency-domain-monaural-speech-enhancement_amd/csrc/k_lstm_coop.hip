@@ -120,15 +120,34 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
                 }
                 __syncthreads();
                 if (!(a.dbg & 2)) {
-                    const floatx4* hb = reinterpret_cast<const floatx4*>(hs + l15 * LDW + l4 * KQ);
+                    // B operand reads run two 16 B groups ahead of the MFMAs that consume them (ring of 3).  The compiler's
+                    // own schedule parks an lgkmcnt(0) behind every ds_read_b128 (H/16 exposed LDS round trips per step) and
+                    // at ~500 registers it will not hoist them: reads and counted waits are asm, the wait names the
+                    // register it releases so that no consumer moves above it
+                    const unsigned haddr = (unsigned)(size_t)(hs + l15 * LDW + l4 * KQ);
+                    floatx4 bq[3];
+#define CO_READ(Q, J) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Q) : "v"(haddr), "n"((J) * 16) : "memory")
+#define CO_WAIT(Q, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q))
+                    CO_READ(bq[0], 0);
+                    CO_READ(bq[1], 1);
                     static_for_c<KQ / 4>([&](auto J_) {
                         constexpr int j = decltype(J_)::value;
-                        const floatx4 b = hb[j];
+                        if constexpr (j + 2 < KQ / 4) {
+                            CO_READ(bq[(j + 2) % 3], j + 2);
+                            CO_WAIT(bq[j % 3], 2);
+                        } else if constexpr (j + 1 < KQ / 4) {
+                            CO_WAIT(bq[j % 3], 1);
+                        } else {
+                            CO_WAIT(bq[j % 3], 0);
+                        }
+                        const floatx4 b = bq[j % 3];
                         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][0], b[0], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][1], b[1], acc1, 0, 0, 0);
                         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][2], b[2], acc2, 0, 0, 0);
                         acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][3], b[3], acc3, 0, 0, 0);
                     });
+#undef CO_READ
+#undef CO_WAIT
                 }
             }
             const floatx4 acc = (acc0 + acc1) + (acc2 + acc3);

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
     constexpr int KQ = H / 4;          // k values per MFMA k-slot (l4)
     constexpr int LDW = H + 4;         // LDS row stride: 16 lanes x 16 B land in 64 distinct banks
     constexpr int US = H / 16;         // unit slices per LSTM
-    extern __shared__ float hs[];      // [16][LDW]  h_{t-1} of the current 16 sequences
+    extern __shared__ float hs[];      // [2][16][LDW]  h_{t-1} of the current / the next 16 sequences
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -79,92 +79,115 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
     float gfirst[4], cfirst = 0.f;
     load_g(0, ss, gfirst);
 
+    // retire the weight loads here: left pending, the compiler re-waits for them inside the MFMA loop (vmcnt retires in
+    // order, so those waits would also drain the next tile's h loads that are meant to fly under the matrix work)
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
     for (int step = 0; step < a.T; ++step) {
         const int t = rev ? a.T - 1 - step : step;
         const float* hprev = hx + (long)(step & 1) * a.S * H;
         float* hnext = hx + (long)((step + 1) & 1) * a.S * H;
-        for (int nt = ss; nt < NT; nt += a.SS) {
-            const int n = nt * 16 + l15;
-            const bool col_ok = n < a.S;
-            float g[4];
-            if (nt == ss) {
+        // h_{t-1} of a tile's 16 sequences, [16][H] fp32, comes through agent-coherent (sc1) 8 B loads - they bypass this
+        // XCD's possibly stale L2 lines, so the exchange needs no cache invalidate (measured: ordinary cached loads from
+        // a one-slab-per-step tensor, which cannot go stale, are no faster - the exchange is not bandwidth bound).  The
+        // loads of the block's NEXT tile (and its gate pre-activations / cell state) are issued before the MFMAs of the
+        // current one and land in the other half of the double-buffered LDS tile: staging overlaps the matrix work and a
+        // tile costs one barrier.  Every step runs the same code (h_{-1} = 0 and c_{-1} = 0 are zero-filled buffers, not
+        // branches): a conditional VMEM issue makes the compiler's wait counts collapse to 0
+        constexpr int NLD = 16 * (H / 2) / 256;
+        unsigned long long v[NLD];
+        auto issue_h = [&](int nt_) {
+            if (a.dbg & 1) return;
+            static_for_c<NLD>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                // row is uniform per i (H / 512 loads of 256 x 8 B per row): scalar row base + one per-lane offset
+                constexpr int row = i / (H / 512), c2i = 256 * (i % (H / 512));
+                const int nn = min(nt_ * 16 + row, a.S - 1);
+                const unsigned long long* src =
+                    reinterpret_cast<const unsigned long long*>(hprev + (long)nn * H + 2 * c2i) + tid;
+                v[i] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
+        };
+        issue_h(ss);
+        float g[4], cprev = cfirst;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = gfirst[q];
-            } else {
-                load_g(step, nt, g);
+        for (int q = 0; q < 4; ++q) g[q] = gfirst[q];
+        // a tile's results go out one tile late (after the next tile's LDS publish): stores issued behind the prefetch
+        // would be the youngest VMEM ops when the next tile waits for its h loads, and vmcnt retires in order
+        float h_p = 0.f, c_p = 0.f;
+        int n_p = 0;
+        auto flush = [&](bool first) {
+            if (n_p < a.S) {
+                if (!first) cell[n_p] = c_p;
+                out[(long)t * a.out_t + n_p] = h_p;
+                __hip_atomic_store(hnext + (long)n_p * H + u, h_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // cell state: a register for the block's first tile (the only one unless S > 16 * SS), global scratch otherwise
-            const float cprev = step == 0 ? 0.f : (nt == ss ? cfirst : cell[min(n, a.S - 1)]);
+        };
+        int kbuf = 0;
+        for (int nt = ss; nt < NT; nt += a.SS, kbuf ^= 1) {
+            const int n = nt * 16 + l15;
             floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-            if (step > 0) {
-                // stage h_{t-1} of the tile's 16 sequences: [16][H] fp32 through agent-coherent (sc1) 8 B loads - they
-                // bypass this XCD's possibly stale L2 lines, so the exchange needs no cache invalidate; all in flight
-                constexpr int NLD = 16 * (H / 2) / 256;
-                unsigned long long v[NLD];
-                if (!(a.dbg & 1)) {
-                    static_for_c<NLD>([&](auto I_) {
-                        constexpr int i = decltype(I_)::value;
-                        const int e = tid + 256 * i, row = e / (H / 2), c2 = e % (H / 2);
-                        const int nn = min(nt * 16 + row, a.S - 1);
-                        v[i] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(hprev + (long)nn * H + 2 * c2),
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    });
-                }
-                if (nt != ss) __syncthreads();                     // previous tile's readers are done with hs
-                if (!(a.dbg & 1)) {
-                    static_for_c<NLD>([&](auto I_) {
-                        constexpr int i = decltype(I_)::value;
-                        const int e = tid + 256 * i, row = e / (H / 2), c2 = e % (H / 2);
-                        *reinterpret_cast<unsigned long long*>(hs + row * LDW + 2 * c2) = v[i];
-                    });
-                }
-                __syncthreads();
-                if (!(a.dbg & 2)) {
-                    // B operand reads run two 16 B groups ahead of the MFMAs that consume them (ring of 3).  The compiler's
-                    // own schedule parks an lgkmcnt(0) behind every ds_read_b128 (H/16 exposed LDS round trips per step) and
-                    // at ~500 registers it will not hoist them: reads and counted waits are asm, the wait names the
-                    // register it releases so that no consumer moves above it
-                    const unsigned haddr = (unsigned)(size_t)(hs + l15 * LDW + l4 * KQ);
-                    floatx4 bq[3];
+            float* hsb = hs + kbuf * (16 * LDW);
+            if (!(a.dbg & 1)) static_for_c<NLD>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                constexpr int row = i / (H / 512), c2i = 256 * (i % (H / 512));
+                reinterpret_cast<unsigned long long*>(hsb + row * LDW + 2 * c2i)[tid] = v[i];
+            });
+            // publishes hsb; the other half was last read two tiles ago, i.e. before the previous tile's barrier
+            __syncthreads();
+            if (nt != ss) flush(nt - a.SS == ss);
+            float gn[4] = {0.f, 0.f, 0.f, 0.f}, cnext = 0.f;
+            if (nt + a.SS < NT) {
+                load_g(step, nt + a.SS, gn);
+                cnext = cell[min(n + 16 * a.SS, a.S - 1)];
+                issue_h(nt + a.SS);
+            }
+            if (!(a.dbg & 2)) {
+                // B operand reads run two 16 B groups ahead of the MFMAs that consume them (ring of 3).  The compiler's
+                // own schedule parks an lgkmcnt(0) behind every ds_read_b128 (H/16 exposed LDS round trips per step) and
+                // at ~500 registers it will not hoist them: reads and counted waits are asm, the wait names the
+                // register it releases so that no consumer moves above it
+                const unsigned haddr = (unsigned)(size_t)(hsb + l15 * LDW + l4 * KQ);
+                floatx4 bq[3];
 #define CO_READ(Q, J) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Q) : "v"(haddr), "n"((J) * 16) : "memory")
 #define CO_WAIT(Q, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Q))
-                    CO_READ(bq[0], 0);
-                    CO_READ(bq[1], 1);
-                    static_for_c<KQ / 4>([&](auto J_) {
-                        constexpr int j = decltype(J_)::value;
-                        if constexpr (j + 2 < KQ / 4) {
-                            CO_READ(bq[(j + 2) % 3], j + 2);
-                            CO_WAIT(bq[j % 3], 2);
-                        } else if constexpr (j + 1 < KQ / 4) {
-                            CO_WAIT(bq[j % 3], 1);
-                        } else {
-                            CO_WAIT(bq[j % 3], 0);
-                        }
-                        const floatx4 b = bq[j % 3];
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][0], b[0], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][1], b[1], acc1, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][2], b[2], acc2, 0, 0, 0);
-                        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][3], b[3], acc3, 0, 0, 0);
-                    });
+                CO_READ(bq[0], 0);
+                CO_READ(bq[1], 1);
+                static_for_c<KQ / 4>([&](auto J_) {
+                    constexpr int j = decltype(J_)::value;
+                    if constexpr (j + 2 < KQ / 4) {
+                        CO_READ(bq[(j + 2) % 3], j + 2);
+                        CO_WAIT(bq[j % 3], 2);
+                    } else if constexpr (j + 1 < KQ / 4) {
+                        CO_WAIT(bq[j % 3], 1);
+                    } else {
+                        CO_WAIT(bq[j % 3], 0);
+                    }
+                    const floatx4 b = bq[j % 3];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][0], b[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][1], b[1], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][2], b[2], acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][3], b[3], acc3, 0, 0, 0);
+                });
 #undef CO_READ
 #undef CO_WAIT
-                }
             }
             const floatx4 acc = (acc0 + acc1) + (acc2 + acc3);
             const float cn = sigm(acc[1] + g[1]) * cprev + sigm(acc[0] + g[0]) * tanhf_fast(acc[2] + g[2]);
             const float h = sigm(acc[3] + g[3]) * tanhf_fast(cn);
             if (nt == ss) cfirst = cn;
-            else if (col_ok) cell[n] = cn;
-            if (col_ok) {
-                out[(long)t * a.out_t + n] = h;
-                __hip_atomic_store(hnext + (long)n * H + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            h_p = h; c_p = cn; n_p = n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = gn[q];
+            cprev = cnext;
         }
+        flush(NT - ss <= a.SS);                 // the step's last tile (it is also the first when the block owns one)
         if (step + 1 < a.T) {
             // unit slices of this (z, sequence slice) exchange h_t: release our writes, wait for the others'
+            // h_t went out as agent-coherent (sc1) write-through stores: each wave waits for the acknowledgement of its
+            // own stores (vmcnt(0) - a workgroup-scope barrier alone does not wait for global stores), the workgroup
+            // barrier collects the four waves, and a relaxed arrival is then enough: no L2 write-back / invalidate per step
+            if (!(a.dbg & 8)) __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();                                       // (also: every wave is done reading hs)
-            // h_t went out as agent-coherent (sc1) stores and the workgroup barrier above waited for their completion,
-            // so a relaxed arrival is enough: no L2 write-back / invalidate per step
             if (tid == 0 && !(a.dbg & 4))
                 __hip_atomic_store(flags + us, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             load_g(step + 1, ss, gfirst);
@@ -193,16 +216,19 @@ void launch_t(LstmCoopArgs a, int n_cu, hipStream_t s) {
     a.SS = std::max(1, std::min(NT, n_cu / (US * a.Z)));
     static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
     a.dbg = dbg;
-    // exchange tensor hx [Z][2][S][H] + 64 arrival flags per (z, sequence slice)
-    const size_t hx_bytes = (size_t)a.Z * 2 * a.S * H * sizeof(float);
+    // 64 arrival flags per (z, sequence slice) + exchange tensor hx [Z][2][S][H]
     constexpr size_t NFLAG = 256 * 64;        // (z, sequence slice) groups x 64 unit-slice words
-    char* sc = coop_scratch(hx_bytes + NFLAG * sizeof(unsigned), s);
-    a.hx = reinterpret_cast<float*>(sc);
-    a.bar = reinterpret_cast<unsigned*>(sc + hx_bytes);
+    const size_t slab = (size_t)a.S * H, hx_bytes = (size_t)a.Z * 2 * slab * sizeof(float);
+    char* sc = coop_scratch(NFLAG * sizeof(unsigned) + hx_bytes, s);
+    a.bar = reinterpret_cast<unsigned*>(sc);
+    a.hx = reinterpret_cast<float*>(sc + NFLAG * sizeof(unsigned));
     // zeroed by a kernel, not a memset node: under hipGraph replay the memset was observed not to be ordered before the
     // cooperative kernel (stale arrival counts let every barrier fall through)
     launch_fill(reinterpret_cast<float*>(a.bar), (long)a.Z * a.SS * 64, 0.f, s);
-    const size_t shmem = (size_t)16 * (H + 4) * sizeof(float);
+    // h_{-1} = 0 and c_{-1} = 0 are data, not branches in the kernel
+    launch_fill(a.hx, (long)a.Z * 2 * slab, 0.f, s);
+    launch_fill(a.cell, (long)a.Z * H * a.S, 0.f, s);
+    const size_t shmem = (size_t)2 * 16 * (H + 4) * sizeof(float);
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {
         SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop_kernel<H>),

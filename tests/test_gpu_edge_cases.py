@@ -111,3 +111,25 @@ def test_graph_replay_is_actually_captured():
     assert r.returncode == 0, r.stderr[-2000:]
     assert 'finite True' in r.stdout
     assert 'se_graph: captured' in r.stderr and 'se_graph: capture failed' not in r.stderr, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('name', ['lstm', 'gcrn'])
+def test_recurrent_exchange_never_serves_a_previous_launch(name):
+    """k_lstm_coop.hip reads h_{t-1} of the other workgroups through ordinary cached loads from a one-slab-per-step
+    exchange tensor that is reused by the next launch: alternating two different batches must reproduce each batch's
+    output bit for bit (a line left in an XCD's L2 by the previous launch would show up here), at more than one
+    16-sequence tile per workgroup (B = 80 > 16 x 4 sequence slices)."""
+    import torch
+    from se_amd.models import MODEL_CLASSES
+    B, L = 80, 16000
+    m = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(5)
+    xa = torch.from_numpy(np.stack([synth.synth_clip(300 + b, 'speech', L) for b in range(B)])).cuda()
+    xb = torch.from_numpy(np.stack([synth.synth_clip(700 + b, 'white', L) for b in range(B)])).cuda()
+    ya = m.enhance_batch(xa).clone()
+    yb = m.enhance_batch(xb).clone()
+    for _ in range(3):
+        assert torch.equal(m.enhance_batch(xa), ya)
+        assert torch.equal(m.enhance_batch(xb), yb)
+    # and the first 16 sequences alone (one tile, another slicing of the chip) give the same waveforms
+    y16 = MODEL_CLASSES[name](max_batch=16, max_samples=L).load_synthetic(5).enhance_batch(xa[:16])
+    assert rms((y16 - ya[:16]).cpu().numpy()) < 1e-6

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
         constexpr int NLD = 16 * (H / 2) / 256;
         unsigned long long v[NLD];
         auto issue_h = [&](int nt_) {
-            if (a.dbg & 1) return;
             static_for_c<NLD>([&](auto I_) {
                 constexpr int i = decltype(I_)::value;
                 // row is uniform per i (H / 512 loads of 256 x 8 B per row): scalar row base + one per-lane offset
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
             const int n = nt * 16 + l15;
             floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
             float* hsb = hs + kbuf * (16 * LDW);
-            if (!(a.dbg & 1)) static_for_c<NLD>([&](auto I_) {
+            static_for_c<NLD>([&](auto I_) {
                 constexpr int i = decltype(I_)::value;
                 constexpr int row = i / (H / 512), c2i = 256 * (i % (H / 512));
                 reinterpret_cast<unsigned long long*>(hsb + row * LDW + 2 * c2i)[tid] = v[i];
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
                 cnext = cell[min(n + 16 * a.SS, a.S - 1)];
                 issue_h(nt + a.SS);
             }
-            if (!(a.dbg & 2)) {
+            {
                 // B operand reads run two 16 B groups ahead of the MFMAs that consume them (ring of 3).  The compiler's
                 // own schedule parks an lgkmcnt(0) behind every ds_read_b128 (H/16 exposed LDS round trips per step) and
                 // at ~500 registers it will not hoist them: reads and counted waits are asm, the wait names the

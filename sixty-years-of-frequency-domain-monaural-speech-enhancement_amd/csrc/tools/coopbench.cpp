@@ -1,5 +1,5 @@
 // Micro-benchmark of the cooperative LSTM recurrence (tuning tool, not product path).
-//   coopbench <H> <S> [T=401] [Z=1]        SE_COOP_DBG bits: 1 = no h staging, 2 = no MFMA, 4 = no exchange barrier
+//   coopbench <H> <S> [T=401] [Z=1]        SE_COOP_DBG bits: 4 = no exchange barrier (wrong results), 8 = no store-acknowledge wait
 #include "../kernels.h"
 #include "../common.h"
 #include <cstdio>

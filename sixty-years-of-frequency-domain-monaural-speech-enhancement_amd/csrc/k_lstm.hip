@@ -39,7 +39,14 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    // XCD-aware order (see lstm_persist4_kernel): the two blocks that share a 128 B line of every gate row meet in one L2
+    int lid;
+    {
+        const int nblk = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3, q8 = nblk >> 3, r8 = nblk & 7;
+        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int n0 = lid * 16;
     const int z = blockIdx.y % a.Z, o = blockIdx.y / a.Z;
     const int n = n0 + l15;
     const bool rev = (a.reverse >> z) & 1;
@@ -147,7 +154,16 @@ __global__ __launch_bounds__(256, 1) void lstm_persist4_kernel(const LstmPersist
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = lane >> 2, j = lane & 3;                  // MFMA block (unit) and column (sequence) of this lane
-    const int n0 = blockIdx.x * 4;
+    // XCD-aware order (block id i runs on XCD i % 8): the 4 sequences of a block are 16 B of every gate-row line, so the
+    // blocks that share those lines are made neighbours inside one XCD's L2 (round robin put them on 4-8 different
+    // XCDs and the L2 <-> fabric counters showed the gate pre-activations fetched 4x)
+    int lid;
+    {
+        const int nblk = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3, q8 = nblk >> 3, r8 = nblk & 7;
+        lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int n0 = lid * 4;
     const int z = blockIdx.y % a.Z, o = blockIdx.y / a.Z;
     const int n = n0 + j;
     const bool rev = (a.reverse >> z) & 1;

@@ -1,0 +1,59 @@
+"""GPU: BASELINE.json's full-size configurations (configs[1]: CRN, 64 x 4 s clips; configs[2]: DCCRN compressed,
+256 x 4 s clips per GPU; configs[3] / [4]: FullSubNet / Uformer shards of 4 s clips) checked through size-independent properties of the decode path, plus the numpy oracle on one
+row of the big batch (the oracle needs seconds per 4 s clip, so it cannot cover the batch).
+
+Properties (each follows from the reference loop, e.g. DCCRN/dccrn_decode_vb.py:25-62):
+  * utterances are independent: row k of a big batch == the same clip decoded in a batch of 2, and a permuted batch
+    gives the permuted output bit for bit;
+  * the loop normalises by c = sqrt(L / sum x^2) and divides by c at the end, so the path is homogeneous of degree 1;
+    for a power-of-two gain the normalised input is bit-identical and the output must scale exactly."""
+import numpy as np
+import pytest
+
+import se_amd  # noqa: F401
+from se_amd import synth
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+L = 64000
+
+
+def _batch(B, seed0):
+    base = synth.synth_batch(16, 'speech', L, seed0=seed0)
+    return np.tile(base, ((B + 15) // 16, 1))[:B].copy()
+
+
+@pytest.mark.parametrize('name,B,kw,oracle', [('dccrn', 256, dict(p_in=0.5, p_out=2.0), True), ('crn', 64, {}, True),
+                                              ('fullsubnet', 32, {}, False), ('uformer', 32, {}, False)])
+def test_full_size_properties(name, B, kw, oracle):
+    import torch
+    from se_amd.models import MODEL_CLASSES
+    from oracle import decode as D
+    x = _batch(B, 500)
+    x[1::16] *= 0.37                                   # rows of one 16-clip period differ in level as well
+    big = MODEL_CLASSES[name](max_batch=B, max_samples=L, **kw).load_synthetic(14)
+    xt = torch.from_numpy(x).cuda()
+    y = big.enhance_batch(xt).clone()
+    assert bool(torch.isfinite(y).all())
+    # (1) independence: rows of the big batch == the same clips in a batch of 2 (another tiling of the chip)
+    small = MODEL_CLASSES[name](max_batch=2, max_samples=L, **kw).load_synthetic(14)
+    for k in (0, B // 2 + 1, B - 2):
+        ys = small.enhance_batch(xt[k:k + 2])
+        for j in (0, 1):
+            ref = ys[j].cpu().numpy()
+            assert rms(y[k + j].cpu().numpy() - ref) < 1e-5 * max(rms(ref), 1e-4), (name, k + j)
+    # (2) permutation of the batch permutes the output, bit for bit
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(B)).cuda()
+    assert torch.equal(big.enhance_batch(xt[perm].contiguous()), y[perm])
+    # (3) degree-1 homogeneity: exact for a power-of-two gain, to rounding for any other
+    assert torch.equal(big.enhance_batch(xt * 4.0), y * 4.0)
+    y3 = big.enhance_batch(xt * 3.0)
+    assert rms((y3 - 3.0 * y).cpu().numpy()) < 1e-5 * rms(y.cpu().numpy())
+    if not oracle:          # configs[3] / configs[4] (per-GPU shard of 32 clips): properties only, their oracle decodes
+        return              # are pinned at fixture sizes in test_gpu_models.py / test_gpu_uformer.py
+    # (4) one row of the full-size batch against the numpy oracle (bar of the north star: 1e-4 RMS)
+    sd = synth.synth_state_dict(small.state_dict_schema(), 14)
+    fn = D.enhance_dccrn if name == 'dccrn' else D.enhance_crn
+    ref = fn(sd, x[5].astype(np.float64), *((kw['p_in'], kw['p_out']) if kw else ()))
+    got = y[5].cpu().numpy()
+    assert len(ref) == len(got) and rms(got - ref) < 1e-4

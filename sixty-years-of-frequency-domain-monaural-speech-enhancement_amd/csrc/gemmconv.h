@@ -96,7 +96,7 @@ struct GCPlan {
     float* dWs = nullptr;
     unsigned* dDesc = nullptr;
     unsigned* dDesc4 = nullptr;
-    GCTail tail[2];          // 32- and 64-column geometries for a mostly empty last time tile
+    GCTail tail[2];          // [0]: 32-column geometry for a mostly empty last time tile; [1]: 64-column geometry of the whole layer for small launches
     float* dBias = nullptr;
     float* dSlope = nullptr;
     int* dTab = nullptr;

@@ -725,6 +725,13 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
                 pl.tail[i].g = gc_build_geom(taps, rows, dtmin, p.nrows, pl.tail[i].Wp, cic, p.KC, gc_bld_max(pl.BM));
             }
         }
+        // 64-column geometry of the whole layer (tail[1]) for launches that would not fill the chip with 128-column
+        // tiles: the batch is only known at launch time, gc_launch picks
+        if (pl.BN == 128 && (pl.BM == 64 || pl.BM == 128) && epi != EPI_LSTM) {
+            pl.tail[1].BN = 64;
+            pl.tail[1].Wp = 64 + (dtmax - dtmin);
+            pl.tail[1].g = gc_build_geom(taps, rows, dtmin, p.nrows, pl.tail[1].Wp, cic, p.KC, gc_bld_max(pl.BM));
+        }
     }
     const int nch0 = (C0 + cic - 1) / cic, nch1 = (Cin - C0 + cic - 1) / cic;
     p.nchunks = nch0 + nch1;
@@ -889,12 +896,31 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
         else gc_small_launch<4>(p, stream);
         return;
     }
+    // small launches: 64-column tiles double the workgroup count (and waste less of the last time tile: T = 401 is
+    // 6.3 x 64).  Measured on the TCM models: 64-row layers gain up to ~1 500 workgroups of 128 columns (G2Net + 7 % at
+    // B = 64, + 4 % at B = 256, + 16 % at B = 8; DCCRN's big grids lose 1 %), 128-row layers only below one workgroup
+    // per CU (B = 8: + 15 %; B = 64: - 3 %)
+    {
+        static const int alt_env = getenv("SE_GC_ALT") ? atoi(getenv("SE_GC_ALT")) : 1;
+        const GCTail& alt = pl.tail[1];
+        const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
+        if (alt_env && alt.BN == 64 && nblk < (pl.BM == 64 ? 1536 : 256)) {
+            GCParams pa = p;
+            pa.t_base = 0;
+            pa.n_ttiles = (p.Tout + 63) / 64;
+            pa.Wp = alt.Wp;
+            pa.tab = alt.g.tab;
+            pa.desc = alt.g.desc;
+            pa.desc4 = alt.g.desc4;
+            if (pl.BM == 64) gc_launch_t<64, 64, 2, 2>(pa, stream);
+            else gc_launch_t<128, 64, 4, 1>(pa, stream);
+            return;
+        }
+    }
     // the last time tile of a row, when it is at most half full, goes to a narrower kernel (own launch, same weights)
     const int full = p.Tout / pl.BN, rem = p.Tout - full * pl.BN;
     const GCTail* tl = nullptr;
-    if (full >= 1 && rem > 0)
-        for (const auto& t : pl.tail)
-            if (!tl && t.BN && rem <= t.BN) tl = &t;
+    if (full >= 1 && rem > 0 && pl.tail[0].BN && rem <= pl.tail[0].BN) tl = &pl.tail[0];
     if (tl) {
         GCParams pt = p;
         pt.t_base = full * pl.BN;

@@ -96,6 +96,7 @@ struct GCPlan {
     float* dWs = nullptr;
     unsigned* dDesc = nullptr;
     unsigned* dDesc4 = nullptr;
+    bool tail_split = false; // tail[0] may be used as a separate launch for the last time tile
     GCTail tail[2];          // [0]: 32-column geometry for a mostly empty last time tile; [1]: 64-column geometry of the whole layer for small launches
     float* dBias = nullptr;
     float* dSlope = nullptr;

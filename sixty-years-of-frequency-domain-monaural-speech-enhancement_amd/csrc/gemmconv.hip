@@ -717,7 +717,10 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
         static const int tail_env = getenv("SE_GC_TAIL") ? atoi(getenv("SE_GC_TAIL")) : 1;
         // (only where the narrow kernel keeps all four waves busy: 128 rows x 32 columns; a 64-row layer would leave half
         // its waves on padding again - measured slower than the skip logic of the full-width tile)
-        if (tail_env && pl.BN == 128 && pl.BM == 128 && !(taps.ntaps == 1 && pw_chunks)) {
+        // (pointwise layers get the geometry for tiny launches only: as a separate tail launch it doubled the launch count
+        // of FullSubNet's per-step LSTM GEMMs)
+        pl.tail_split = !(taps.ntaps == 1 && pw_chunks);
+        if (tail_env && pl.BN == 128 && pl.BM == 128) {
             for (int i = 0; i < 1; ++i) {
                 const int bn = 32;
                 pl.tail[i].BN = bn;
@@ -912,6 +915,17 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
             pa.tab = alt.g.tab;
             pa.desc = alt.g.desc;
             pa.desc4 = alt.g.desc4;
+            static const int alt32_env = getenv("SE_GC_ALT32") ? atoi(getenv("SE_GC_ALT32")) : 512;
+            const long nblk64 = (long)p.Z * p.B * p.Q * pa.n_ttiles * p.n_mtiles;
+            if (pl.BM == 128 && pl.tail[0].BN == 32 && nblk64 < alt32_env) {       // tiny launches: 32 columns
+                pa.n_ttiles = (p.Tout + 31) / 32;
+                pa.Wp = pl.tail[0].Wp;
+                pa.tab = pl.tail[0].g.tab;
+                pa.desc = pl.tail[0].g.desc;
+                pa.desc4 = pl.tail[0].g.desc4;
+                gc_launch_t<128, 32, 4, 1>(pa, stream);
+                return;
+            }
             if (pl.BM == 64) gc_launch_t<64, 64, 2, 2>(pa, stream);
             else gc_launch_t<128, 64, 4, 1>(pa, stream);
             return;
@@ -920,7 +934,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     // the last time tile of a row, when it is at most half full, goes to a narrower kernel (own launch, same weights)
     const int full = p.Tout / pl.BN, rem = p.Tout - full * pl.BN;
     const GCTail* tl = nullptr;
-    if (full >= 1 && rem > 0 && pl.tail[0].BN && rem <= pl.tail[0].BN) tl = &pl.tail[0];
+    if (pl.tail_split && full >= 1 && rem > 0 && pl.tail[0].BN && rem <= pl.tail[0].BN) tl = &pl.tail[0];
     if (tl) {
         GCParams pt = p;
         pt.t_base = full * pl.BN;

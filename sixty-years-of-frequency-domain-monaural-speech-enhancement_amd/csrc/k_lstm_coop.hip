@@ -9,11 +9,13 @@
 // MI355X mapping: a workgroup owns 16 hidden units (64 gate rows); wave w keeps the 16 rows of its 4 units as
 // v_mfma_f32_16x16x4_f32 A-fragments in H/4 VGPRs for the whole utterance.  H/16 workgroups ("unit slices") cover
 // one LSTM; the remaining CUs are filled by slicing the sequences (SS "sequence slices", weights replicated).  Per
-// step a workgroup stages h_{t-1} of 16 sequences ([16][H], coalesced 16 B loads) into LDS, every wave multiplies
-// its rows against it, the cell update is lane-local (gate-interleaved rows) and h_t is published to a
-// double-buffered exchange tensor hx[2][S][H]; unit slices of the same sequence slice then meet at a release /
-// acquire counter barrier in global memory (cross-XCD: agent-scope fences).  The K order is permuted
-// (k = l4*H/4 + kg) identically on both operands so that a lane's B values are contiguous (ds_read_b128).
+// step and 16-sequence tile a workgroup stages h_{t-1} ([16][H], coalesced 8 B agent-scope loads) into LDS, every
+// wave multiplies its rows against it, the cell update is lane-local (gate-interleaved rows) and h_t is published with
+// agent-scope write-through stores to a double-buffered exchange tensor hx[2][S][H]; unit slices of the same
+// sequence slice then meet at a flag barrier in global memory (one relaxed agent-scope flag word per producer, written
+// after the producer's stores have been acknowledged; no cache write-back / invalidate per step).  The K order is
+// permuted (k = l4*H/4 + kg) identically on both operands so that a lane's B values are contiguous (ds_read_b128).
+// DESIGN.md 3.2 has the measurements and the protocols that were tried and dropped.
 #include "kernels.h"
 #include "common.h"
 #include <type_traits>

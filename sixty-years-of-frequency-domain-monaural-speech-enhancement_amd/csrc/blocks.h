@@ -31,6 +31,38 @@ inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int 
         launch_instnorm_prelu(x, y, n.g, n.b, n.s, B, C, F * T, st, res);
     }
 }
+// conv / deconv -> InstanceNorm -> PReLU (+ res): the conv's epilogue hands the norm its statistics as per-tile partial
+// sums, so the norm pass reads the plane once instead of twice (SE_IN_STATS=0: separate statistics pass).  Falls back to
+// the two-kernel sequence for the cumulative-LayerNorm variants and for tile configurations without the epilogue.
+inline bool in_stats_enabled() {
+    static const bool on = !(getenv("SE_IN_STATS") && atoi(getenv("SE_IN_STATS")) == 0);
+    return on;
+}
+inline float* in_stats_scratch(int B, int C, int F, int T, hipStream_t st) {
+    return reinterpret_cast<float*>(device_scratch(2, (size_t)B * C * F * ((T + 31) / 32) * 2 * sizeof(float), st));
+}
+inline void conv_norm2d_prelu(const GCPlan& pl, const NormAct& n, const Act4& s0, const Act4* s1, float* y, float* out, int C,
+                              int Fout, int B, int T, hipStream_t st, Profiler* pf, const float* res = nullptr) {
+    if (!n.cum && in_stats_enabled() && conv_stats_supported(pl)) {
+        float* stats = in_stats_scratch(B, C, Fout, T, st);
+        run_conv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
+        launch_instnorm_prelu_stats(y, out, n.g, n.b, n.s, stats, Fout * ((T + 31) / 32), B, C, Fout * T, st, res);
+        return;
+    }
+    run_conv(pl, s0, s1, y, C, Fout, B, T, T, st, pf);
+    norm2d_prelu(n, y, out, B, C, Fout, T, st, res);
+}
+inline void deconv_norm2d_prelu(const DeconvPlan& pl, const NormAct& n, const Act4& s0, const Act4* s1, float* y, float* out,
+                                int C, int Fout, int B, int T, hipStream_t st, Profiler* pf, const float* res = nullptr) {
+    if (!n.cum && in_stats_enabled() && deconv_stats_supported(pl)) {
+        float* stats = in_stats_scratch(B, C, Fout, T, st);
+        run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
+        launch_instnorm_prelu_stats(y, out, n.g, n.b, n.s, stats, Fout * ((T + 31) / 32), B, C, Fout * T, st, res);
+        return;
+    }
+    run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf);
+    norm2d_prelu(n, y, out, B, C, Fout, T, st, res);
+}
 // PReLU -> norm -> shared FIR on x [B][C][T]
 inline void tcm_head(const NormAct& n, const float* fir, int K, const float* x, float* y, int B, int C, int T, hipStream_t st) {
     if (n.cum) launch_cln(x, y, n.g, n.b, n.s, nullptr, fir, K, B, C, 1, T, st);

@@ -73,7 +73,11 @@ struct GCParams {
     int pw4;                 // per launch: 1 -> stage the patch in 16 B groups
     int causal;              // no tap looks ahead in time (dt <= 0 for every tap)
     const unsigned* desc;    // host-built patch-slot descriptors [NB][256]: w | r << 12 | cil << 16 | staged << 31
-    const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]
+    const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]    // optional (EPI_ACT on 64-row tiles, EPI_GLU): per (b, output channel, output frequency row, group of 32 frames)
+    // partial (sum, sum of squares) of the values this launch stores - [B][Mo][Fstat][ceil(Tout / 32)][2] floats - so that
+    // the InstanceNorm that follows does not have to read the plane for its statistics (blocks.h: conv_norm2d_prelu)
+    float* stats;
+    long st_b, st_c, st_f;   // float strides of the statistics tensor
 };
 
 // Device tables of one patch geometry (owned by the plan)
@@ -124,6 +128,8 @@ void gc_register_overread_range(const void* lo, size_t bytes);
 void gc_unregister_overread_range(const void* lo);
 
 // Launch: p must have src/dst pointers, strides, B/Q/Tout/Fin/Tin/C0/C1 filled in.
+// true when launches of this plan can emit the per-tile statistics of GCParams::stats
+bool gc_stats_supported(const GCPlan& pl);
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream);
 
 }  // namespace se

@@ -108,6 +108,14 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 #define GC_T(SLOT)
 #endif
 
+// sum over the 8 lanes that share (lane >> 3): quad swaps, then the mirrored half row; every lane ends with the total
+__device__ __forceinline__ float dpp_add8(float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    return x;
+}
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {
 #ifdef GC_TIMING
@@ -398,6 +406,9 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     // barrier has retired every reader) and are private to a wave: DS operations of one wave execute in order, so the
     // write -> read-back hand-over needs a wave-level fence only, no block barrier.
     constexpr int OROWS = (EPI == EPI_GLU) ? TM * 16 : TM * 32;   // output rows of one wave's strip
+    // statistics epilogue only where an InstanceNorm can follow (64-channel layers): not in the 128-row EPI_ACT tile, whose
+    // register budget (3 workgroups per CU) is the tightest and which carries the DCCRN bench
+    constexpr bool GC_STATS = (EPI == EPI_GLU) || (EPI == EPI_ACT && BM == 64);
     constexpr int OST = 32 + 4;                                    // LDS row stride of the strip (one 32-column MFMA tile wide)
     float* strip = smem + wave * (TM * 32 * OST);
 #define GC_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -442,6 +453,27 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             for (int it = 0; it < OROWS / 8; ++it) {
                 const int row = it * 8 + lr, m = mo0 + row;
                 floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * OST + lc);
+                if constexpr (GC_STATS) {
+                    // statistics of the stored values for the InstanceNorm behind this layer: the 8 lanes that hold one
+                    // row of the 32-column sub-tile add up their 4 frames each (frames >= Tout masked), fixed order
+                    if (p.stats) {
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float xk = (tg + k < p.Tout) ? v[k] : 0.f;
+                            s += xk;
+                            q = fmaf(xk, xk, q);
+                        }
+                        s = dpp_add8(s);
+                        q = dpp_add8(q);
+                        const int tb = tg - lc;                  // first frame of the sub-tile
+                        if ((lane & 7) == 0 && m < Mo && tb < p.Tout) {
+                            float* sp = p.stats + (long)b * p.st_b + (long)m * p.st_c + (long)fo * p.st_f + (tb >> 5) * 2;
+                            sp[0] = s;
+                            sp[1] = q;
+                        }
+                    }
+                }
                 if (m < Mo) {
                     float* __restrict__ dp = dst + (long)m * p.d_c + tg;
                     if (tg + 3 < p.Tout) {
@@ -878,6 +910,10 @@ static void gc_launch_t(const GCParams& p, hipStream_t stream) {
     }
 }
 
+bool gc_stats_supported(const GCPlan& pl) {
+    return !pl.p.Ws && (pl.p.epi == EPI_GLU || (pl.p.epi == EPI_ACT && pl.BM == 64));
+}
+
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     p.n_ttiles = (p.Tout + pl.BN - 1) / pl.BN;
     static const int dbg_env = getenv("SE_GC_DBG") ? atoi(getenv("SE_GC_DBG")) : 0;
@@ -891,6 +927,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     // 16 B staging groups: exact when no group straddles the end of a row (Tin % 4 == 0); for causal tap sets a straddling
     // group only feeds output frames >= Tin, which are never stored - then it merely has to stay inside mapped memory
     p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || (p.causal && gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
+    SE_CHECK(!p.stats || gc_stats_supported(pl), "gc_launch: this tile configuration has no statistics epilogue");
     SE_CHECK(p.pw4 || p.CI_C * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256,
              "pointwise layer with a row length that is not a multiple of 4 needs its sources inside the engine arena");
     if (p.Ws) {

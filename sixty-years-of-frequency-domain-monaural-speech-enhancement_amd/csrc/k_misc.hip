@@ -247,6 +247,41 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
         yp[i] = rp ? o + rp[i] : o;
     }
 }
+// the same with the statistics handed over by the producing conv's epilogue (GCParams::stats): nslot (sum, sum of squares)
+// pairs per (b, c) plane, combined in fp64 in a fixed order; the plane itself is read once
+__global__ __launch_bounds__(256) void instnorm_prelu_stats_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   const float* __restrict__ slope, const float* res,
+                                                                   const float* __restrict__ stats, int nslot, int C, int P) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x % C;
+    const float* xp = x + (long)blockIdx.x * P;
+    float* yp = y + (long)blockIdx.x * P;
+    const float* rp = res ? res + (long)blockIdx.x * P : nullptr;
+    const float2* sp = reinterpret_cast<const float2*>(stats) + (long)blockIdx.x * nslot;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nslot; i += 256) {
+        const float2 v = sp[i];
+        s += v.x;
+        q += v.y;
+    }
+    const double mu = block_sum_d(s, sh) / P;
+    const double var = fmax(block_sum_d(q, sh) / P - mu * mu, 0.0);
+    const float rs = (float)(1.0 / sqrt(var + 1e-5)), muf = (float)mu;
+    const float g = gamma[c], bt = beta[c], sl = slope ? slope[c] : 1.f;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        float o = (xp[i] - muf) * rs * g + bt;
+        o = o >= 0.f ? o : sl * o;
+        yp[i] = rp ? o + rp[i] : o;
+    }
+}
+void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, const float* beta, const float* slope,
+                                 const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res) {
+    hipLaunchKernelGGL(instnorm_prelu_stats_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, res, stats, nslot,
+                       C, P);
+    SE_HIP(hipGetLastError());
+}
 void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
                            int C, int P, hipStream_t s, const float* res) {
     hipLaunchKernelGGL(instnorm_prelu_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, res, C, P);

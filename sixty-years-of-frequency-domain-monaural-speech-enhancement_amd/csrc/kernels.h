@@ -48,6 +48,9 @@ void launch_fill(float* p, long n, float v, hipStream_t s);
 //   res (optional, [B][C][P], may alias y): y = PReLU(norm(x)) + res
 void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
                            int C, int P, hipStream_t s, const float* res = nullptr);
+// statistics from the producing conv (nslot (sum, sum of squares) pairs per (b, c) plane, GCParams::stats)
+void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, const float* beta, const float* slope,
+                                 const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res = nullptr);
 
 // TCM branch head (CTSNet/Step1_network.py:161-176): y = ShareSepConv( InstanceNorm1d( PReLU(x) ) ) per (b, c) row of
 // T frames; fir [K] is the single FIR shared by all channels (causal, left pad K-1), K = 0 -> no FIR.

@@ -75,10 +75,13 @@ struct Act4 {          // a view of an activation tensor
 inline Act4 act4(const float* p, int C, int F, int Tp) { return Act4{p, C, F, (long)C * F * Tp, (long)F * Tp, (long)Tp}; }
 
 struct Profiler;
+// stats (optional): [B][dstC][Fout][ceil(T / 32)][2] partial sums of the stored output (GCParams::stats)
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof = nullptr);
+              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr);
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
-                int Tp, hipStream_t st, Profiler* prof = nullptr);
+                int Tp, hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr);
+bool conv_stats_supported(const GCPlan& pl);
+bool deconv_stats_supported(const DeconvPlan& pl);
 
 // HIP-event timing of the dominant kernel family (gemmconv launches) on the launch stream.
 struct Profiler {

@@ -337,9 +337,24 @@ static void fill_src(GCParams& p, const Act4& s0, const Act4* s1) {
     }
 }
 
+static void set_stats(GCParams& p, float* stats, int dstC, int Fout, int T) {
+    const long ns = (T + 31) / 32;
+    p.stats = stats;
+    p.st_f = ns * 2;
+    p.st_c = (long)Fout * p.st_f;
+    p.st_b = (long)dstC * p.st_c;
+}
+bool conv_stats_supported(const GCPlan& pl) { return gc_stats_supported(pl); }
+bool deconv_stats_supported(const DeconvPlan& pl) {
+    for (const auto& g : pl.par)
+        if (!gc_stats_supported(g)) return false;
+    return true;
+}
+
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof) {
+              hipStream_t st, Profiler* prof, float* stats) {
     GCParams p = pl.p;
+    if (stats) set_stats(p, stats, dstC, Fout, T);
     fill_src(p, s0, s1);
     p.Fin = s0.F;
     p.Tin = T;
@@ -354,9 +369,10 @@ void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int 
 }
 
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
-                int Tp, hipStream_t st, Profiler* prof) {
+                int Tp, hipStream_t st, Profiler* prof, float* stats) {
     for (const auto& g : pl.par) {
         GCParams p = g.p;
+        if (stats) set_stats(p, stats, dstC, Fout, T);
         fill_src(p, s0, s1);
         p.Fin = s0.F;
         p.Tin = T;

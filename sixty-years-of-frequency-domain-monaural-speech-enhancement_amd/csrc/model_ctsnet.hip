@@ -37,8 +37,7 @@ struct GatedEncoder {
     void run(const Act4& in0, const Act4* in1, float* const E[5], int B, int T, hipStream_t st, Profiler* pf) const {
         Act4 x = in0;
         for (int i = 0; i < 5; ++i) {
-            run_conv(conv[i], x, i == 0 ? in1 : nullptr, E[i], 64, EF[i], B, T, T, st, pf);
-            norm2d_prelu(na[i], E[i], E[i], B, 64, EF[i], T, st);
+            conv_norm2d_prelu(conv[i], na[i], x, i == 0 ? in1 : nullptr, E[i], E[i], 64, EF[i], B, T, st, pf);
             x = act4(E[i], 64, EF[i], T);
         }
     }
@@ -72,8 +71,7 @@ struct GatedDecoder {
         for (int i = 0; i < 5; ++i) {
             const int co = i == 4 ? 1 : 64;
             Act4 a1 = act4(E[4 - i], 64, a0.F, T);
-            run_deconv(dc[i], a0, &a1, D[i], co, DF[i], B, T, T, st, pf);
-            norm2d_prelu(na[i], D[i], D[i], B, co, DF[i], T, st);
+            deconv_norm2d_prelu(dc[i], na[i], a0, &a1, D[i], D[i], co, DF[i], B, T, st, pf);
             a0 = act4(D[i], co, DF[i], T);
         }
         GCParams p = fc.p;    // Linear(161,161) over F

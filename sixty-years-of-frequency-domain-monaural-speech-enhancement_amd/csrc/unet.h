@@ -142,11 +142,9 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
              Profiler* pf) const {
         const int F0 = out_F(in0.F);
         if (de) {
-            run_deconv(in_d.plan, in0, in1, out, 64, F0, B, T, T, st, pf);
-            norm2d_prelu(in_d.na, out, out, B, 64, F0, T, st);
+            deconv_norm2d_prelu(in_d.plan, in_d.na, in0, in1, out, out, 64, F0, B, T, st, pf);
         } else {
-            run_conv(in_c.plan, in0, in1, out, 64, F0, B, T, T, st, pf);
-            norm2d_prelu(in_c.na, out, out, B, 64, F0, T, st);
+            conv_norm2d_prelu(in_c.plan, in_c.na, in0, in1, out, out, 64, F0, B, T, st, pf);
         }
         int Fs[6];
         Fs[0] = F0;
@@ -157,8 +155,7 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
         for (int i = 0; i < scale; ++i) {
             Fs[i + 1] = (Fs[i] - 3) / 2 + 1;
             float* y = s.lev[lvl(Fs[i + 1])];
-            run_conv(enco[i].plan, act4(xs[i], 64, Fs[i], T), nullptr, y, 64, Fs[i + 1], B, T, T, st, pf);
-            norm2d_prelu(enco[i].na, y, y, B, 64, Fs[i + 1], T, st);
+            conv_norm2d_prelu(enco[i].plan, enco[i].na, act4(xs[i], 64, Fs[i], T), nullptr, y, y, 64, Fs[i + 1], B, T, st, pf);
             xs[i + 1] = y;
         }
         const float* x = xs[scale];
@@ -166,15 +163,11 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
             const int Fi = Fs[scale - i], Fo = Fs[scale - i - 1];
             float* y = s.dec[lvl(Fo)];
             Act4 a0 = act4(x, 64, Fi, T);
-            if (i == 0) {
-                run_deconv(deco[i].plan, a0, nullptr, y, 64, Fo, B, T, T, st, pf);
-            } else {
-                Act4 a1 = act4(xs[scale - i], 64, Fi, T);          // x_list[-(i+1)]
-                run_deconv(deco[i].plan, a0, &a1, y, 64, Fo, B, T, T, st, pf);
-            }
+            Act4 a1 = act4(xs[scale - i], 64, Fi, T);              // x_list[-(i+1)] ('cat' levels, i > 0)
             // the last decoder level also adds the module's residual (x_resi + x): folded into its norm pass
-            if (i + 1 == scale) norm2d_prelu(deco[i].na, y, out, B, 64, Fo, T, st, out);
-            else norm2d_prelu(deco[i].na, y, y, B, 64, Fo, T, st);
+            const bool lastlvl = i + 1 == scale;
+            deconv_norm2d_prelu(deco[i].plan, deco[i].na, a0, i == 0 ? nullptr : &a1, y, lastlvl ? out : y, 64, Fo, B, T, st, pf,
+                                lastlvl ? out : nullptr);
             x = y;
         }
     }
@@ -204,8 +197,7 @@ struct U2Encoder {      // U2Net_Encoder (TaylorSENet.py:336-370)
             m[i].run(x, nullptr, ens[i], s, B, T, st, pf);
             x = act4(ens[i], 64, F[i], T);
         }
-        run_conv(last.plan, x, nullptr, ens[4], 64, 4, B, T, T, st, pf);
-        norm2d_prelu(last.na, ens[4], ens[4], B, 64, 4, T, st);
+        conv_norm2d_prelu(last.plan, last.na, x, nullptr, ens[4], ens[4], 64, 4, B, T, st, pf);
     }
 };
 

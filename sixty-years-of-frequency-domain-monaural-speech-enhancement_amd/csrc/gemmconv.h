@@ -92,6 +92,11 @@ struct GCTail {
     GCGeom g;
 };
 
+// Tap extents of a layer on the direct (<= 4 output channels) path
+struct GCSmallGeom {
+    int dfmin = 0, dfmax = 0, dtmin = 0, dtmax = 0;
+};
+
 // Host-side description of one dense layer, built once at finalize.
 struct GCPlan {
     GCParams p{};            // static part (taps, chunking, weights); pointers for activations filled per launch
@@ -100,6 +105,7 @@ struct GCPlan {
     float* dWs = nullptr;
     unsigned* dDesc = nullptr;
     unsigned* dDesc4 = nullptr;
+    GCSmallGeom small;       // direct path only
     bool tail_split = false; // tail[0] may be used as a separate launch for the last time tile
     GCTail tail[2];          // [0]: 32-column geometry for a mostly empty last time tile; [1]: 64-column geometry of the whole layer for small launches
     float* dBias = nullptr;

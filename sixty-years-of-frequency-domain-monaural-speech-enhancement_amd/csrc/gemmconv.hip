@@ -620,8 +620,138 @@ __global__ __launch_bounds__(256) void gc_small_kernel(const GCParams p) {
     }
 }
 
+// LDS-tiled form of the direct path: a workgroup owns SQB neighbouring output rows x 256 frames, stages the input rows all
+// of their taps touch (SQB * si + tap span rows, CC channels at a time) in LDS once and reads every tap from there.  With
+// one row per workgroup (gc_small_kernel) the three frequency taps of a row came from three workgroups and the
+// L2 <-> fabric counters showed the input fetched 3x; two rows per thread straight from L1 made it 5x.
+constexpr int SQB = 8;
+constexpr int SWT = 264;        // LDS row stride of the patch: 256 frames + tap span (<= 8), compile time so that the
+                                // reads of the 8 rows are one base register + immediate offsets
+template <int MM, int EPI, int SI>
+__global__ __launch_bounds__(256) void gc_small_lds_kernel(const GCParams p, const int CC, const int NR, const int dfmin,
+                                                           const int dtlo) {
+    extern __shared__ float patch[];                 // [CC][NR][SWT]
+    __shared__ int s_off[GC_MAX_TAPS];
+    __shared__ float s_w[8 * GC_MAX_TAPS * MM];      // weights of the staged channels (a global load per tap would be
+                                                     // waited for inside the tap loop)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < p.ntaps)                               // patch offset of tap j for the block's first output row
+        s_off[tid] = (p.tab[p.tab[GC_MAX_ROWS + tid]] - dfmin) * SWT + (p.tab[GC_MAX_ROWS + GC_MAX_TAPS + tid] - dtlo);
+    const int QG = (p.Q + SQB - 1) / SQB;
+    int rest = blockIdx.x;
+    const int q0 = (rest % QG) * SQB;
+    rest /= QG;
+    const int nt = (p.Tout + 255) >> 8;
+    const int tt = rest % nt;
+    rest /= nt;
+    const int b = rest % p.B, z = rest / p.B;
+    const int t = tt * 256 + tid;
+    const int f0 = q0 * SI + dfmin, tb = tt * 256 + dtlo;            // input coordinates of patch element (0, 0)
+    float acc[SQB][MM];
+#pragma unroll
+    for (int qq = 0; qq < SQB; ++qq)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[qq][m] = 0.f;
+    const float* __restrict__ W = p.Ws + (long)z * (p.C0 + p.C1) * p.ntaps * MM;
+    const int plane = NR * SWT;
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+        const int C = seg ? p.C1 : p.C0;
+        if (C == 0) continue;
+        const float* __restrict__ src = seg ? p.src1 + (long)z * p.src1_z + (long)b * p.s1_b
+                                            : p.src0 + (long)z * p.src0_z + (long)b * p.s0_b;
+        const long s_c = seg ? p.s1_c : p.s0_c, s_f = seg ? p.s1_f : p.s0_f;
+        const float* __restrict__ Wc = W + (long)(seg ? p.C0 : 0) * p.ntaps * MM;
+#pragma unroll 1
+        for (int c0 = 0; c0 < C; c0 += CC) {
+            const int cc = min(CC, C - c0);
+            __syncthreads();                         // the previous chunk has been consumed (and s_off is visible)
+            for (int e = tid; e < cc * p.ntaps * MM; e += 256) s_w[e] = Wc[(long)c0 * p.ntaps * MM + e];
+            // stage [cc][NR][SWT]: a wave takes whole rows, 64 consecutive frames per load; outside the plane: zeros
+            for (int row = wave; row < cc * NR; row += 4) {
+                const int c = row / NR, r = row - c * NR;
+                const int fi = f0 + r;
+                const bool rok = fi >= 0 && fi < p.Fin;
+                const float* __restrict__ sp = src + (long)(c0 + c) * s_c + (long)min(max(fi, 0), p.Fin - 1) * s_f;
+                float* __restrict__ dp = patch + c * plane + r * SWT;
+#pragma unroll
+                for (int w = lane; w < SWT; w += 64) {
+                    const int ti = tb + w;
+                    const bool ok = rok && ti >= 0 && ti < p.Tin;
+                    const float v = sp[min(max(ti, 0), p.Tin - 1)];
+                    dp[w] = ok ? v : 0.f;
+                }
+            }
+            __syncthreads();
+            for (int c = 0; c < cc; ++c) {
+                const float* __restrict__ pc = patch + c * plane + tid;
+                const float* wc = s_w + c * p.ntaps * MM;
+#pragma unroll 2
+                for (int j = 0; j < p.ntaps; ++j) {
+                    const float* __restrict__ pj = pc + s_off[j];
+                    float w[MM];
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) w[m] = wc[j * MM + m];
+#pragma unroll
+                    for (int qq = 0; qq < SQB; ++qq) {
+                        const float x = pj[qq * SI * SWT];
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) acc[qq][m] = fmaf(w[m], x, acc[qq][m]);
+                    }
+                }
+            }
+        }
+    }
+    if (t >= p.Tout) return;
+#pragma unroll
+    for (int qq = 0; qq < SQB; ++qq) {
+        if (q0 + qq >= p.Q) break;
+        const int fo = (q0 + qq) * p.so + p.po;
+        const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
+        float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
+        const float* __restrict__ res = (EPI != EPI_ACT) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            if (m < p.M) {
+                float v = acc[qq][m] + (bias ? bias[m] : 0.f);
+                v = act_apply(v, p.act, p.slope ? p.slope[m] : 0.f);
+                if (EPI == EPI_ADD) v += res[(long)m * p.x_c + t];
+                if (EPI == EPI_MUL) v *= res[(long)m * p.x_c + t];
+                dst[(long)m * p.d_c + t] = v;
+            }
+        }
+    }
+}
+
+template <int MM, int EPI>
+static void gc_small_lds_launch(const GCParams& p, dim3 grid, size_t shm, int CC, int NR, const GCSmallGeom& sg, hipStream_t stream) {
+    if (p.si == 1) hipLaunchKernelGGL((gc_small_lds_kernel<MM, EPI, 1>), grid, dim3(256), shm, stream, p, CC, NR, sg.dfmin, sg.dtmin);
+    else hipLaunchKernelGGL((gc_small_lds_kernel<MM, EPI, 2>), grid, dim3(256), shm, stream, p, CC, NR, sg.dfmin, sg.dtmin);
+}
+
 template <int MM>
-static void gc_small_launch(const GCParams& p, hipStream_t stream) {
+static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_t stream) {
+    // LDS-tiled form when the launch still fills the chip with 8-row workgroups and the patch of at least 2 channels fits
+    static const int lds_env = getenv("SE_GC_SMALL_LDS") ? atoi(getenv("SE_GC_SMALL_LDS")) : 1;
+    const int NR = (SQB - 1) * p.si + (sg.dfmax - sg.dfmin) + 1;
+    const int CC = std::min(8, (int)(40 * 1024 / ((size_t)NR * SWT * sizeof(float))));      // <= 8: s_w holds 8 channels
+    const long nblk8 = (long)((p.Tout + 255) / 256) * ((p.Q + SQB - 1) / SQB) * p.B * p.Z;
+    // (worth it from three frequency rows per output row on: with one or two the plain kernel's caches do as well - CRN /
+    // DPCRN last layers measured 1-3 % slower here, DCCRN's 5-tap deconv 1 % faster with a third of the fetches)
+    if (lds_env && CC >= 2 && p.Q >= SQB && (p.si == 1 || p.si == 2) && sg.dtmax - sg.dtmin <= SWT - 256 &&
+        ((nblk8 >= 4 * 256 && sg.dfmax - sg.dfmin >= 2) || lds_env == 2)) {        // 2: always (tests)
+        SE_CHECK(nblk8 < (1L << 31), "grid size");
+        const size_t shm = (size_t)CC * NR * SWT * sizeof(float);
+        dim3 grid((unsigned)nblk8);
+        switch (p.epi) {
+            case EPI_ACT: gc_small_lds_launch<MM, EPI_ACT>(p, grid, shm, CC, NR, sg, stream); break;
+            case EPI_ADD: gc_small_lds_launch<MM, EPI_ADD>(p, grid, shm, CC, NR, sg, stream); break;
+            case EPI_MUL: gc_small_lds_launch<MM, EPI_MUL>(p, grid, shm, CC, NR, sg, stream); break;
+            default: SE_CHECK(false, "direct small-M path: unsupported epilogue");
+        }
+        SE_HIP(hipGetLastError());
+        return;
+    }
     const long nblk = (long)((p.Tout + 255) / 256) * p.Q * p.B * p.Z;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
     dim3 grid((unsigned)nblk);
@@ -808,6 +938,15 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
                         ws[(((size_t)z * Cin + ci) * taps.ntaps + j) * MM + m] = w[(((size_t)z * M + m) * Cin + ci) * taps.ntaps + j];
         pl.dWs = to_device(ws);
         p.Ws = pl.dWs;
+        // exact tap extents for the LDS-tiled form of the direct kernel
+        pl.small.dfmin = pl.small.dfmax = taps.df[0];
+        pl.small.dtmin = pl.small.dtmax = taps.dt[0];
+        for (int j = 1; j < taps.ntaps; ++j) {
+            pl.small.dfmin = std::min(pl.small.dfmin, taps.df[j]);
+            pl.small.dfmax = std::max(pl.small.dfmax, taps.df[j]);
+            pl.small.dtmin = std::min(pl.small.dtmin, taps.dt[j]);
+            pl.small.dtmax = std::max(pl.small.dtmax, taps.dt[j]);
+        }
     }
     if (!bias.empty()) {
         SE_CHECK((long)bias.size() == (long)Z * M, "bias size");
@@ -931,9 +1070,9 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     SE_CHECK(p.pw4 || p.CI_C * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256,
              "pointwise layer with a row length that is not a multiple of 4 needs its sources inside the engine arena");
     if (p.Ws) {
-        if (p.M <= 1) gc_small_launch<1>(p, stream);
-        else if (p.M <= 2) gc_small_launch<2>(p, stream);
-        else gc_small_launch<4>(p, stream);
+        if (p.M <= 1) gc_small_launch<1>(p, pl.small, stream);
+        else if (p.M <= 2) gc_small_launch<2>(p, pl.small, stream);
+        else gc_small_launch<4>(p, pl.small, stream);
         return;
     }
     // small launches: 64-column tiles double the workgroup count (and waste less of the last time tile: T = 401 is

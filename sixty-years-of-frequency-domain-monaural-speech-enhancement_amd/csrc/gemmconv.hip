@@ -739,7 +739,8 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
     // (worth it from three frequency rows per output row on: with one or two the plain kernel's caches do as well - CRN /
     // DPCRN last layers measured 1-3 % slower here, DCCRN's 5-tap deconv 1 % faster with a third of the fetches)
     if (lds_env && CC >= 2 && p.Q >= SQB && (p.si == 1 || p.si == 2) && sg.dtmax - sg.dtmin <= SWT - 256 &&
-        ((nblk8 >= 4 * 256 && sg.dfmax - sg.dfmin >= 2) || lds_env == 2)) {        // 2: always (tests)
+        ((nblk8 >= 4 * 256 && (sg.dfmax - sg.dfmin >= 2 || (sg.dfmax - sg.dfmin >= 1 && MM >= 2 && p.C0 + p.C1 >= 64))) ||
+         lds_env == 2)) {        // 2: always (tests)
         SE_CHECK(nblk8 < (1L << 31), "grid size");
         const size_t shm = (size_t)CC * NR * SWT * sizeof(float);
         dim3 grid((unsigned)nblk8);

@@ -50,7 +50,7 @@ def main():
                      'mfma_util': round(busy / (act / 8 * 256 * 4), 4) if act else None,
                      'mfma_tflop_per_step': round(mops * 512 / steps / 1e12, 3)})
     rows.sort(key=lambda r: -(r['read_GB_per_step'] + r['write_GB_per_step']))
-    gc = [r for r in rows if 'gc_kernel' in r['kernel'] or 'gc_small_kernel' in r['kernel']]   # everything gc_launch dispatches
+    gc = [r for r in rows if 'gc_kernel' in r['kernel'] or 'gc_small_' in r['kernel']]   # everything gc_launch dispatches
     fam = {'launches_per_step': sum(r['launches'] for r in gc) / steps,
            'read_GB_per_step': round(sum(r['read_GB_per_step'] for r in gc), 3),
            'write_GB_per_step': round(sum(r['write_GB_per_step'] for r in gc), 3)}

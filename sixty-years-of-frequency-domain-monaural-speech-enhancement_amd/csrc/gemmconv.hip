@@ -1084,7 +1084,8 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
         static const int alt_env = getenv("SE_GC_ALT") ? atoi(getenv("SE_GC_ALT")) : 1;
         const GCTail& alt = pl.tail[1];
         const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
-        if (alt_env && alt.BN == 64 && nblk < (pl.BM == 64 ? 1536 : 256)) {
+        static const int alt_n64 = getenv("SE_GC_ALT_N64") ? atoi(getenv("SE_GC_ALT_N64")) : 4096;
+        if (alt_env && alt.BN == 64 && nblk < (pl.BM == 64 ? alt_n64 : 256)) {
             GCParams pa = p;
             pa.t_base = 0;
             pa.n_ttiles = (p.Tout + 63) / 64;

@@ -43,7 +43,7 @@ def main():
         wb = 1024.0 * sum(w)
         busy, act = sum(s.get('SQ_VALU_MFMA_BUSY_CYCLES', [])), sum(s.get('GRBM_GUI_ACTIVE', []))
         mops = sum(s.get('SQ_INSTS_VALU_MFMA_MOPS_F32', []))
-        rows.append({'kernel': k.replace('void ', '').split('(')[0], 'launches': n,
+        rows.append({'kernel': k.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0], 'launches': n,
                      'read_GB_per_launch': round(rd / max(len(f), 1) / 1e9, 4),
                      'write_GB_per_launch': round(wb / max(len(w), 1) / 1e9, 4),
                      'read_GB_per_step': round(rd / steps / 1e9, 3), 'write_GB_per_step': round(wb / steps / 1e9, 3),

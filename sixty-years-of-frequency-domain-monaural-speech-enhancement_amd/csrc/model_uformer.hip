@@ -92,16 +92,34 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
                 q[d] = hq[(long)d * P + t] * 0.25f;       // / hidden_channel ** 0.5
                 o[d] = 0.f;
             }
+            // online softmax over chunks of 8 keys: one running-maximum update (one rescale of the 16 accumulators) per
+            // chunk instead of per key, hardware exp (v_exp_f32, ~1 ulp: the weights are normalised by their own sum)
             float mx = -3.0e38f, l = 0.f;
-            for (int s = 0; s < T; ++s) {
-                float e = 0.f;
+            for (int s0 = 0; s0 < T; s0 += 8) {
+                float e[8];
+                float cm = -3.0e38f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) e += q[d] * Ks[d * T + s];
-                const float mn = fmaxf(mx, e);
-                const float corr = expf(mx - mn), pe = expf(e - mn);
-                l = l * corr + pe;
+                for (int k = 0; k < 8; ++k) {
+                    const int s = min(s0 + k, T - 1);
+                    float a = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) o[d] = o[d] * corr + pe * Vs[d * T + s];
+                    for (int d = 0; d < HD; ++d) a = fmaf(q[d], Ks[d * T + s], a);
+                    e[k] = (s0 + k < T) ? a : -3.0e38f;
+                    cm = fmaxf(cm, e[k]);
+                }
+                const float mn = fmaxf(mx, cm);
+                const float corr = __expf(mx - mn);
+                l *= corr;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) o[d] *= corr;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int s = min(s0 + k, T - 1);
+                    const float pe = __expf(e[k] - mn);          // masked keys: exp(-3e38 - mn) = 0
+                    l += pe;
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) o[d] = fmaf(pe, Vs[d * T + s], o[d]);
+                }
                 mx = mn;
             }
             const float inv = 1.f / l;

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
                         const float a = acc[i][j][r] + ep[mw + dm];
                         const float g = acc[i][j][r + 1] + ep[mw + dm + 1];
                         const int ol = (mw + dm) >> 1;
-                        float v = a * sigmoidf_(g);
+                        float v = a * fsig_(g);          // hardware exp + reciprocal (as in the LSTM cells): the libm pair was ~15 % of a small-K GLU tile
                         v = v * ep[2 * BM + ol] + ep[3 * BM + ol];
                         strip[((4 * hi + dm) >> 1) * OST + l31] = act_apply(v, p.act, ep[BM + ol]);
                     }

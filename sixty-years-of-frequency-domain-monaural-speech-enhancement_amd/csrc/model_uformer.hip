@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void uf_fusion_kernel(float* __restrict__ cplx
 // signs into out [B][nout*16][F][T] (complex: heads 0-3 -> real (+,-,-,-), heads 4-7 -> imag (+,+,+,-); real: 1 head).
 __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__ pq, float* __restrict__ out, int F, int T,
                                                        int nh) {
-    extern __shared__ float kv[];          // K [16][T], V [16][T]
+    extern __shared__ float kv[];          // K [T][16], V [T][16]
     float* Ks = kv;
     float* Vs = kv + HD * T;
     const int f = blockIdx.x % F, b = blockIdx.x / F;
@@ -79,10 +79,12 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
     for (int h = 0; h < nh; ++h) {
         const float* hq = base + (long)h * 48 * P;
         __syncthreads();
+        // K / V of the head as [T][16] in LDS (key-major): the 16 values of a key are four broadcast 16 B reads in the loop
+        // below instead of sixteen 4 B ones - the loop was bound by LDS instruction issue, not by its FMAs
         for (int i = threadIdx.x; i < HD * T; i += 256) {
             const int d = i / T, s = i - d * T;
-            Ks[i] = hq[(long)(HD + d) * P + s];
-            Vs[i] = hq[(long)(2 * HD + d) * P + s];
+            Ks[s * HD + d] = hq[(long)(HD + d) * P + s];
+            Vs[s * HD + d] = hq[(long)(2 * HD + d) * P + s];
         }
         __syncthreads();
         if (t < T) {
@@ -102,8 +104,15 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
                 for (int k = 0; k < 8; ++k) {
                     const int s = min(s0 + k, T - 1);
                     float a = 0.f;
+                    const float4* kp = reinterpret_cast<const float4*>(Ks + s * HD);
 #pragma unroll
-                    for (int d = 0; d < HD; ++d) a = fmaf(q[d], Ks[d * T + s], a);
+                    for (int d4 = 0; d4 < HD / 4; ++d4) {
+                        const float4 kk = kp[d4];
+                        a = fmaf(q[4 * d4 + 0], kk.x, a);
+                        a = fmaf(q[4 * d4 + 1], kk.y, a);
+                        a = fmaf(q[4 * d4 + 2], kk.z, a);
+                        a = fmaf(q[4 * d4 + 3], kk.w, a);
+                    }
                     e[k] = (s0 + k < T) ? a : -3.0e38f;
                     cm = fmaxf(cm, e[k]);
                 }
@@ -117,8 +126,15 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
                     const int s = min(s0 + k, T - 1);
                     const float pe = __expf(e[k] - mn);          // masked keys: exp(-3e38 - mn) = 0
                     l += pe;
+                    const float4* vp = reinterpret_cast<const float4*>(Vs + s * HD);
 #pragma unroll
-                    for (int d = 0; d < HD; ++d) o[d] = fmaf(pe, Vs[d * T + s], o[d]);
+                    for (int d4 = 0; d4 < HD / 4; ++d4) {
+                        const float4 vv = vp[d4];
+                        o[4 * d4 + 0] = fmaf(pe, vv.x, o[4 * d4 + 0]);
+                        o[4 * d4 + 1] = fmaf(pe, vv.y, o[4 * d4 + 1]);
+                        o[4 * d4 + 2] = fmaf(pe, vv.z, o[4 * d4 + 2]);
+                        o[4 * d4 + 3] = fmaf(pe, vv.w, o[4 * d4 + 3]);
+                    }
                 }
                 mx = mn;
             }

@@ -48,17 +48,18 @@ __global__ __launch_bounds__(256) void uf_prep_kernel(const float* __restrict__ 
 }
 
 // ---- fusion.py:13-19 on cplx [B][2C][P] / mag [B][C][P], in place
-__global__ __launch_bounds__(256) void uf_fusion_kernel(float* __restrict__ cplx, float* __restrict__ mag, long CP, long total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const long b = i / CP, r = i - b * CP;
+__global__ __launch_bounds__(256) void uf_fusion_kernel(float* __restrict__ cplx, float* __restrict__ mag, long CP) {
+    // grid (ceil(CP / 256), B): no 64-bit division per element; hardware exp for the two sigmoids
+    const long r = (long)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (r >= CP) return;
     float* cr = cplx + b * 2 * CP + r;
-    const float re = cr[0], im = cr[CP], m = mag[i];
+    float* mp = mag + b * CP + r;
+    const float re = cr[0], im = cr[CP], m = mp[0];
     const float cm = sqrtf(fmaxf(re * re + im * im, UEPS));
-    const float s = 1.f / (1.f + expf(-m));
+    const float s = __frcp_rn(1.f + __expf(-m));
     cr[0] = re + s;
     cr[CP] = im + s;
-    mag[i] = m + 1.f / (1.f + expf(-cm));
+    mp[0] = m + __frcp_rn(1.f + __expf(-cm));
 }
 
 // ---- attention along T (t_att_cplx.py:15-40, :58-67): pq [B][nh*48][F][T] rows (q,k,v) x 16 per head.
@@ -523,8 +524,7 @@ class Uformer final : public Model {
         gc_launch_prof(pl, p, st, &ctx.prof);
     }
     void fusion(float* c, float* m, int B, long CP, hipStream_t st) {
-        const long tot = (long)B * CP;
-        hipLaunchKernelGGL(uf_fusion_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c, m, CP, tot);
+        hipLaunchKernelGGL(uf_fusion_kernel, dim3((unsigned)((CP + 255) / 256), B), dim3(256), 0, st, c, m, CP);
     }
     // LayerNorm over C of a [Bv][C][P] view
     void ln(const LnW& w, const float* x, float* y, int Bv, int C, long P, hipStream_t st, int post = 0, const float* slope = nullptr,

@@ -86,6 +86,8 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
     SE_HIP(hipGetLastError());
 }
 
+constexpr int NU = 8;      // independent loads per thread in the streaming passes of the norm kernels
+
 // ---- LayerNorm over (C, F) per (b, t) + residual ------------------------------------------------------------
 // block = 64 frames x 4 row groups: the C*F rows of a frame are split over 4 waves (partial sums meet in LDS), so a
 // launch has 4x the blocks and a quarter of the serial row walk of a thread-per-frame layout
@@ -101,10 +103,24 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
     const int n = C * F;
     // one statistics pass (sum and sum of squares in fp64), then the normalise pass
     double s = 0.0, v = 0.0;
-    for (int i = rg; i < n; i += 4) {
-        const double xv = x[base + (long)i * T];
-        s += xv;
-        v += xv * xv;
+    {
+        int i = rg;
+        for (; i + 4 * (NU - 1) < n; i += 4 * NU) {         // NU rows in flight per thread, summed in row order
+            float xr[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) xr[u] = x[base + (long)(i + 4 * u) * T];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const double xv = xr[u];
+                s += xv;
+                v += xv * xv;
+            }
+        }
+        for (; i < n; i += 4) {
+            const double xv = x[base + (long)i * T];
+            s += xv;
+            v += xv * xv;
+        }
     }
     red[rg][tl] = s;
     red2[rg][tl] = v;
@@ -115,14 +131,29 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
     const float rs = (float)(1.0 / sqrt(vard + (double)eps));
     if (!ok) return;
     const float slope = prelu_slope ? prelu_slope[0] : 1.f;
-    for (int i = rg; i < n; i += 4) {
+    auto finish = [&](int i, float xv, float rv) {
         const int c = i / F, f = i - c * F;
-        const long o = base + (long)i * T;
-        float y = (x[o] - mu) * rs * w[f * C + c] + bb[f * C + c];
+        float y = (xv - mu) * rs * w[f * C + c] + bb[f * C + c];
         if (post == 1) y = y / (1.f + expf(-y));
         if (prelu_slope) y = y >= 0.f ? y : slope * y;
-        if (res) y += res[o];
-        out[o] = y;
+        if (res) y += rv;
+        out[base + (long)i * T] = y;
+    };
+    int i = rg;
+    for (; i + 4 * (NU - 1) < n; i += 4 * NU) {
+        float xr[NU], rr[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const long o = base + (long)(i + 4 * u) * T;
+            xr[u] = x[o];
+            rr[u] = res ? res[o] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) finish(i + 4 * u, xr[u], rr[u]);
+    }
+    for (; i < n; i += 4) {
+        const long o = base + (long)i * T;
+        finish(i, x[o], res ? res[o] : 0.f);
     }
 }
 void launch_layernorm_cf(const float* x, const float* res, const float* w, const float* b, float* out, int B, int C,
@@ -220,6 +251,31 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// y = PReLU((x - mu) * rs * g + bt) (+ r) over one plane, NU elements per thread in flight (r may alias y)
+__device__ __forceinline__ void norm_apply_pass(const float* __restrict__ xp, float* yp, const float* rp, int P, float muf,
+                                                float rs, float g, float bt, float sl) {
+    int i = threadIdx.x;
+    for (; i + (NU - 1) * 256 < P; i += NU * 256) {
+        float v[NU], r[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            v[u] = xp[i + u * 256];
+            r[u] = rp ? rp[i + u * 256] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float o = (v[u] - muf) * rs * g + bt;
+            o = o >= 0.f ? o : sl * o;
+            yp[i + u * 256] = rp ? o + r[u] : o;
+        }
+    }
+    for (; i < P; i += 256) {
+        float o = (xp[i] - muf) * rs * g + bt;
+        o = o >= 0.f ? o : sl * o;
+        yp[i] = rp ? o + rp[i] : o;
+    }
+}
+
 __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ slope, const float* res, int C,
@@ -231,21 +287,33 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
     const float* rp = res ? res + (long)blockIdx.x * P : nullptr;     // optional residual, may alias y
     // one statistics pass: sum and sum of squares in fp64 (the cancellation in E[x^2] - mu^2 costs ~1e-16 * mu^2 / var,
     // far below fp32 resolution), then one normalise pass: 2 reads + 1 write of the plane instead of 3 + 1
+    // NU loads in flight per thread (the compiler does not unroll these loops: one load, one vmcnt(0) per element left the
+    // pass latency bound); sums keep their element order
     double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < P; i += 256) {
-        const double v = xp[i];
-        s += v;
-        q += v * v;
+    {
+        int i = threadIdx.x;
+        for (; i + (NU - 1) * 256 < P; i += NU * 256) {
+            float v[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) v[u] = xp[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const double d = v[u];
+                s += d;
+                q += d * d;
+            }
+        }
+        for (; i < P; i += 256) {
+            const double d = xp[i];
+            s += d;
+            q += d * d;
+        }
     }
     const double mu = block_sum_d(s, sh) / P;
     const double var = fmax(block_sum_d(q, sh) / P - mu * mu, 0.0);
     const float rs = (float)(1.0 / sqrt(var + 1e-5)), muf = (float)mu;
     const float g = gamma[c], bt = beta[c], sl = slope ? slope[c] : 1.f;
-    for (int i = threadIdx.x; i < P; i += 256) {
-        float o = (xp[i] - muf) * rs * g + bt;
-        o = o >= 0.f ? o : sl * o;
-        yp[i] = rp ? o + rp[i] : o;
-    }
+    norm_apply_pass(xp, yp, rp, P, muf, rs, g, bt, sl);
 }
 // the same with the statistics handed over by the producing conv's epilogue (GCParams::stats): nslot (sum, sum of squares)
 // pairs per (b, c) plane, combined in fp64 in a fixed order; the plane itself is read once
@@ -270,11 +338,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_stats_kernel(const float* 
     const double var = fmax(block_sum_d(q, sh) / P - mu * mu, 0.0);
     const float rs = (float)(1.0 / sqrt(var + 1e-5)), muf = (float)mu;
     const float g = gamma[c], bt = beta[c], sl = slope ? slope[c] : 1.f;
-    for (int i = threadIdx.x; i < P; i += 256) {
-        float o = (xp[i] - muf) * rs * g + bt;
-        o = o >= 0.f ? o : sl * o;
-        yp[i] = rp ? o + rp[i] : o;
-    }
+    norm_apply_pass(xp, yp, rp, P, muf, rs, g, bt, sl);
 }
 void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, const float* beta, const float* slope,
                                  const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res) {
@@ -300,11 +364,22 @@ __global__ __launch_bounds__(256) void tcm_head_kernel(const float* __restrict__
     float* yp = y + (long)blockIdx.x * T;
     const float sl = slope[c];
     double s = 0.0;
-    for (int i = threadIdx.x; i < T; i += 256) {
-        float v = xp[i];
-        v = v >= 0.f ? v : sl * v;
-        row[i] = v;
-        s += v;
+    {
+        int i = threadIdx.x;
+        for (; i + 256 < T; i += 512) {       // two loads in flight: a 4 s clip (T = 401) is one round
+            const float v0 = xp[i], v1 = xp[i + 256];
+            const float a0 = v0 >= 0.f ? v0 : sl * v0, a1 = v1 >= 0.f ? v1 : sl * v1;
+            row[i] = a0;
+            row[i + 256] = a1;
+            s += a0;
+            s += a1;
+        }
+        for (; i < T; i += 256) {
+            float a = xp[i];
+            a = a >= 0.f ? a : sl * a;
+            row[i] = a;
+            s += a;
+        }
     }
     const double mu = block_sum_d(s, sh) / T;
     double vv = 0.0;

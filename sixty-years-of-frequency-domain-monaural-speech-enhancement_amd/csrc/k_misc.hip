@@ -424,12 +424,20 @@ __global__ __launch_bounds__(256) void cln_stats_kernel(const float* __restrict_
     double s = 0.0, q = 0.0;
     if (t < T) {
         const float* xp = x + (long)b * R * T + t;
-        for (int r = rg; r < R; r += 4) {
-            float v = xp[(long)r * T];
+        auto take = [&](int r, float v) {
             if (pre_slope) v = v >= 0.f ? v : pre_slope[r / F] * v;
             s += v;
             q += (double)v * v;
+        };
+        int r = rg;
+        for (; r + 4 * (NU - 1) < R; r += 4 * NU) {         // NU rows in flight per thread, summed in row order
+            float xr[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) xr[u] = xp[(long)(r + 4 * u) * T];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) take(r + 4 * u, xr[u]);
         }
+        for (; r < R; r += 4) take(r, xp[(long)r * T]);
     }
     sh[0][rg][tl] = s;
     sh[1][rg][tl] = q;

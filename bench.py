@@ -8,7 +8,9 @@ DCCRN complex-mask, compressed input (p_in 0.5 / p_out 2.0), batch 256 per MI355
 ranks (weak scaling: per-GPU batch fixed).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
+  N > 1: either launched as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+  bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or from a bare shell - then it starts its own
+  ranks that way.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -108,12 +110,30 @@ def cpu_baseline(seed, p_in, p_out):
             "value_per_worker_best": round(clips / min(spans), 4)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start one rank per GPU under torch.distributed.run (rendezvous on
+    127.0.0.1, a free port) with the same arguments and hand back its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=256, help='clips per GPU per step')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='torch.distributed backend of the waveform gather (nccl = RCCL over xGMI; gloo stages through the host)')
+    ap.add_argument('--force-pg', action='store_true',
+                    help='initialise the process group and run the gather collective even with one rank (RCCL smoke on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--cpu-worker', type=int, default=0, help='internal: decode N clips with the numpy oracle, print seconds')
@@ -123,6 +143,8 @@ def main():
         seed, p_in, p_out = args.cpu_worker_args.split(',')
         print(_cpu_worker((int(seed), float(p_in), float(p_out), args.cpu_worker)), flush=True)
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -135,11 +157,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # one rank per GPU; SE_BENCH_SHARE_GPU=1 (the 1-GPU test box) folds the ranks onto the devices that exist
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and os.environ.get('SE_BENCH_SHARE_GPU') != '1':
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible")
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_pg = world > 1 or args.force_pg
+    if use_pg:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank) if args.backend == 'nccl' else None)
 
     B, p_in, p_out, seed = args.batch, 0.5, 2.0, 14
     model = DCCRN(rnn_units=256, masking_mode='E', use_clstm=True, kernel_num=[32, 64, 128, 256, 256, 256],
@@ -153,7 +182,7 @@ def main():
     from se_amd import shard
     # enhanced waveforms of every rank end up device-resident on rank 0: asynchronous RCCL gather, double-buffered so
     # that the gather of step k overlaps the compute of step k + 1 (se_amd/shard.py:GatherPipe); N = 1: no collective
-    pipe = shard.GatherPipe(B, n_out, torch.device('cuda', local_rank), dst=0)
+    pipe = shard.GatherPipe(B, n_out, torch.device('cuda', local_rank), dst=0, single_rank=args.force_pg)
     out = None
 
     def step():
@@ -163,7 +192,7 @@ def main():
         pipe.submit()
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,19 +205,21 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    pipe.finish()           # every gather of the timed steps has landed on rank 0
+    rows = pipe.finish()    # every gather of the timed steps has landed on rank 0
     fence()
     dt = time.perf_counter() - t0
     prof = eng.get_profile() if not args.no_profile else None
     eng.set_profiling(False)
 
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    if use_pg:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     if rank == 0:
         assert bool(torch.isfinite(out).all()), "non-finite output"
+        if use_pg:          # the gathered rows of the last step: rank r's rows are its own clips' enhancement
+            assert len(rows) == world and all(bool(torch.isfinite(r).all()) for r in rows), "non-finite gathered rows"
         utts = world * B * args.steps
         value = utts / dt
         res = {
@@ -229,7 +260,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(seed, p_in, p_out)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

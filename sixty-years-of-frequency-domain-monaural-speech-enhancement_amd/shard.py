@@ -53,13 +53,19 @@ class GatherPipe:
         rows = pipe.finish()                   # rank dst: list of `world` tensors of the LAST batch, else None
     """
 
-    def __init__(self, n_local, n_samples, device, dst=0, group=None, dtype=torch.float32):
+    def __init__(self, n_local, n_samples, device, dst=0, group=None, dtype=torch.float32, single_rank=False):
+        # single_rank: run the collective even in a one-rank group (exercises the RCCL path on a 1-GPU box)
         self.group, self.dst = group, dst
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank)
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.send = [torch.empty((n_local, n_samples), dtype=dtype, device=device) for _ in range(2)]
-        self.recv = [[torch.empty((n_local, n_samples), dtype=dtype, device=device) for _ in range(self.world)]
+        # gloo has no device-side gather: the rows are staged through pinned host memory (CPU tests, or a GPU box
+        # whose RCCL cannot be used); nccl (= RCCL over xGMI) gathers device to device
+        self.host = self.on and dist.get_backend(group) == 'gloo' and torch.device(device).type != 'cpu'
+        rdev = 'cpu' if self.host else device
+        self.stage = [torch.empty((n_local, n_samples), dtype=dtype).pin_memory() for _ in range(2)] if self.host else None
+        self.recv = [[torch.empty((n_local, n_samples), dtype=dtype, device=rdev) for _ in range(self.world)]
                      for _ in range(2)] if (self.on and self.rank == dst) else [None, None]
         self.work = [None, None]
         self.k = 0
@@ -74,7 +80,11 @@ class GatherPipe:
     def submit(self):
         i = self.k & 1
         if self.on:
-            self.work[i] = dist.gather(self.send[i], self.recv[i], dst=self.dst, group=self.group, async_op=True)
+            src = self.send[i]
+            if self.host:
+                self.stage[i].copy_(src)          # synchronous D2H on the current stream
+                src = self.stage[i]
+            self.work[i] = dist.gather(src, self.recv[i], dst=self.dst, group=self.group, async_op=True)
         self.k += 1
 
     def finish(self):

@@ -23,20 +23,27 @@ def _batch(B, seed0):
     return np.tile(base, ((B + 15) // 16, 1))[:B].copy()
 
 
-@pytest.mark.parametrize('name,B,kw,oracle', [('dccrn', 256, dict(p_in=0.5, p_out=2.0), True), ('crn', 64, {}, True),
-                                              ('fullsubnet', 32, {}, False), ('uformer', 32, {}, False)])
-def test_full_size_properties(name, B, kw, oracle):
+CPRS = dict(p_in=0.5, p_out=2.0)
+
+
+@pytest.mark.parametrize('name,B,kw,wseed,oracle', [('dccrn', 256, CPRS, 14, True), ('crn', 64, {}, 14, True),
+                                                    ('fullsubnet', 32, CPRS, 15, False), ('uformer', 32, {}, 21, False)])
+def test_full_size_properties(name, B, kw, wseed, oracle):
     import torch
     from se_amd.models import MODEL_CLASSES
     from oracle import decode as D
+    from conftest import load_golden
     x = _batch(B, 500)
     x[1::16] *= 0.37                                   # rows of one 16-clip period differ in level as well
-    big = MODEL_CLASSES[name](max_batch=B, max_samples=L, **kw).load_synthetic(14)
+    if not oracle:                                     # row 5 = the clip of the reference-generated full-size fixture
+        G = load_golden('full_' + name)
+        x[5] = synth.synth_clip(int(G['seed']), 'speech', L)
+    big = MODEL_CLASSES[name](max_batch=B, max_samples=L, **kw).load_synthetic(wseed)
     xt = torch.from_numpy(x).cuda()
     y = big.enhance_batch(xt).clone()
     assert bool(torch.isfinite(y).all())
     # (1) independence: rows of the big batch == the same clips in a batch of 2 (another tiling of the chip)
-    small = MODEL_CLASSES[name](max_batch=2, max_samples=L, **kw).load_synthetic(14)
+    small = MODEL_CLASSES[name](max_batch=2, max_samples=L, **kw).load_synthetic(wseed)
     for k in (0, B // 2 + 1, B - 2):
         ys = small.enhance_batch(xt[k:k + 2])
         for j in (0, 1):
@@ -49,11 +56,13 @@ def test_full_size_properties(name, B, kw, oracle):
     assert torch.equal(big.enhance_batch(xt * 4.0), y * 4.0)
     y3 = big.enhance_batch(xt * 3.0)
     assert rms((y3 - 3.0 * y).cpu().numpy()) < 1e-5 * rms(y.cpu().numpy())
-    if not oracle:          # configs[3] / configs[4] (per-GPU shard of 32 clips): properties only, their oracle decodes
-        return              # are pinned at fixture sizes in test_gpu_models.py / test_gpu_uformer.py
+    got = y[5].cpu().numpy()
+    if not oracle:          # configs[3] / configs[4] (per-GPU shard of 32 clips): row 5 of the shard against the reference's
+        ref = G['enh4_cprs']        # own decode of that clip (tests/golden/full_<name>.npz, imported reference)
+        assert len(ref) == len(got) and rms(got - ref) < 1e-4, (name, rms(got - ref))
+        return
     # (4) one row of the full-size batch against the numpy oracle (bar of the north star: 1e-4 RMS)
-    sd = synth.synth_state_dict(small.state_dict_schema(), 14)
+    sd = synth.synth_state_dict(small.state_dict_schema(), wseed)
     fn = D.enhance_dccrn if name == 'dccrn' else D.enhance_crn
     ref = fn(sd, x[5].astype(np.float64), *((kw['p_in'], kw['p_out']) if kw else ()))
-    got = y[5].cpu().numpy()
     assert len(ref) == len(got) and rms(got - ref) < 1e-4

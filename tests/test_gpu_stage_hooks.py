@@ -1,0 +1,85 @@
+"""GPU: the se_stft / se_istft / se_rms_scale stage hooks diffed ALONE (not through a network) at every front-end geometry
+of the zoo, against oracle/stft.py (itself pinned to torch.stft / torch.istft fp64 fixtures,
+tests/test_oracle_golden.py) and against the torch fixtures directly:
+  320/160/320  librosa family + CTSNet / TaylorSENet    (engine of CRN)
+  512/128/512  DCCRN
+  512/256/512  FullSubNet
+  512/160/400  Uformer (window shorter than the FFT, centred)
+Lengths: the fixture's 4 000 samples, BASELINE's 64 000, and a ragged 5 003 (not a hop multiple)."""
+import numpy as np
+import pytest
+
+import se_amd  # noqa: F401
+from se_amd import synth
+from conftest import load_golden, rms
+
+pytestmark = pytest.mark.gpu
+GEOMS = [('crn', 320, 160, 320), ('dccrn', 512, 128, 512), ('fullsubnet', 512, 256, 512), ('uformer', 512, 160, 400)]
+WSEED = {'crn': 12, 'dccrn': 14, 'fullsubnet': 15, 'uformer': 21}
+
+
+def _engine(name, B, L):
+    from se_amd.models import MODEL_CLASSES
+    return MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(WSEED[name]).engine
+
+
+@pytest.mark.parametrize('name,n_fft,hop,win', GEOMS)
+def test_stft_istft_hooks_match_torch_fixture(name, n_fft, hop, win):
+    import torch
+    G = load_golden('stft')
+    tag = f'{n_fft}_{hop}_{win}'
+    x = G['x_' + tag].astype(np.float32)                               # [2, 4000]
+    eng = _engine(name, 2, 8000)
+    spec = eng.stft(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = G['spec_' + tag]                                             # torch.stft fp64, [2, F, T]
+    if name == 'dccrn':                                                # DCCRN's script tail-pads to a hop multiple first
+        T = ref.shape[-1]
+        spec = spec[..., :T]                                           # frames that do not touch the padding are equal
+        ok = slice(0, T - 3)
+    else:
+        ok = slice(None)
+    assert spec.shape[2] == ref.shape[1]
+    got = spec[:, 0] + 1j * spec[:, 1]
+    assert got.shape[-1] == ref.shape[-1] or name == 'dccrn'
+    e = rms((got - ref)[..., ok])
+    assert e < 2e-6 * rms(np.abs(ref)), (name, e)
+    # inverse: the fp64 torch spectrum through se_istft == torch.istft(length=4000)
+    sp = np.ascontiguousarray(np.stack([ref.real, ref.imag], axis=1).astype(np.float32))
+    y = eng.istft(torch.from_numpy(sp).cuda(), 4000).cpu().numpy()
+    assert rms(y - G['ylen_' + tag]) < 2e-6 * rms(G['ylen_' + tag])
+    # no `length` (CTSNet `[:wav_len]`, Uformer): hop * (T - 1) samples
+    n2 = G['ynolen_' + tag].shape[-1]
+    y2 = eng.istft(torch.from_numpy(sp).cuda(), n2).cpu().numpy()
+    assert rms(y2 - G['ynolen_' + tag]) < 2e-6 * rms(G['ynolen_' + tag])
+
+
+@pytest.mark.parametrize('name,n_fft,hop,win', GEOMS)
+@pytest.mark.parametrize('L', [64000, 5003])
+def test_stft_istft_hooks_match_oracle_at_size(name, n_fft, hop, win, L):
+    import torch
+    from oracle import stft as S
+    B = 3
+    x = np.stack([synth.synth_clip(700 + i, k, L) for i, k in enumerate(('speech', 'white', 'gap'))])
+    eng = _engine(name, B, L)
+    xd = torch.from_numpy(x).cuda()
+    c = eng.rms_scale(xd)
+    cr = S.rms_scale(x)
+    assert np.allclose(c.cpu().numpy(), cr, rtol=2e-6)
+    spec = eng.stft(xd, c=c, p_in=0.5).cpu().numpy()
+    T = eng.num_frames(L)
+    assert spec.shape == (B, 2, n_fft // 2 + 1, T)
+    xs = x.astype(np.float64) * cr[:, None]
+    if name == 'dccrn':
+        xs = S.pad_to_hop(xs, n_fft, hop)
+    ref = S.stft(xs, n_fft, hop, win)
+    assert ref.shape[-1] == T
+    refc = np.abs(ref) ** 0.5 * np.exp(1j * np.angle(ref))
+    got = spec[:, 0] + 1j * spec[:, 1]
+    e = rms(got - refc)
+    assert e < 5e-6 * rms(np.abs(refc)), (name, L, e)
+    # inverse with the de-normalisation: se_istft(spec, c) == istft(spec) / c
+    n_out = int(eng.output_samples(L)) if name != 'dccrn' else xs.shape[-1]
+    sp = np.ascontiguousarray(np.stack([ref.real, ref.imag], axis=1).astype(np.float32))
+    y = eng.istft(torch.from_numpy(sp).cuda(), n_out, c=c).cpu().numpy()
+    yr = S.istft(ref, n_fft, hop, win, length=n_out) / cr[:, None]
+    assert rms(y - yr) < 3e-6 * rms(yr), (name, L, rms(y - yr), rms(yr))

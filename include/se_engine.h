@@ -89,6 +89,17 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
                      float* wav_out_dev, int64_t out_pitch, void* stream);
 int64_t se_output_samples(const se_engine* e, int32_t n_samples);
 
+/* The same loop body for a batch of clips of DIFFERENT lengths (the reference decodes one clip at a time, so every clip
+ * has its own length: ~824 distinct lengths on VoiceBank+DEMAND, `for file_id in file_list`, DCCRN/dccrn_decode_vb.py:24).
+ * `lengths` is a HOST array of `batch` sample counts; row b of wav_in_dev holds lengths[b] valid samples (the rest of the
+ * row is ignored), row b of wav_out_dev receives se_output_samples(e, lengths[b]) samples followed by zeros up to
+ * se_output_samples(e, max lengths).  Each row gets exactly the result of decoding it alone: its own unit-RMS scale, its
+ * own reflect padding and frame count in the STFT / iSTFT, and utterance-wide statistics (InstanceNorm - CTSNet, G2Net,
+ * TaylorSENet, e.g. CTSNet/Step1_network.py:121-145; FullSubNet's offline_laplace_norm, base_model.py:197-209) taken over
+ * its own frames only.  Fails for models that look ahead in time without a bound (Uformer): batch those by equal length. */
+int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, int32_t batch, const int32_t* lengths,
+                      float* wav_out_dev, int64_t out_pitch, void* stream);
+
 /* Stage hooks, so each oracle-pinned stage can be diffed alone (engine-internal spectrogram layout
  * [B][2][F][T] re/im planes, T contiguous, row pitch = T).
  *   se_stft     : torch.stft / librosa.stft call of the model's decode script, fused with x*c and |X|^p_in.
@@ -120,7 +131,7 @@ int se_resample(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n_
                 float* out_dev, int64_t out_pitch, void* stream);
 
 /* ABI version of this header. */
-int32_t se_abi_version(void);
+int32_t se_abi_version(void);   /* 2: se_enhance_ragged */
 
 #ifdef __cplusplus
 }

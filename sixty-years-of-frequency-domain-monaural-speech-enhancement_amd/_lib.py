@@ -18,7 +18,7 @@ SYMBOLS = [
     'se_abi_version', 'se_last_error', 'se_engine_create', 'se_engine_destroy', 'se_engine_set_tensor',
     'se_engine_finalize', 'se_forward', 'se_enhance_batch', 'se_output_samples', 'se_rms_scale', 'se_stft',
     'se_istft', 'se_num_frames', 'se_num_bins', 'se_set_profiling', 'se_get_profile', 'se_resample',
-    'se_resample_samples',
+    'se_resample_samples', 'se_enhance_ragged',
 ]
 
 
@@ -51,6 +51,7 @@ def load():
     lib.se_engine_finalize.argtypes = [vp]
     lib.se_forward.argtypes = [vp, vp, C.POINTER(i64), i32, vp, vp]
     lib.se_enhance_batch.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp]
+    lib.se_enhance_ragged.argtypes = [vp, vp, i64, i32, C.POINTER(i32), vp, i64, vp]
     lib.se_output_samples.restype = i64
     lib.se_output_samples.argtypes = [vp, i32]
     lib.se_rms_scale.argtypes = [vp, vp, i64, i32, i32, vp, vp]

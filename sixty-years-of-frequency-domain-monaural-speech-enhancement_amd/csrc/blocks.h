@@ -28,7 +28,7 @@ inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int 
         launch_cln(x, y == res ? const_cast<float*>(x) : y, n.g, n.b, nullptr, n.s, nullptr, 0, B, C, F, T, st);
         if (res) launch_add(res, y == res ? x : y, y, (long)B * C * F * T, st);
     } else {
-        launch_instnorm_prelu(x, y, n.g, n.b, n.s, B, C, F * T, st, res);
+        launch_instnorm_prelu(x, y, n.g, n.b, n.s, B, C, F * T, st, res, T);
     }
 }
 // conv / deconv -> InstanceNorm -> PReLU (+ res): the conv's epilogue hands the norm its statistics as per-tile partial
@@ -36,7 +36,7 @@ inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int 
 // the two-kernel sequence for the cumulative-LayerNorm variants and for tile configurations without the epilogue.
 inline bool in_stats_enabled() {
     static const bool on = !(getenv("SE_IN_STATS") && atoi(getenv("SE_IN_STATS")) == 0);
-    return on;
+    return on && !ragged_ctx();      // per-tile partial sums cannot be cut at a row's own frame count
 }
 inline float* in_stats_scratch(int B, int C, int F, int T, hipStream_t st) {
     return reinterpret_cast<float*>(device_scratch(2, (size_t)B * C * F * ((T + 31) / 32) * 2 * sizeof(float), st));

@@ -93,10 +93,13 @@ inline bool first_on_device(bool (&seen)[64]) {
 
 // Engine-lifetime scratch that grows on first use, one buffer per (purpose, device, stream): work that can be in flight
 // at the same time is on different streams (two handles driven asynchronously, one handle's auxiliary streams), work on
-// one stream is ordered - so a buffer is never shared by two running kernels.  Growth synchronises the stream (never on
-// the steady path).
+// one stream is ordered - so a buffer is never shared by two running kernels.
+// A buffer that is outgrown is RETIRED, not freed: a hipGraph captured for a smaller shape keeps the old pointer baked
+// into its kernel nodes (cooperative-LSTM exchange / flags, cLN statistics, InstanceNorm partial sums) and the old
+// buffer is large enough for that shape, so replaying it after a larger shape has grown the slot stays valid.  Capacity
+// at least doubles on growth, so the retired buffers of a slot sum to less than its final size.
 inline char* device_scratch(int purpose, size_t need, hipStream_t s) {
-    struct Slot { char* p = nullptr; size_t cap = 0; };
+    struct Slot { char* p = nullptr; size_t cap = 0; std::vector<char*> retired; };
     static std::map<std::tuple<int, int, hipStream_t>, Slot> slots;
     static std::mutex mu;
     int dev = 0;
@@ -104,12 +107,10 @@ inline char* device_scratch(int purpose, size_t need, hipStream_t s) {
     std::lock_guard<std::mutex> lk(mu);
     Slot& sl = slots[std::make_tuple(purpose, dev, s)];
     if (need > sl.cap) {
-        if (sl.p) {
-            SE_HIP(hipStreamSynchronize(s));
-            SE_HIP(hipFree(sl.p));
-        }
-        SE_HIP(hipMalloc(&sl.p, need));
-        sl.cap = need;
+        if (sl.p) sl.retired.push_back(sl.p);
+        const size_t cap = need > 2 * sl.cap ? need : 2 * sl.cap;
+        SE_HIP(hipMalloc(&sl.p, cap));
+        sl.cap = cap;
     }
     return sl.p;
 }

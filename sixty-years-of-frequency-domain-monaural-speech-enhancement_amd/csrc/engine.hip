@@ -26,6 +26,13 @@ struct se_engine {
     std::vector<GraphEntry> graphs;
     std::vector<std::pair<int, int>> warmed;
     float *stage_in = nullptr, *stage_out = nullptr;
+    // se_enhance_ragged: per-row sizes (len | lpad | tlen | olen, max_batch ints each) go host -> device through a small
+    // ring of pinned slots, so back-to-back calls never wait for each other's copy
+    static constexpr int RAG_SLOTS = 8;
+    int* rag_host = nullptr;       // pinned [RAG_SLOTS][4 * max_batch]
+    int* rag_dev = nullptr;        // device [RAG_SLOTS][4 * max_batch]
+    hipEvent_t rag_ev[RAG_SLOTS] = {};
+    int rag_next = 0;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -34,15 +41,23 @@ static std::string g_create_err;
 
 template <typename F>
 static int guard(se_engine* e, F&& f) {
+    // the engine's device is current while the call runs; the caller's current device is restored on the way out
+    int prev = -1;
+    int rc = 0;
     try {
-        if (e) SE_HIP(hipSetDevice(e->cfg.device));
+        if (e) {
+            SE_HIP(hipGetDevice(&prev));
+            if (prev != e->cfg.device) SE_HIP(hipSetDevice(e->cfg.device));
+            else prev = -1;
+        }
         f();
-        return 0;
     } catch (const std::exception& ex) {
         if (e) e->err = ex.what();
         else g_create_err = ex.what();
-        return 1;
+        rc = 1;
     }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
 }
 
 extern "C" {
@@ -61,12 +76,14 @@ int se_resample(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n_
     });
 }
 
-int32_t se_abi_version(void) { return 1; }
+int32_t se_abi_version(void) { return 2; }
 
 const char* se_last_error(const se_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 
 int se_engine_create(const se_config* cfg, se_engine** out) {
     se_engine* e = nullptr;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     int rc = guard(nullptr, [&] {
         SE_CHECK(cfg && out, "null argument");
         int ndev = 0;
@@ -107,11 +124,14 @@ int se_engine_create(const se_config* cfg, se_engine** out) {
     if (rc && e) {
         delete e;
     }
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     return rc;
 }
 
 int se_engine_destroy(se_engine* e) {
     if (!e) return 0;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
     if (e->frames_scratch) (void)hipFree(e->frames_scratch);
@@ -122,10 +142,15 @@ int se_engine_destroy(se_engine* e) {
         (void)hipEventDestroy(e->ev_fork);
         (void)hipEventDestroy(e->ev_join);
     }
+    if (e->rag_host) (void)hipHostFree(e->rag_host);
+    if (e->rag_dev) (void)hipFree(e->rag_dev);
+    for (auto& ev : e->rag_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     if (e->ctx.arena.base()) gc_unregister_overread_range(e->ctx.arena.base());
     delete e;
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     return 0;
 }
 
@@ -261,6 +286,54 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
         SE_HIP(hipGraphLaunch(ge->exec, st));
         SE_HIP(hipMemcpy2DAsync(wav_out_dev, (size_t)out_pitch * sizeof(float), e->stage_out, (size_t)n_out * sizeof(float),
                                 (size_t)n_out * sizeof(float), batch, hipMemcpyDeviceToDevice, st));
+    });
+}
+
+int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, int32_t batch, const int32_t* lengths,
+                      float* wav_out_dev, int64_t out_pitch, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(e->finalized, "engine not finalized");
+        SE_CHECK(wav_in_dev && wav_out_dev && lengths, "null argument");
+        SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
+        SE_CHECK(e->model->ragged_supported(),
+                 "this model looks ahead in time (non-causal convolutions / attention): batch only clips of equal length");
+        int Lmax = 0;
+        for (int b = 0; b < batch; ++b) {
+            SE_CHECK(lengths[b] >= e->ctx.geom.n_fft && lengths[b] <= e->ctx.max_samples,
+                     "lengths[" + std::to_string(b) + "] outside [n_fft, max_samples]");
+            Lmax = std::max(Lmax, (int)lengths[b]);
+        }
+        SE_CHECK(in_pitch >= Lmax && out_pitch >= e->model->output_samples(Lmax), "row pitch too small");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int MB = e->ctx.max_batch;
+        if (!e->rag_host) {
+            SE_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->rag_host), sizeof(int) * 4 * MB * se_engine::RAG_SLOTS, hipHostMallocDefault));
+            SE_HIP(hipMalloc(reinterpret_cast<void**>(&e->rag_dev), sizeof(int) * 4 * MB * se_engine::RAG_SLOTS));
+            for (auto& ev : e->rag_ev) SE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        const int slot = e->rag_next;
+        e->rag_next = (slot + 1) % se_engine::RAG_SLOTS;
+        SE_HIP(hipEventSynchronize(e->rag_ev[slot]));      // the copy that last used this slot has run (no-op when unused)
+        int* h = e->rag_host + (size_t)slot * 4 * MB;
+        int* d = e->rag_dev + (size_t)slot * 4 * MB;
+        const int hop = e->ctx.geom.hop;
+        for (int b = 0; b < batch; ++b) {
+            const int L = lengths[b], Lp = e->model->padded_samples(L);
+            h[b] = L;
+            h[MB + b] = Lp;
+            h[2 * MB + b] = 1 + Lp / hop;
+            h[3 * MB + b] = (int)e->model->output_samples(L);
+        }
+        SE_HIP(hipMemcpyAsync(d, h, sizeof(int) * 4 * MB, hipMemcpyHostToDevice, st));
+        SE_HIP(hipEventRecord(e->rag_ev[slot], st));
+        e->ctx.prof.reset();
+        Ragged rg{d, d + MB, d + 2 * MB, d + 3 * MB};
+        struct Scope {          // the per-row sizes are visible to the launchers only while this call enqueues work
+            explicit Scope(const Ragged* r) { set_ragged_ctx(r); }
+            ~Scope() { set_ragged_ctx(nullptr); }
+        } scope(&rg);
+        e->model->enhance(wav_in_dev, in_pitch, batch, Lmax, wav_out_dev, out_pitch, st);
     });
 }
 

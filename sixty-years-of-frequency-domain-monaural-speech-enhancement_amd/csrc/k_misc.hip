@@ -1,6 +1,7 @@
 // Elementwise / layout kernels of the decode path (HBM-bound; T-contiguous rows, one pass each).
 #include "kernels.h"
 #include "common.h"
+#include <algorithm>
 
 namespace se {
 
@@ -276,6 +277,48 @@ __device__ __forceinline__ void norm_apply_pass(const float* __restrict__ xp, fl
     }
 }
 
+// Ragged batch: the statistics of row b cover only its own tlen[b] frames of every T-frame line of the plane (the
+// reference decodes each clip alone: InstanceNorm never sees another clip's padding); the normalise pass still covers the
+// whole plane - the tail frames are dead values no valid frame ever reads (every conv on these models is causal in time).
+__global__ __launch_bounds__(256) void instnorm_prelu_ragged_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta,
+                                                                    const float* __restrict__ slope, const float* res, int C,
+                                                                    int P, int T, const int* __restrict__ tlen) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x % C, b = blockIdx.x / C;
+    const int Tb = tlen[b];
+    const float* xp = x + (long)blockIdx.x * P;
+    float* yp = y + (long)blockIdx.x * P;
+    const float* rp = res ? res + (long)blockIdx.x * P : nullptr;
+    double s = 0.0, q = 0.0;
+    {
+        int i = threadIdx.x;
+        for (; i + (NU - 1) * 256 < P; i += NU * 256) {
+            float v[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) v[u] = xp[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const double d = ((i + u * 256) % T < Tb) ? v[u] : 0.f;
+                s += d;
+                q += d * d;
+            }
+        }
+        for (; i < P; i += 256) {
+            const double d = (i % T < Tb) ? xp[i] : 0.f;
+            s += d;
+            q += d * d;
+        }
+    }
+    const double cnt = (double)(P / T) * Tb;
+    const double mu = block_sum_d(s, sh) / cnt;
+    const double var = fmax(block_sum_d(q, sh) / cnt - mu * mu, 0.0);
+    const float rs = (float)(1.0 / sqrt(var + 1e-5)), muf = (float)mu;
+    const float g = gamma[c], bt = beta[c], sl = slope ? slope[c] : 1.f;
+    norm_apply_pass(xp, yp, rp, P, muf, rs, g, bt, sl);
+}
+
 __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ slope, const float* res, int C,
@@ -342,12 +385,20 @@ __global__ __launch_bounds__(256) void instnorm_prelu_stats_kernel(const float* 
 }
 void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, const float* beta, const float* slope,
                                  const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res) {
+    SE_CHECK(!ragged_ctx(), "epilogue statistics cannot be length-masked: ragged batches take the norm's own statistics pass");
     hipLaunchKernelGGL(instnorm_prelu_stats_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, res, stats, nslot,
                        C, P);
     SE_HIP(hipGetLastError());
 }
 void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
-                           int C, int P, hipStream_t s, const float* res) {
+                           int C, int P, hipStream_t s, const float* res, int T) {
+    if (const Ragged* rg = ragged_ctx()) {
+        SE_CHECK(T > 0 && P % T == 0, "ragged InstanceNorm needs the frame count of the plane's lines");
+        hipLaunchKernelGGL(instnorm_prelu_ragged_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, res, C, P, T,
+                           rg->tlen);
+        SE_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(instnorm_prelu_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, res, C, P);
     SE_HIP(hipGetLastError());
 }
@@ -356,10 +407,11 @@ void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const f
 __global__ __launch_bounds__(256) void tcm_head_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ slope, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ fir, int K,
-                                                       int C, int T) {
+                                                       int C, int T, const int* __restrict__ tlen) {
     extern __shared__ float row[];      // [T] normalised row, then FIR input
     __shared__ double sh[4];
     const int c = blockIdx.x % C;
+    const int Ts = tlen ? tlen[blockIdx.x / C] : T;      // frames the statistics cover (ragged batch: the row's own)
     const float* xp = x + (long)blockIdx.x * T;
     float* yp = y + (long)blockIdx.x * T;
     const float sl = slope[c];
@@ -371,23 +423,23 @@ __global__ __launch_bounds__(256) void tcm_head_kernel(const float* __restrict__
             const float a0 = v0 >= 0.f ? v0 : sl * v0, a1 = v1 >= 0.f ? v1 : sl * v1;
             row[i] = a0;
             row[i + 256] = a1;
-            s += a0;
-            s += a1;
+            if (i < Ts) s += a0;
+            if (i + 256 < Ts) s += a1;
         }
         for (; i < T; i += 256) {
             float a = xp[i];
             a = a >= 0.f ? a : sl * a;
             row[i] = a;
-            s += a;
+            if (i < Ts) s += a;
         }
     }
-    const double mu = block_sum_d(s, sh) / T;
+    const double mu = block_sum_d(s, sh) / Ts;
     double vv = 0.0;
-    for (int i = threadIdx.x; i < T; i += 256) {
+    for (int i = threadIdx.x; i < Ts; i += 256) {
         const double d = row[i] - mu;
         vv += d * d;
     }
-    const double var = block_sum_d(vv, sh) / T;
+    const double var = block_sum_d(vv, sh) / Ts;
     const float rs = (float)(1.0 / sqrt(var + 1e-5)), muf = (float)mu, g = gamma[c], bt = beta[c];
     for (int i = threadIdx.x; i < T; i += 256) row[i] = (row[i] - muf) * rs * g + bt;
     __syncthreads();
@@ -408,7 +460,9 @@ __global__ __launch_bounds__(256) void tcm_head_kernel(const float* __restrict__
 void launch_tcm_head(const float* x, float* y, const float* slope, const float* gamma, const float* beta,
                      const float* fir, int K, int B, int C, int T, hipStream_t s) {
     SE_CHECK((size_t)T * 4 <= 60000, "TCM row too long for the LDS-resident head kernel");
-    hipLaunchKernelGGL(tcm_head_kernel, dim3(B * C), dim3(256), (size_t)T * 4, s, x, y, slope, gamma, beta, fir, K, C, T);
+    const Ragged* rg = ragged_ctx();
+    hipLaunchKernelGGL(tcm_head_kernel, dim3(B * C), dim3(256), (size_t)T * 4, s, x, y, slope, gamma, beta, fir, K, C, T,
+                       rg ? rg->tlen : nullptr);
     SE_HIP(hipGetLastError());
 }
 
@@ -535,6 +589,27 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
 }
 void launch_add(const float* a, const float* b, float* y, long n, hipStream_t s) {
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, y, n);
+    SE_HIP(hipGetLastError());
+}
+
+// ragged batch: x[b][r][t] = 0 for t >= tlen[b]  (rows r of T frames).  Operators that look a bounded number of frames
+// ahead see the zeros a per-clip decode has past its end (DCCRN's decoder: one frame per transposed conv, the
+// `out[..., 1:]` crop of DCCRN_cprs.py:199); only the tail is touched.
+__global__ __launch_bounds__(256) void zero_tail_kernel(float* __restrict__ x, long rows, int T, const int* __restrict__ tlen) {
+    const int b = blockIdx.y, Tb = tlen[b];
+    const int n = T - Tb;
+    if (n <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        float* xp = x + ((long)b * rows + r) * T + Tb;
+        for (int i = lane; i < n; i += 64) xp[i] = 0.f;
+    }
+}
+void launch_zero_tail(float* x, int B, long rows, int T, hipStream_t s) {
+    const Ragged* rg = ragged_ctx();
+    if (!rg) return;
+    const unsigned gx = (unsigned)std::min<long>((rows + 3) / 4, 4096);
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(gx, B), dim3(256), 0, s, x, rows, T, rg->tlen);
     SE_HIP(hipGetLastError());
 }
 

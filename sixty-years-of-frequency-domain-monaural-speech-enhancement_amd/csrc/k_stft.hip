@@ -19,6 +19,10 @@
 
 namespace se {
 
+static thread_local const Ragged* g_ragged = nullptr;
+const Ragged* ragged_ctx() { return g_ragged; }
+void set_ragged_ctx(const Ragged* r) { g_ragged = r; }
+
 constexpr int FPB = 16;  // frames per block
 constexpr int PPB = 8;   // complex transforms per block: frames are transformed in pairs (two-for-one real FFT)
 
@@ -122,6 +126,7 @@ __device__ __forceinline__ void init_tables(float2* tw, float* win, int win_len,
 struct StftArgs {
     const float* wav; long pitch; int B, L, Lpad; const float* c_scale; float p_in;
     float* spec; float* mag; int T, Tp, hop, win;
+    const int *len, *lpad, *tlen;      // ragged batch: per-row L, Lpad, T (else null)
 };
 
 // two-for-one: a block owns 16 consecutive frames as 8 complex transforms z = x_{2p} + i x_{2p+1}
@@ -139,22 +144,52 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
     __syncthreads();
     const float c = a.c_scale ? a.c_scale[b] : 1.f;
     const float* x = a.wav + (long)b * a.pitch;
+    // ragged batch: this row's own length, padded length and frame count; frames in [Tb, T) come out as zeros
+    const int L = a.len ? a.len[b] : a.L, Lpad = a.lpad ? a.lpad[b] : a.Lpad, Tb = a.tlen ? a.tlen[b] : a.T;
     auto sample = [&](int t, int n) {
         float v = 0.f;
-        if (t < a.T) {
+        if (t < Tb) {
             int idx = t * a.hop + n - N / 2;
             if (idx < 0) idx = -idx;
-            if (idx >= a.Lpad) idx = 2 * (a.Lpad - 1) - idx;
-            if (idx >= 0 && idx < a.L) v = x[idx] * c * win[n];
+            if (idx >= Lpad) idx = 2 * (Lpad - 1) - idx;
+            if (idx >= 0 && idx < L) v = x[idx] * c * win[n];
         }
         return v;
     };
+    if (t0 >= Tb) {            // ragged batch: the block lies wholly in the row's zero tail (block-uniform)
+        for (int idx = tid; idx < F * FPB; idx += 256) {
+            const int t = t0 + (idx & (FPB - 1)), k = idx >> 4;
+            if (t >= a.T) continue;
+            if (a.spec) {
+                a.spec[(((long)b * 2 + 0) * F + k) * a.Tp + t] = 0.f;
+                a.spec[(((long)b * 2 + 1) * F + k) * a.Tp + t] = 0.f;
+            }
+            if (a.mag) a.mag[((long)b * F + k) * a.Tp + t] = 0.f;
+        }
+        return;
+    }
+    // A frame whose windowed samples are all exactly zero (digital silence) must transform to EXACT zeros: the decode
+    // scripts take atan2 of the spectrum (np.angle(0) = 0) and the mapping models re-use that phase at full magnitude
+    // (LSTM/lstm_decode_vb.py:47-49, CTSNet/two_stage_com_decode_vb.py:80-81).  The two-for-one split of a (silent,
+    // non-silent) frame pair would leave rounding residue of the partner's spectrum - a random phase - in the silent one.
+    __shared__ int nzflag[FPB];
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
         const int pi = wave + 4 * rep, t = t0 + 2 * pi;
         float2* b0 = bufs + (pi * 2) * N;
         float2* b1 = b0 + N;
-        for (int n = lane; n < N; n += 64) b0[n] = make_float2(sample(t, n), sample(t + 1, n));
+        bool nz0 = false, nz1 = false;
+        for (int n = lane; n < N; n += 64) {
+            const float2 v = make_float2(sample(t, n), sample(t + 1, n));
+            nz0 |= (v.x != 0.f);
+            nz1 |= (v.y != 0.f);
+            b0[n] = v;
+        }
+        const bool a0 = __any(nz0), a1 = __any(nz1);
+        if (lane == 0) {
+            nzflag[2 * pi] = a0;
+            nzflag[2 * pi + 1] = a1;
+        }
         __syncthreads();
         fft_frame<N, false>(b0, b1, tw, lane);
     }
@@ -169,6 +204,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
         float2 v;
         if (fi & 1) v = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));      // (Z[k] - conj Z[N-k]) / (2i)
         else v = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));              // (Z[k] + conj Z[N-k]) / 2
+        if (!nzflag[fi]) v = make_float2(0.f, 0.f);                                    // silent frame: exact zeros
         const float m = sqrtf(v.x * v.x + v.y * v.y);
         float mp = m;
         if (a.p_in != 1.f) {
@@ -187,6 +223,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
 
 struct IstftArgs {
     const float* spec; int B, T, Tp; float* frames; int win;
+    const int* tlen;      // ragged batch: frames of row b (else null)
 };
 
 // inverse two-for-one: Z = X_{2p} + i X_{2p+1} on the Hermitian-extended spectra -> z = x_{2p} + i x_{2p+1}
@@ -199,6 +236,8 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
     float* win = reinterpret_cast<float*>(bufs + PPB * 2 * N);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, t0 = blockIdx.x * FPB;
+    const int Tb = a.tlen ? a.tlen[b] : a.T;
+    if (t0 >= Tb) return;                                   // ragged batch: nothing of this row left (block-uniform)
     init_tables<N>(tw, win, a.win, tid);
     // 8 lanes x 2 frames = 16 consecutive frames of one bin (64 contiguous bytes per plane)
     for (int idx = tid; idx < F * PPB; idx += 256) {
@@ -207,8 +246,8 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
         float2 xa = make_float2(0.f, 0.f), xb = make_float2(0.f, 0.f);
         const float* re = a.spec + (((long)b * 2 + 0) * F + k) * a.Tp;
         const float* im = a.spec + (((long)b * 2 + 1) * F + k) * a.Tp;
-        if (t < a.T) xa = make_float2(re[t], im[t]);
-        if (t + 1 < a.T) xb = make_float2(re[t + 1], im[t + 1]);
+        if (t < Tb) xa = make_float2(re[t], im[t]);
+        if (t + 1 < Tb) xb = make_float2(re[t + 1], im[t + 1]);
         float2* b0 = bufs + (pi * 2) * N;
         if (k == 0 || k == N / 2) {
             b0[k] = make_float2(xa.x, xb.x);                // C2R ignores the imaginary part of DC / Nyquist
@@ -228,7 +267,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
     for (int idx = tid; idx < N * FPB; idx += 256) {
         const int fi = idx / N, n = idx - fi * N;
         const int t = t0 + fi;
-        if (t >= a.T) continue;
+        if (t >= Tb) continue;
         const float2 z = (bufs + ((fi >> 1) * 2) * N + ((N == 512) ? N : 0))[n];
         a.frames[((long)b * a.T + t) * N + n] = ((fi & 1) ? z.y : z.x) * invN * win[n];
     }
@@ -236,17 +275,23 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
 
 struct OlaArgs {
     const float* frames; int B, T, N, hop, win; const float* c_scale; float* out; long out_pitch; int Lout;
+    const int *tlen, *olen;     // ragged batch: frames / output samples of row b (else null); samples in [olen, Lout) = 0
 };
 
 __global__ void ola_kernel(const OlaArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (i >= a.Lout) return;
+    const int Tb = a.tlen ? a.tlen[b] : a.T;
+    if (a.olen && i >= a.olen[b]) {
+        a.out[(long)b * a.out_pitch + i] = 0.f;
+        return;
+    }
     const int pos = i + a.N / 2;
     int tlo = (pos - a.N + a.hop) / a.hop;       // ceil((pos - N + 1) / hop) for pos-N+1 possibly negative
     if (pos - a.N + 1 <= 0) tlo = 0;
     int thi = pos / a.hop;
-    if (thi > a.T - 1) thi = a.T - 1;
+    if (thi > Tb - 1) thi = Tb - 1;
     const int left = (a.N - a.win) / 2;
     float acc = 0.f, env = 0.f;
     for (int t = tlo; t <= thi; ++t) {
@@ -262,8 +307,10 @@ __global__ void ola_kernel(const OlaArgs a) {
     a.out[(long)b * a.out_pitch + i] = y;
 }
 
-__global__ __launch_bounds__(256) void rms_scale_kernel(const float* wav, int L, long pitch, float* c_out) {
+__global__ __launch_bounds__(256) void rms_scale_kernel(const float* wav, int L, long pitch, float* c_out,
+                                                        const int* len) {
     const int b = blockIdx.x;
+    if (len) L = len[b];
     const float* x = wav + (long)b * pitch;
     double s = 0.0;
     for (int i = threadIdx.x; i < L; i += 256) {
@@ -281,7 +328,8 @@ __global__ __launch_bounds__(256) void rms_scale_kernel(const float* wav, int L,
 }
 
 void launch_rms_scale(const float* wav, int B, int L, long pitch, float* c_out, hipStream_t s) {
-    hipLaunchKernelGGL(rms_scale_kernel, dim3(B), dim3(256), 0, s, wav, L, pitch, c_out);
+    const Ragged* rg = ragged_ctx();
+    hipLaunchKernelGGL(rms_scale_kernel, dim3(B), dim3(256), 0, s, wav, L, pitch, c_out, rg ? rg->len : nullptr);
     SE_HIP(hipGetLastError());
 }
 
@@ -296,7 +344,9 @@ static void set_lds_attr(K kernel, size_t bytes) {
 
 void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, int Lpad, const float* c_scale,
                  float p_in, float* spec_ri, float* mag, int T, int Tp, hipStream_t s) {
-    StftArgs a{wav, pitch, B, L, Lpad, c_scale, p_in, spec_ri, mag, T, Tp, g.hop, g.win};
+    const Ragged* rg = ragged_ctx();
+    StftArgs a{wav, pitch, B, L, Lpad, c_scale, p_in, spec_ri, mag, T, Tp, g.hop, g.win,
+               rg ? rg->len : nullptr, rg ? rg->lpad : nullptr, rg ? rg->tlen : nullptr};
     dim3 grid((T + FPB - 1) / FPB, B);
     if (g.n_fft == 512) {
         static bool seen[64] = {};
@@ -314,7 +364,8 @@ void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, 
 
 void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* frames, const float* c_scale,
                   float* wav_out, long out_pitch, int Lout, hipStream_t s) {
-    IstftArgs a{spec_ri, B, T, Tp, frames, g.win};
+    const Ragged* rg = ragged_ctx();
+    IstftArgs a{spec_ri, B, T, Tp, frames, g.win, rg ? rg->tlen : nullptr};
     dim3 grid((T + FPB - 1) / FPB, B);
     if (g.n_fft == 512) {
         static bool seen[64] = {};
@@ -328,7 +379,8 @@ void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp,
         SE_CHECK(false, "unsupported n_fft");
     }
     SE_HIP(hipGetLastError());
-    OlaArgs o{frames, B, T, g.n_fft, g.hop, g.win, c_scale, wav_out, out_pitch, Lout};
+    OlaArgs o{frames, B, T, g.n_fft, g.hop, g.win, c_scale, wav_out, out_pitch, Lout, rg ? rg->tlen : nullptr,
+              rg ? rg->olen : nullptr};
     hipLaunchKernelGGL(ola_kernel, dim3((Lout + 255) / 256, B), dim3(256), 0, s, o);
     SE_HIP(hipGetLastError());
 }

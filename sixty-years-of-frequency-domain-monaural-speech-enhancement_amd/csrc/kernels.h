@@ -5,6 +5,20 @@
 
 namespace se {
 
+// Ragged batches (se_enhance_ragged): rows of one call have different lengths.  The engine publishes the per-row sizes
+// for the duration of Model::enhance(); every launcher whose arithmetic depends on the utterance length reads them:
+// unit-RMS scale, STFT (reflect pad at the row's own end, frames >= tlen[b] written as zeros), iSTFT / overlap-add,
+// and every statistic taken over the whole utterance (InstanceNorm, the TCM head, FullSubNet's utterance means).
+// Everything else on the path is causal in time, so frames >= tlen[b] never reach a valid frame.
+struct Ragged {
+    const int* len = nullptr;    // device [B]: samples of row b
+    const int* lpad = nullptr;   // device [B]: samples the STFT sees (decode scripts that tail-pad to a hop multiple)
+    const int* tlen = nullptr;   // device [B]: frames of row b
+    const int* olen = nullptr;   // device [B]: output samples of row b
+};
+const Ragged* ragged_ctx();              // nullptr: equal-length batch
+void set_ragged_ctx(const Ragged* r);    // thread-local (a handle is driven by one thread at a time)
+
 struct StftGeom {
     int n_fft, hop, win;   // win <= n_fft (window centred in n_fft, torch.stft convention)
     int F() const { return n_fft / 2 + 1; }
@@ -41,13 +55,17 @@ void launch_copy4(const float* in, float* out, int B, int C, int I, int J, long 
                   long so_b, long so_c, long so_i, hipStream_t s);
 
 void launch_fill(float* p, long n, float v, hipStream_t s);
+// ragged batches only (no-op otherwise): x [B][rows][T], frames t >= tlen[b] of every row set to zero
+void launch_zero_tail(float* x, int B, long rows, int T, hipStream_t s);
 
 // nn.InstanceNorm2d / InstanceNorm1d (affine, per-utterance statistics, biased variance, eps 1e-5) over the contiguous
 // plane of P values of every (b, c), optionally followed by a per-channel PReLU; in place allowed.
 //   x [B][C][P];  gamma/beta [C];  slope [C] or null
 //   res (optional, [B][C][P], may alias y): y = PReLU(norm(x)) + res
+// T (ragged batches only): frames per line of the plane (P = lines * T), so that the statistics can stop at the row's
+// own frame count
 void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
-                           int C, int P, hipStream_t s, const float* res = nullptr);
+                           int C, int P, hipStream_t s, const float* res = nullptr, int T = 0);
 // statistics from the producing conv (nslot (sum, sum of squares) pairs per (b, c) plane, GCParams::stats)
 void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, const float* beta, const float* slope,
                                  const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res = nullptr);

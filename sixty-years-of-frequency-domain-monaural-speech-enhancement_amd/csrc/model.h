@@ -72,6 +72,9 @@ class Model {
     // samples the STFT sees (decode scripts that tail-pad to a hop multiple)
     virtual int padded_samples(int L) const { return L; }
     int num_frames(int L) const { return 1 + padded_samples(L) / ctx.geom.hop; }
+    // false: the model has operators that look ahead in time beyond a fixed, zero-padded look-ahead (Uformer: non-causal
+    // dilated convolutions and full self-attention over time), so rows of different lengths cannot share a call
+    virtual bool ragged_supported() const { return true; }
     // false: enhance() forks onto auxiliary streams and is not replayed from a captured hipGraph (SE_CFG_GRAPHS)
     virtual bool graph_capturable() const { return true; }
 

@@ -232,6 +232,9 @@ class Dccrn final : public Model {
         int F = 256;
         for (int k = 0; k < NL; ++k) {
             run_conv(enc[k], x, nullptr, b.E[k], KN[k + 1], F / 2, B, T, T, st, pf);
+            // ragged batch: the decoder looks one frame ahead per layer (`out[..., 1:]`, :199) into its (previous, skip)
+            // inputs, and a clip decoded alone has zeros past its last frame
+            launch_zero_tail(b.E[k], B, (long)KN[k + 1] * (F / 2), T, st);
             F /= 2;
             x = act4(b.E[k], KN[k + 1], F, T);
         }
@@ -268,6 +271,7 @@ class Dccrn final : public Model {
         for (int part = 0; part < 2; ++part)
             launch_transpose_akt(b.P + (size_t)part * 512 * B, b.D[0] + (size_t)part * 512 * T, T, 512, B, 1024L * B, B,
                                  1024L * T, T, st);
+        launch_zero_tail(b.D[0], B, 1024L, T, st);
         // ---- decoder with two-source skips (:196-199)
         F = 4;
         for (int k = 0; k < NL; ++k) {
@@ -275,6 +279,7 @@ class Dccrn final : public Model {
             Act4 a0 = act4(b.D[k], cin, F, T);
             Act4 a1 = act4(b.E[NL - 1 - k], cin, F, T);
             run_deconv(dec[k], a0, &a1, b.D[k + 1], KN[NL - k - 1], 2 * F, B, T, T, st, pf);
+            if (k + 1 < NL) launch_zero_tail(b.D[k + 1], B, (long)KN[NL - k - 1] * (2 * F), T, st);
             F *= 2;
         }
     }

@@ -22,9 +22,11 @@ namespace {
 constexpr int NFFT = 512, HOP = 256, NBIN = 257, LA = 2, SBN = 15, SBW = 2 * SBN + 2;   // 31 noisy + 1 full-band
 
 // sum over (f, t) of mag[b][f][t]  ->  mu[b] = sum / (F * (T + LA))   (the look-ahead pad frames are zeros)
+// ragged batch (tlen != null): frames >= tlen[b] of mag are zeros (the STFT wrote them), so only the denominator changes
 __global__ __launch_bounds__(256) void fsn_mean_kernel(const float* __restrict__ mag, int n, float denom,
-                                                       float* __restrict__ mu) {
+                                                       float* __restrict__ mu, const int* __restrict__ tlen) {
     const int b = blockIdx.x;
+    if (tlen) denom = (float)NBIN * (tlen[b] + LA);
     const float* x = mag + (long)b * n;
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += x[i];
@@ -67,15 +69,18 @@ __global__ __launch_bounds__(256) void fsn_build_sb_kernel(const float* __restri
 // (per-block partials in a fixed order, then a fixed-order fp64 sum) - no float atomics, so repeated decodes are
 // bit-identical
 constexpr int FSN_SUM_BLOCKS = 1024;
+// ragged batch: rows are (t, k, n) t-major; utterance b only counts its own tlen[b] + LA frames
 __global__ __launch_bounds__(256) void fsn_colsum_kernel(const float* __restrict__ x, long rows, int B,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, const int* __restrict__ tlen) {
     __shared__ float sh[256];
     // thread handles column (tid % B) of rows tid / B + k * (256 / B)
     const int per = 256 / B;
     const int b = threadIdx.x % B, r0 = threadIdx.x / B;
     float s = 0.f;
-    if (per > 0 && r0 < per)
-        for (long r = (long)blockIdx.x * per + r0; r < rows; r += (long)gridDim.x * per) s += x[r * B + b];
+    if (per > 0 && r0 < per) {
+        const long rmax = tlen ? (long)(tlen[b] + LA) * SBW * NBIN : rows;
+        for (long r = (long)blockIdx.x * per + r0; r < rmax; r += (long)gridDim.x * per) s += x[r * B + b];
+    }
     sh[threadIdx.x] = s;
     __syncthreads();
     if (per > 0 && r0 == 0) {
@@ -84,9 +89,11 @@ __global__ __launch_bounds__(256) void fsn_colsum_kernel(const float* __restrict
         part[(long)blockIdx.x * B + b] = t;
     }
 }
-__global__ void fsn_finish_mean_kernel(const float* __restrict__ part, float* __restrict__ mu, float denom, int B) {
+__global__ void fsn_finish_mean_kernel(const float* __restrict__ part, float* __restrict__ mu, float denom, int B,
+                                       const int* __restrict__ tlen) {
     const int b = threadIdx.x;
     if (b >= B) return;
+    if (tlen) denom = (float)(tlen[b] + LA) * SBW * NBIN;
     double s = 0.0;
     for (int k = 0; k < FSN_SUM_BLOCKS; ++k) s += part[(long)k * B + b];
     mu[b] = (float)(s / denom);
@@ -218,7 +225,9 @@ class FullSubNet final : public Model {
         const int B = b.B, T = b.T, Tp = T + LA, S = NBIN * B;
         Profiler* pf = &ctx.prof;
         // ---- full-band model (model.py:84-85): utterance-mean normalisation, LSTM(257->512)x2, Linear + ReLU
-        hipLaunchKernelGGL(fsn_mean_kernel, dim3(B), dim3(256), 0, st, mag, NBIN * T, (float)NBIN * Tp, b.mu);
+        const Ragged* rg = ragged_ctx();
+        const int* tlen = rg ? rg->tlen : nullptr;
+        hipLaunchKernelGGL(fsn_mean_kernel, dim3(B), dim3(256), 0, st, mag, NBIN * T, (float)NBIN * Tp, b.mu, tlen);
         launch_fill(b.magT + (size_t)T * S, (long)LA * S, 0.f, st);                                // look-ahead pad :79 (a kernel, not a memset node: graph-replay safe)
         launch_transpose_akt(mag, b.magT, B, NBIN, T, (long)NBIN * T, T, (long)NBIN * B, B, st);
         const long nfb = (long)Tp * S;
@@ -230,8 +239,8 @@ class FullSubNet final : public Model {
         hipLaunchKernelGGL(fsn_build_sb_kernel, dim3((S + 255) / 256, SBW, Tp), dim3(256), 0, st, b.magT, b.fbo, b.sb, B);
         const long rows = (long)Tp * SBW * NBIN;
         SE_CHECK(B <= 256, "FullSubNet batch per call is limited to 256 utterances");
-        hipLaunchKernelGGL(fsn_colsum_kernel, dim3(FSN_SUM_BLOCKS), dim3(256), 0, st, b.sb, rows, B, b.part);
-        hipLaunchKernelGGL(fsn_finish_mean_kernel, dim3(1), dim3(256), 0, st, b.part, b.mu2, (float)rows, B);
+        hipLaunchKernelGGL(fsn_colsum_kernel, dim3(FSN_SUM_BLOCKS), dim3(256), 0, st, b.sb, rows, B, b.part, tlen);
+        hipLaunchKernelGGL(fsn_finish_mean_kernel, dim3(1), dim3(256), 0, st, b.part, b.mu2, (float)rows, B, tlen);
         const long nsb = rows * B;
         hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, st, b.sb, b.sb, nsb, B, b.mu2);
         SE_HIP(hipGetLastError());

@@ -383,6 +383,7 @@ class Uformer final : public Model {
         lnC.free();
         lnR.free();
     }
+    bool ragged_supported() const override { return false; }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, WIN}; }
     int64_t output_samples(int L) const override { return (int64_t)HOP * (L / HOP); }   // istft without length (:276)
 

@@ -42,10 +42,20 @@ class Engine:
         except Exception:
             pass
 
-    @staticmethod
-    def _stream():
+    def _stream(self):
+        """torch's current stream of THIS engine's device (not of torch's current device)."""
         import torch
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_tensor(self, t, what, dim=None):
+        import torch
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise EngineError(f"{what}: expected a float32 cuda tensor, got {t.dtype} on {t.device}")
+        if t.device.index != self.device:
+            raise EngineError(f"{what}: tensor on cuda:{t.device.index} but the engine lives on cuda:{self.device}")
+        if dim is not None and (t.dim() != dim or t.stride(-1) != 1):
+            raise EngineError(f"{what}: expected a {dim}-D tensor with unit inner stride, got shape {tuple(t.shape)} "
+                              f"strides {t.stride()}")
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd):
@@ -67,7 +77,8 @@ class Engine:
     # ------------------------------------------------------------------ compute (torch tensors on the GPU)
     def forward(self, x, out_shape=None):
         import torch
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        self._check_tensor(x, 'forward input')
+        assert x.is_contiguous()
         out = torch.empty(out_shape or x.shape, dtype=torch.float32, device=x.device)
         shape = (C.c_int64 * x.dim())(*x.shape)
         self._check(self._lib.se_forward(self._h, C.c_void_p(x.data_ptr()), shape, x.dim(),
@@ -86,16 +97,43 @@ class Engine:
     def enhance_batch(self, wav, out=None):
         """wav [B, L] float32 cuda tensor -> [B, output_samples(L)]."""
         import torch
-        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.stride(1) == 1
+        self._check_tensor(wav, 'enhance_batch input', 2)
         B, L = wav.shape
         n_out = self.output_samples(L)
         if out is None:
             out = torch.empty((B, n_out), dtype=torch.float32, device=wav.device)
+        else:
+            self._check_tensor(out, 'enhance_batch output', 2)
+            if out.shape[0] != B or out.shape[1] < n_out:
+                raise EngineError(f"enhance_batch output: need [{B}, >= {n_out}], got {tuple(out.shape)}")
         # the stride of a size-1 dimension is arbitrary in torch / numpy: a single row has pitch L
         in_pitch = wav.stride(0) if B > 1 else L
         out_pitch = out.stride(0) if B > 1 else n_out
         self._check(self._lib.se_enhance_batch(self._h, C.c_void_p(wav.data_ptr()), in_pitch, B, L,
                                                C.c_void_p(out.data_ptr()), out_pitch, self._stream()))
+        return out
+
+    def enhance_ragged(self, wav, lengths, out=None):
+        """wav [B, >= max(lengths)] float32 cuda tensor, lengths: B sample counts (host ints) ->
+        [B, output_samples(max(lengths))]; row b holds output_samples(lengths[b]) samples, then zeros."""
+        import torch
+        self._check_tensor(wav, 'enhance_ragged input', 2)
+        B = wav.shape[0]
+        lengths = [int(n) for n in lengths]
+        if len(lengths) != B or max(lengths) > wav.shape[1]:
+            raise EngineError(f"enhance_ragged: {len(lengths)} lengths (max {max(lengths)}) for a {tuple(wav.shape)} batch")
+        n_out = self.output_samples(max(lengths))
+        if out is None:
+            out = torch.empty((B, n_out), dtype=torch.float32, device=wav.device)
+        else:
+            self._check_tensor(out, 'enhance_ragged output', 2)
+            if out.shape[0] != B or out.shape[1] < n_out:
+                raise EngineError(f"enhance_ragged output: need [{B}, >= {n_out}], got {tuple(out.shape)}")
+        in_pitch = wav.stride(0) if B > 1 else wav.shape[1]
+        out_pitch = out.stride(0) if B > 1 else out.shape[1]
+        arr = (C.c_int32 * B)(*lengths)
+        self._check(self._lib.se_enhance_ragged(self._h, C.c_void_p(wav.data_ptr()), in_pitch, B, arr,
+                                                C.c_void_p(out.data_ptr()), out_pitch, self._stream()))
         return out
 
     # ------------------------------------------------------------------ stage hooks

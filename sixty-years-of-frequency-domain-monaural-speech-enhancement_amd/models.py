@@ -69,6 +69,9 @@ class _EngineModule:
     def enhance_batch(self, wav):
         return self.engine.enhance_batch(wav)
 
+    def enhance_ragged(self, wav, lengths):
+        return self.engine.enhance_ragged(wav, lengths)
+
 
 class DCCRN(_EngineModule):
     """DCCRN/DCCRN_cprs.py:8 as built by DCCRN/dccrn_decode_vb.py:11.  forward: [B,2,257,T] -> [B,2,257,T]."""
@@ -191,6 +194,9 @@ class CTSNet:
 
     def enhance_batch(self, wav):
         return self.engine.enhance_batch(wav)
+
+    def enhance_ragged(self, wav, lengths):
+        return self.engine.enhance_ragged(wav, lengths)
 
 
 class TaylorSENet(_EngineModule):

@@ -85,6 +85,33 @@ def test_graph_replay_matches_eager(name):
             assert np.array_equal(ye, yg), (name, rep, B, L, np.abs(ye - yg).max())
 
 
+@pytest.mark.parametrize('name', ['lstm', 'ctsnet_new_like'])
+def test_graph_replay_survives_scratch_growth(name):
+    """captured graphs bake in the pointers of the lazily grown scratch buffers (cooperative-LSTM exchange /
+    flags, cLN statistics, InstanceNorm partial sums).  Capture a SMALL shape first, then send a larger shape (its eager
+    warm-up grows those slots), then replay the small graph: it must still reproduce the eager result bit for bit."""
+    torch = _torch()
+    from se_amd import models_new  # noqa: F401
+    from se_amd.models import MODEL_CLASSES
+    key, seed = ('lstm', 11) if name == 'lstm' else ('taylorsenet_new', 19)
+    eager = MODEL_CLASSES[key](max_batch=4, max_samples=8000).load_synthetic(seed)
+    graph = MODEL_CLASSES[key](max_batch=4, max_samples=8000, graphs=True).load_synthetic(seed)
+
+    def clips(B, L, s0):
+        return torch.from_numpy(np.stack([synth.synth_clip(s0 + b, 'speech', L) for b in range(B)])).cuda()
+    small = [clips(1, 2000, 40 + 3 * i) for i in range(4)]
+    big = [clips(4, 8000, 80 + 5 * i) for i in range(3)]
+    want_small = [eager.enhance_batch(x).clone() for x in small]
+    want_big = [eager.enhance_batch(x).clone() for x in big]
+    for i in range(3):                                   # eager warm-up, capture, first replay of the small shape
+        assert torch.equal(graph.enhance_batch(small[i]), want_small[i])
+    for i in range(3):                                   # larger shape: grows every lazily sized scratch slot
+        assert torch.equal(graph.enhance_batch(big[i]), want_big[i])
+    for i in range(4):                                   # the small graph again, after its scratch was outgrown
+        assert torch.equal(graph.enhance_batch(small[i]), want_small[i]), (name, i)
+    torch.cuda.synchronize()
+
+
 def test_graph_replay_is_actually_captured():
     """The replay path must really run from an instantiated graph for a capturable model (not silently stay eager):
     the C ABI exposes no graph state, so this checks the side channel - a third call on fresh tensors is bit-identical

@@ -76,7 +76,12 @@ def test_stft_istft_hooks_match_oracle_at_size(name, n_fft, hop, win, L):
     refc = np.abs(ref) ** 0.5 * np.exp(1j * np.angle(ref))
     got = spec[:, 0] + 1j * spec[:, 1]
     e = rms(got - refc)
-    assert e < 5e-6 * rms(np.abs(refc)), (name, L, e)
+    # sqrt compression doubles the relative weight of the small bins, where the fp32 FFT's absolute error (set by the
+    # frame's energy) is largest relative to the bin: 1.5e-5 compressed, 3e-6 uncompressed
+    assert e < 1.5e-5 * rms(np.abs(refc)), (name, L, e)
+    spec1 = eng.stft(xd, c=c).cpu().numpy()
+    e1 = rms((spec1[:, 0] + 1j * spec1[:, 1]) - ref)
+    assert e1 < 3e-6 * rms(np.abs(ref)), (name, L, e1)
     # inverse with the de-normalisation: se_istft(spec, c) == istft(spec) / c
     n_out = int(eng.output_samples(L)) if name != 'dccrn' else xs.shape[-1]
     sp = np.ascontiguousarray(np.stack([ref.real, ref.imag], axis=1).astype(np.float32))

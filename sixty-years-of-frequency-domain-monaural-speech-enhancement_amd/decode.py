@@ -3,7 +3,8 @@
 Same argparse surface (`--mix_file_path`, `--esti_clean_file_path` or `--esti_file_path`, `--fs`), same iteration
 order (`os.listdir`), same output file names and PCM_16 WAV output; the per-utterance arithmetic
 (normalise -> STFT -> network -> iSTFT -> de-normalise) runs batched in the HIP engine.  Utterances of equal length
-are decoded together (results are batch-invariant: every utterance is an independent sequence).
+are decoded together (results are batch-invariant: every utterance is an independent sequence); utterances of
+different lengths share a call through se_enhance_ragged (each one still gets exactly its batch-1 result).
 """
 import argparse
 import os
@@ -57,35 +58,81 @@ def _build(model, checkpoint, state_dict, **kw):
     return net
 
 
-def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_batch=64, state_dict=None):
-    """p_in / p_out None -> the exponents checked in at the model's decode script (host class defaults)."""
+RAGGED_MODELS = frozenset(MODELS) - {'uformer'}     # Uformer looks ahead in time without a bound: equal lengths only
+
+
+def plan_batches(lengths, max_batch, batch_samples, ragged):
+    """Group clip indices into engine calls.  ragged: clips sorted by length, consecutive runs of up to `max_batch` clips
+    whose padded size (count x longest) stays within `batch_samples` - the padding a call carries is the spread of
+    lengths inside one run, a few percent on a corpus like VoiceBank+DEMAND (824 clips, ~700 distinct lengths).
+    Not ragged (Uformer): only clips of exactly equal length share a call, as in round 1."""
+    order = sorted(range(len(lengths)), key=lambda i: (lengths[i], i))
+    batches, cur = [], []
+    for i in order:
+        same = not cur or lengths[cur[0]] == lengths[i]
+        fits = len(cur) < max_batch and (len(cur) + 1) * lengths[i] <= max(batch_samples, lengths[i])
+        if cur and not (fits and (ragged or same)):
+            batches.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_batch=64, state_dict=None,
+            batch_samples=64 * 64000):
+    """p_in / p_out None -> the exponents checked in at the model's decode script (host class defaults).
+    Clips of different lengths are decoded together through se_enhance_ragged (each clip gets exactly its batch-1
+    result); under torch.distributed the list of engine calls is sharded contiguously over the ranks (one GPU each),
+    every rank writing its own output files - the reference's `for file_id in file_list` split across GPUs."""
     import torch
+    import torch.distributed as dist
+    from . import shard
     mix, out_dir = args.mix_file_path, getattr(args, 'esti_clean_file_path', None) or args.esti_file_path
     if getattr(args, 'noise_type', None):
         # WSJ0-SI84 grid drivers (`*_decode.py`, e.g. CRN/crn_decode.py:28-32): one (noise, seen/unseen, SNR) cell
         mix = os.path.join(mix, args.noise_type, args.seen, str(args.snr))
         out_dir = os.path.join(out_dir, args.noise_type, args.seen, str(args.snr))
     os.makedirs(out_dir, exist_ok=True)
-    files = os.listdir(mix)
-    clips = {}
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    device = torch.cuda.current_device()
+    files = sorted(os.listdir(mix)) if world > 1 else os.listdir(mix)     # ranks must agree on the order
+    clips = []
     for name in files:
         x, fs = wavio.read_wav(os.path.join(mix, name))
         if fs != 16000:
             # librosa.resample(feat_wav, orig_fs, 16000, fix=True, scale=False), e.g. DCCRN/dccrn_decode_vb.py:26
             x = resample.resample(torch.from_numpy(x.astype(np.float32)).cuda(), fs, 16000).cpu().numpy()
-        clips.setdefault(len(x), []).append((name, x.astype(np.float32)))
-    max_len = max(clips) if clips else 0
-    net = _build(model, checkpoint, state_dict, max_batch=max_batch, max_samples=max(max_len, 512), p_in=p_in, p_out=p_out)
+        clips.append((name, x.astype(np.float32)))
+    if not clips:
+        return 0
+    lengths = [len(x) for _, x in clips]
+    ragged = model in RAGGED_MODELS
+    batches = plan_batches(lengths, max_batch, batch_samples, ragged)
+    lo, hi = shard.shard_range(len(batches), rank, world)
+    batches = batches[lo:hi]
+    if not batches:
+        return 0
+    # the workspace is sized for the calls this rank actually makes, not for max_batch x the longest clip
+    eng_batch = max(len(b) for b in batches)
+    eng_len = max(lengths[i] for b in batches for i in b)
+    net = _build(model, checkpoint, state_dict, device=device, max_batch=eng_batch, max_samples=max(eng_len, 512),
+                 p_in=p_in, p_out=p_out)
     cnt = 0
-    for length, items in clips.items():
-        for i in range(0, len(items), max_batch):
-            chunk = items[i:i + max_batch]
-            wav = torch.from_numpy(np.stack([x for _, x in chunk])).cuda()
-            y = net.enhance_batch(wav).cpu().numpy()
-            for (name, _), yy in zip(chunk, y):
-                wavio.write_wav_pcm16(os.path.join(out_dir, name), yy, args.fs)
-                cnt += 1
-                print(' The %d utterance has been decoded!' % cnt)
+    for b in batches:
+        lens = [lengths[i] for i in b]
+        wav = np.zeros((len(b), max(lens)), np.float32)
+        for r, i in enumerate(b):
+            wav[r, :lens[r]] = clips[i][1]
+        wt = torch.from_numpy(wav).cuda()
+        y = (net.enhance_batch(wt) if min(lens) == max(lens) else net.enhance_ragged(wt, lens)).cpu().numpy()
+        for r, i in enumerate(b):
+            n = net.engine.output_samples(lens[r])
+            wavio.write_wav_pcm16(os.path.join(out_dir, clips[i][0]), y[r, :n], args.fs)
+            cnt += 1
+            print(' The %d utterance has been decoded!' % cnt)
     return cnt
 
 

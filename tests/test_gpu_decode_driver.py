@@ -73,3 +73,31 @@ def test_ctsnet_driver_two_state_dicts(tmp_path):
     y, _ = wavio.read_wav(os.path.join(out, name))
     ref = D.enhance_ctsnet(sd1, sd2, x.astype(np.float64), 0.5, 2.0)
     assert rms(y - ref) < 1e-4 and np.abs(_pcm16(ref) - np.round(y * 32768.0).astype(np.int64)).max() <= 1
+
+
+def test_vb_driver_batches_clips_of_different_lengths(tmp_path):
+    """A VoiceBank+DEMAND-like directory: every clip has its own length.  The driver must decode them in a few ragged
+    calls (not one call per clip) and every file must equal the oracle's per-clip decode.  CTSNet: the model whose
+    InstanceNorm makes zero-padding non-neutral."""
+    from oracle import decode as D
+    mix, out = str(tmp_path / 'noisy'), str(tmp_path / 'enh')
+    lengths = [5000, 3210, 4444, 6100, 3999, 5001, 4800]
+    clips = _write_clips(mix, lengths, 70)
+    sd1 = synth.synth_state_dict(schemas.SCHEMAS['cts_step1'](), 17)
+    sd2 = synth.synth_state_dict(schemas.SCHEMAS['cts_step2'](), 18)
+    args = types.SimpleNamespace(mix_file_path=mix, esti_file_path=out, fs=16000)
+    calls = []
+    from se_amd.engine import Engine
+    orig_r, orig_b = Engine.enhance_ragged, Engine.enhance_batch
+    Engine.enhance_ragged = lambda self, wav, lens, out=None: (calls.append(len(lens)), orig_r(self, wav, lens, out))[1]
+    Engine.enhance_batch = lambda self, wav, out=None: (calls.append(wav.shape[0]), orig_b(self, wav, out))[1]
+    try:
+        assert decode.enhance(args, 'ctsnet', state_dict=(sd1, sd2), max_batch=4, p_in=0.5, p_out=2.0) == len(lengths)
+    finally:
+        Engine.enhance_ragged, Engine.enhance_batch = orig_r, orig_b
+    assert sorted(calls) == [3, 4], calls                       # 7 distinct lengths in two engine calls
+    for name, x in clips.items():
+        y, _ = wavio.read_wav(os.path.join(out, name))
+        ref = D.enhance_ctsnet(sd1, sd2, x.astype(np.float64), 0.5, 2.0)
+        assert len(y) == len(ref) and rms(y - ref) < 1e-4, (name, rms(y - ref))
+        assert np.abs(_pcm16(ref) - np.round(y * 32768.0).astype(np.int64)).max() <= 1

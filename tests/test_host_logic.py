@@ -108,6 +108,22 @@ def test_gather_pipe_gloo(tmp_path):
     assert torch.equal(rows[0], torch.full((3, 4), 400.0)) and torch.equal(rows[1], torch.full((3, 4), 401.0))
 
 
+def test_decode_driver_batch_plan():
+    """se_amd/decode.py:plan_batches - ragged: sorted runs bounded by count and padded size; not ragged: equal lengths."""
+    from se_amd.decode import plan_batches
+    lens = [5000, 3210, 4444, 6100, 3999, 5001, 4800, 3210]
+    b = plan_batches(lens, 3, 10 ** 9, True)
+    assert sorted(i for g in b for i in g) == list(range(len(lens))) and max(len(g) for g in b) <= 3 and len(b) == 3
+    flat = [lens[i] for g in b for i in g]
+    assert flat == sorted(lens)                                  # runs of neighbouring lengths: little padding
+    b = plan_batches(lens, 8, 2 * 5001, True)                    # padded-size budget: count x longest <= 10 002
+    assert all(len(g) * max(lens[i] for i in g) <= 10002 for g in b)
+    b = plan_batches([70000], 4, 64000, True)                    # a clip longer than the budget still gets its own call
+    assert b == [[0]]
+    b = plan_batches(lens, 8, 10 ** 9, False)                    # Uformer: only exactly equal lengths share a call
+    assert sorted(map(sorted, b)) == sorted([[1, 7], [0], [2], [3], [4], [5], [6]])
+
+
 def test_bench_roofline_inputs():
     """bench.py's algorithmic figures: 53.4 GFLOP per DCCRN utterance is SURVEY 8(d)'s number; the algorithmic HBM bytes of
     the 21 tap-table GEMM launches of a step are what `roofline.traffic` (PMC) is compared with; the committed PMC

@@ -29,6 +29,7 @@ import numpy as np  # noqa: E402
 CLIP_SAMPLES = 64000          # 4 s @ 16 kHz
 CLIP_SECONDS = 4.0
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md)
 DCCRN_GFLOP_PER_UTT = 53.4    # algorithmic 2*MAC per 4 s utterance (T = 501)
 
 
@@ -49,11 +50,14 @@ def dccrn_conv_bytes(B, T=501):
 def pmc_traffic():
     """HBM bytes per launch of the gc_kernel family from the committed rocprofv3 --pmc passes of this same command
     (tools/pmc_summary.py -> profiles/r01_pmc_dccrn.json); None when the summary is absent."""
-    p = os.path.join(ROOT, 'profiles', 'r01_pmc_dccrn.json')
-    if not os.path.exists(p):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_dccrn.json')))
+    if not cands:
         return None
-    with open(p) as f:
-        return json.load(f)['gc_family']
+    with open(cands[-1]) as f:            # the latest round's summary
+        d = json.load(f)['gc_family']
+    d['source'] = os.path.relpath(cands[-1], ROOT)
+    return d
 
 
 def _cpu_worker(args):
@@ -85,7 +89,16 @@ def cpu_baseline(seed, p_in, p_out):
     would be spread over a host."""
     import subprocess
     ncpu = os.cpu_count() or 1
-    P, clips = min(ncpu, 64), 2
+    P, clips = ncpu, 2          # every logical CPU of the host gets one single-thread copy of the reference loop
+    cpu_model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('model name'):
+                    cpu_model = ln.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
     env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1',
                HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', str(clips), '--cpu-worker-args',
@@ -95,18 +108,20 @@ def cpu_baseline(seed, p_in, p_out):
     spans = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=max(5.0, 150.0 - (time.time() - t0)))
+            out, _ = p.communicate(timeout=max(5.0, 240.0 - (time.time() - t0)))
             spans.append(float(out.strip().splitlines()[-1]))
         except Exception:           # a worker that is late or died is dropped from the sample (and reaped)
             p.kill()
             p.communicate()
     if not spans:
-        return {"value": None, "unit": "utt/s", "cores": 0, "kind": "port", "sample": "no CPU worker finished within 150 s"}
+        return {"value": None, "unit": "utt/s", "cores": 0, "kind": "port", "sample": "no CPU worker finished within 240 s",
+                "cpu_model": cpu_model}
     wall = max(spans)
     return {"value": round(len(spans) * clips / wall, 3), "unit": "utt/s", "cores": len(spans), "kind": "port",
             "sample": f"{len(spans)} single-thread worker processes x {clips} x 4 s clips, batch-1 loop each, numpy oracle "
                       f"(oracle/decode.py:enhance_dccrn), slowest worker {wall:.1f} s, {time.time() - t0:.1f} s with start-up; "
-                      f"host has {ncpu} logical CPUs",
+                      f"host has {ncpu} logical CPUs ({cpu_model})",
+            "cpu_model": cpu_model, "logical_cpus": ncpu,
             "value_per_worker_best": round(clips / min(spans), 4)}
 
 
@@ -209,6 +224,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = eng.get_profile() if not args.no_profile else None
+    stages = eng.get_stage_profile() if not args.no_profile else None
     eng.set_profiling(False)
 
     if use_pg:
@@ -245,7 +261,7 @@ def main():
                 "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": pmc['traffic_GB_per_launch'] if pmc and B == 256 else None,
                 "traffic_unit": "GB of HBM traffic per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 "
-                                "--pmc passes of this command at batch 256: profiles/r01_pmc_dccrn.md)",
+                                "--pmc passes of this command at batch 256: %s)" % (pmc['source'] if pmc else 'profiles/'),
                 "algorithmic_GB_per_launch": round((rd_b + wr_b) / 1e9 / max(prof['gemm_launches'], 1), 3),
                 "launches_per_step": prof['gemm_launches'],
                 "algorithmic_gflop_per_step": round(prof['gemm_flops'] / 1e9, 1),
@@ -257,6 +273,20 @@ def main():
                 "achieved": round(value / world * DCCRN_GFLOP_PER_UTT / 1e3, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s per GPU (utt/s x 53.4 GFLOP/utt, SURVEY 8(d))",
                 "frac": round(value / world * DCCRN_GFLOP_PER_UTT / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)}
+        if stages:
+            # the HBM-bound front / back-end kernels of the same (last timed) step: algorithmic bytes over
+            # their HIP-event time, against the HBM peak
+            names = {'rms': 'se::rms_partial_kernel + rms_finish_kernel (c = sqrt(L / sum x^2))',
+                     'stft': 'se::stft_kernel<512> (frame, reflect pad, Hann, LDS Stockham FFT, x*c, |X|^p)',
+                     'mask': 'se::dccrn_mask_kernel (E mask + decompress)',
+                     'istft': 'se::istft_ola_kernel<512> (inverse FFT + overlap-add + /c, frames stay in LDS)'}
+            res["roofline_stages"] = [
+                {"stage": k, "kernel": names[k], "bound": "hbm", "ms_per_step": round(v['ms'], 4),
+                 "algorithmic_GB_per_step": round(v['bytes'] / 1e9, 4),
+                 "achieved": round(v['bytes'] / 1e9 / max(v['ms'] * 1e-3, 1e-12), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(v['bytes'] / 1e9 / max(v['ms'] * 1e-3, 1e-12) / HBM_PEAK_GBS, 4),
+                 "share_of_step": round(v['ms'] / (1e3 * dt / args.steps), 5)}
+                for k, v in stages.items() if v['launches'] > 0]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(seed, p_in, p_out)
         print(json.dumps(res), flush=True)

@@ -46,6 +46,17 @@ enum se_model_id {
  * measured on MI355X the replay does not shorten a batch-1 decode (the path is bound by its chain of dependent small
  * kernels, not by launch submission); models that fork onto auxiliary streams (FullSubNet) always run eagerly. */
 #define SE_CFG_GRAPHS 1
+/* DCCRN only.  `DCCRN/DCCRN_cprs.py:6` imports its operators from a third-party `complexnn.py` that is absent from the
+ * reference and unversioned.  The engine follows the published upstream (huyanxin/DeepComplexCRN) as restated in
+ * oracle/_complexnn_recall.py; the two conventions DCCRN_cprs.py itself does not determine can be
+ * flipped here - they are weight-preparation switches at se_engine_finalize, so adopting the real file, should it differ,
+ * is a flag and a fixture regeneration, not a kernel change.
+ *   SE_CFG_DCCRN_BIAS_PER_PART: each part adds its own conv's bias once (real += b_real, imag += b_imag) instead of the
+ *                               two-real-conv combination real += b_real - b_imag, imag += b_real + b_imag
+ *   SE_CFG_DCCRN_PLAIN_CAT    : complex_cat([out, skip], 1) is a plain channel concat ([out_r, out_i, skip_r, skip_i])
+ *                               instead of real halves together, imaginary halves together */
+#define SE_CFG_DCCRN_BIAS_PER_PART 2
+#define SE_CFG_DCCRN_PLAIN_CAT 4
 
 typedef struct se_config {
     int32_t model;        /* enum se_model_id */
@@ -116,11 +127,19 @@ int se_istft(se_engine* e, const float* spec_dev, int32_t batch, int32_t n_frame
 int32_t se_num_frames(const se_engine* e, int32_t n_samples);
 int32_t se_num_bins(const se_engine* e);
 
-/* Wall time of the dominant kernel family (f32-MFMA implicit-GEMM convolution) inside the last
- * se_enhance_batch / se_forward, measured with HIP events on `stream`; enabled by se_set_profiling(e, 1).
+/* Kernel time of the dominant kernel family (f32-MFMA implicit-GEMM convolution) inside the last
+ * se_enhance_batch / se_forward, measured with HIP events on the stream each launch runs on (the caller's `stream` and the
+ * engine's auxiliary streams: launches that overlap on two streams both count); enabled by se_set_profiling(e, 1).
  * Returns accumulated milliseconds and the launch count through the out-params. */
 int se_set_profiling(se_engine* e, int32_t on);
 int se_get_profile(se_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+
+/* The HBM-bound front / back-end kernels of the last profiled se_enhance_batch / se_enhance_ragged, per stage: accumulated
+ * HIP-event milliseconds on `stream`, launch count, and the stage's ALGORITHMIC bytes (what it has to read and write once:
+ * RMS 4L; STFT 4L + 8FT (+4FT magnitudes); mask apply / decompress 16-24 FT; iSTFT + overlap-add 8FT + 4L - per utterance,
+ * SURVEY.md 8(d)).  bytes / ms against the HBM peak is the stage's roofline fraction (bench.py `roofline_stages`). */
+enum se_stage { SE_STAGE_RMS = 0, SE_STAGE_STFT = 1, SE_STAGE_MASK = 2, SE_STAGE_ISTFT = 3 };
+int se_get_stage_profile(se_engine* e, int32_t stage, double* ms, int64_t* launches, double* bytes);
 
 /* Sample-rate conversion in front of the path: librosa.resample(y, sr_in, sr_out, fix=True, scale=False) as called at
  * DCCRN/dccrn_decode_vb.py:26 and LSTM/lstm_decode_vb.py:34 (VoiceBank+DEMAND ships at 48 kHz; the models run at 16 kHz).

@@ -116,7 +116,19 @@ def dpcrn_forward(sd, inpt):
 # third-party `complexnn.py` restated from upstream huyanxin/DeepComplexCRN -
 # PARITY UNPINNED at that boundary, see oracle/_complexnn_recall.py)
 # ----------------------------------------------------------------------------
-def _cplx_conv2d(sd, p, x, pad_f, pad_t):
+# The two conventions DCCRN_cprs.py does not determine, mirrored from include/se_engine.h
+# (SE_CFG_DCCRN_BIAS_PER_PART, SE_CFG_DCCRN_PLAIN_CAT): default = the published upstream as restated in _complexnn_recall.py
+DCCRN_BIAS_PER_PART, DCCRN_PLAIN_CAT = 2, 4
+
+
+def _cplx_combine(f, r, i, wr, br, wi, bi, variant):
+    if variant & DCCRN_BIAS_PER_PART:
+        z = np.zeros_like(br)
+        return f(r, wr, br) - f(i, wi, z), f(r, wi, bi) + f(i, wr, z)
+    return f(r, wr, br) - f(i, wi, bi), f(r, wi, bi) + f(i, wr, br)
+
+
+def _cplx_conv2d(sd, p, x, pad_f, pad_t, variant=0):
     """complexnn.ComplexConv2d(causal=True, complex_axis=1) as called at
     DCCRN_cprs.py:66-72: time padded on the left only by padding[1], frequency
     symmetric by padding[0]; two real convs applied to both halves,
@@ -126,20 +138,18 @@ def _cplx_conv2d(sd, p, x, pad_f, pad_t):
     wr, br = sd[p + 'real_conv.weight'], sd[p + 'real_conv.bias']
     wi, bi = sd[p + 'imag_conv.weight'], sd[p + 'imag_conv.bias']
     conv = lambda a, w, b: nn.conv2d(a, w, b, stride=(2, 1), padding=(pad_f, 0))
-    real = conv(r, wr, br) - conv(i, wi, bi)
-    imag = conv(r, wi, bi) + conv(i, wr, br)
+    real, imag = _cplx_combine(conv, r, i, wr, br, wi, bi, variant)
     return np.concatenate([real, imag], axis=1)
 
 
-def _cplx_deconv2d(sd, p, x):
+def _cplx_deconv2d(sd, p, x, variant=0):
     """complexnn.ComplexConvTranspose2d as called at DCCRN_cprs.py:108-115:
     kernel (5,2), stride (2,1), padding (2,0), output_padding (1,0)."""
     r, i = np.split(x, 2, axis=1)
     wr, br = sd[p + 'real_conv.weight'], sd[p + 'real_conv.bias']
     wi, bi = sd[p + 'imag_conv.weight'], sd[p + 'imag_conv.bias']
     dc = lambda a, w, b: nn.conv_transpose2d(a, w, b, stride=(2, 1), padding=(2, 0), output_padding=(1, 0))
-    real = dc(r, wr, br) - dc(i, wi, bi)
-    imag = dc(r, wi, bi) + dc(i, wr, br)
+    real, imag = _cplx_combine(dc, r, i, wr, br, wi, bi, variant)
     return np.concatenate([real, imag], axis=1)
 
 
@@ -165,7 +175,7 @@ def _navie_complex_lstm(sd, p, r, i, proj):
     return ro, io
 
 
-def dccrn_forward(sd, inputs, n_layers=6, masking_mode='E'):
+def dccrn_forward(sd, inputs, n_layers=6, masking_mode='E', variant=0):
     """inputs [B,2,F=257,T] -> [B,2,257,T].  DCCRN.forward DCCRN_cprs.py:142-226
     for the decode script's constructor (use_clstm=True, use_cbn=False,
     kernel_num=[32,64,128,256,256,256], rnn_layers=2; dccrn_decode_vb.py:11)."""
@@ -175,7 +185,7 @@ def dccrn_forward(sd, inputs, n_layers=6, masking_mode='E'):
     out = inputs[:, :, 1:]                                      # drop DC :166
     enc = []
     for k in range(n_layers):                                   # :170-173
-        out = _cplx_conv2d(sd, f'encoder.{k}.0.', out, 2, 1)
+        out = _cplx_conv2d(sd, f'encoder.{k}.0.', out, 2, 1, variant)
         out = nn.prelu(_bn(sd, f'encoder.{k}.1.', out), sd[f'encoder.{k}.2.weight'])
         enc.append(out)
     B, C, D, T = out.shape                                      # :175
@@ -189,8 +199,8 @@ def dccrn_forward(sd, inputs, n_layers=6, masking_mode='E'):
     out = np.concatenate([r, i], axis=2)                        # :185
     out = np.transpose(out, (1, 2, 3, 0))                       # :194
     for k in range(n_layers):                                   # :196-199
-        out = _complex_cat(out, enc[-1 - k])
-        out = _cplx_deconv2d(sd, f'decoder.{k}.0.', out)
+        out = np.concatenate([out, enc[-1 - k]], axis=1) if variant & DCCRN_PLAIN_CAT else _complex_cat(out, enc[-1 - k])
+        out = _cplx_deconv2d(sd, f'decoder.{k}.0.', out, variant)
         if k < n_layers - 1:
             out = nn.prelu(_bn(sd, f'decoder.{k}.1.', out), sd[f'decoder.{k}.2.weight'])
         out = out[..., 1:]

@@ -14,8 +14,6 @@ struct se_engine {
     std::unique_ptr<Model> model;
     bool finalized = false;
     std::string err;
-    float* frames_scratch = nullptr;     // for the se_istft stage hook
-    size_t frames_scratch_n = 0;
     // hipGraph replay of se_enhance_batch (SE_CFG_GRAPHS): one instantiated graph per (batch, samples) shape, captured
     // on the second call of a shape (the first, eager call sets kernel attributes and grows the lazy scratch buffers);
     // caller buffers are decoupled from the graph by engine-owned staging rows
@@ -60,6 +58,12 @@ static int guard(se_engine* e, F&& f) {
     return rc;
 }
 
+// the stage profiler is visible to the launchers only while a profiled call enqueues work
+struct StageProfScope {
+    explicit StageProfScope(se_engine* e) { set_stage_prof(e->ctx.prof.on ? &e->ctx.stage_prof : nullptr); }
+    ~StageProfScope() { set_stage_prof(nullptr); }
+};
+
 extern "C" {
 
 int64_t se_resample_samples(int32_t n_in, int32_t sr_in, int32_t sr_out) {
@@ -101,6 +105,7 @@ int se_engine_create(const se_config* cfg, se_engine** out) {
         e->ctx.max_samples = cfg->max_samples > 0 ? cfg->max_samples : 64000;
         e->ctx.p_in = cfg->p_in > 0.f ? cfg->p_in : 1.f;
         e->ctx.p_out = cfg->p_out > 0.f ? cfg->p_out : 1.f;
+        e->ctx.flags = cfg->flags;
         switch (cfg->model) {
             case SE_MODEL_DCCRN: e->model = make_dccrn(e->ctx); break;
             case SE_MODEL_CRN: e->model = make_crn(e->ctx); break;
@@ -134,7 +139,6 @@ int se_engine_destroy(se_engine* e) {
     (void)hipGetDevice(&prev_dev);
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
-    if (e->frames_scratch) (void)hipFree(e->frames_scratch);
     for (auto& g : e->graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (e->cap_stream) {
@@ -206,7 +210,7 @@ int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
         SE_CHECK(in_dev && out_dev && in_shape, "null argument");
-        e->ctx.prof.reset();
+        e->ctx.prof_reset();
         e->model->forward(in_dev, in_shape, in_ndim, out_dev, static_cast<hipStream_t>(stream));
     });
 }
@@ -221,7 +225,8 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
         SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples,
                  "n_samples outside [n_fft, max_samples]");
         SE_CHECK(in_pitch >= n_samples && out_pitch >= e->model->output_samples(n_samples), "row pitch too small");
-        e->ctx.prof.reset();
+        e->ctx.prof_reset();
+        StageProfScope sps(e);
         hipStream_t st = static_cast<hipStream_t>(stream);
         static const int graphs_env = getenv("SE_GRAPH") ? atoi(getenv("SE_GRAPH")) : -1;
         const bool want_graph = (graphs_env >= 0 ? graphs_env != 0 : (e->cfg.flags & SE_CFG_GRAPHS) != 0) && !e->ctx.prof.on &&
@@ -327,7 +332,8 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
         }
         SE_HIP(hipMemcpyAsync(d, h, sizeof(int) * 4 * MB, hipMemcpyHostToDevice, st));
         SE_HIP(hipEventRecord(e->rag_ev[slot], st));
-        e->ctx.prof.reset();
+        e->ctx.prof_reset();
+        StageProfScope sps(e);
         Ragged rg{d, d + MB, d + 2 * MB, d + 3 * MB};
         struct Scope {          // the per-row sizes are visible to the launchers only while this call enqueues work
             explicit Scope(const Ragged* r) { set_ragged_ctx(r); }
@@ -362,29 +368,42 @@ int se_istft(se_engine* e, const float* spec_dev, int32_t batch, int32_t n_frame
              int64_t pitch, int32_t n_out, void* stream) {
     if (!e) return 1;
     return guard(e, [&] {
-        const size_t need = (size_t)batch * n_frames * e->ctx.geom.n_fft;
-        if (need > e->frames_scratch_n) {
-            if (e->frames_scratch) SE_HIP(hipFree(e->frames_scratch));
-            SE_HIP(hipMalloc(&e->frames_scratch, need * sizeof(float)));
-            e->frames_scratch_n = need;
-        }
-        launch_istft(e->ctx.geom, spec_dev, batch, n_frames, n_frames, e->frames_scratch, c_dev, wav_dev, pitch, n_out,
+        launch_istft(e->ctx.geom, spec_dev, batch, n_frames, n_frames, nullptr, c_dev, wav_dev, pitch, n_out,
                      static_cast<hipStream_t>(stream));
     });
 }
 
 int se_set_profiling(se_engine* e, int32_t on) {
     if (!e) return 1;
-    e->ctx.prof.on = on != 0;
+    e->ctx.prof_set(on != 0);
     return 0;
 }
 
 int se_get_profile(se_engine* e, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops) {
     if (!e) return 1;
     return guard(e, [&] {
-        if (gemm_ms) *gemm_ms = e->ctx.prof.total_ms();
-        if (gemm_launches) *gemm_launches = e->ctx.prof.launches;
-        if (gemm_flops) *gemm_flops = e->ctx.prof.flops;
+        // launches on the auxiliary streams (FullSubNet's sub-band halves) run concurrently with the main stream's: the sum
+        // of their durations is kernel time, not wall time
+        double ms = e->ctx.prof.total_ms(), fl = e->ctx.prof.flops;
+        int64_t n = e->ctx.prof.launches;
+        for (auto& p : e->ctx.aux_prof) {
+            ms += p.total_ms();
+            fl += p.flops;
+            n += p.launches;
+        }
+        if (gemm_ms) *gemm_ms = ms;
+        if (gemm_launches) *gemm_launches = n;
+        if (gemm_flops) *gemm_flops = fl;
+    });
+}
+
+int se_get_stage_profile(se_engine* e, int32_t stage, double* ms, int64_t* launches, double* bytes) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(stage >= 0 && stage < STAGE_COUNT, "stage id out of range");
+        if (ms) *ms = e->ctx.stage_prof.ms(stage);
+        if (launches) *launches = e->ctx.stage_prof.slot[stage].launches;
+        if (bytes) *bytes = e->ctx.stage_prof.slot[stage].bytes;
     });
 }
 

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict
 
 void launch_dccrn_mask(const float* mask, const float* spec, float* est, int B, int F, int T, int Tp, float p_out,
                        hipStream_t s) {
+    StageScope prof(STAGE_MASK, s, (8.0 * (F - 1) + 16.0 * F) * T * B);
     hipLaunchKernelGGL(dccrn_mask_kernel, dim3((T + 255) / 256, F, B), dim3(256), 0, s, mask, spec, est, F, T, Tp, p_out);
     SE_HIP(hipGetLastError());
 }
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256) void cmask_apply_kernel(const float* __restric
 void launch_cmask_apply(const float* mask, const float* spec, float* out, int B, int F, int T, float p_out,
                         hipStream_t s) {
     const long plane = (long)F * T, total = plane * B;
+    StageScope prof(STAGE_MASK, s, 24.0 * total);
     hipLaunchKernelGGL(cmask_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mask, spec, out, plane,
                        total, p_out);
     SE_HIP(hipGetLastError());
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(256) void mag_phase_kernel(const float* __restrict_
 void launch_mag_phase(const float* mag, const float* spec, float* out, int B, int F, int T, float p_out,
                       hipStream_t s) {
     const long plane = (long)F * T, total = plane * B;
+    StageScope prof(STAGE_MASK, s, 20.0 * total);
     hipLaunchKernelGGL(mag_phase_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mag, spec, out, plane,
                        total, p_out);
     SE_HIP(hipGetLastError());
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(256) void polar_pow_kernel(const float* __restrict_
 }
 void launch_polar_pow(const float* x, float* out, int B, int F, int T, float p_out, hipStream_t s) {
     const long plane = (long)F * T, total = plane * B;
+    StageScope prof(STAGE_MASK, s, 16.0 * total);
     hipLaunchKernelGGL(polar_pow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, plane, total, p_out);
     SE_HIP(hipGetLastError());
 }

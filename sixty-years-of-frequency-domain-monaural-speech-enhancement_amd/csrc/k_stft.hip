@@ -23,6 +23,49 @@ static thread_local const Ragged* g_ragged = nullptr;
 const Ragged* ragged_ctx() { return g_ragged; }
 void set_ragged_ctx(const Ragged* r) { g_ragged = r; }
 
+static thread_local StageProf* g_stage_prof = nullptr;
+StageProf* stage_prof() { return g_stage_prof; }
+void set_stage_prof(StageProf* p) { g_stage_prof = p; }
+void StageProf::begin(int stage, hipStream_t st) {
+    Slot& s = slot[stage];
+    if (s.used + 2 > s.ev.size())
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            SE_HIP(hipEventCreate(&e));
+            s.ev.push_back(e);
+        }
+    SE_HIP(hipEventRecord(s.ev[s.used], st));
+}
+void StageProf::end(int stage, hipStream_t st, double bytes) {
+    Slot& s = slot[stage];
+    SE_HIP(hipEventRecord(s.ev[s.used + 1], st));
+    s.used += 2;
+    s.bytes += bytes;
+    s.launches += 1;
+}
+void StageProf::reset() {
+    for (auto& s : slot) {
+        s.used = 0;
+        s.bytes = 0.0;
+        s.launches = 0;
+    }
+}
+double StageProf::ms(int stage) {
+    Slot& s = slot[stage];
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < s.used; i += 2) {
+        SE_HIP(hipEventSynchronize(s.ev[i + 1]));
+        float m = 0.f;
+        SE_HIP(hipEventElapsedTime(&m, s.ev[i], s.ev[i + 1]));
+        tot += m;
+    }
+    return tot;
+}
+StageProf::~StageProf() {
+    for (auto& s : slot)
+        for (auto e : s.ev) (void)hipEventDestroy(e);
+}
+
 constexpr int FPB = 16;  // frames per block
 constexpr int PPB = 8;   // complex transforms per block: frames are transformed in pairs (two-for-one real FFT)
 
@@ -222,32 +265,51 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
 }
 
 struct IstftArgs {
-    const float* spec; int B, T, Tp; float* frames; int win;
-    const int* tlen;      // ragged batch: frames of row b (else null)
+    const float* spec; int B, T, Tp; int hop, win;
+    const float* c_scale; float* out; long out_pitch; int Lout;
+    int own, halo;        // overlap-add positions a block owns = own * hop; frames it transforms = FPB = own + halo
+    const int *tlen, *olen;     // ragged batch: frames / output samples of row b (else null); samples in [olen, Lout) = 0
 };
 
-// inverse two-for-one: Z = X_{2p} + i X_{2p+1} on the Hermitian-extended spectra -> z = x_{2p} + i x_{2p+1}
+// Inverse STFT with the overlap-add fused in: a block transforms FPB = 16 consecutive frames (two-for-one: Z = X_{2p} +
+// i X_{2p+1} on the Hermitian-extended spectra -> z = x_{2p} + i x_{2p+1}), keeps the windowed frames in LDS and writes
+// the `own * hop` output samples whose contributing frames all lie inside its window: the first `halo` (= ceil(N/hop) - 1,
+// rounded up to even for the frame pairing) frames are recomputed by the neighbouring block instead of travelling through
+// a [B][T][N] scratch tensor in HBM (round 1: frames written and re-read by a second kernel, 4.2x the algorithmic bytes).
+// Divides by the overlap-added squared window and by the utterance's c.
 template <int N>
-__global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
+__global__ __launch_bounds__(256) void istft_ola_kernel(const IstftArgs a) {
     constexpr int F = N / 2 + 1;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float2* tw = reinterpret_cast<float2*>(smem_f);
     float2* bufs = tw + N;
     float* win = reinterpret_cast<float*>(bufs + PPB * 2 * N);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.x * FPB;
+    const int b = blockIdx.y;
     const int Tb = a.tlen ? a.tlen[b] : a.T;
-    if (t0 >= Tb) return;                                   // ragged batch: nothing of this row left (block-uniform)
+    const int Lo = a.olen ? a.olen[b] : a.Lout;
+    const int span = a.own * a.hop;
+    const int pos0 = blockIdx.x * span;                     // first overlap-add position (pos = sample + N/2) of the block
+    const int tb = blockIdx.x * a.own - a.halo;             // first frame of the window (may be negative)
+    float* outp = a.out + (long)b * a.out_pitch;
+    // nothing of this row left (ragged batch, or the rounding of the grid): zeros up to Lout (block-uniform branch)
+    if (pos0 - N / 2 >= Lo || tb >= Tb) {
+        for (int i = tid; i < span; i += 256) {
+            const int o = pos0 + i - N / 2;
+            if (o >= 0 && o < a.Lout) outp[o] = 0.f;
+        }
+        return;
+    }
     init_tables<N>(tw, win, a.win, tid);
     // 8 lanes x 2 frames = 16 consecutive frames of one bin (64 contiguous bytes per plane)
     for (int idx = tid; idx < F * PPB; idx += 256) {
         const int pi = idx & (PPB - 1), k = idx >> 3;
-        const int t = t0 + 2 * pi;
+        const int t = tb + 2 * pi;
         float2 xa = make_float2(0.f, 0.f), xb = make_float2(0.f, 0.f);
         const float* re = a.spec + (((long)b * 2 + 0) * F + k) * a.Tp;
         const float* im = a.spec + (((long)b * 2 + 1) * F + k) * a.Tp;
-        if (t < Tb) xa = make_float2(re[t], im[t]);
-        if (t + 1 < Tb) xb = make_float2(re[t + 1], im[t + 1]);
+        if (t >= 0 && t < Tb) xa = make_float2(re[t], im[t]);
+        if (t + 1 >= 0 && t + 1 < Tb) xb = make_float2(re[t + 1], im[t + 1]);
         float2* b0 = bufs + (pi * 2) * N;
         if (k == 0 || k == N / 2) {
             b0[k] = make_float2(xa.x, xb.x);                // C2R ignores the imaginary part of DC / Nyquist
@@ -263,73 +325,78 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const IstftArgs a) {
         float2* b0 = bufs + (pi * 2) * N;
         fft_frame<N, true>(b0, b0 + N, tw, lane);
     }
+    // overlap-add out of LDS: position pos gets frame t = tb + fi at n = pos - t * hop for every frame that covers it
     const float invN = 1.f / N;
-    for (int idx = tid; idx < N * FPB; idx += 256) {
-        const int fi = idx / N, n = idx - fi * N;
-        const int t = t0 + fi;
-        if (t >= Tb) continue;
-        const float2 z = (bufs + ((fi >> 1) * 2) * N + ((N == 512) ? N : 0))[n];
-        a.frames[((long)b * a.T + t) * N + n] = ((fi & 1) ? z.y : z.x) * invN * win[n];
+    const float cinv = a.c_scale ? 1.f / a.c_scale[b] : 1.f;
+    for (int i = tid; i < span; i += 256) {
+        const int pos = pos0 + i, o = pos - N / 2;
+        if (o < 0 || o >= a.Lout) continue;
+        if (o >= Lo) {
+            outp[o] = 0.f;
+            continue;
+        }
+        int thi = pos / a.hop;
+        if (thi > Tb - 1) thi = Tb - 1;
+        float acc = 0.f, env = 0.f;
+        for (int t = thi; t >= 0 && pos - t * a.hop < N; --t) {
+            const int n = pos - t * a.hop, fi = t - tb;          // fi >= 0 by construction of halo
+            const float2 z = (bufs + ((fi >> 1) * 2) * N + ((N == 512) ? N : 0))[n];
+            const float w = win[n];
+            acc += ((fi & 1) ? z.y : z.x) * invN * w;
+            env += w * w;
+        }
+        // summed newest frame first above; the reference order (oldest first) differs only in fp32 rounding
+        float y = env > 1e-11f ? acc / env : acc;
+        outp[o] = y * cinv;
     }
 }
 
-struct OlaArgs {
-    const float* frames; int B, T, N, hop, win; const float* c_scale; float* out; long out_pitch; int Lout;
-    const int *tlen, *olen;     // ragged batch: frames / output samples of row b (else null); samples in [olen, Lout) = 0
-};
-
-__global__ void ola_kernel(const OlaArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    if (i >= a.Lout) return;
-    const int Tb = a.tlen ? a.tlen[b] : a.T;
-    if (a.olen && i >= a.olen[b]) {
-        a.out[(long)b * a.out_pitch + i] = 0.f;
-        return;
-    }
-    const int pos = i + a.N / 2;
-    int tlo = (pos - a.N + a.hop) / a.hop;       // ceil((pos - N + 1) / hop) for pos-N+1 possibly negative
-    if (pos - a.N + 1 <= 0) tlo = 0;
-    int thi = pos / a.hop;
-    if (thi > Tb - 1) thi = Tb - 1;
-    const int left = (a.N - a.win) / 2;
-    float acc = 0.f, env = 0.f;
-    for (int t = tlo; t <= thi; ++t) {
-        const int n = pos - t * a.hop;
-        if (n >= a.N) continue;
-        acc += a.frames[((long)b * a.T + t) * a.N + n];
-        float w = 0.f;
-        if (n >= left && n < left + a.win) w = (float)(0.5 - 0.5 * cospi(2.0 * (n - left) / a.win));
-        env += w * w;
-    }
-    float y = env > 1e-11f ? acc / env : acc;
-    if (a.c_scale) y /= a.c_scale[b];
-    a.out[(long)b * a.out_pitch + i] = y;
-}
-
-__global__ __launch_bounds__(256) void rms_scale_kernel(const float* wav, int L, long pitch, float* c_out,
-                                                        const int* len) {
-    const int b = blockIdx.x;
+// c[b] = sqrt(L / sum x^2) in two steps: RMS_SPLIT blocks per utterance each sum a slice in fp64 (one block per utterance
+// pulled 256 kB through a single CU: 100 us flat whatever the batch), then one thread per utterance adds the slices in
+// slice order - deterministic, no atomics.
+constexpr int RMS_SPLIT = 16;
+__global__ __launch_bounds__(256) void rms_partial_kernel(const float* __restrict__ wav, int L, long pitch,
+                                                          double* __restrict__ part, const int* __restrict__ len) {
+    const int b = blockIdx.y, k = blockIdx.x;
     if (len) L = len[b];
+    const int per = (L + RMS_SPLIT - 1) / RMS_SPLIT;
+    const int lo = k * per, hi = min(L, lo + per);
     const float* x = wav + (long)b * pitch;
     double s = 0.0;
-    for (int i = threadIdx.x; i < L; i += 256) {
+    int i = lo + threadIdx.x;
+    for (; i + 3 * 256 < hi; i += 4 * 256) {          // four independent loads in flight per thread
+        const float v0 = x[i], v1 = x[i + 256], v2 = x[i + 512], v3 = x[i + 768];
+        s += (double)v0 * v0;
+        s += (double)v1 * v1;
+        s += (double)v2 * v2;
+        s += (double)v3 * v3;
+    }
+    for (; i < hi; i += 256) {
         const double v = x[i];
         s += v * v;
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    __shared__ double part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const double tot = part[0] + part[1] + part[2] + part[3];
-        c_out[b] = (float)sqrt((double)L / tot);
-    }
+    if (threadIdx.x == 0) part[(long)b * RMS_SPLIT + k] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void rms_finish_kernel(const double* __restrict__ part, int L, float* __restrict__ c_out,
+                                  const int* __restrict__ len, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (len) L = len[b];
+    double tot = 0.0;
+    for (int k = 0; k < RMS_SPLIT; ++k) tot += part[(long)b * RMS_SPLIT + k];
+    c_out[b] = (float)sqrt((double)L / tot);
 }
 
 void launch_rms_scale(const float* wav, int B, int L, long pitch, float* c_out, hipStream_t s) {
     const Ragged* rg = ragged_ctx();
-    hipLaunchKernelGGL(rms_scale_kernel, dim3(B), dim3(256), 0, s, wav, L, pitch, c_out, rg ? rg->len : nullptr);
+    StageScope prof(STAGE_RMS, s, 4.0 * L * B);
+    double* part = reinterpret_cast<double*>(device_scratch(3, (size_t)B * RMS_SPLIT * sizeof(double), s));
+    hipLaunchKernelGGL(rms_partial_kernel, dim3(RMS_SPLIT, B), dim3(256), 0, s, wav, L, pitch, part, rg ? rg->len : nullptr);
+    hipLaunchKernelGGL(rms_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part, L, c_out, rg ? rg->len : nullptr, B);
     SE_HIP(hipGetLastError());
 }
 
@@ -345,6 +412,7 @@ static void set_lds_attr(K kernel, size_t bytes) {
 void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, int Lpad, const float* c_scale,
                  float p_in, float* spec_ri, float* mag, int T, int Tp, hipStream_t s) {
     const Ragged* rg = ragged_ctx();
+    StageScope prof(STAGE_STFT, s, 4.0 * L * B + (spec_ri ? 8.0 : 0.0) * g.F() * T * B + (mag ? 4.0 : 0.0) * g.F() * T * B);
     StftArgs a{wav, pitch, B, L, Lpad, c_scale, p_in, spec_ri, mag, T, Tp, g.hop, g.win,
                rg ? rg->len : nullptr, rg ? rg->lpad : nullptr, rg ? rg->tlen : nullptr};
     dim3 grid((T + FPB - 1) / FPB, B);
@@ -362,26 +430,29 @@ void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, 
     SE_HIP(hipGetLastError());
 }
 
-void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* frames, const float* c_scale,
-                  float* wav_out, long out_pitch, int Lout, hipStream_t s) {
+void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* /*frames: unused since the fused kernel*/,
+                  const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s) {
     const Ragged* rg = ragged_ctx();
-    IstftArgs a{spec_ri, B, T, Tp, frames, g.win, rg ? rg->tlen : nullptr};
-    dim3 grid((T + FPB - 1) / FPB, B);
+    StageScope prof(STAGE_ISTFT, s, 8.0 * g.F() * T * B + 4.0 * Lout * B);
+    int halo = (g.n_fft + g.hop - 1) / g.hop - 1;
+    halo += halo & 1;                                       // frames are transformed in pairs
+    SE_CHECK(halo < FPB, "hop too small for the fused overlap-add window");
+    const int own = FPB - halo;
+    IstftArgs a{spec_ri, B, T, Tp, g.hop, g.win, c_scale, wav_out, out_pitch, Lout, own, halo,
+                rg ? rg->tlen : nullptr, rg ? rg->olen : nullptr};
+    const int span = own * g.hop;
+    dim3 grid((g.n_fft / 2 + Lout + span - 1) / span, B);
     if (g.n_fft == 512) {
         static bool seen[64] = {};
-        if (first_on_device(seen)) set_lds_attr(istft_frames_kernel<512>, fft_lds_bytes<512>());
-        hipLaunchKernelGGL(istft_frames_kernel<512>, grid, dim3(256), fft_lds_bytes<512>(), s, a);
+        if (first_on_device(seen)) set_lds_attr(istft_ola_kernel<512>, fft_lds_bytes<512>());
+        hipLaunchKernelGGL(istft_ola_kernel<512>, grid, dim3(256), fft_lds_bytes<512>(), s, a);
     } else if (g.n_fft == 320) {
         static bool seen[64] = {};
-        if (first_on_device(seen)) set_lds_attr(istft_frames_kernel<320>, fft_lds_bytes<320>());
-        hipLaunchKernelGGL(istft_frames_kernel<320>, grid, dim3(256), fft_lds_bytes<320>(), s, a);
+        if (first_on_device(seen)) set_lds_attr(istft_ola_kernel<320>, fft_lds_bytes<320>());
+        hipLaunchKernelGGL(istft_ola_kernel<320>, grid, dim3(256), fft_lds_bytes<320>(), s, a);
     } else {
         SE_CHECK(false, "unsupported n_fft");
     }
-    SE_HIP(hipGetLastError());
-    OlaArgs o{frames, B, T, g.n_fft, g.hop, g.win, c_scale, wav_out, out_pitch, Lout, rg ? rg->tlen : nullptr,
-              rg ? rg->olen : nullptr};
-    hipLaunchKernelGGL(ola_kernel, dim3((Lout + 255) / 256, B), dim3(256), 0, s, o);
     SE_HIP(hipGetLastError());
 }
 

@@ -2,6 +2,7 @@
 // Engine-internal spectrogram layout: [B][C][F][Tp] with T contiguous, Tp = row pitch (>= T).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 
 namespace se {
 
@@ -18,6 +19,36 @@ struct Ragged {
 };
 const Ragged* ragged_ctx();              // nullptr: equal-length batch
 void set_ragged_ctx(const Ragged* r);    // thread-local (a handle is driven by one thread at a time)
+
+// HIP-event timing of the HBM-bound front / back-end kernels (se_get_stage_profile): every launcher below brackets its
+// launches with events on the launch stream and books the ALGORITHMIC bytes of the stage (what it must read + write once,
+// SURVEY 8(d)), so that bench.py can put bytes / time next to the 8 TB/s HBM peak.  Published thread-locally by the
+// engine while profiling is on; null otherwise (no events, no overhead).
+enum Stage : int { STAGE_RMS = 0, STAGE_STFT = 1, STAGE_MASK = 2, STAGE_ISTFT = 3, STAGE_COUNT = 4 };
+struct StageProf {
+    struct Slot {
+        std::vector<hipEvent_t> ev;
+        size_t used = 0;
+        double bytes = 0.0;
+        long launches = 0;
+    } slot[STAGE_COUNT];
+    void begin(int stage, hipStream_t st);
+    void end(int stage, hipStream_t st, double bytes);
+    void reset();
+    double ms(int stage);
+    ~StageProf();
+};
+StageProf* stage_prof();
+void set_stage_prof(StageProf* p);
+struct StageScope {       // RAII bracket used by the launchers
+    int stage; hipStream_t st; double bytes; StageProf* p;
+    StageScope(int stage_, hipStream_t st_, double bytes_) : stage(stage_), st(st_), bytes(bytes_), p(stage_prof()) {
+        if (p) p->begin(stage, st);
+    }
+    ~StageScope() {
+        if (p) p->end(stage, st, bytes);
+    }
+};
 
 struct StftGeom {
     int n_fft, hop, win;   // win <= n_fft (window centred in n_fft, torch.stft convention)

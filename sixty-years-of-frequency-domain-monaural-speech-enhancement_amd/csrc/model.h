@@ -11,9 +11,21 @@ namespace se {
 struct EngineCtx {
     int max_batch = 1, max_samples = 64000;
     float p_in = 1.f, p_out = 1.f;
+    int flags = 0;          // se_config.flags
     StftGeom geom{0, 0, 0};
     Arena arena;
     Profiler prof;
+    Profiler aux_prof[3];   // one per auxiliary stream (events are recorded on the stream they time); se_get_profile sums all
+    StageProf stage_prof;   // HBM-bound front / back-end kernels (se_get_stage_profile)
+    void prof_reset() {
+        prof.reset();
+        for (auto& p : aux_prof) p.reset();
+        stage_prof.reset();
+    }
+    void prof_set(bool on) {
+        prof.on = on;
+        for (auto& p : aux_prof) p.on = on;
+    }
     // second stream for independent sub-problems of one call (fork / join through events around the caller's stream)
     static constexpr int MAX_AUX = 3;
     hipStream_t aux[MAX_AUX] = {};

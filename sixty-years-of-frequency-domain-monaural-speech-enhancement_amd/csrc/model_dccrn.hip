@@ -17,6 +17,7 @@
 //     frame covering both LSTMs (blockIdx.z) and all 2B sequences; r-i / r+i combinations are folded into the
 //     next layer's weights ([W,-W] / [W,W] two-source GEMMs).
 #include "model.h"
+#include "../../include/se_engine.h"
 
 namespace se {
 
@@ -56,13 +57,29 @@ class Dccrn final : public Model {
 
     void finalize(const TrackedSD& sd) override {
         const int tout = 501;
+        // The two conventions of the ABSENT `complexnn` that DCCRN_cprs.py alone does not determine
+        // are weight-preparation switches, not kernel code: if the real upstream file turns out to differ, the fix is a
+        // flag + a fixture regeneration.
+        const bool bias_per_part = (ctx.flags & SE_CFG_DCCRN_BIAS_PER_PART) != 0;
+        const bool plain_cat = (ctx.flags & SE_CFG_DCCRN_PLAIN_CAT) != 0;
+        auto cplx = [&](const DenseW& wr, const DenseW& wi) {
+            DenseW w = complex_expand(wr, wi);          // default: real rows get br - bi, imag rows br + bi
+            if (bias_per_part) {
+                const int co = wr.M;
+                for (int m = 0; m < co; ++m) {
+                    w.bias[m] = wr.bias[m];
+                    w.bias[co + m] = wi.bias[m];
+                }
+            }
+            return w;
+        };
         // ---- encoder (DCCRN_cprs.py:62-77): ComplexConv2d(k=(5,2), s=(2,1), pad=(2,1) causal) + BN + PReLU
         for (int k = 0; k < NL; ++k) {
             const std::string p = "encoder." + std::to_string(k) + ".";
             const int ci = KN[k] / 2, co = KN[k + 1] / 2;
             DenseW wr = conv_weights(sd.get(p + "0.real_conv.weight", {co, ci, 5, 2}), &sd.get(p + "0.real_conv.bias", {co}), false);
             DenseW wi = conv_weights(sd.get(p + "0.imag_conv.weight", {co, ci, 5, 2}), &sd.get(p + "0.imag_conv.bias", {co}), false);
-            DenseW w = complex_expand(wr, wi);
+            DenseW w = cplx(wr, wi);
             fold_bn(w, sd.get(p + "1.weight", {2 * co}), sd.get(p + "1.bias", {2 * co}), sd.get(p + "1.running_mean", {2 * co}),
                     sd.get(p + "1.running_var", {2 * co}));
             enc[k] = make_conv_plan(w, 2, 2, 1, 1, 1, ACT_PRELU, prelu_slopes(sd.get(p + "2.weight"), 2 * co), EPI_ACT, tout);
@@ -74,9 +91,10 @@ class Dccrn final : public Model {
             const int ci = KN[idx], co = KN[idx - 1] / 2;     // per-half channel counts (input = cat -> 2*KN/2)
             DenseW wr = deconv_weights(sd.get(p + "0.real_conv.weight", {ci, co, 5, 2}), &sd.get(p + "0.real_conv.bias", {co}), false);
             DenseW wi = deconv_weights(sd.get(p + "0.imag_conv.weight", {ci, co, 5, 2}), &sd.get(p + "0.imag_conv.bias", {co}), false);
-            DenseW w = complex_expand(wr, wi);
+            DenseW w = cplx(wr, wi);
             // reference channel order after complex_cat([out, skip]) (:197): [out_r, skip_r, out_i, skip_i];
-            // engine order (two-source K loop): [out_r, out_i | skip_r, skip_i]
+            // engine order (two-source K loop): [out_r, out_i | skip_r, skip_i].  SE_CFG_DCCRN_PLAIN_CAT: complex_cat is
+            // a plain torch.cat - the reference order is already the engine order
             const int h = ci / 2;
             std::vector<int> perm(4 * h);
             for (int c = 0; c < h; ++c) {
@@ -85,7 +103,7 @@ class Dccrn final : public Model {
                 perm[2 * h + c] = h + c;
                 perm[3 * h + c] = 3 * h + c;
             }
-            permute_cin(w, perm);
+            if (!plain_cat) permute_cin(w, perm);
             std::vector<float> slope;
             int act = ACT_NONE;
             if (k < NL - 1) {

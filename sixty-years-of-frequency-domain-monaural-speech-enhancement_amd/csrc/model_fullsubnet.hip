@@ -264,7 +264,7 @@ class FullSubNet final : public Model {
                 const int c0 = i * Sp, Sn = std::min(Sp, S - c0);
                 if (Sn <= 0) break;
                 SE_HIP(hipStreamWaitEvent(ctx.aux[i - 1], ctx.ev_fork, 0));
-                part(c0, Sn, ctx.aux[i - 1], nullptr);
+                part(c0, Sn, ctx.aux[i - 1], &ctx.aux_prof[i - 1]);
                 SE_HIP(hipEventRecord(ctx.ev_join[i - 1], ctx.aux[i - 1]));
             }
             part(0, std::min(Sp, S), st, pf);

@@ -14,12 +14,12 @@ class Engine:
     """One engine handle = one model replica on one GPU (one per rank)."""
 
     def __init__(self, model, device=0, max_batch=1, max_samples=64000, p_in=1.0, p_out=1.0,
-                 n_fft=0, hop=0, win=0, graphs=False):
+                 n_fft=0, hop=0, win=0, graphs=False, flags=0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.model = model
         cfg = _lib.SeConfig(_lib.MODEL_IDS[model], device, max_batch, max_samples, p_in, p_out, n_fft, hop, win,
-                            1 if graphs else 0)        # SE_CFG_GRAPHS
+                            (1 if graphs else 0) | int(flags))        # SE_CFG_GRAPHS | model-specific SE_CFG_* bits
         if self._lib.se_engine_create(C.byref(cfg), C.byref(self._h)):
             raise EngineError(self._lib.se_last_error(None).decode())
         self.device = device
@@ -172,3 +172,14 @@ class Engine:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         self._check(self._lib.se_get_profile(self._h, C.byref(ms), C.byref(n), C.byref(fl)))
         return {'gemm_ms': ms.value, 'gemm_launches': n.value, 'gemm_flops': fl.value}
+
+    STAGES = ('rms', 'stft', 'mask', 'istft')
+
+    def get_stage_profile(self):
+        """{stage: {'ms', 'launches', 'bytes'}} of the HBM-bound front / back-end kernels of the last profiled call."""
+        out = {}
+        for i, name in enumerate(self.STAGES):
+            ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+            self._check(self._lib.se_get_stage_profile(self._h, i, C.byref(ms), C.byref(n), C.byref(by)))
+            out[name] = {'ms': ms.value, 'launches': n.value, 'bytes': by.value}
+        return out

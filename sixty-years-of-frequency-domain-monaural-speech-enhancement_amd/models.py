@@ -17,7 +17,8 @@ class _EngineModule:
     p_in = 1.0             # magnitude exponents the decode script applies around the network
     p_out = 1.0
 
-    def __init__(self, device=0, max_batch=1, max_samples=64000, p_in=None, p_out=None, graphs=False):
+    def __init__(self, device=0, max_batch=1, max_samples=64000, p_in=None, p_out=None, graphs=False, flags=0):
+        self._flags = flags            # model-specific SE_CFG_* bits (include/se_engine.h)
         self._graphs = graphs          # replay enhance_batch as a hipGraph per shape (small, launch-bound batches)
         self._device = device
         self._max_batch = max_batch
@@ -41,7 +42,7 @@ class _EngineModule:
         if missing or unexpected:
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
         self.engine = Engine(self._model, self._device, self._max_batch, self._max_samples, self.p_in, self.p_out,
-                             graphs=self._graphs)
+                             graphs=self._graphs, flags=self._flags)
         self.engine.load_state_dict(sd)
         return self
 

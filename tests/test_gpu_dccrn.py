@@ -82,3 +82,20 @@ def test_enhance_vs_oracle_batch_and_lengths():
             e = rms(y[b] - ref)
             print(L, kinds[b], "rms err", e, "rms ref", rms(ref))
             assert e < 1e-4 and e < 5e-4 * max(rms(ref), 1e-3), (L, kinds[b], e, rms(ref))
+
+
+@pytest.mark.parametrize('flags', [2, 4, 6])
+def test_complexnn_convention_flags(flags):
+    """SE_CFG_DCCRN_BIAS_PER_PART (2) / SE_CFG_DCCRN_PLAIN_CAT (4): the conventions of the absent `complexnn` that
+    DCCRN_cprs.py does not determine are weight-preparation switches; each matches the oracle's same variant and differs
+    from the default (so the switch is live)."""
+    torch = _torch()
+    from se_amd.models import DCCRN
+    from oracle import models as M
+    G = load_golden('dccrn')
+    sd = synth.synth_state_dict(DCCRN.state_dict_schema(), 14)
+    x = torch.from_numpy(G['x']).cuda()
+    y = DCCRN(**CTOR, flags=flags).load_synthetic(14)(x).cpu().numpy()
+    ref = M.dccrn_forward(sd, G['x'], variant=flags)
+    assert rms(y - ref) < 1e-5 * max(rms(ref), 1.0)
+    assert rms(y - G['y']) > 1e-3 * rms(G['y'])

@@ -89,16 +89,23 @@ def cpu_baseline(seed, p_in, p_out):
     would be spread over a host."""
     import subprocess
     ncpu = os.cpu_count() or 1
-    P, clips = ncpu, 2          # every logical CPU of the host gets one single-thread copy of the reference loop
-    cpu_model = 'unknown'
+    clips = 2
+    cpu_model, cores = 'unknown', set()
     try:
         with open('/proc/cpuinfo') as f:
+            phys = None
             for ln in f:
-                if ln.startswith('model name'):
+                if ln.startswith('model name') and cpu_model == 'unknown':
                     cpu_model = ln.split(':', 1)[1].strip()
-                    break
+                elif ln.startswith('physical id'):
+                    phys = ln.split(':', 1)[1].strip()
+                elif ln.startswith('core id'):
+                    cores.add((phys, ln.split(':', 1)[1].strip()))
     except OSError:
         pass
+    # one single-thread copy of the reference loop per PHYSICAL core: measured on the 2 x 64-core / 256-thread host of the
+    # GPU box, 64 workers decode 12.0 utt/s, 256 (one per SMT thread) only 5.3 - the port is memory-bound
+    P = len(cores) if cores else max(1, ncpu // 2)
     env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1',
                HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', str(clips), '--cpu-worker-args',
@@ -121,7 +128,7 @@ def cpu_baseline(seed, p_in, p_out):
             "sample": f"{len(spans)} single-thread worker processes x {clips} x 4 s clips, batch-1 loop each, numpy oracle "
                       f"(oracle/decode.py:enhance_dccrn), slowest worker {wall:.1f} s, {time.time() - t0:.1f} s with start-up; "
                       f"host has {ncpu} logical CPUs ({cpu_model})",
-            "cpu_model": cpu_model, "logical_cpus": ncpu,
+            "cpu_model": cpu_model, "logical_cpus": ncpu, "physical_cores": P,
             "value_per_worker_best": round(clips / min(spans), 4)}
 
 

@@ -134,21 +134,26 @@ __device__ __forceinline__ void fft_stage(const float2* __restrict__ x, float2* 
 }
 
 // Full transform of the frame held in buf0; returns the buffer holding the natural-order result.
-// Every wave of the block must call this the same number of times (block barriers between stages).
+// A frame pair belongs to ONE wave from its first stage to its last (the wave also filled buf0 in the forward kernel), so
+// the stages hand over through LDS inside the wave: DS operations of a wave execute in order, a wave-level fence (no
+// block barrier) is all the write -> read hand-over needs.  Ten block barriers per block made every wave wait for the
+// slowest one at each of the five stages; the callers keep one block barrier before data crosses waves.
+#define SE_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <int N, bool INV>
 __device__ __forceinline__ float2* fft_frame(float2* buf0, float2* buf1, const float2* tw, int lane) {
+    SE_WAVE_FENCE();
     if (N == 512) {
-        fft_stage<512, 4, INV>(buf0, buf1, tw, 512, 0, lane); __syncthreads();
-        fft_stage<512, 4, INV>(buf1, buf0, tw, 128, 2, lane); __syncthreads();
-        fft_stage<512, 4, INV>(buf0, buf1, tw, 32, 4, lane);  __syncthreads();
-        fft_stage<512, 4, INV>(buf1, buf0, tw, 8, 6, lane);   __syncthreads();
-        fft_stage<512, 2, INV>(buf0, buf1, tw, 2, 8, lane);   __syncthreads();
+        fft_stage<512, 4, INV>(buf0, buf1, tw, 512, 0, lane); SE_WAVE_FENCE();
+        fft_stage<512, 4, INV>(buf1, buf0, tw, 128, 2, lane); SE_WAVE_FENCE();
+        fft_stage<512, 4, INV>(buf0, buf1, tw, 32, 4, lane);  SE_WAVE_FENCE();
+        fft_stage<512, 4, INV>(buf1, buf0, tw, 8, 6, lane);   SE_WAVE_FENCE();
+        fft_stage<512, 2, INV>(buf0, buf1, tw, 2, 8, lane);   SE_WAVE_FENCE();
         return buf1;
     } else {   // 320
-        fft_stage<320, 4, INV>(buf0, buf1, tw, 320, 0, lane); __syncthreads();
-        fft_stage<320, 4, INV>(buf1, buf0, tw, 80, 2, lane);  __syncthreads();
-        fft_stage<320, 4, INV>(buf0, buf1, tw, 20, 4, lane);  __syncthreads();
-        fft_stage<320, 5, INV>(buf1, buf0, tw, 5, 6, lane);   __syncthreads();
+        fft_stage<320, 4, INV>(buf0, buf1, tw, 320, 0, lane); SE_WAVE_FENCE();
+        fft_stage<320, 4, INV>(buf1, buf0, tw, 80, 2, lane);  SE_WAVE_FENCE();
+        fft_stage<320, 4, INV>(buf0, buf1, tw, 20, 4, lane);  SE_WAVE_FENCE();
+        fft_stage<320, 5, INV>(buf1, buf0, tw, 5, 6, lane);   SE_WAVE_FENCE();
         return buf0;
     }
 }
@@ -233,9 +238,9 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
             nzflag[2 * pi] = a0;
             nzflag[2 * pi + 1] = a1;
         }
-        __syncthreads();
         fft_frame<N, false>(b0, b1, tw, lane);
     }
+    __syncthreads();        // the spectra of all eight frame pairs (and the silence flags) are read across waves below
     // write [F][T]-major: the 16 frames of one bin are 64 contiguous bytes
     for (int idx = tid; idx < F * FPB; idx += 256) {
         const int fi = idx & (FPB - 1), k = idx >> 4;
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftArgs a) {
         float2* b0 = bufs + (pi * 2) * N;
         fft_frame<N, true>(b0, b0 + N, tw, lane);
     }
+    __syncthreads();        // the overlap-add reads every wave's frames
     // overlap-add out of LDS: position pos gets frame t = tb + fi at n = pos - t * hop for every frame that covers it
     const float invN = 1.f / N;
     const float cinv = a.c_scale ? 1.f / a.c_scale[b] : 1.f;

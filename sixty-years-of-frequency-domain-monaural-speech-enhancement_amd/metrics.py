@@ -1,4 +1,4 @@
-"""Objective scorers for the decode output: STOI and SDR, host side, numpy / scipy.
+"""Objective scorers for the decode output: STOI, ESTOI and SDR, host side, numpy / scipy.
 
 The reference evaluates with MATLAB files it ships under `DeepXi/deepxi/` (`stoi.m`, `composite.m`, `pesq.m`); nothing
 runnable is shipped for Python.  `stoi` below restates `DeepXi/deepxi/stoi.m` line by line (1/3-octave TF units,
@@ -89,6 +89,43 @@ def stoi(x, y, fs_signal):
         xn /= np.sqrt(np.sum(xn ** 2, axis=1, keepdims=True))
         yn /= np.sqrt(np.sum(yn ** 2, axis=1, keepdims=True))
         d.append(np.sum(xn * yn, axis=1))
+    return float(np.mean(d))
+
+
+def estoi(x, y, fs_signal):
+    """Extended STOI (Jensen & Taal, IEEE/ACM TASLP 2016) - the `ESTOI` column of the reference's tables
+    (`Figure/t11.jpg`, `t12.jpg`; the reference ships no code for it: `G2Net_VB/Backup.py:17` imports the third-party
+    `pystoi`, whose `extended=True` branch this follows).  Same front end as `stoi` (10 kHz, silent-frame removal,
+    1/3-octave bands, 384 ms segments); each 15 x 30 segment is mean / norm normalised along time (rows), then along
+    frequency (columns), and the score is the mean inner product of the normalised columns - no clipping stage."""
+    x, y = np.asarray(x, dtype=np.float64).ravel(), np.asarray(y, dtype=np.float64).ravel()
+    if len(x) != len(y):
+        raise ValueError('x and y should have the same length')
+    if fs_signal != FS:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(FS, int(fs_signal))
+        x = resample_poly(x, FS // g, int(fs_signal) // g)
+        y = resample_poly(y, FS // g, int(fs_signal) // g)
+    H = _thirdoct(FS, K_FFT, J_BANDS, MN)
+    x, y = _remove_silent_frames(x, y, DYN, N_FRAME, N_FRAME // 2)
+    xh = _stdft(x, N_FRAME, N_FRAME // 2, K_FFT)[:, :K_FFT // 2 + 1].T
+    yh = _stdft(y, N_FRAME, N_FRAME // 2, K_FFT)[:, :K_FFT // 2 + 1].T
+    if xh.shape[1] < N_SEG:
+        raise ValueError('not enough non-silent frames for one 384 ms ESTOI segment')
+    X = np.sqrt(H @ np.abs(xh) ** 2)
+    Y = np.sqrt(H @ np.abs(yh) ** 2)
+    eps = np.finfo(np.float64).eps
+
+    def row_col_normalise(s):
+        s = s - s.mean(axis=1, keepdims=True)
+        s = s / (np.linalg.norm(s, axis=1, keepdims=True) + eps)
+        s = s - s.mean(axis=0, keepdims=True)
+        return s / (np.linalg.norm(s, axis=0, keepdims=True) + eps)
+    d = []
+    for m in range(N_SEG, X.shape[1] + 1):
+        xn, yn = row_col_normalise(X[:, m - N_SEG:m]), row_col_normalise(Y[:, m - N_SEG:m])
+        d.append(np.sum(xn * yn) / N_SEG)
     return float(np.mean(d))
 
 

@@ -32,6 +32,25 @@ def test_stoi_properties():
     assert abs(metrics.stoi(x, x, 10000) - 1.0) < 1e-9
 
 
+def test_estoi_properties():
+    """ESTOI (the column the reference's tables report): 1 for identical signals, monotone in SNR, level invariant, and
+    below STOI for noisy speech at low SNR (no clipping stage, column normalisation)."""
+    x = _speechlike(0)
+    rng = np.random.default_rng(1)
+    assert abs(metrics.estoi(x, x, 16000) - 1.0) < 1e-9
+    prev = 1.0
+    for snr in (20, 10, 0, -10):
+        noise = rng.standard_normal(len(x))
+        noise *= np.sqrt(np.sum(x ** 2) / np.sum(noise ** 2)) * 10 ** (-snr / 20)
+        d = metrics.estoi(x, x + noise, 16000)
+        assert -0.1 < d < prev, (snr, d, prev)
+        prev = d
+    assert metrics.estoi(x, 3.7 * x, 16000) > 0.999
+    noise = rng.standard_normal(len(x))
+    noise *= np.sqrt(np.sum(x ** 2) / np.sum(noise ** 2))
+    assert metrics.estoi(x, x + noise, 16000) < metrics.stoi(x, x + noise, 16000)
+
+
 def test_sdr_values():
     x = _speechlike(2)
     n = np.random.default_rng(3).standard_normal(len(x))
@@ -55,3 +74,5 @@ def test_engine_and_oracle_outputs_score_identically():
     s_eng, s_ref = metrics.stoi(clean, y, 16000), metrics.stoi(clean, ref, 16000)
     assert round(s_eng, 3) == round(s_ref, 3) and abs(s_eng - s_ref) < 1e-6, (s_eng, s_ref)
     assert abs(metrics.sdr(clean, y) - metrics.sdr(clean, ref)) < 1e-4
+    e_eng, e_ref = metrics.estoi(clean, y, 16000), metrics.estoi(clean, ref, 16000)
+    assert round(e_eng, 3) == round(e_ref, 3) and abs(e_eng - e_ref) < 1e-6, (e_eng, e_ref)

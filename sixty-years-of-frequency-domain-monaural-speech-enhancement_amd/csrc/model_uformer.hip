@@ -161,6 +161,115 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
     }
 }
 
+// ---- the same attention on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32 products): scores and P.V of a
+// 16-query x 16-key tile are 4 + 4 MFMAs instead of 2 x 16 x 16 x 16 VALU FMAs fed by LDS broadcast reads.
+//   S^T[key][query] = K[key][:] . Q[query][:]      A = K tile (lane (m = key, g) holds K[key][4j + g]),  B = Q^T
+//   O^T[d][query]  += V^T[d][key] . P^T[key][query] A = V^T (lane (m = d, g) holds V[4g + j][d]),          B = P^T
+// The accumulator of S^T (lane (n = query, g), register i  <->  key 4g + i) IS the B operand of the second product with
+// the key order 4g + j, so the probabilities never leave their registers; the softmax statistics are per query = per
+// lane column, reduced over the four 16-lane groups with two cross-lane swaps.  One wave owns QT query tiles, a block
+// (4 waves) 64 * QT queries of one (b, f); K ([16][Tk], dim-major) and V ([T][17], key-major) of a head sit in LDS.
+typedef float uf_x4 __attribute__((ext_vector_type(4)));
+constexpr int UF_QT = 2;
+__global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restrict__ pq, float* __restrict__ out, int F,
+                                                            int T, int nh, int Tk) {
+    extern __shared__ float kv[];
+    float* Ks = kv;                        // [16][Tk], Tk % 32 == 16: the four dim rows of an A fragment hit distinct banks
+    float* Vs = kv + HD * Tk;              // [Tk][17]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int f = blockIdx.x % F, b = blockIdx.x / F;
+    const int q0 = blockIdx.y * (64 * UF_QT) + wave * (16 * UF_QT);
+    const long P = (long)F * T;
+    const float* base = pq + (long)b * nh * 48 * P + (long)f * T;
+    const int nkt = (T + 15) >> 4;
+    uf_x4 accr[UF_QT], acci[UF_QT];
+#pragma unroll
+    for (int qt = 0; qt < UF_QT; ++qt) accr[qt] = acci[qt] = uf_x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < nh; ++h) {
+        const float* hq = base + (long)h * 48 * P;
+        __syncthreads();
+        for (int i = tid; i < HD * Tk; i += 256) {
+            const int d = i / Tk, s = i - d * Tk;
+            Ks[i] = s < T ? hq[(long)(HD + d) * P + s] : 0.f;
+        }
+        for (int i = tid; i < HD * (nkt * 16); i += 256) {
+            const int d = i / (nkt * 16), s = i - d * (nkt * 16);
+            Vs[s * 17 + d] = s < T ? hq[(long)(2 * HD + d) * P + s] : 0.f;
+        }
+        __syncthreads();
+        float qf[UF_QT][4], mx[UF_QT], l[UF_QT];
+        uf_x4 o[UF_QT];
+#pragma unroll
+        for (int qt = 0; qt < UF_QT; ++qt) {
+            const int t = min(q0 + 16 * qt + n, T - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf[qt][j] = hq[(long)(4 * j + g) * P + t] * 0.25f;      // / hidden_channel ** 0.5
+            mx[qt] = -3.0e38f;
+            l[qt] = 0.f;
+            o[qt] = uf_x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int key0 = kt * 16;
+            float ka[4], va[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ka[j] = Ks[(4 * j + g) * Tk + key0 + n];
+                va[j] = Vs[(key0 + 4 * g + j) * 17 + n];
+            }
+#pragma unroll
+            for (int qt = 0; qt < UF_QT; ++qt) {
+                uf_x4 sc = uf_x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j], qf[qt][j], sc, 0, 0, 0);
+                float cm = -3.0e38f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (key0 + 4 * g + i >= T) sc[i] = -3.0e38f;
+                    cm = fmaxf(cm, sc[i]);
+                }
+                cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+                cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+                const float mn = fmaxf(mx[qt], cm);
+                const float corr = __expf(mx[qt] - mn);
+                float ps = 0.f;
+                uf_x4 pe;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pe[i] = __expf(sc[i] - mn);          // masked keys: exp(-3e38 - mn) = 0
+                    ps += pe[i];
+                }
+                ps += __shfl_xor(ps, 16, 64);
+                ps += __shfl_xor(ps, 32, 64);
+                l[qt] = l[qt] * corr + ps;
+                o[qt] *= corr;
+                mx[qt] = mn;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[j], pe[j], o[qt], 0, 0, 0);
+            }
+        }
+        const float sg = (nh == 1) ? 1.f : ((h == 0 || (h >= 4 && h < 7)) ? 1.f : -1.f);
+#pragma unroll
+        for (int qt = 0; qt < UF_QT; ++qt) {
+            const float w = sg / l[qt];
+            if (nh == 1 || h < 4) accr[qt] += o[qt] * w;
+            else acci[qt] += o[qt] * w;
+        }
+    }
+    const int nout = nh == 1 ? 1 : 2;
+#pragma unroll
+    for (int qt = 0; qt < UF_QT; ++qt) {
+        const int t = q0 + 16 * qt + n;
+        if (t >= T) continue;
+        float* ob = out + (long)b * nout * HD * P + (long)f * T + t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ob[(long)(4 * g + i) * P] = accr[qt][i];
+            if (nout == 2) ob[(long)(HD + 4 * g + i) * P] = acci[qt][i];
+        }
+    }
+}
+
 // ---- attention along F (f_att_cplx.py:13-29): one thread per (b, f_q, t)
 __global__ __launch_bounds__(256) void uf_att_f_kernel(const float* __restrict__ pq, float* __restrict__ out, int F, int T,
                                                        int nh) {
@@ -545,9 +654,24 @@ class Uformer final : public Model {
         ln(a.ln1, x, b.t1, m * B, CC, P, st);
         pw(a.proj, b.t1, m * CC, b.pq, a.nh * 48, nullptr, B, P, st);
         if (along_t) {
-            const size_t lds = (size_t)2 * HD * T * sizeof(float);
-            SE_CHECK(lds <= 64 * 1024, "utterance too long for the LDS-resident T-attention K/V tiles");
-            hipLaunchKernelGGL(uf_att_t_kernel, dim3(B * F, (T + 255) / 256), dim3(256), lds, st, b.pq, b.t2, F, T, a.nh);
+            // SE_UF_ATT_MFMA=0: the round-1 VALU kernel (kept for the A/B measurement in profiles/)
+            static const bool mfma = !(getenv("SE_UF_ATT_MFMA") && atoi(getenv("SE_UF_ATT_MFMA")) == 0);
+            if (mfma) {
+                int Tk = (T + 15) / 16 * 16;
+                if (Tk % 32 != 16) Tk += 16;
+                const size_t lds = ((size_t)HD * Tk + (size_t)((T + 15) / 16 * 16) * 17) * sizeof(float);
+                SE_CHECK(lds <= 150 * 1024, "utterance too long for the LDS-resident T-attention K/V tiles");
+                static bool seen[64] = {};
+                if (first_on_device(seen))
+                    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(uf_att_t_mfma_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                hipLaunchKernelGGL(uf_att_t_mfma_kernel, dim3(B * F, (T + 64 * UF_QT - 1) / (64 * UF_QT)), dim3(256), lds, st,
+                                   b.pq, b.t2, F, T, a.nh, Tk);
+            } else {
+                const size_t lds = (size_t)2 * HD * T * sizeof(float);
+                SE_CHECK(lds <= 64 * 1024, "utterance too long for the LDS-resident T-attention K/V tiles");
+                hipLaunchKernelGGL(uf_att_t_kernel, dim3(B * F, (T + 255) / 256), dim3(256), lds, st, b.pq, b.t2, F, T, a.nh);
+            }
         } else {
             SE_CHECK(F <= 8, "F-attention kernel is built for the 4-bin bottleneck");
             hipLaunchKernelGGL(uf_att_f_kernel, dim3((T + 255) / 256, F, B), dim3(256), 0, st, b.pq, b.t2, F, T, a.nh);

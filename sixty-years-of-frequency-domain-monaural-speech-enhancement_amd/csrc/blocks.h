@@ -71,6 +71,7 @@ inline void tcm_head(const NormAct& n, const float* fir, int K, const float* x, 
 
 struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:126-158)
     GCPlan in_conv, convL, convR, out_conv;
+    TcmFusedW fused;       // the same block as one kernel per utterance (k_tcm.hip), built when every norm is an InstanceNorm
     NormAct nL, nR, nO;
     float *firL = nullptr, *firR = nullptr;
     int K = 0, d = 1;
@@ -89,10 +90,16 @@ struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:
             w4.shape = {co, ci, 1, k};
             return conv_weights(w4, nullptr, false);
         };
-        in_conv = make_pointwise_plan(c1(p + "in_conv.weight", 64, 256, 1), ACT_NONE, {}, 401);
-        if (gated) convR = make_conv_plan(c1(p + right + ci, 64, 64, ks), 1, 0, (ks - 1) * d, 1, d, ACT_SIGMOID, {}, EPI_ACT, 401);
-        convL = make_conv_plan(c1(p + left + ci, 64, 64, ks), 1, 0, (ks - 1) * d, 1, d, ACT_NONE, {}, gated ? EPI_MUL : EPI_ACT, 401);
-        out_conv = make_pointwise_plan(c1(p + "out_conv.2.weight", 256, 64, 1), ACT_NONE, {}, 401, EPI_ADD);
+        const DenseW w_in = c1(p + "in_conv.weight", 64, 256, 1), w_l = c1(p + left + ci, 64, 64, ks),
+                     w_out = c1(p + "out_conv.2.weight", 256, 64, 1);
+        DenseW w_r;
+        if (gated) w_r = c1(p + right + ci, 64, 64, ks);
+        in_conv = make_pointwise_plan(w_in, ACT_NONE, {}, 401);
+        if (gated) convR = make_conv_plan(w_r, 1, 0, (ks - 1) * d, 1, d, ACT_SIGMOID, {}, EPI_ACT, 401);
+        convL = make_conv_plan(w_l, 1, 0, (ks - 1) * d, 1, d, ACT_NONE, {}, gated ? EPI_MUL : EPI_ACT, 401);
+        out_conv = make_pointwise_plan(w_out, ACT_NONE, {}, 401, EPI_ADD);
+        if ((ks == 3 || ks == 5) && !sd.has(p + left + ".1.gain"))       // cLN variants keep the multi-launch path
+            fused = tcm_fused_build(w_in.w, w_l.w, gated ? &w_r.w : nullptr, w_out.w, ks);
         nL.load(sd, p + left + ".1.", p + left + ".0.");
         if (gated) nR.load(sd, p + right + ".1.", p + right + ".0.");
         nO.load(sd, p + "out_conv.1.", p + "out_conv.0.");
@@ -103,6 +110,7 @@ struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:
     }
     void free() {
         for (GCPlan* g : {&in_conv, &convL, &convR, &out_conv}) gc_free_plan(*g);
+        tcm_fused_free(fused);
         nL.free();
         nR.free();
         nO.free();
@@ -116,7 +124,20 @@ struct TcmScratch {
 };
 
 // x [B][256][T] -> y [B][256][T]
+// batch from which one workgroup per utterance beats the multi-launch path (SE_TCM_FUSED_MINB; 0 = never fuse)
+inline int tcm_fused_min_batch() {
+    static const int v = getenv("SE_TCM_FUSED_MINB") ? atoi(getenv("SE_TCM_FUSED_MINB")) : 96;
+    return v;
+}
 inline void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratch& s, int B, int T, hipStream_t st, Profiler* pf) {
+    if (k.fused.w1 && tcm_fused_min_batch() > 0 && B >= tcm_fused_min_batch() && tcm_fused_supported(T)) {
+        const TcmFusedHeads hd{k.nL.s, k.nL.g, k.nL.b, k.firL, k.nR.s, k.nR.g, k.nR.b, k.firR, k.nO.s, k.nO.g, k.nO.b};
+        const bool timed = pf && pf->on;
+        if (timed) pf->begin(st);
+        launch_tcm_fused(k.fused, hd, x, y, B, T, k.d, k.K, st);
+        if (timed) pf->end(st, 2.0 * B * T * (64.0 * 256 * 2 + 64.0 * 64 * k.fused.ks * (k.gated ? 2 : 1)));
+        return;
+    }
     run_pointwise(k.in_conv, x, 256L * T, T, s.h, 64L * T, T, B, T, st, pf);
     if (k.gated) {
         tcm_head(k.nR, k.firR, k.K, s.h, s.a, B, 64, T, st);

@@ -1,0 +1,415 @@
+// One TCM / GLU block of the gated-U-Net models in ONE kernel (CTSNet Step1_network.py:158-188 `Glu`,
+// Step2_network.py:126-158 `glu`, G2Net_VB/gaf_net_320.py:245-274 `Glu`, TaylorSENet/TaylorSENet.py:641-685 `SqueezedTCM`):
+//
+//   x [256][T] -> 1x1 conv (256 -> 64) -> per branch { PReLU -> InstanceNorm1d -> [shared causal FIR] -> dilated causal
+//   Conv1d (64 -> 64, k taps) } -> [left * sigmoid(right)] -> PReLU -> InstanceNorm1d -> 1x1 conv (64 -> 256) -> + x
+//
+// Round 1 ran this as 3 (4) tap-table GEMM launches + 2 (3) norm/FIR launches per block - 64-row tiles that fill a quarter
+// of the chip at 40 us each and an HBM round trip of the [64][T] tensor between every pair.  The
+// InstanceNorm statistics span the whole utterance, so the unit that can run a block without leaving the chip is ONE
+// UTTERANCE: a 512-thread workgroup per utterance keeps the 64-channel bottleneck tensor in its registers (the MFMA
+// accumulators of the 1x1 conv ARE the tensor: 2 row tiles x 2 column tiles x 16 per lane) and the normalised copy that
+// the next GEMM reads in LDS ([64][Tp] floats, 104 KB at T = 401).  All three GEMMs run on v_mfma_f32_32x32x2_f32 (exact
+// fp32 products); weights are packed on the host in MFMA fragment order and come straight from L2 into registers, the
+// 256-channel input is read once from HBM as the B operand of the first GEMM and once as the residual.
+//
+// Used when the batch fills the chip (one workgroup per CU); small batches keep the multi-launch path (blocks.h).
+#include "kernels.h"
+#include "common.h"
+
+namespace se {
+
+typedef float tcm_x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TCM_C = 64, TCM_CIO = 256, TCM_NW = 8;      // bottleneck channels, block in/out channels, waves per workgroup
+
+__device__ __forceinline__ float half_sum32(float v) {     // sum over the 32 lanes that share (lane >> 5)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }      // MFMA 32x32 D layout
+
+}  // namespace
+
+struct HeadParams {
+    const float *slope, *gamma, *beta, *fir;
+};
+
+struct TcmFusedArgs {
+    const float* x; float* y;
+    int B, T, Tp;
+    const float *w1, *w2L, *w2R, *w3;
+    HeadParams hL, hR, hO;
+    int dil, K;
+    const int* tlen;
+    int dbg;       // tuning ablations (SE_TCM_DBG): 1 no GEMM 1, 2 no head statistics, 4 no dilated conv, 8 no GEMM 3, 16 no FIR
+};
+
+template <int KS, bool GATED>
+__global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Tp = a.Tp, T = a.T;
+    float* A = lds;                            // [64][Tp] normalised tensor = B operand of the next GEMM
+    float* part = lds + TCM_C * Tp;            // [8 waves][64] per-wave partial sums
+    float* prm = part + TCM_NW * TCM_C;        // [5][64]: slope, scale = rstd * gamma, shift = beta - mean * scale, mean, FIR taps
+    float* Ws = prm + 5 * TCM_C;               // [2][16 k-pairs][2 row tiles][64]: weight fragments of the running GEMM, double-buffered
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x;
+    const int Tv = a.tlen ? a.tlen[b] : T;     // frames the statistics cover (ragged batch: the row's own)
+    const float* xb = a.x + (long)b * TCM_CIO * T;
+    float* yb = a.y + (long)b * TCM_CIO * T;
+    const int ntiles = (T + 31) >> 5;
+    const int tj0 = 32 * wave + l31, tj1 = 32 * (wave + TCM_NW) + l31;      // this lane's two columns
+    const bool v1 = wave + TCM_NW < ntiles;                                 // wave-uniform: second column tile exists
+    const int tc0 = min(tj0, T - 1), tc1 = min(tj1, T - 1);
+
+    // Weights: every wave needs the same A fragments, so a GEMM's packed weights stream through LDS in chunks of CK k-pairs
+    // x 2 row tiles (8 KB: one float4 per thread), the next chunk's global load in flight under this chunk's MFMAs.  (Loading
+    // fragments straight into registers, per wave and without lookahead, left every phase bound by one L2 round trip per
+    // 4 k-pairs: 117 us for the last GEMM against 27 us of matrix work.)
+    constexpr int CK = 16;
+    typedef float wf4 __attribute__((ext_vector_type(4)));
+    // fragment (kp, mt) of a [K/2][MT][64] packed matrix; this thread's float4 of chunk c (row tiles mt0, mt0 + 1)
+    auto w_load = [&](const float* __restrict__ wg, int MT, int mt0, int c) __attribute__((always_inline)) {
+        const int e = 4 * tid, kpl = e >> 7, mt = (e >> 6) & 1, l0 = e & 63;
+        return *reinterpret_cast<const wf4*>(wg + ((long)(c * CK + kpl) * MT + mt0 + mt) * 64 + l0);
+    };
+    auto w_store = [&](int buf, wf4 v) __attribute__((always_inline)) {
+        *reinterpret_cast<wf4*>(Ws + buf * (CK * 128) + 4 * tid) = v;
+    };
+
+    // ---------------------------------------------------------------- GEMM 1: h = W_in (64 x 256) . x (256 x T)
+    tcm_x16 h[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[i][j][r] = 0.f;
+    if (!(a.dbg & 1)) {
+        // B operand (this wave's two 32-frame column tiles of x) straight from HBM into registers, one whole chunk ahead
+        const float* xr = xb + hi * T;
+        float b0[CK][2], b1[CK][2];
+        auto x_load = [&](float (&bv)[CK][2], int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                bv[u][0] = xr[(2 * (c * CK + u)) * T + tc0];          // 32-bit offsets: 256 * T fits easily
+                bv[u][1] = xr[(2 * (c * CK + u)) * T + tc1];
+            }
+        };
+        auto mma = [&](const float (&bv)[CK][2], int buf) __attribute__((always_inline)) {
+            const float* wb = Ws + buf * (CK * 128) + lane;
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                const float a0 = wb[u * 128], a1 = wb[u * 128 + 64];
+                // all four tiles unconditionally: a wave without a second column tile (T = 401: waves 5-7) would only idle
+                // at the next barrier, and a branch around 16-register accumulators costs copies
+                h[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[u][0], h[0][0], 0, 0, 0);
+                h[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[u][0], h[1][0], 0, 0, 0);
+                h[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[u][1], h[0][1], 0, 0, 0);
+                h[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[u][1], h[1][1], 0, 0, 0);
+            }
+        };
+        constexpr int NC = TCM_CIO / 2 / CK;       // 8 chunks
+        x_load(b0, 0);
+        w_store(0, w_load(a.w1, 2, 0, 0));
+        __syncthreads();
+        for (int c = 0; c < NC; c += 2) {
+            wf4 wn = w_load(a.w1, 2, 0, c + 1);
+            x_load(b1, c + 1);
+            mma(b0, 0);
+            w_store(1, wn);
+            __syncthreads();
+            if (c + 2 < NC) {
+                wn = w_load(a.w1, 2, 0, c + 2);
+                x_load(b0, c + 2);
+            }
+            mma(b1, 1);
+            if (c + 2 < NC) w_store(0, wn);
+            __syncthreads();
+        }
+    }
+
+    // PReLU -> InstanceNorm1d (two-pass statistics over the Tv valid frames) -> A[c][t], then the shared causal FIR in place
+    auto head = [&](const tcm_x16 (&src)[2][2], const HeadParams& hp, int K) __attribute__((always_inline)) {
+        __syncthreads();                                   // every reader of the previous A / prm is done
+        if (tid < TCM_C) prm[tid] = hp.slope[tid];
+        if (K > 0 && tid >= TCM_C && tid < TCM_C + K) prm[4 * TCM_C + tid - TCM_C] = hp.fir[tid - TCM_C];     // K <= 64
+        __syncthreads();
+        // pass 1: mean of PReLU(src) per channel
+        const bool in0 = tj0 < Tv, in1 = v1 && tj1 < Tv;
+        if (!(a.dbg & 2)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mt + acc_row(r, hi);
+                const float sl = prm[row];
+                float v0 = src[mt][0][r], vv1 = src[mt][1][r];
+                v0 = v0 >= 0.f ? v0 : sl * v0;
+                vv1 = vv1 >= 0.f ? vv1 : sl * vv1;
+                const float s = half_sum32((in0 ? v0 : 0.f) + (in1 ? vv1 : 0.f));
+                if (l31 == 0) part[wave * TCM_C + row] = s;
+            }
+        __syncthreads();
+        if (tid < TCM_C) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < TCM_NW; ++w) s += part[w * TCM_C + tid];
+            prm[3 * TCM_C + tid] = s / (float)Tv;
+        }
+        __syncthreads();
+        // pass 2: biased variance around that mean
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mt + acc_row(r, hi);
+                const float sl = prm[row], mu = prm[3 * TCM_C + row];
+                float v0 = src[mt][0][r], vv1 = src[mt][1][r];
+                v0 = (v0 >= 0.f ? v0 : sl * v0) - mu;
+                vv1 = (vv1 >= 0.f ? vv1 : sl * vv1) - mu;
+                const float s = half_sum32((in0 ? v0 * v0 : 0.f) + (in1 ? vv1 * vv1 : 0.f));
+                if (l31 == 0) part[wave * TCM_C + row] = s;
+            }
+        __syncthreads();
+        if (tid < TCM_C) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < TCM_NW; ++w) s += part[w * TCM_C + tid];
+            const float rstd = 1.f / sqrtf(s / (float)Tv + 1e-5f);
+            const float sc = rstd * hp.gamma[tid];
+            prm[1 * TCM_C + tid] = sc;
+            prm[2 * TCM_C + tid] = hp.beta[tid] - prm[3 * TCM_C + tid] * sc;
+        }
+        __syncthreads();
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mt + acc_row(r, hi);
+                const float sl = prm[row], sc = prm[TCM_C + row], sh = prm[2 * TCM_C + row];
+                float v0 = src[mt][0][r], vv1 = src[mt][1][r];
+                v0 = v0 >= 0.f ? v0 : sl * v0;
+                vv1 = vv1 >= 0.f ? vv1 : sl * vv1;
+                if (tj0 < Tp) A[row * Tp + tj0] = v0 * sc + sh;
+                if (v1 && tj1 < Tp) A[row * Tp + tj1] = vv1 * sc + sh;
+            }
+        __syncthreads();
+        if (K > 0 && !(a.dbg & 16)) {
+            // ShareSepConv (Step1_network.py:190-204): y[t] = sum_k fir[k] * n[t - (K-1) + k], one wave per row, in place -
+            // every output of the row is formed in registers before the first one is written back
+            constexpr int NI = 8;                          // T <= 512
+            for (int row = wave; row < TCM_C; row += TCM_NW) {
+                float* Ar = A + row * Tp;
+                float o[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) o[i] = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    const float w = prm[4 * TCM_C + k];      // taps from LDS: a global (scalar) load per tap cost 131 us per block
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int ti = lane + 64 * i - (K - 1) + k;
+                        if (ti >= 0 && ti < Tp) o[i] = fmaf(w, Ar[ti], o[i]);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int t = lane + 64 * i;
+                    if (t < Tp) Ar[t] = o[i];
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    // dilated causal Conv1d 64 -> 64 from A: acc[co][t] = sum_{tap, ci} W[co][ci][tap] * A[ci][t - (KS-1-tap) * dil]
+    // (GEMM K index tap-major: k-pair kp = tap * 32 + ci / 2, so a 16-k-pair weight chunk lies inside one tap)
+    auto dconv = [&](tcm_x16 (&acc)[2][2], const float* __restrict__ w2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (a.dbg & 4) return;
+        constexpr int NC = KS * (TCM_C / 2) / CK;      // 2 chunks per tap
+        const float* Ah = A + hi * Tp;
+        __syncthreads();                               // Ws is free (the previous GEMM's last chunk has been read)
+        w_store(0, w_load(w2, 2, 0, 0));
+        __syncthreads();
+        for (int c = 0; c < NC; ++c) {
+            wf4 wn;
+            if (c + 1 < NC) wn = w_load(w2, 2, 0, c + 1);
+            const int tap = c >> 1, cp0 = (c & 1) * CK;
+            const int shift = (KS - 1 - tap) * a.dil;
+            const int t0 = tj0 - shift, t1 = tj1 - shift;
+            const bool ok0 = t0 >= 0 && t0 < Tp, ok1 = t1 >= 0 && t1 < Tp;
+            const float* wb = Ws + (c & 1) * (CK * 128) + lane;
+            const float* A0 = Ah + (2 * cp0) * Tp + (ok0 ? t0 : 0);
+            const float* A1 = Ah + (2 * cp0) * Tp + (ok1 ? t1 : 0);
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                const float a0 = wb[u * 128], a1 = wb[u * 128 + 64];
+                float bx = A0[2 * u * Tp], by = A1[2 * u * Tp];
+                bx = ok0 ? bx : 0.f;
+                by = ok1 ? by : 0.f;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bx, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bx, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, by, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, by, acc[1][1], 0, 0, 0);
+            }
+            if (c + 1 < NC) w_store((c + 1) & 1, wn);
+            __syncthreads();
+        }
+    };
+
+    tcm_x16 m[2][2];
+    if constexpr (GATED) {
+        tcm_x16 g[2][2];
+        head(h, a.hR, a.K);
+        dconv(g, a.w2R);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[i][j][r] = __frcp_rn(1.f + __expf(-g[i][j][r]));      // hardware exp / reciprocal, as in the gc_kernel GLU epilogue
+        head(h, a.hL, a.K);
+        dconv(m, a.w2L);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) m[i][j] *= g[i][j];
+    } else {
+        head(h, a.hL, a.K);
+        dconv(m, a.w2L);
+    }
+    head(m, a.hO, 0);
+
+    // ---------------------------------------------------------------- GEMM 3: y = W_out (256 x 64) . A + x, 2 row tiles per pass
+    if (!(a.dbg & 8)) {
+        const float* Ah = A + hi * Tp;
+        const int ta0 = min(tj0, Tp - 1), ta1 = min(tj1, Tp - 1);
+        constexpr int NC = (TCM_CIO / 64) * (TCM_C / 2 / CK);      // 4 passes x 2 chunks
+        __syncthreads();
+        w_store(0, w_load(a.w3, 8, 0, 0));
+        __syncthreads();
+        tcm_x16 acc[2][2];
+        for (int c = 0; c < NC; ++c) {
+            const int ps = c >> 1, half = c & 1;
+            wf4 wn;
+            // chunk c + 1: pass (c + 1) / 2, k-pairs 16 * ((c + 1) % 2) ..  -> packed fragment row (kp, 2 ps' + mt)
+            if (c + 1 < NC) {
+                const int e = 4 * tid, kpl = e >> 7, mt = (e >> 6) & 1, l0 = e & 63, psn = (c + 1) >> 1, hn = (c + 1) & 1;
+                wn = *reinterpret_cast<const wf4*>(a.w3 + ((long)(hn * CK + kpl) * 8 + 2 * psn + mt) * 64 + l0);
+            }
+            if (half == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+            const float* wb = Ws + (c & 1) * (CK * 128) + lane;
+            const float* A0 = Ah + (2 * half * CK) * Tp + ta0;
+            const float* A1 = Ah + (2 * half * CK) * Tp + ta1;
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                const float a0 = wb[u * 128], a1 = wb[u * 128 + 64];
+                const float bx = A0[2 * u * Tp], by = A1[2 * u * Tp];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bx, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bx, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, by, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, by, acc[1][1], 0, 0, 0);
+            }
+            if (c + 1 < NC) w_store((c + 1) & 1, wn);
+            if (half == 1 && !(a.dbg & 32)) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // 32-bit element offsets (a 64-bit address per element held 128 VGPRs and spilled the accumulators)
+                        const int row = 64 * ps + 32 * mt + acc_row(r, hi);
+                        const int o0 = row * T + tj0, o1 = row * T + tj1;
+                        if (tj0 < T) yb[o0] = acc[mt][0][r] + ((a.dbg & 64) ? 0.f : xb[o0]);
+                        if (v1 && tj1 < T) yb[o1] = acc[mt][1][r] + ((a.dbg & 64) ? 0.f : xb[o1]);
+                    }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// w[m][k] (row-major, M x K) -> MFMA A fragments [K/2][M/32][64]: lane l of fragment (kp, mt) holds w[32 mt + l % 32][2 kp + l / 32]
+static std::vector<float> pack_frag(const std::vector<float>& w, int M, int K) {
+    std::vector<float> p((size_t)M * K);
+    for (int kp = 0; kp < K / 2; ++kp)
+        for (int mt = 0; mt < M / 32; ++mt)
+            for (int l = 0; l < 64; ++l)
+                p[((size_t)kp * (M / 32) + mt) * 64 + l] = w[(size_t)(32 * mt + (l & 31)) * K + 2 * kp + (l >> 5)];
+    return p;
+}
+
+TcmFusedW tcm_fused_build(const std::vector<float>& w_in, const std::vector<float>& w_left, const std::vector<float>* w_right,
+                          const std::vector<float>& w_out, int ks) {
+    TcmFusedW f;
+    f.ks = ks;
+    f.w1 = to_device(pack_frag(w_in, TCM_C, TCM_CIO));
+    // dilated conv weights arrive as [co][ci][tap]; GEMM K index is tap-major: k = tap * 64 + ci
+    auto tapmajor = [&](const std::vector<float>& w) {
+        std::vector<float> r((size_t)TCM_C * TCM_C * ks);
+        for (int co = 0; co < TCM_C; ++co)
+            for (int ci = 0; ci < TCM_C; ++ci)
+                for (int t = 0; t < ks; ++t) r[(size_t)co * (TCM_C * ks) + t * TCM_C + ci] = w[((size_t)co * TCM_C + ci) * ks + t];
+        return pack_frag(r, TCM_C, TCM_C * ks);
+    };
+    f.w2L = to_device(tapmajor(w_left));
+    if (w_right) f.w2R = to_device(tapmajor(*w_right));
+    f.w3 = to_device(pack_frag(w_out, TCM_CIO, TCM_C));
+    return f;
+}
+
+void tcm_fused_free(TcmFusedW& f) {
+    for (float* p : {f.w1, f.w2L, f.w2R, f.w3})
+        if (p) (void)hipFree(p);
+    f = TcmFusedW{};
+}
+
+bool tcm_fused_supported(int T) { return T >= 32 && T <= 512; }
+
+void launch_tcm_fused(const TcmFusedW& f, const TcmFusedHeads& hd, const float* x, float* y, int B, int T, int dil, int K,
+                      hipStream_t s) {
+    SE_CHECK(tcm_fused_supported(T) && f.w1, "fused TCM block: unsupported shape");
+    const int Tp = (T + 31) / 32 * 32;
+    const Ragged* rg = ragged_ctx();
+    TcmFusedArgs a{x, y, B, T, Tp, f.w1, f.w2L, f.w2R, f.w3,
+                   {hd.sL, hd.gL, hd.bL, hd.firL}, {hd.sR, hd.gR, hd.bR, hd.firR}, {hd.sO, hd.gO, hd.bO, nullptr},
+                   dil, K, rg ? rg->tlen : nullptr, getenv("SE_TCM_DBG") ? atoi(getenv("SE_TCM_DBG")) : 0};
+    const size_t lds = ((size_t)TCM_C * Tp + TCM_NW * TCM_C + 5 * TCM_C + 2 * 16 * 128) * sizeof(float);
+    const bool gated = f.w2R != nullptr;
+    auto go = [&](auto kern) {
+        static bool seen[64] = {};
+        if (first_on_device(seen))
+            SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds, s, a);
+    };
+    if (f.ks == 5 && gated) go(tcm_fused_kernel<5, true>);
+    else if (f.ks == 5) go(tcm_fused_kernel<5, false>);
+    else if (f.ks == 3 && gated) go(tcm_fused_kernel<3, true>);
+    else if (f.ks == 3) go(tcm_fused_kernel<3, false>);
+    else SE_CHECK(false, "fused TCM block: kernel size must be 3 or 5");
+    SE_HIP(hipGetLastError());
+}
+
+}  // namespace se

@@ -106,6 +106,21 @@ void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, c
 void launch_tcm_head(const float* x, float* y, const float* slope, const float* gamma, const float* beta,
                      const float* fir, int K, int B, int C, int T, hipStream_t s);
 
+// One whole TCM / GLU block per utterance in a single kernel (k_tcm.hip): x [B][256][T] -> y [B][256][T].
+struct TcmFusedW {          // device weights in MFMA fragment order, owned by the block
+    float *w1 = nullptr, *w2L = nullptr, *w2R = nullptr, *w3 = nullptr;     // w2R == nullptr: single branch (no gate)
+    int ks = 0;
+};
+struct TcmFusedHeads {      // per-channel [64] PReLU slopes / InstanceNorm affine of the three heads, branch FIRs [K]
+    const float *sL, *gL, *bL, *firL, *sR, *gR, *bR, *firR, *sO, *gO, *bO;
+};
+TcmFusedW tcm_fused_build(const std::vector<float>& w_in, const std::vector<float>& w_left, const std::vector<float>* w_right,
+                          const std::vector<float>& w_out, int ks);
+void tcm_fused_free(TcmFusedW& f);
+bool tcm_fused_supported(int T);
+void launch_tcm_fused(const TcmFusedW& f, const TcmFusedHeads& hd, const float* x, float* y, int B, int T, int dil, int K,
+                      hipStream_t s);
+
 // CumulativeLayerNorm2d / 1d of the `_new` variants (CTSNet_new/Step1_network.py:213-286): frame t is normalised by the
 // statistics of all C*F values of frames 0..t;  x [B][C][F][T] (F = 1 for 1-D), gain / bias [C].
 //   y = FIR_K( cLN( PReLU_pre(x) ) )   (TCM branch head, K > 0, not in place)   or   y = PReLU_post( cLN(x) )

@@ -111,6 +111,26 @@ int64_t se_output_samples(const se_engine* e, int32_t n_samples);
 int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, int32_t batch, const int32_t* lengths,
                       float* wav_out_dev, int64_t out_pitch, void* stream);
 
+/* Frame-online ("streaming") decoding for the causal models - SURVEY.md 8(f) rank 4.  The reference only ever runs its
+ * causal architectures offline (`for file_id in file_list`, whole utterance per forward, e.g. CRN/crn_decode_vb.py:33-52;
+ * CRN.py:38 / :112-117 pad-top-1 + Chomp_T make every (de)conv look back exactly one frame, the LSTMs are unidirectional).
+ * Here the same decode runs incrementally over `batch` parallel streams: se_stream_push() appends n_new samples per row,
+ * transforms every STFT frame whose samples have all arrived, advances the network by those frames (one history frame per
+ * conv layer and the LSTM (h, c) are carried in the engine) and returns the output samples that are now final - those
+ * covered by no future frame - at the start of each row of out_dev; *n_out (host) = their count (same for all rows, 0 is
+ * normal for short pushes: the algorithmic latency is n_fft / 2 + 1 samples plus up to one hop).  se_stream_flush() ends
+ * the stream: the remaining frames (reflected right edge, as the offline STFT) and samples; the concatenated outputs equal
+ * se_enhance_batch() of the whole signal sample for sample (up to fp32 rounding of the differently tiled recurrence).
+ *   c_dev: the utterance scale c (se_rms_scale) cannot be known before the utterance ends; the caller provides one value
+ *          per stream (e.g. from a calibration run or a running estimate), NULL = 1.0.  With the offline c the two paths
+ *          agree exactly - that is what the tests check.
+ *   max_chunk_frames: frames advanced per internal step (latency / efficiency trade-off, default 16).
+ * Supported: SE_MODEL_CRN, SE_MODEL_LSTM.  Streams are limited to max_samples of se_config. */
+int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, void* stream);
+int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_new, float* out_dev, int64_t out_pitch,
+                   int32_t* n_out, void* stream);
+int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_out, void* stream);
+
 /* Stage hooks, so each oracle-pinned stage can be diffed alone (engine-internal spectrogram layout
  * [B][2][F][T] re/im planes, T contiguous, row pitch = T).
  *   se_stft     : torch.stft / librosa.stft call of the model's decode script, fused with x*c and |X|^p_in.
@@ -150,7 +170,7 @@ int se_resample(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n_
                 float* out_dev, int64_t out_pitch, void* stream);
 
 /* ABI version of this header. */
-int32_t se_abi_version(void);   /* 2: se_enhance_ragged */
+int32_t se_abi_version(void);   /* 2: se_enhance_ragged, se_get_stage_profile, se_stream_* */
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,13 @@ struct se_engine {
     int rag_next = 0;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // se_stream_*: the samples received so far ([batch][max_samples]), frames transformed, samples emitted
+    struct Stream {
+        bool active = false;
+        int batch = 0, max_chunk = 0, n_total = 0, t_done = 0, o_done = 0;
+        float* wav = nullptr;
+        float* c = nullptr;
+    } strm;
 };
 
 static std::string g_create_err;
@@ -146,6 +153,8 @@ int se_engine_destroy(se_engine* e) {
         (void)hipEventDestroy(e->ev_fork);
         (void)hipEventDestroy(e->ev_join);
     }
+    if (e->strm.wav) (void)hipFree(e->strm.wav);
+    if (e->strm.c) (void)hipFree(e->strm.c);
     if (e->rag_host) (void)hipHostFree(e->rag_host);
     if (e->rag_dev) (void)hipFree(e->rag_dev);
     for (auto& ev : e->rag_ev)
@@ -340,6 +349,101 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
             ~Scope() { set_ragged_ctx(nullptr); }
         } scope(&rg);
         e->model->enhance(wav_in_dev, in_pitch, batch, Lmax, wav_out_dev, out_pitch, st);
+    });
+}
+
+// frames [e->strm.t_done, t_end) of the stream through the network, then every output sample they complete (all of them up to
+// n_final when `last`); returns the number of samples appended to out row b at out_dev[b * out_pitch + *written ...]
+static void stream_process(se_engine* e, int t_end, bool last, float* out_dev, int64_t out_pitch, int* written, hipStream_t st) {
+    se_engine::Stream& S = e->strm;
+    const StftGeom& g = e->ctx.geom;
+    const int HC = Model::STREAM_HC, B = S.batch;
+    while (S.t_done < t_end) {
+        const int t0 = S.t_done, n = std::min(S.max_chunk, t_end - t0), Tw = HC + n;
+        float *spec = nullptr, *mag = nullptr, *est = nullptr;
+        e->model->stream_bufs(B, n, &spec, &mag, &est);
+        // a frame that is transformed before the end of the stream never touches the end reflection (se_stream_push only
+        // releases frames whose last sample has arrived), so L = Lpad = samples received is exact for both cases
+        launch_stft(g, S.wav, e->ctx.max_samples, B, S.n_total, S.n_total, S.c, e->ctx.p_in, spec, mag, t0 + n, Tw, st, t0, HC);
+        e->model->stream_chunk(B, t0, n, st);
+        S.t_done = t0 + n;
+        // samples whose every covering frame exists: positions below t_done * hop (all the rest once the stream has ended)
+        const int o_hi = (last && S.t_done == t_end) ? S.n_total : std::min(S.n_total, S.t_done * g.hop - g.n_fft / 2);
+        if (o_hi > S.o_done) {
+            launch_istft(g, est, B, S.t_done, Tw, nullptr, S.c, out_dev + *written, out_pitch, o_hi, st, t0 - HC,
+                         std::max(0, t0 - HC), S.o_done);
+            *written += o_hi - S.o_done;
+            S.o_done = o_hi;
+        }
+    }
+}
+
+int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(e->finalized, "engine not finalized");
+        SE_CHECK(e->model->stream_supported(), "this model has no frame-online mode (CRN and LSTM have)");
+        SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
+        const StftGeom& g = e->ctx.geom;
+        SE_CHECK((g.n_fft + g.hop - 1) / g.hop - 1 <= Model::STREAM_HC, "front end overlaps more frames than the history holds");
+        SE_CHECK(e->model->padded_samples(12345) == 12345, "streaming needs a decode script without tail padding");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        se_engine::Stream& S = e->strm;
+        const int tmax = e->model->num_frames(e->ctx.max_samples);
+        S.max_chunk = std::max(1, std::min(max_chunk_frames > 0 ? max_chunk_frames : 16, tmax - Model::STREAM_HC));
+        if (!S.wav) {
+            SE_HIP(hipMalloc(&S.wav, (size_t)e->ctx.max_batch * e->ctx.max_samples * sizeof(float)));
+            SE_HIP(hipMalloc(&S.c, (size_t)e->ctx.max_batch * sizeof(float)));
+        }
+        if (c_dev) SE_HIP(hipMemcpyAsync(S.c, c_dev, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, st));
+        else launch_fill(S.c, batch, 1.f, st);
+        S.batch = batch;
+        S.n_total = S.t_done = S.o_done = 0;
+        e->model->stream_begin(batch, S.max_chunk, st);
+        S.active = true;
+    });
+}
+
+int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_new, float* out_dev, int64_t out_pitch,
+                   int32_t* n_out, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        se_engine::Stream& S = e->strm;
+        SE_CHECK(S.active, "se_stream_push without se_stream_begin");
+        SE_CHECK(wav_dev && out_dev && n_out && n_new >= 0, "bad argument");
+        SE_CHECK(S.n_total + n_new <= e->ctx.max_samples, "stream longer than max_samples given at create");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const StftGeom& g = e->ctx.geom;
+        if (n_new > 0)
+            SE_HIP(hipMemcpy2DAsync(S.wav + S.n_total, (size_t)e->ctx.max_samples * sizeof(float), wav_dev,
+                                    (size_t)pitch * sizeof(float), (size_t)n_new * sizeof(float), S.batch,
+                                    hipMemcpyDeviceToDevice, st));
+        S.n_total += n_new;
+        // frame t is final once sample t * hop + n_fft / 2 has arrived (its right half is real signal, and frame 0's reflected
+        // left half needs sample n_fft / 2 as well)
+        const int t_avail = S.n_total > g.n_fft / 2 ? (S.n_total - g.n_fft / 2 - 1) / g.hop + 1 : 0;
+        int written = 0;
+        const int will = std::max(0, std::min(S.n_total, t_avail * g.hop - g.n_fft / 2) - S.o_done);
+        SE_CHECK(out_pitch >= will, "output row pitch too small for the samples this push completes");
+        e->ctx.prof_reset();
+        stream_process(e, std::max(t_avail, S.t_done), false, out_dev, out_pitch, &written, st);
+        *n_out = written;
+    });
+}
+
+int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_out, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        se_engine::Stream& S = e->strm;
+        SE_CHECK(S.active, "se_stream_flush without se_stream_begin");
+        SE_CHECK(out_dev && n_out, "bad argument");
+        SE_CHECK(S.n_total >= e->ctx.geom.n_fft, "stream shorter than one FFT frame");
+        SE_CHECK(out_pitch >= S.n_total - S.o_done, "output row pitch too small for the rest of the stream");
+        int written = 0;
+        e->ctx.prof_reset();
+        stream_process(e, e->model->num_frames(S.n_total), true, out_dev, out_pitch, &written, static_cast<hipStream_t>(stream));
+        *n_out = written;
+        S.active = false;
     });
 }
 

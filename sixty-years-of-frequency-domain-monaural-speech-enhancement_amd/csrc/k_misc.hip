@@ -617,6 +617,29 @@ void launch_zero_tail(float* x, int B, long rows, int T, hipStream_t s) {
     SE_HIP(hipGetLastError());
 }
 
+// ---- streaming history columns -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hist_kernel(float* __restrict__ buf, float* __restrict__ state, long nrows, int Tw,
+                                                   int hc, int save) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrows * hc) return;
+    const long r = i / hc;
+    const int k = (int)(i - r * hc);
+    if (save) state[i] = buf[r * Tw + (Tw - hc) + k];
+    else buf[r * Tw + k] = state[i];
+}
+void launch_hist_restore(float* buf, const float* state, int B, long rows, int Tw, int hc, hipStream_t s) {
+    const long n = (long)B * rows * hc;
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, buf, const_cast<float*>(state),
+                       (long)B * rows, Tw, hc, 0);
+    SE_HIP(hipGetLastError());
+}
+void launch_hist_save(const float* buf, float* state, int B, long rows, int Tw, int hc, hipStream_t s) {
+    const long n = (long)B * rows * hc;
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, const_cast<float*>(buf), state,
+                       (long)B * rows, Tw, hc, 1);
+    SE_HIP(hipGetLastError());
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;

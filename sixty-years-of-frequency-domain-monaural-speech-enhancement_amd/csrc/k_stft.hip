@@ -175,6 +175,7 @@ struct StftArgs {
     const float* wav; long pitch; int B, L, Lpad; const float* c_scale; float p_in;
     float* spec; float* mag; int T, Tp, hop, win;
     const int *len, *lpad, *tlen;      // ragged batch: per-row L, Lpad, T (else null)
+    int t_first, col0;                 // frames [t_first, T) are transformed, frame t lands in column t - t_first + col0
 };
 
 // two-for-one: a block owns 16 consecutive frames as 8 complex transforms z = x_{2p} + i x_{2p+1}
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
     float2* bufs = tw + N;                                  // [PPB][2][N]
     float* win = reinterpret_cast<float*>(bufs + PPB * 2 * N);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.x * FPB;
+    const int b = blockIdx.y, t0 = a.t_first + blockIdx.x * FPB;
+    const int cshift = a.col0 - a.t_first;          // output column of frame t = t + cshift
     init_tables<N>(tw, win, a.win, tid);
     __syncthreads();
     const float c = a.c_scale ? a.c_scale[b] : 1.f;
@@ -209,10 +211,10 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
             const int t = t0 + (idx & (FPB - 1)), k = idx >> 4;
             if (t >= a.T) continue;
             if (a.spec) {
-                a.spec[(((long)b * 2 + 0) * F + k) * a.Tp + t] = 0.f;
-                a.spec[(((long)b * 2 + 1) * F + k) * a.Tp + t] = 0.f;
+                a.spec[(((long)b * 2 + 0) * F + k) * a.Tp + t + cshift] = 0.f;
+                a.spec[(((long)b * 2 + 1) * F + k) * a.Tp + t + cshift] = 0.f;
             }
-            if (a.mag) a.mag[((long)b * F + k) * a.Tp + t] = 0.f;
+            if (a.mag) a.mag[((long)b * F + k) * a.Tp + t + cshift] = 0.f;
         }
         return;
     }
@@ -262,10 +264,10 @@ __global__ __launch_bounds__(256) void stft_kernel(const StftArgs a) {
             v.y *= sc;
         }
         if (a.spec) {
-            a.spec[(((long)b * 2 + 0) * F + k) * a.Tp + t] = v.x;
-            a.spec[(((long)b * 2 + 1) * F + k) * a.Tp + t] = v.y;
+            a.spec[(((long)b * 2 + 0) * F + k) * a.Tp + t + cshift] = v.x;
+            a.spec[(((long)b * 2 + 1) * F + k) * a.Tp + t + cshift] = v.y;
         }
-        if (a.mag) a.mag[((long)b * F + k) * a.Tp + t] = mp;
+        if (a.mag) a.mag[((long)b * F + k) * a.Tp + t + cshift] = mp;
     }
 }
 
@@ -274,6 +276,9 @@ struct IstftArgs {
     const float* c_scale; float* out; long out_pitch; int Lout;
     int own, halo;        // overlap-add positions a block owns = own * hop; frames it transforms = FPB = own + halo
     const int *tlen, *olen;     // ragged batch: frames / output samples of row b (else null); samples in [olen, Lout) = 0
+    // streaming window (offline: all zero): frame t sits in spec column t - t_off, frames [t_lo, T) exist, the launch emits
+    // output samples [o_lo, Lout) into out[o - o_lo], block 0 starts at overlap-add position pos_base (a hop multiple)
+    int t_off, t_lo, o_lo, pos_base;
 };
 
 // Inverse STFT with the overlap-add fused in: a block transforms FPB = 16 consecutive frames (two-for-one: Z = X_{2p} +
@@ -294,14 +299,14 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftArgs a) {
     const int Tb = a.tlen ? a.tlen[b] : a.T;
     const int Lo = a.olen ? a.olen[b] : a.Lout;
     const int span = a.own * a.hop;
-    const int pos0 = blockIdx.x * span;                     // first overlap-add position (pos = sample + N/2) of the block
-    const int tb = blockIdx.x * a.own - a.halo;             // first frame of the window (may be negative)
-    float* outp = a.out + (long)b * a.out_pitch;
+    const int pos0 = a.pos_base + blockIdx.x * span;        // first overlap-add position (pos = sample + N/2) of the block
+    const int tb = pos0 / a.hop - a.halo;                   // first frame of the window (may be negative)
+    float* outp = a.out + (long)b * a.out_pitch - a.o_lo;
     // nothing of this row left (ragged batch, or the rounding of the grid): zeros up to Lout (block-uniform branch)
     if (pos0 - N / 2 >= Lo || tb >= Tb) {
         for (int i = tid; i < span; i += 256) {
             const int o = pos0 + i - N / 2;
-            if (o >= 0 && o < a.Lout) outp[o] = 0.f;
+            if (o >= a.o_lo && o < a.Lout) outp[o] = 0.f;
         }
         return;
     }
@@ -311,10 +316,10 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftArgs a) {
         const int pi = idx & (PPB - 1), k = idx >> 3;
         const int t = tb + 2 * pi;
         float2 xa = make_float2(0.f, 0.f), xb = make_float2(0.f, 0.f);
-        const float* re = a.spec + (((long)b * 2 + 0) * F + k) * a.Tp;
-        const float* im = a.spec + (((long)b * 2 + 1) * F + k) * a.Tp;
-        if (t >= 0 && t < Tb) xa = make_float2(re[t], im[t]);
-        if (t + 1 >= 0 && t + 1 < Tb) xb = make_float2(re[t + 1], im[t + 1]);
+        const float* re = a.spec + (((long)b * 2 + 0) * F + k) * a.Tp - a.t_off;
+        const float* im = a.spec + (((long)b * 2 + 1) * F + k) * a.Tp - a.t_off;
+        if (t >= a.t_lo && t < Tb) xa = make_float2(re[t], im[t]);
+        if (t + 1 >= a.t_lo && t + 1 < Tb) xb = make_float2(re[t + 1], im[t + 1]);
         float2* b0 = bufs + (pi * 2) * N;
         if (k == 0 || k == N / 2) {
             b0[k] = make_float2(xa.x, xb.x);                // C2R ignores the imaginary part of DC / Nyquist
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftArgs a) {
     const float cinv = a.c_scale ? 1.f / a.c_scale[b] : 1.f;
     for (int i = tid; i < span; i += 256) {
         const int pos = pos0 + i, o = pos - N / 2;
-        if (o < 0 || o >= a.Lout) continue;
+        if (o < a.o_lo || o >= a.Lout) continue;
         if (o >= Lo) {
             outp[o] = 0.f;
             continue;
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const IstftArgs a) {
         int thi = pos / a.hop;
         if (thi > Tb - 1) thi = Tb - 1;
         float acc = 0.f, env = 0.f;
-        for (int t = thi; t >= 0 && pos - t * a.hop < N; --t) {
+        for (int t = thi; t >= a.t_lo && pos - t * a.hop < N; --t) {
             const int n = pos - t * a.hop, fi = t - tb;          // fi >= 0 by construction of halo
             const float2 z = (bufs + ((fi >> 1) * 2) * N + ((N == 512) ? N : 0))[n];
             const float w = win[n];
@@ -416,12 +421,13 @@ static void set_lds_attr(K kernel, size_t bytes) {
 }
 
 void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, int Lpad, const float* c_scale,
-                 float p_in, float* spec_ri, float* mag, int T, int Tp, hipStream_t s) {
+                 float p_in, float* spec_ri, float* mag, int T, int Tp, hipStream_t s, int t_first, int col0) {
     const Ragged* rg = ragged_ctx();
+    SE_CHECK(t_first >= 0 && t_first < T, "launch_stft: empty frame range");
     StageScope prof(STAGE_STFT, s, 4.0 * L * B + (spec_ri ? 8.0 : 0.0) * g.F() * T * B + (mag ? 4.0 : 0.0) * g.F() * T * B);
     StftArgs a{wav, pitch, B, L, Lpad, c_scale, p_in, spec_ri, mag, T, Tp, g.hop, g.win,
-               rg ? rg->len : nullptr, rg ? rg->lpad : nullptr, rg ? rg->tlen : nullptr};
-    dim3 grid((T + FPB - 1) / FPB, B);
+               rg ? rg->len : nullptr, rg ? rg->lpad : nullptr, rg ? rg->tlen : nullptr, t_first, col0};
+    dim3 grid((T - t_first + FPB - 1) / FPB, B);
     if (g.n_fft == 512) {
         static bool seen[64] = {};
         if (first_on_device(seen)) set_lds_attr(stft_kernel<512>, fft_lds_bytes<512>());
@@ -437,7 +443,7 @@ void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, 
 }
 
 void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* /*frames: unused since the fused kernel*/,
-                  const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s) {
+                  const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo) {
     const Ragged* rg = ragged_ctx();
     StageScope prof(STAGE_ISTFT, s, 8.0 * g.F() * T * B + 4.0 * Lout * B);
     int halo = (g.n_fft + g.hop - 1) / g.hop - 1;
@@ -445,9 +451,12 @@ void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp,
     SE_CHECK(halo < FPB, "hop too small for the fused overlap-add window");
     const int own = FPB - halo;
     IstftArgs a{spec_ri, B, T, Tp, g.hop, g.win, c_scale, wav_out, out_pitch, Lout, own, halo,
-                rg ? rg->tlen : nullptr, rg ? rg->olen : nullptr};
+                rg ? rg->tlen : nullptr, rg ? rg->olen : nullptr, t_off, t_lo, o_lo, 0};
     const int span = own * g.hop;
-    dim3 grid((g.n_fft / 2 + Lout + span - 1) / span, B);
+    // first block: the hop-aligned position at or below the first emitted sample
+    a.pos_base = (o_lo + g.n_fft / 2) / g.hop * g.hop;
+    SE_CHECK(Lout > o_lo, "launch_istft: empty output range");
+    dim3 grid((g.n_fft / 2 + Lout - a.pos_base + span - 1) / span, B);
     if (g.n_fft == 512) {
         static bool seen[64] = {};
         if (first_on_device(seen)) set_lds_attr(istft_ola_kernel<512>, fft_lds_bytes<512>());

@@ -63,13 +63,22 @@ void launch_rms_scale(const float* wav, int B, int L, long pitch, float* c_out, 
 // magnitude power-compression |X|^p * e^{j angle X}.
 //   wav [B][pitch] (first L samples valid; samples in [L, Lpad) are the decode scripts' zero tail pad)
 //   spec_ri [B][2][F][Tp]   (may be null)     mag [B][F][Tp] = |X|^p (may be null)
+// Streaming: only frames [t_first, T) are transformed, frame t lands in column t - t_first + col0 of the Tp-pitch rows.
 void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, int Lpad, const float* c_scale,
-                 float p_in, float* spec_ri, float* mag, int T, int Tp, hipStream_t s);
+                 float p_in, float* spec_ri, float* mag, int T, int Tp, hipStream_t s, int t_first = 0, int col0 = 0);
 
 // Inverse: spec_ri [B][2][F][Tp] -> windowed frames [B][T][n_fft] (scratch) -> overlap-add, divide by the
 // overlap-added squared window, drop n_fft/2 head, write Lout samples, divide by c.
+// Streaming window: frame t sits in spec column t - t_off, frames [t_lo, T) exist; output samples [o_lo, Lout) are written
+// to wav_out[o - o_lo] (every frame covering them must be in the window).
 void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* frames_scratch,
-                  const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s);
+                  const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s, int t_off = 0, int t_lo = 0,
+                  int o_lo = 0);
+
+// Streaming history columns of a [B][rows][Tw] activation: restore the first `hc` columns from state [B][rows][hc] (the
+// producing kernel recomputed them without their own history), or save the last `hc` columns into it.
+void launch_hist_restore(float* buf, const float* state, int B, long rows, int Tw, int hc, hipStream_t s);
+void launch_hist_save(const float* buf, float* state, int B, long rows, int Tw, int hc, hipStream_t s);
 
 // DCCRN 'E' mask (DCCRN_cprs.py:201-225) + the decode script's mag/phase/decompress (dccrn_decode_vb.py:45-58):
 //   mask [B][2][F-1][Tp] (bins 1..F-1), spec [B][2][F][Tp] -> est [B][2][F][Tp], DC bin = 0.

@@ -87,6 +87,15 @@ class Model {
     // false: the model has operators that look ahead in time beyond a fixed, zero-padded look-ahead (Uformer: non-causal
     // dilated convolutions and full self-attention over time), so rows of different lengths cannot share a call
     virtual bool ragged_supported() const { return true; }
+    // ---- frame-online decoding (se_stream_*): the causal models carry their state (one history frame per conv layer,
+    // LSTM (h, c), the iSTFT's overlap) across calls instead of seeing the whole utterance.  stream_chunk() handles frames
+    // [t0, t0 + n) of B parallel streams: the engine has written their STFT into columns [STREAM_HC, STREAM_HC + n) of
+    // stream_spec() / stream_mag() (row pitch STREAM_HC + n) and reads the estimate from stream_est() in the same layout.
+    static constexpr int STREAM_HC = 2;     // history columns in front of every chunk tensor (convs look back 1 frame, the iSTFT 1)
+    virtual bool stream_supported() const { return false; }
+    virtual void stream_begin(int B, int max_chunk, hipStream_t st) { SE_CHECK(false, "this model has no streaming mode"); }
+    virtual void stream_bufs(int B, int n, float** spec, float** mag, float** est) { SE_CHECK(false, "no streaming mode"); }
+    virtual void stream_chunk(int B, int t0, int n, hipStream_t st) { SE_CHECK(false, "no streaming mode"); }
     // false: enhance() forks onto auxiliary streams and is not replayed from a captured hipGraph (SE_CFG_GRAPHS)
     virtual bool graph_capturable() const { return true; }
 

@@ -11,12 +11,40 @@
 // epilogue, skip concatenations are two-source K loops; the 1024-wide LSTMs run time-major ([T][feature][B]) as one
 // input-projection GEMM over all frames plus one fused GEMM + cell-update launch per frame.
 #include "rnn.h"
+#include <algorithm>
+#include <vector>
 
 namespace se {
 
 namespace {
 
 constexpr int NFFT = 320, HOP = 160, NBIN = 161;
+
+// per-stream state of the frame-online mode: history columns of every chunk tensor, LSTM (h, c)
+struct StreamState {
+    int B = 0;
+    bool first = true;
+    std::vector<float*> hist;
+    float *h[3] = {}, *c[3] = {};
+    void release() {
+        for (float* p : hist)
+            if (p) (void)hipFree(p);
+        hist.clear();
+        for (int l = 0; l < 3; ++l) {
+            if (h[l]) (void)hipFree(h[l]);
+            if (c[l]) (void)hipFree(c[l]);
+            h[l] = c[l] = nullptr;
+        }
+        B = 0;
+    }
+    ~StreamState() { release(); }
+};
+static float* zeros(size_t n, hipStream_t st) {
+    float* p = nullptr;
+    SE_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
+    SE_HIP(hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(float), st));
+    return p;
+}
 
 // ------------------------------------------------------------------------------------------------ CRN
 class Crn final : public Model {
@@ -77,6 +105,64 @@ class Crn final : public Model {
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :50-52
     }
 
+    // ---- frame-online mode (model.h): every conv / deconv looks back exactly one frame (CRN.py:38 ConstantPad2d top 1 +
+    // kernel 2 in time; :112-117 Chomp_T), the LSTMs carry (h, c)
+    bool stream_supported() const override { return true; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        ss.release();
+        ss.B = B;
+        ss.first = true;
+        for (long rows : stream_rows()) ss.hist.push_back(zeros((size_t)B * rows * STREAM_HC, st));
+        for (int l = 0; l < 2; ++l) {
+            ss.h[l] = zeros((size_t)1024 * B, st);
+            ss.c[l] = zeros((size_t)1024 * B, st);
+        }
+        (void)max_chunk;
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, STREAM_HC + n);
+        *spec = b.spec;
+        *mag = b.mag;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+        SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
+        const int HC = STREAM_HC, Tw = HC + n;
+        Bufs& b = bufs(B, Tw);
+        Profiler* pf = &ctx.prof;
+        const std::vector<long> rows = stream_rows();
+        float* tens[13] = {b.spec, b.mag, b.E[0], b.E[1], b.E[2], b.E[3], b.E[4], b.D[0], b.D[1], b.D[2], b.D[3], b.D[4], b.D[5]};
+        auto restore = [&](int k) { launch_hist_restore(tens[k], ss.hist[k], B, rows[k], Tw, HC, st); };
+        restore(0);
+        restore(1);
+        const int EC[5] = {16, 32, 64, 128, 256}, EF[5] = {80, 39, 19, 9, 4};
+        Act4 x = act4(b.mag, 1, NBIN, Tw);
+        for (int i = 0; i < 5; ++i) {
+            run_conv(enc[i], x, nullptr, b.E[i], EC[i], EF[i], B, Tw, Tw, st, pf);
+            restore(2 + i);                     // column 0 was recomputed without its own history
+            x = act4(b.E[i], EC[i], EF[i], Tw);
+        }
+        launch_transpose_akt(b.E[4] + HC, b.X, B, 1024, n, 1024L * Tw, Tw, 1024L * B, B, st);
+        lstm[0].run_stream(b.X, b.G, ss.c[0], ss.h[0], b.Hs[0], n, B, ss.first, st, pf);
+        lstm[1].run_stream(b.Hs[0], b.G, ss.c[1], ss.h[1], b.Hs[1], n, B, ss.first, st, pf);
+        launch_transpose_akt(b.Hs[1], b.D[0] + HC, n, 1024, B, 1024L * B, B, 1024L * Tw, Tw, st);
+        restore(7);
+        const int DCo[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
+        int cin = 256, fin = 4;
+        for (int i = 0; i < 5; ++i) {
+            Act4 a0 = act4(b.D[i], cin, fin, Tw);
+            Act4 a1 = act4(b.E[4 - i], cin, fin, Tw);
+            run_deconv(dec[i], a0, &a1, b.D[i + 1], DCo[i], DF[i], B, Tw, Tw, st, pf);
+            restore(8 + i);
+            cin = DCo[i];
+            fin = DF[i];
+        }
+        launch_mag_phase(b.D[5], b.spec, b.est, B, NBIN, Tw, ctx.p_out, st);     // history columns come out as last time
+        for (int k = 0; k < 13; ++k) launch_hist_save(tens[k], ss.hist[k], B, rows[k], Tw, HC, st);
+        ss.first = false;
+        (void)t0;
+    }
+
   private:
     struct Bufs {
         int B = 0, T = 0;
@@ -85,6 +171,11 @@ class Crn final : public Model {
     GCPlan enc[5];
     DeconvPlan dec[5];
     LstmBig lstm[2];
+    StreamState ss;
+    static std::vector<long> stream_rows() {      // rows (C * F) of spec, mag, E[0..4], D[0..5]
+        return {2L * NBIN, NBIN, 16L * 80, 32L * 39, 64L * 19, 128L * 9, 256L * 4, 1024L, 128L * 9, 64L * 19, 32L * 39, 16L * 80,
+                1L * 161};
+    }
 
     Bufs& bufs(int B, int T) {
         if (cur.B == B && cur.T == T) return cur;
@@ -189,6 +280,46 @@ class LstmNet final : public Model {
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :50-52
     }
 
+    // ---- frame-online mode: the network is three unidirectional LSTMs + a per-frame Linear, so the state is (h, c) x 3
+    bool stream_supported() const override { return true; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        ss.release();
+        ss.B = B;
+        ss.first = true;
+        ss.hist.push_back(zeros((size_t)B * 2 * NBIN * STREAM_HC, st));      // spec
+        ss.hist.push_back(zeros((size_t)B * NBIN * STREAM_HC, st));          // est magnitudes
+        for (int l = 0; l < 3; ++l) {
+            ss.h[l] = zeros((size_t)1024 * B, st);
+            ss.c[l] = zeros((size_t)1024 * B, st);
+        }
+        (void)max_chunk;
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, STREAM_HC + n);
+        *spec = b.spec;
+        *mag = b.mag;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+        SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
+        const int HC = STREAM_HC, Tw = HC + n;
+        Bufs& b = bufs(B, Tw);
+        Profiler* pf = &ctx.prof;
+        launch_hist_restore(b.spec, ss.hist[0], B, 2L * NBIN, Tw, HC, st);
+        launch_transpose_akt(b.mag + HC, b.X, B, NBIN, n, (long)NBIN * Tw, Tw, (long)NBIN * B, B, st);      // new frames only
+        lstm[0].run_stream(b.X, b.G, ss.c[0], ss.h[0], b.Hs[0], n, B, ss.first, st, pf);
+        lstm[1].run_stream(b.Hs[0], b.G, ss.c[1], ss.h[1], b.Hs[1], n, B, ss.first, st, pf);
+        lstm[2].run_stream(b.Hs[1], b.G, ss.c[2], ss.h[2], b.Hs[0], n, B, ss.first, st, pf);
+        run_pointwise(fc, b.Hs[0], 1024L * B, B, b.Y, (long)NBIN * B, B, n, B, st, pf);
+        launch_transpose_akt(b.Y, b.mag + HC, n, NBIN, B, (long)NBIN * B, B, (long)NBIN * Tw, Tw, st);
+        launch_hist_restore(b.mag, ss.hist[1], B, NBIN, Tw, HC, st);          // estimated magnitudes of the last two frames
+        launch_mag_phase(b.mag, b.spec, b.est, B, NBIN, Tw, ctx.p_out, st);
+        launch_hist_save(b.spec, ss.hist[0], B, 2L * NBIN, Tw, HC, st);
+        launch_hist_save(b.mag, ss.hist[1], B, NBIN, Tw, HC, st);
+        ss.first = false;
+        (void)t0;
+    }
+
   private:
     struct Bufs {
         int B = 0, T = 0;
@@ -196,6 +327,7 @@ class LstmNet final : public Model {
     } cur;
     LstmBig lstm[3];
     GCPlan fc;
+    StreamState ss;
 
     Bufs& bufs(int B, int T) {
         if (cur.B == B && cur.T == T) return cur;

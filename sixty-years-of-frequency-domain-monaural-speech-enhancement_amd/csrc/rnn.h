@@ -107,6 +107,38 @@ struct LstmBig {
                      hipStream_t st, Profiler* prof) const {
         run_cols(x, x_t, G, cell, out, out_t, out_rs, T, S, 0, S, st, prof);
     }
+    // Streaming: T more steps of S sequences continuing from (h_state [H][S], cell [H][S]) - one fused GEMM + cell launch
+    // per step (the weight-stationary cooperative kernel starts every launch from a zero state); `first` = the stream's very
+    // first step (state is zero).  h_state / cell are left holding the state after the last step.
+    void run_stream(const float* x, float* G, float* cell, float* h_state, float* out, int T, int S, bool first, hipStream_t st,
+                    Profiler* prof) const {
+        run_pointwise_cols(gin, x, (long)I * S, S, G, 4L * H * S, S, T, S, st, prof);
+        for (int t = 0; t < T; ++t) {
+            GCParams p = step.p;
+            p.first_step = (first && t == 0);
+            p.src0 = t > 0 ? out + (size_t)(t - 1) * H * S : h_state;
+            p.s0_b = 0;
+            p.s0_c = S;
+            p.s0_f = 0;
+            p.src1 = nullptr;
+            p.Fin = 1;
+            p.Tin = S;
+            p.B = 1;
+            p.Q = 1;
+            p.Tout = S;
+            p.aux = G + (size_t)t * 4 * H * S;
+            p.x_b = 0;
+            p.x_c = S;
+            p.x_f = 0;
+            p.dst = out + (size_t)t * H * S;
+            p.d_b = 0;
+            p.d_c = S;
+            p.d_f = 0;
+            p.cell = cell;
+            gc_launch_prof(step, p, st, prof);
+        }
+        SE_HIP(hipMemcpyAsync(h_state, out + (size_t)(T - 1) * H * S, (size_t)H * S * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     // the same on the sequence columns [c0, c0 + Sn) of tensors whose rows hold S sequences: sequences are independent,
     // so disjoint column ranges can run concurrently on different streams (FullSubNet's 257 * B sub-band sequences)
     void run_cols(const float* x, long x_t, float* G, float* cell, float* out, long out_t, int out_rs, int T, int S, int c0,

@@ -136,6 +136,36 @@ class Engine:
                                                 C.c_void_p(out.data_ptr()), out_pitch, self._stream()))
         return out
 
+    # ------------------------------------------------------------------ frame-online decoding
+    def stream_begin(self, batch, c=None, max_chunk_frames=16):
+        """Start `batch` parallel streams; c: per-stream scale tensor (what rms_scale() returns offline) or None = 1."""
+        if c is not None:
+            self._check_tensor(c, 'stream_begin c')
+        self._stream_batch = batch
+        self._check(self._lib.se_stream_begin(self._h, batch, max_chunk_frames,
+                                              C.c_void_p(c.data_ptr()) if c is not None else None, self._stream()))
+
+    def stream_push(self, wav):
+        """wav [batch, n_new] -> the output samples that became final, [batch, n_out] (n_out may be 0)."""
+        import torch
+        self._check_tensor(wav, 'stream_push input', 2)
+        B, n = wav.shape
+        out = torch.empty((B, n + 1024), dtype=torch.float32, device=wav.device)
+        n_out = C.c_int32(0)
+        pitch = wav.stride(0) if B > 1 else max(n, 1)
+        self._check(self._lib.se_stream_push(self._h, C.c_void_p(wav.data_ptr()), pitch, n, C.c_void_p(out.data_ptr()),
+                                             out.stride(0), C.byref(n_out), self._stream()))
+        return out[:, :n_out.value]
+
+    def stream_flush(self):
+        """End of the streams: the remaining output samples, [batch, n_out]."""
+        import torch
+        out = torch.empty((self._stream_batch, self.max_samples), dtype=torch.float32, device=torch.device('cuda', self.device))
+        n_out = C.c_int32(0)
+        self._check(self._lib.se_stream_flush(self._h, C.c_void_p(out.data_ptr()), out.stride(0), C.byref(n_out),
+                                              self._stream()))
+        return out[:, :n_out.value]
+
     # ------------------------------------------------------------------ stage hooks
     def rms_scale(self, wav):
         import torch

@@ -1,0 +1,71 @@
+"""GPU: frame-online decoding (se_stream_*) - the causal models fed piecewise, with the engine
+carrying one history frame per conv layer, the LSTM (h, c) and the iSTFT overlap, must reproduce the offline decode of the
+whole signal sample for sample (CRN/CRN.py:38,112-117 causal pad + Chomp_T; LSTM/LSTM.py:24-28 unidirectional LSTMs).
+The utterance scale c is handed over from the offline path (it is not causal: c = sqrt(L / sum x^2))."""
+import numpy as np
+import pytest
+
+import se_amd  # noqa: F401
+from se_amd import synth
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+SEEDS = {'crn': 12, 'lstm': 11}
+
+
+def _offline_and_streamed(name, L, pieces, chunk, B=2, p=(1.0, 1.0)):
+    import torch
+    from se_amd.models import MODEL_CLASSES
+    x = np.stack([synth.synth_clip(800 + b, 'speech' if b % 2 == 0 else 'white', L) for b in range(B)])
+    m = MODEL_CLASSES[name](max_batch=B, max_samples=L, p_in=p[0], p_out=p[1]).load_synthetic(SEEDS[name])
+    xt = torch.from_numpy(x).cuda()
+    ref = m.enhance_batch(xt).cpu().numpy()
+    eng = m.engine
+    c = eng.rms_scale(xt)
+    eng.stream_begin(B, c=c, max_chunk_frames=chunk)
+    outs, pos = [], 0
+    for n in pieces:
+        n = min(n, L - pos)
+        if n <= 0:
+            break
+        outs.append(eng.stream_push(xt[:, pos:pos + n].contiguous()).cpu().numpy())
+        pos += n
+    while pos < L:                                             # the rest in pieces of the last size
+        n = min(pieces[-1], L - pos)
+        outs.append(eng.stream_push(xt[:, pos:pos + n].contiguous()).cpu().numpy())
+        pos += n
+    outs.append(eng.stream_flush().cpu().numpy())
+    return ref, np.concatenate(outs, axis=1), outs
+
+
+@pytest.mark.parametrize('name', ['crn', 'lstm'])
+@pytest.mark.parametrize('pieces,chunk', [([160], 1), ([37, 1000, 3, 481, 2000], 4), ([4000], 16), ([7777, 160], 5)])
+def test_streamed_output_equals_offline(name, pieces, chunk):
+    L = 12000
+    ref, got, outs = _offline_and_streamed(name, L, pieces, chunk)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    e = rms(got - ref)
+    print(name, pieces, chunk, 'streamed vs offline rms err', e, 'rms ref', rms(ref))
+    assert e < 1e-6 + 2e-5 * rms(ref), (name, e, rms(ref))
+    # frame-online: output arrives while the input is still coming in, within one hop + half a window of latency
+    fed = 0
+    emitted = 0
+    for n, o in zip(pieces, outs):
+        fed += min(n, L - fed)
+        emitted += o.shape[1]
+        assert emitted >= fed - (160 + 161) - 160 or fed < 321, (fed, emitted)
+
+
+def test_streaming_compressed_exponents_and_ragged_end():
+    """cprs exponents 0.5 / 2.0 and a length that is not a hop multiple (the last frames see the reflected right edge)."""
+    ref, got, _ = _offline_and_streamed('crn', 9001, [1234], 8, B=3, p=(0.5, 2.0))
+    assert got.shape == ref.shape and rms(got - ref) < 1e-6 + 2e-5 * rms(ref)
+
+
+def test_streaming_is_refused_where_the_model_is_not_causal():
+    import torch
+    from se_amd.models import MODEL_CLASSES
+    from se_amd.engine import EngineError
+    m = MODEL_CLASSES['dpcrn'](max_batch=1, max_samples=4000).load_synthetic(13)
+    with pytest.raises(EngineError):
+        m.engine.stream_begin(1)

@@ -607,7 +607,21 @@ __global__ __launch_bounds__(256) void gc_small_kernel(const GCParams p) {
     const int fo = q * p.so + p.po;
     const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
     float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
-    const float* __restrict__ res = (EPI != EPI_ACT) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+    const float* __restrict__ res = (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+    if constexpr (EPI == EPI_GLU) {
+        // rows are (value, gate) pairs: out[j] = act(((a + bias) * sigmoid(g + bias)) * post_scale + post_shift), same fast
+        // sigmoid as the MFMA tile's GLU epilogue
+#pragma unroll
+        for (int j = 0; j < MM / 2; ++j) {
+            if (2 * j + 1 < p.M) {
+                const float a = acc[2 * j] + (bias ? bias[2 * j] : 0.f), g = acc[2 * j + 1] + (bias ? bias[2 * j + 1] : 0.f);
+                float v = a * fsig_(g);
+                if (p.post_scale) v = v * p.post_scale[j] + p.post_shift[j];
+                dst[(long)j * p.d_c + t] = act_apply(v, p.act, p.slope ? p.slope[j] : 0.f);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
         if (m < p.M) {
@@ -709,7 +723,19 @@ __global__ __launch_bounds__(256) void gc_small_lds_kernel(const GCParams p, con
         const int fo = (q0 + qq) * p.so + p.po;
         const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : (p.bias ? p.bias + (long)z * p.bias_z : nullptr);
         float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
-        const float* __restrict__ res = (EPI != EPI_ACT) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+        const float* __restrict__ res = (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+        if constexpr (EPI == EPI_GLU) {
+#pragma unroll
+            for (int j = 0; j < MM / 2; ++j) {
+                if (2 * j + 1 < p.M) {
+                    const float a = acc[qq][2 * j] + (bias ? bias[2 * j] : 0.f), g = acc[qq][2 * j + 1] + (bias ? bias[2 * j + 1] : 0.f);
+                    float v = a * fsig_(g);
+                    if (p.post_scale) v = v * p.post_scale[j] + p.post_shift[j];
+                    dst[(long)j * p.d_c + t] = act_apply(v, p.act, p.slope ? p.slope[j] : 0.f);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int m = 0; m < MM; ++m) {
             if (m < p.M) {
@@ -748,6 +774,9 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
             case EPI_ACT: gc_small_lds_launch<MM, EPI_ACT>(p, grid, shm, CC, NR, sg, stream); break;
             case EPI_ADD: gc_small_lds_launch<MM, EPI_ADD>(p, grid, shm, CC, NR, sg, stream); break;
             case EPI_MUL: gc_small_lds_launch<MM, EPI_MUL>(p, grid, shm, CC, NR, sg, stream); break;
+            case EPI_GLU:
+                if constexpr (MM >= 2) gc_small_lds_launch<MM, EPI_GLU>(p, grid, shm, CC, NR, sg, stream);
+                break;
             default: SE_CHECK(false, "direct small-M path: unsupported epilogue");
         }
         SE_HIP(hipGetLastError());
@@ -760,6 +789,9 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
         case EPI_ACT: hipLaunchKernelGGL((gc_small_kernel<MM, EPI_ACT>), grid, dim3(256), 0, stream, p); break;
         case EPI_ADD: hipLaunchKernelGGL((gc_small_kernel<MM, EPI_ADD>), grid, dim3(256), 0, stream, p); break;
         case EPI_MUL: hipLaunchKernelGGL((gc_small_kernel<MM, EPI_MUL>), grid, dim3(256), 0, stream, p); break;
+        case EPI_GLU:
+            if constexpr (MM >= 2) hipLaunchKernelGGL((gc_small_kernel<MM, EPI_GLU>), grid, dim3(256), 0, stream, p);
+            break;
         default: SE_CHECK(false, "direct small-M path: unsupported epilogue");
     }
     SE_HIP(hipGetLastError());
@@ -929,7 +961,7 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     p.A = pl.dA;
     // direct path (gc_small_kernel): plain weights [z][ci][tap][MM] for layers with <= 4 output channels
     static const int small_env = getenv("SE_GC_SMALL") ? atoi(getenv("SE_GC_SMALL")) : 1;
-    if (small_env && M <= 4 && (epi == EPI_ACT || epi == EPI_ADD || epi == EPI_MUL)) {
+    if (small_env && M <= 4 && (epi == EPI_ACT || epi == EPI_ADD || epi == EPI_MUL || (epi == EPI_GLU && M % 2 == 0))) {
         const int MM = M <= 1 ? 1 : (M <= 2 ? 2 : 4);
         std::vector<float> ws((size_t)Z * Cin * taps.ntaps * MM, 0.f);
         for (int z = 0; z < Z; ++z)

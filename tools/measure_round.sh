@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round measurements on the GPU box (run through gpurun): the driver's bench line, the rocprofv3 kernel summary of the same
+# command, and the three separate --pmc passes tools/pmc_summary.py reads.  Every step has its own timeout.
+#   bash tools/measure_round.sh r02      -> gpurun_out/r02_m/
+set -u
+TAG=${1:-rXX}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/${TAG}_m
+mkdir -p $OUT $OUT/pmc
+cd /tmp && export TMPDIR=/tmp
+timeout 400 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o s -- \
+    python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/kt.log 2>&1
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"; do
+    D=$OUT/pmc/$(echo $C | cut -d' ' -f1)
+    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o p -- \
+        python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $D.log 2>&1
+done
+ls -la $OUT $OUT/pmc/*/ | head -40
+tail -c 600 $OUT/bench.json

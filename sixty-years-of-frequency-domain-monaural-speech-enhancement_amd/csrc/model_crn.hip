@@ -20,32 +20,6 @@ namespace {
 
 constexpr int NFFT = 320, HOP = 160, NBIN = 161;
 
-// per-stream state of the frame-online mode: history columns of every chunk tensor, LSTM (h, c)
-struct StreamState {
-    int B = 0;
-    bool first = true;
-    std::vector<float*> hist;
-    float *h[3] = {}, *c[3] = {};
-    void release() {
-        for (float* p : hist)
-            if (p) (void)hipFree(p);
-        hist.clear();
-        for (int l = 0; l < 3; ++l) {
-            if (h[l]) (void)hipFree(h[l]);
-            if (c[l]) (void)hipFree(c[l]);
-            h[l] = c[l] = nullptr;
-        }
-        B = 0;
-    }
-    ~StreamState() { release(); }
-};
-static float* zeros(size_t n, hipStream_t st) {
-    float* p = nullptr;
-    SE_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
-    SE_HIP(hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(float), st));
-    return p;
-}
-
 // ------------------------------------------------------------------------------------------------ CRN
 class Crn final : public Model {
   public:

@@ -110,11 +110,44 @@ class Gcrn final : public Model {
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :56-58
     }
 
+    // ---- frame-online mode (model.h): the (1,3) convs have no extent in time (GCRN_noncprs.py:42-83), LayerNorm is per
+    // frame, so the only state is (h, c) of the four grouped LSTMs (:5-39) - and the last estimate frames for the iSTFT
+    bool stream_supported() const override { return true; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        ss.release();
+        ss.B = B;
+        ss.first = true;
+        ss.hist.push_back(zeros((size_t)B * 2 * NBIN * STREAM_HC, st));      // est
+        for (int l = 0; l < 4; ++l) {
+            ss.h[l] = zeros((size_t)512 * B, st);
+            ss.c[l] = zeros((size_t)1024 * B, st);          // layer 1 writes its units to every other row (stride 2 S)
+        }
+        (void)max_chunk;
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, STREAM_HC + n);
+        *spec = b.spec;
+        *mag = nullptr;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+        SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
+        const int HC = STREAM_HC, Tw = HC + n;
+        Bufs& b = bufs(B, Tw);
+        network(b, st, n);
+        launch_polar_pow(b.est, b.est, B, NBIN, Tw, ctx.p_out, st);
+        launch_hist_restore(b.est, ss.hist[0], B, 2L * NBIN, Tw, HC, st);     // the history columns saw no LSTM output
+        launch_hist_save(b.est, ss.hist[0], B, 2L * NBIN, Tw, HC, st);
+        ss.first = false;
+        (void)t0;
+    }
+
   private:
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *est, *frames, *E[5], *EE[4], *D[2][5], *X, *Y, *Z, *G, *cell, *L0;
     } cur;
+    StreamState ss;
     GCPlan enc[5], fc[2];
     DeconvPlan dec[2][5];
     LstmBig l1[2], l2[2];
@@ -173,8 +206,9 @@ class Gcrn final : public Model {
         return cur;
     }
 
-    // b.spec [B][2][161][T] -> b.est [B][2][161][T]
-    void network(Bufs& b, hipStream_t st) {
+    // b.spec [B][2][161][T] -> b.est [B][2][161][T];  n_stream > 0: frame-online chunk - only the last n_stream columns are
+    // new frames, the LSTMs continue from the carried state
+    void network(Bufs& b, hipStream_t st, int n_stream = 0) {
         const int B = b.B, T = b.T;
         Profiler* pf = &ctx.prof;
         Act4 x = act4(b.spec, 2, NBIN, T);
@@ -185,6 +219,20 @@ class Gcrn final : public Model {
         for (int k = 0; k < 4; ++k) launch_elu(b.E[k], b.EE[k], (long)B * EC[k + 1] * EF[k] * T, st);
         // ---- GLSTM, time-major [T][1024][B]
         const long S = B;
+        if (n_stream > 0) {
+            const int n = n_stream, c0 = T - n;
+            const long gh = (long)n * 2048 * S;
+            launch_transpose_akt(b.E[4] + c0, b.X, B, 1024, n, 1024L * T, T, 1024L * S, S, st);
+            l1[0].run_stream_strided(b.X, 1024L * S, b.G, ss.c[0], ss.h[0], b.Y, 1024L * S, 2, n, (int)S, ss.first, st, pf);
+            l1[1].run_stream_strided(b.X + 512L * S, 1024L * S, b.G + gh, ss.c[1], ss.h[1], b.Y + S, 1024L * S, 2, n, (int)S,
+                                     ss.first, st, pf);
+            launch_layernorm_cf(b.Y, nullptr, ln_w[0], ln_b[0], b.Z, n, 1024, 1, (int)S, 1e-5f, st);
+            l2[0].run_stream_strided(b.Z, 1024L * S, b.G, ss.c[2], ss.h[2], b.Y, 1024L * S, 1, n, (int)S, ss.first, st, pf);
+            l2[1].run_stream_strided(b.Z + 512L * S, 1024L * S, b.G + gh, ss.c[3], ss.h[3], b.Y + 512L * S, 1024L * S, 1, n,
+                                     (int)S, ss.first, st, pf);
+            launch_layernorm_cf(b.Y, nullptr, ln_w[1], ln_b[1], b.Z, n, 1024, 1, (int)S, 1e-5f, st);
+            launch_transpose_akt(b.Z, b.L0 + c0, n, 1024, B, 1024L * S, S, 1024L * T, T, st);
+        } else {
         launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, 1024L * S, S, st);
         // group i reads features [512i, 512i+512); outputs interleaved (row 2j+i) :26-29; both groups in one launch
         run_lstm_pair(l1[0], l1[1], whh_pair[0], b.X, b.X + 512L * S, 1024L * S, b.G, b.cell, b.Y, S, 1024L * S, 2, T, (int)S,
@@ -194,6 +242,7 @@ class Gcrn final : public Model {
                       (int)S, st, pf);                                                             // :32-33 (cat)
         launch_layernorm_cf(b.Y, nullptr, ln_w[1], ln_b[1], b.Z, T, 1024, 1, (int)S, 1e-5f, st);
         launch_transpose_akt(b.Z, b.L0, T, 1024, B, 1024L * S, S, 1024L * T, T, st);
+        }
         // ---- two decoders
         const int DCO[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
         for (int br = 0; br < 2; ++br) {

@@ -4,6 +4,8 @@
 //   * time-major activations: x [T][I][S], gates G [T][4H][S], h [T][H][S]  (S sequences contiguous).
 #pragma once
 #include "model.h"
+#include <algorithm>
+#include <vector>
 
 namespace se {
 
@@ -28,6 +30,32 @@ inline LstmW load_lstm(const TrackedSD& sd, const std::string& prefix, int layer
     permute_rows(w.wih, perm);
     permute_rows(w.whh, perm);
     return w;
+}
+
+// per-stream state of the frame-online mode: history columns of every chunk tensor, LSTM (h, c)
+struct StreamState {
+    int B = 0;
+    bool first = true;
+    std::vector<float*> hist;
+    float *h[4] = {}, *c[4] = {};
+    void release() {
+        for (float* p : hist)
+            if (p) (void)hipFree(p);
+        hist.clear();
+        for (int l = 0; l < 4; ++l) {
+            if (h[l]) (void)hipFree(h[l]);
+            if (c[l]) (void)hipFree(c[l]);
+            h[l] = c[l] = nullptr;
+        }
+        B = 0;
+    }
+    ~StreamState() { release(); }
+};
+inline float* zeros(size_t n, hipStream_t st) {
+    float* p = nullptr;
+    SE_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
+    SE_HIP(hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(float), st));
+    return p;
 }
 
 inline TapSpec one_tap() {
@@ -112,13 +140,19 @@ struct LstmBig {
     // first step (state is zero).  h_state / cell are left holding the state after the last step.
     void run_stream(const float* x, float* G, float* cell, float* h_state, float* out, int T, int S, bool first, hipStream_t st,
                     Profiler* prof) const {
-        run_pointwise_cols(gin, x, (long)I * S, S, G, 4L * H * S, S, T, S, st, prof);
+        run_stream_strided(x, (long)I * S, G, cell, h_state, out, (long)H * S, 1, T, S, first, st, prof);
+    }
+    // general form (as run_strided): per-step input stride x_t, h_t unit j written to row j * out_rs of a tensor with
+    // per-step stride out_t; h_state stays a dense [H][S] tensor
+    void run_stream_strided(const float* x, long x_t, float* G, float* cell, float* h_state, float* out, long out_t, int out_rs,
+                            int T, int S, bool first, hipStream_t st, Profiler* prof) const {
+        run_pointwise_cols(gin, x, x_t, S, G, 4L * H * S, S, T, S, st, prof);
         for (int t = 0; t < T; ++t) {
             GCParams p = step.p;
             p.first_step = (first && t == 0);
-            p.src0 = t > 0 ? out + (size_t)(t - 1) * H * S : h_state;
+            p.src0 = t > 0 ? out + (size_t)(t - 1) * out_t : h_state;
             p.s0_b = 0;
-            p.s0_c = S;
+            p.s0_c = t > 0 ? (long)out_rs * S : S;
             p.s0_f = 0;
             p.src1 = nullptr;
             p.Fin = 1;
@@ -130,14 +164,15 @@ struct LstmBig {
             p.x_b = 0;
             p.x_c = S;
             p.x_f = 0;
-            p.dst = out + (size_t)t * H * S;
+            p.dst = out + (size_t)t * out_t;
             p.d_b = 0;
-            p.d_c = S;
+            p.d_c = (long)out_rs * S;
             p.d_f = 0;
             p.cell = cell;
             gc_launch_prof(step, p, st, prof);
         }
-        SE_HIP(hipMemcpyAsync(h_state, out + (size_t)(T - 1) * H * S, (size_t)H * S * sizeof(float), hipMemcpyDeviceToDevice, st));
+        SE_HIP(hipMemcpy2DAsync(h_state, (size_t)S * sizeof(float), out + (size_t)(T - 1) * out_t,
+                                (size_t)out_rs * S * sizeof(float), (size_t)S * sizeof(float), H, hipMemcpyDeviceToDevice, st));
     }
     // the same on the sequence columns [c0, c0 + Sn) of tensors whose rows hold S sequences: sequences are independent,
     // so disjoint column ranges can run concurrently on different streams (FullSubNet's 257 * B sub-band sequences)

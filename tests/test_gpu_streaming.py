@@ -1,6 +1,7 @@
 """GPU: frame-online decoding (se_stream_*) - the causal models fed piecewise, with the engine
 carrying one history frame per conv layer, the LSTM (h, c) and the iSTFT overlap, must reproduce the offline decode of the
-whole signal sample for sample (CRN/CRN.py:38,112-117 causal pad + Chomp_T; LSTM/LSTM.py:24-28 unidirectional LSTMs).
+whole signal sample for sample (CRN/CRN.py:38,112-117 causal pad + Chomp_T; LSTM/LSTM.py:24-28 unidirectional LSTMs;
+GCRN/GCRN_noncprs.py:5-39 grouped LSTMs between convs without any extent in time).
 The utterance scale c is handed over from the offline path (it is not causal: c = sqrt(L / sum x^2))."""
 import numpy as np
 import pytest
@@ -10,7 +11,7 @@ from se_amd import synth
 from conftest import rms
 
 pytestmark = pytest.mark.gpu
-SEEDS = {'crn': 12, 'lstm': 11}
+SEEDS = {'crn': 12, 'lstm': 11, 'gcrn': 16}
 
 
 def _offline_and_streamed(name, L, pieces, chunk, B=2, p=(1.0, 1.0)):
@@ -38,7 +39,7 @@ def _offline_and_streamed(name, L, pieces, chunk, B=2, p=(1.0, 1.0)):
     return ref, np.concatenate(outs, axis=1), outs
 
 
-@pytest.mark.parametrize('name', ['crn', 'lstm'])
+@pytest.mark.parametrize('name', ['crn', 'lstm', 'gcrn'])
 @pytest.mark.parametrize('pieces,chunk', [([160], 1), ([37, 1000, 3, 481, 2000], 4), ([4000], 16), ([7777, 160], 5)])
 def test_streamed_output_equals_offline(name, pieces, chunk):
     L = 12000

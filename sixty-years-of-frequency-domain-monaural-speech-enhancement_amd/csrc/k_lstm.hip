@@ -68,11 +68,19 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
 
     float c[MT];
     float gcur[MT][4], gnxt[MT][4];
+    // streaming: continue from the carried state (a.st_h / a.st_c, [H][S] per LSTM) instead of zeros
+    const bool carry = a.st_h != nullptr;
+    float* __restrict__ sth = carry ? a.st_h + (long)z * a.st_z : nullptr;
+    float* __restrict__ stc = carry ? a.st_c + (long)z * a.st_z : nullptr;
     static_for_l<MT>([&](auto M_) {
         constexpr int mt = decltype(M_)::value;
-        c[mt] = 0.f;
+        const int u = wave * (H / 4) + mt * 4 + l4;
+        c[mt] = (carry && col_ok) ? stc[(long)u * a.S + n] : 0.f;
     });
-    for (int i = tid; i < H * 16; i += 256) hs[0][i] = 0.f;
+    for (int i = tid; i < H * 16; i += 256) {
+        const int u = i >> 4, col = n0 + (i & 15);
+        hs[0][i] = (carry && col < a.S) ? sth[(long)u * a.S + col] : 0.f;
+    }
 
     auto load_gx = [&](int step, float (&g)[MT][4]) {
         const int t = rev ? a.T - 1 - step : step;
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             constexpr int mt = decltype(M_)::value;
             acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
         });
-        if (step > 0) {
+        if (step > 0 || carry) {
             // h_{t-1} operand reads run PF k-groups ahead of the MFMAs that consume them (ring of 2 * PF registers): the
             // compiler's own schedule waits lgkmcnt(0) behind every LDS read, 16-32 exposed LDS round trips per step
             const float* hb = &hs[cur][l4 * 16 + l15];
@@ -131,6 +139,10 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             const float h = fast_sigmoid(go) * fast_tanh(cn);
             hs[cur ^ 1][u * 16 + l15] = h;
             if (col_ok) op[(long)u * a.out_row] = h;
+            if (carry && col_ok && step == a.T - 1) {
+                sth[(long)u * a.S + n] = h;
+                stc[(long)u * a.S + n] = cn;
+            }
         });
         static_for_l<MT>([&](auto M_) {
             constexpr int mt = decltype(M_)::value;
@@ -272,7 +284,8 @@ void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s) {
     SE_CHECK(a.H == 64 || a.H == 128, "persistent LSTM kernel is built for H = 64 / 128");
     // few sequences: 4 per workgroup (4x4x1 MFMA) fill the chip where 16-sequence tiles would not
     static const int p4_max = getenv("SE_LSTM_P4") ? atoi(getenv("SE_LSTM_P4")) : 128;      // 0 disables
-    if (a.H == 128 && ((a.S + 15) / 16) * a.Z * a.O <= p4_max) {
+    SE_CHECK(!a.st_h || (a.st_c && a.O == 1), "persistent LSTM: carried state needs both tensors and O = 1");
+    if (a.H == 128 && !a.st_h && ((a.S + 15) / 16) * a.Z * a.O <= p4_max) {
         hipLaunchKernelGGL(lstm_persist4_kernel<128>, dim3((a.S + 3) / 4, a.Z * a.O), dim3(256), 0, s, a);
         SE_HIP(hipGetLastError());
         return;

@@ -174,6 +174,11 @@ struct LstmPersistArgs {
     long whh_z;
     long out_o, out_z, out_t, out_row;
     int H, T, S, Z, O, reverse;   // reverse: bit z set -> LSTM z walks the steps backwards (BiLSTM)
+    // streaming (optional, O = 1): start from (st_h, st_c) instead of zeros and leave the state after the last step there;
+    // element (z, u, n) at z * st_z + u * S + n
+    float* st_h = nullptr;
+    float* st_c = nullptr;
+    long st_z = 0;
 };
 void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s);
 

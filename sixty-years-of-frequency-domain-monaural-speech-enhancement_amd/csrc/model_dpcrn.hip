@@ -110,7 +110,69 @@ class Dpcrn final : public Model {
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :58-60
     }
 
+    // ---- frame-online mode (model.h): (de)convs look back one frame (DPCRN.py:94-166, same pad / chomp scheme as CRN), the
+    // intra-frame BiLSTM runs over frequency inside one frame, LayerNorm is per frame; the inter-frame LSTM (2 layers,
+    // applied in both DPRNN passes with shared weights, :28-29) carries (h, c) - four states
+    bool stream_supported() const override { return true; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        ss.release();
+        ss.B = B;
+        ss.first = true;
+        for (long rows : stream_rows()) ss.hist.push_back(zeros((size_t)B * rows * STREAM_HC, st));
+        for (int l = 0; l < 4; ++l) {
+            ss.h[l] = zeros((size_t)CH * NF * B, st);
+            ss.c[l] = zeros((size_t)CH * NF * B, st);
+        }
+        (void)max_chunk;
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, STREAM_HC + n);
+        *spec = b.spec;
+        *mag = nullptr;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+        SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
+        const int HC = STREAM_HC, Tw = HC + n;
+        Bufs& b = bufs(B, Tw);
+        Profiler* pf = &ctx.prof;
+        const std::vector<long> rows = stream_rows();
+        float* tens[13] = {b.spec, b.E[0], b.E[1], b.E[2], b.E[3], b.E[4], b.P1, b.D[0], b.D[1], b.D[2], b.D[3], b.D[4], b.D[5]};
+        auto restore = [&](int k) { launch_hist_restore(tens[k], ss.hist[k], B, rows[k], Tw, HC, st); };
+        restore(0);
+        const int EC[5] = {32, 32, 32, 64, 128}, EF[5] = {80, 39, 19, 9, 4};
+        Act4 x = act4(b.spec, 2, NBIN, Tw);
+        for (int i = 0; i < 5; ++i) {
+            run_conv(enc[i], x, nullptr, b.E[i], EC[i], EF[i], B, Tw, Tw, st, pf);
+            restore(1 + i);
+            x = act4(b.E[i], EC[i], EF[i], Tw);
+        }
+        dprnn(b, b.E[4], b.P1, st, n, 0);
+        restore(6);                              // the history columns of a DPRNN output saw no inter-frame LSTM
+        dprnn(b, b.P1, b.D[0], st, n, 1);
+        restore(7);
+        const int DCo[5] = {64, 32, 32, 32, 2}, DF[5] = {9, 19, 39, 80, 161};
+        int cin = CH, fin = NF;
+        for (int i = 0; i < 5; ++i) {
+            Act4 a0 = act4(b.D[i], cin, fin, Tw);
+            Act4 a1 = act4(b.E[4 - i], cin, fin, Tw);
+            run_deconv(dec[i], a0, &a1, b.D[i + 1], DCo[i], DF[i], B, Tw, Tw, st, pf);
+            restore(8 + i);
+            cin = DCo[i];
+            fin = DF[i];
+        }
+        launch_cmask_apply(b.D[5], b.spec, b.est, B, NBIN, Tw, ctx.p_out, st);
+        for (int k = 0; k < 13; ++k) launch_hist_save(tens[k], ss.hist[k], B, rows[k], Tw, HC, st);
+        ss.first = false;
+        (void)t0;
+    }
+
   private:
+    StreamState ss;
+    static std::vector<long> stream_rows() {      // rows (C * F) of spec, E[0..4], P1, D[0..5]
+        return {2L * NBIN, 32L * 80, 32L * 39, 32L * 19, 64L * 9, 128L * 4, (long)CH * NF, (long)CH * NF, 64L * 9, 32L * 19, 32L * 39,
+                32L * 80, 2L * 161};
+    }
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *est, *frames, *E[5], *D[6];
@@ -156,8 +218,11 @@ class Dpcrn final : public Model {
     }
 
     // DPRNN.forward (DPCRN.py:59-92): x [B][128][4][T] -> out [B][128][4][T]
-    void dprnn(Bufs& b, const float* x, float* out, hipStream_t st) {
+    // n_stream > 0: frame-online chunk - only the last n_stream columns are new frames, the inter-frame LSTMs of DPRNN pass
+    // `pass` continue from their carried state
+    void dprnn(Bufs& b, const float* x, float* out, hipStream_t st, int n_stream = 0, int pass = 0) {
         const int B = b.B, T = b.T;
+        const int nT = n_stream > 0 ? n_stream : T, c0 = T - nT;        // inter-frame steps and their first column
         Profiler* pf = &ctx.prof;
         const long plane = (long)NF * T;            // one channel
         // ---- intra: BiLSTM(128 -> 64 x2, 2 layers) over F for every (b, t)
@@ -179,23 +244,27 @@ class Dpcrn final : public Model {
         // ---- inter: LSTM(128 -> 128, 2 layers) over T for every (b, f);  time-major, s = f*B + b
         const int S = NF * B;
         for (int f = 0; f < NF; ++f)
-            launch_transpose_akt(b.R1 + (size_t)f * T, b.Xt + (size_t)f * B, B, CH, T, (long)CH * plane, plane,
+            launch_transpose_akt(b.R1 + (size_t)f * T + c0, b.Xt + (size_t)f * B, B, CH, nT, (long)CH * plane, plane,
                                  (long)CH * S, S, st);
         const float* tin = b.Xt;
         for (int l = 0; l < 2; ++l) {
-            run_pointwise(inter_in[l], tin, (long)CH * S, S, b.Gt, 512L * S, S, T, S, st, pf);
+            run_pointwise(inter_in[l], tin, (long)CH * S, S, b.Gt, 512L * S, S, nT, S, st, pf);
             LstmPersistArgs a{};
             a.gx = b.Gt; a.whh = inter_whh[l]; a.out = b.Ht[l];
             a.gx_o = 0; a.gx_z = 0; a.gx_t = 512L * S; a.gx_row = S;
             a.whh_z = 0;
             a.out_o = 0; a.out_z = 0; a.out_t = (long)CH * S; a.out_row = S;
-            a.H = CH; a.T = T; a.S = S; a.Z = 1; a.O = 1; a.reverse = 0;
+            a.H = CH; a.T = nT; a.S = S; a.Z = 1; a.O = 1; a.reverse = 0;
+            if (n_stream > 0) {
+                a.st_h = ss.h[2 * pass + l];
+                a.st_c = ss.c[2 * pass + l];
+            }
             launch_lstm_persist(a, st);
             tin = b.Ht[l];
         }
-        run_pointwise(inter_fc, b.Ht[1], (long)CH * S, S, b.Yt, (long)CH * S, S, T, S, st, pf);
+        run_pointwise(inter_fc, b.Ht[1], (long)CH * S, S, b.Yt, (long)CH * S, S, nT, S, st, pf);
         for (int f = 0; f < NF; ++f)
-            launch_transpose_akt(b.Yt + (size_t)f * B, b.R2 + (size_t)f * T, T, CH, B, (long)CH * S, S, (long)CH * plane,
+            launch_transpose_akt(b.Yt + (size_t)f * B, b.R2 + (size_t)f * T + c0, nT, CH, B, (long)CH * S, S, (long)CH * plane,
                                  plane, st);
         launch_layernorm_cf(b.R2, b.R1, ln_w[1], ln_b[1], out, B, CH, NF, T, 1e-5f, st);           // :87-88
     }

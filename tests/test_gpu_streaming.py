@@ -11,7 +11,7 @@ from se_amd import synth
 from conftest import rms
 
 pytestmark = pytest.mark.gpu
-SEEDS = {'crn': 12, 'lstm': 11, 'gcrn': 16}
+SEEDS = {'crn': 12, 'lstm': 11, 'gcrn': 16, 'dpcrn': 13}
 
 
 def _offline_and_streamed(name, L, pieces, chunk, B=2, p=(1.0, 1.0)):
@@ -39,7 +39,7 @@ def _offline_and_streamed(name, L, pieces, chunk, B=2, p=(1.0, 1.0)):
     return ref, np.concatenate(outs, axis=1), outs
 
 
-@pytest.mark.parametrize('name', ['crn', 'lstm', 'gcrn'])
+@pytest.mark.parametrize('name', ['crn', 'lstm', 'gcrn', 'dpcrn'])
 @pytest.mark.parametrize('pieces,chunk', [([160], 1), ([37, 1000, 3, 481, 2000], 4), ([4000], 16), ([7777, 160], 5)])
 def test_streamed_output_equals_offline(name, pieces, chunk):
     L = 12000
@@ -63,10 +63,32 @@ def test_streaming_compressed_exponents_and_ragged_end():
     assert got.shape == ref.shape and rms(got - ref) < 1e-6 + 2e-5 * rms(ref)
 
 
+def test_dpcrn_real_checkpoint_streams_like_offline():
+    """The one network with real weights (DPCRN/BEST_MODEL/vb_dpcrn_noncprs_model.pth, fixture copy): a 4 s clip pushed in
+    20 ms pieces equals the offline decode, which tests/test_gpu_models.py pins to the reference's own output."""
+    import torch
+    from se_amd.models import dpcrn
+    from conftest import load_golden
+    G = load_golden('dpcrn')
+    m = dpcrn(max_batch=1, max_samples=64000)
+    m.load_state_dict(dict(load_golden('ckpt_vb_dpcrn_noncprs')))
+    wav = synth.synth_clip(0, 'speech', 64000)
+    xt = torch.from_numpy(wav[None]).cuda()
+    eng = m.engine
+    eng.stream_begin(1, c=eng.rms_scale(xt), max_chunk_frames=8)
+    outs = [eng.stream_push(xt[:, p:p + 320].contiguous()).cpu().numpy() for p in range(0, 64000, 320)]
+    outs.append(eng.stream_flush().cpu().numpy())
+    got = np.concatenate(outs, axis=1)[0]
+    assert got.shape == G['enh_real'].shape
+    e = rms(got - G['enh_real'])
+    print('dpcrn real checkpoint, streamed vs the reference decode: rms err', e, rms(G['enh_real']))
+    assert e < 1e-4 and e < 5e-4 * rms(G['enh_real'])
+
+
 def test_streaming_is_refused_where_the_model_is_not_causal():
     import torch
     from se_amd.models import MODEL_CLASSES
     from se_amd.engine import EngineError
-    m = MODEL_CLASSES['dpcrn'](max_batch=1, max_samples=4000).load_synthetic(13)
+    m = MODEL_CLASSES['fullsubnet'](max_batch=1, max_samples=4000).load_synthetic(15)
     with pytest.raises(EngineError):
         m.engine.stream_begin(1)

@@ -163,7 +163,7 @@ class Crn final : public Model {
         b.spec = a.alloc_f(BT * 2 * NBIN);
         b.mag = a.alloc_f(BT * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         const int EC[5] = {16, 32, 64, 128, 256}, EF[5] = {80, 39, 19, 9, 4};
         for (int i = 0; i < 5; ++i) b.E[i] = a.alloc_f(BT * EC[i] * EF[i]);
         const int DCo[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
@@ -315,7 +315,7 @@ class LstmNet final : public Model {
         b.spec = a.alloc_f(BT * 2 * NBIN);
         b.mag = a.alloc_f(BT * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         b.X = a.alloc_f(BT * NBIN);
         b.Y = a.alloc_f(BT * NBIN);
         b.G = a.alloc_f(BT * 4096);

@@ -182,7 +182,7 @@ class CtsNet final : public Model {
         b.est1 = a.alloc_f(BT * NBIN);
         b.s1 = a.alloc_f(BT * 2 * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         for (int i = 0; i < 5; ++i) b.E[i] = a.alloc_f(BT * 64 * EF[i]);
         for (int i = 0; i < 5; ++i) b.D[i] = a.alloc_f(BT * 64 * DF[i]);
         b.X[0] = a.alloc_f(BT * 256);

@@ -206,7 +206,7 @@ class Dccrn final : public Model {
         b.c = a.alloc_f(B);
         b.spec = a.alloc_f(BT * 2 * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         int F = 256;
         for (int k = 0; k < NL; ++k) {
             F /= 2;

@@ -194,7 +194,7 @@ class Dpcrn final : public Model {
         b.c = a.alloc_f(B);
         b.spec = a.alloc_f(BT * 2 * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         const int EC[5] = {32, 32, 32, 64, 128}, EF[5] = {80, 39, 19, 9, 4};
         for (int i = 0; i < 5; ++i) b.E[i] = a.alloc_f(BT * EC[i] * EF[i]);
         const int DCo[5] = {64, 32, 32, 32, 2}, DF[5] = {9, 19, 39, 80, 161};

@@ -203,7 +203,7 @@ class FullSubNet final : public Model {
         b.spec = a.alloc_f(BT * 2 * NBIN);
         b.mag = a.alloc_f(BT * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         b.magT = a.alloc_f(Tp * S);
         b.xfb = a.alloc_f(Tp * S);
         b.fbo = a.alloc_f(Tp * S);

@@ -152,7 +152,7 @@ class G2Net final : public Model {
         b.pre[1] = a.alloc_f(BT * 2 * NBIN);
         b.resi = a.alloc_f(BT * 2 * NBIN);
         b.gain = a.alloc_f(BT * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         for (int i = 0; i < 5; ++i) b.ens[i] = a.alloc_f(BT * 64 * F[i]);
         b.hx = a.alloc_f(BT * 256);
         b.X[0] = a.alloc_f(BT * 256);

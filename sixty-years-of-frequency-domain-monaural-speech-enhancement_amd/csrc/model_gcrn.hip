@@ -190,7 +190,7 @@ class Gcrn final : public Model {
         b.c = a.alloc_f(B);
         b.spec = a.alloc_f(BT * 2 * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         for (int i = 0; i < 5; ++i) b.E[i] = a.alloc_f(BT * EC[i + 1] * EF[i]);
         for (int i = 0; i < 4; ++i) b.EE[i] = a.alloc_f(BT * EC[i + 1] * EF[i]);
         const int DCO[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};

@@ -159,7 +159,7 @@ class TaylorSENet final : public Model {
         b.est = a.alloc_f(BT * 2 * NBIN);
         b.zero = a.alloc_f(BT * 2 * NBIN);
         b.hob = a.alloc_f(BT * 2 * NBIN);
-        b.frames = a.alloc_f(BT * NFFT);
+        b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         for (int i = 0; i < 5; ++i) {
             b.ens[i] = a.alloc_f(BT * 64 * F[i]);
             b.sens[i] = a.alloc_f(BT * 64 * F[i]);

@@ -5,8 +5,8 @@ runnable is shipped for Python.  `stoi` below restates `DeepXi/deepxi/stoi.m` li
 384 ms segments, clipping at -15 dB SDR, silent-frame removal with a 40 dB range).  One step is not pinned: stoi.m
 resamples to 10 kHz with MATLAB/Octave `resample`, restated here by `scipy.signal.resample_poly` (polyphase FIR, Kaiser
 beta 5) - scores agree with the published measure to about the third decimal, and the engine-vs-reference comparison
-the tests make (same scorer on both outputs) does not depend on it.  PESQ (`pesq.m`, 2 700 lines of ITU-T P.862) is not
-restated: bit-identical PCM_16 output files (tests/test_gpu_decode_driver.py) make PESQ identical by construction.
+the tests make (same scorer on both outputs) does not depend on it.  PESQ (`pesq.m`, ITU-T P.862 wide-band) is restated
+in `se_amd/pesq.py` (`from se_amd.pesq import pesq`).
 """
 import numpy as np
 

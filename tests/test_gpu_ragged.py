@@ -126,3 +126,29 @@ def test_ragged_argument_checks():
         m.enhance_ragged(x, [4000, 5000])           # longer than the row
     with pytest.raises(EngineError):
         m.enhance_ragged(x, [4000])                 # one length per row
+
+
+@pytest.mark.parametrize('name', ['ctsnet', 'g2net', 'taylorsenet'])
+def test_fused_tcm_block_matches_multi_launch_path(name):
+    """From batch 96 a TCM / GLU block runs as ONE kernel per utterance (k_tcm.hip); below, as 3-4 GEMM + 2-3 norm
+    launches.  A batch of 100 (fused) must reproduce, clip for clip, what the fixture-pinned small-batch path gives - for
+    equal lengths and for a ragged batch (statistics over each row's own frames inside the fused kernel)."""
+    import torch
+    L, B = 6000, 100
+    clips = np.stack([synth.synth_clip(1500 + i, 'speech' if i % 3 else 'white', L) for i in range(5)])
+    x = clips[np.arange(B) % 5].copy()
+    big = _make(name, B, L, p_in=0.5, p_out=2.0)
+    small = _make(name, 5, L, p_in=0.5, p_out=2.0)
+    yb = big.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+    ys = small.enhance_batch(torch.from_numpy(clips).cuda()).cpu().numpy()
+    for k in range(B):
+        e = rms(yb[k] - ys[k % 5])
+        assert e < 2e-5 * max(rms(ys[k % 5]), 1e-3), (name, k, e)
+    lengths = [L - 97 * (k % 7) for k in range(B)]
+    yr = big.enhance_ragged(torch.from_numpy(x).cuda(), lengths).cpu().numpy()
+    one = _make(name, 1, L, p_in=0.5, p_out=2.0)
+    for k in (0, 1, 6, 13, 99):
+        n = lengths[k]
+        ref = one.enhance_batch(torch.from_numpy(x[k:k + 1, :n].copy()).cuda()).cpu().numpy()[0]
+        e = rms(yr[k, :len(ref)] - ref)
+        assert e < 2e-5 * max(rms(ref), 1e-3), (name, 'ragged', k, e)

@@ -48,6 +48,7 @@ struct TcmFusedArgs {
     HeadParams hL, hR, hO;
     int dil, K;
     const int* tlen;
+    int strip;     // 1: the output tile leaves through a per-wave LDS strip (needs 36 KB more LDS)
     int dbg;       // tuning ablations (SE_TCM_DBG): 1 no GEMM 1, 2 no head statistics, 4 no dilated conv, 8 no GEMM 3, 16 no FIR
 };
 
@@ -334,6 +335,38 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
             }
             if (c + 1 < NC) w_store((c + 1) & 1, wn);
             if (half == 1 && !(a.dbg & 32)) {
+                if (a.strip) {
+                    // the accumulator layout gives 2 rows x 128 B per memory instruction (measured 2.1 / 3.4 TB/s for the
+                    // residual read / the store); a 32 x 32 tile goes through a per-wave LDS strip instead and leaves as
+                    // 8 rows x 128 B per instruction, 16 B per lane along t
+                    float* strip = Ws + 2 * CK * 128 + wave * (32 * 36);
+                    const int lr = lane >> 3, lc = (lane & 7) * 4;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            if (j == 1 && !v1) continue;
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the previous tile has been read back
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) strip[acc_row(r, hi) * 36 + l31] = acc[mt][j][r];
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            const int tg = 32 * (wave + TCM_NW * j) + lc;
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) {
+                                const int row = it * 8 + lr;
+                                wf4 v = *reinterpret_cast<const wf4*>(strip + row * 36 + lc);
+                                const int o = (64 * ps + 32 * mt + row) * T + tg;
+                                if (tg + 3 < T) {
+                                    v += *reinterpret_cast<const wf4*>(xb + o);
+                                    *reinterpret_cast<wf4*>(yb + o) = v;
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k)
+                                        if (tg + k < T) yb[o + k] = v[k] + xb[o + k];
+                                }
+                            }
+                        }
+                } else {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -344,6 +377,7 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
                         if (tj0 < T) yb[o0] = acc[mt][0][r] + ((a.dbg & 64) ? 0.f : xb[o0]);
                         if (v1 && tj1 < T) yb[o1] = acc[mt][1][r] + ((a.dbg & 64) ? 0.f : xb[o1]);
                     }
+                }
             }
             __syncthreads();
         }
@@ -395,8 +429,14 @@ void launch_tcm_fused(const TcmFusedW& f, const TcmFusedHeads& hd, const float* 
     const Ragged* rg = ragged_ctx();
     TcmFusedArgs a{x, y, B, T, Tp, f.w1, f.w2L, f.w2R, f.w3,
                    {hd.sL, hd.gL, hd.bL, hd.firL}, {hd.sR, hd.gR, hd.bR, hd.firR}, {hd.sO, hd.gO, hd.bO, nullptr},
-                   dil, K, rg ? rg->tlen : nullptr, getenv("SE_TCM_DBG") ? atoi(getenv("SE_TCM_DBG")) : 0};
-    const size_t lds = ((size_t)TCM_C * Tp + TCM_NW * TCM_C + 5 * TCM_C + 2 * 16 * 128) * sizeof(float);
+                   dil, K, rg ? rg->tlen : nullptr, 0, getenv("SE_TCM_DBG") ? atoi(getenv("SE_TCM_DBG")) : 0};
+    size_t lds = ((size_t)TCM_C * Tp + TCM_NW * TCM_C + 5 * TCM_C + 2 * 16 * 128) * sizeof(float);
+    static const bool strip_env = !(getenv("SE_TCM_STRIP") && atoi(getenv("SE_TCM_STRIP")) == 0);
+    const size_t strip_bytes = (size_t)TCM_NW * 32 * 36 * sizeof(float);
+    if (strip_env && lds + strip_bytes <= 160 * 1024) {      // T <= 416: the strips fit next to the [64][Tp] tensor
+        a.strip = 1;
+        lds += strip_bytes;
+    }
     const bool gated = f.w2R != nullptr;
     auto go = [&](auto kern) {
         static bool seen[64] = {};

@@ -125,7 +125,8 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
  *          per stream (e.g. from a calibration run or a running estimate), NULL = 1.0.  With the offline c the two paths
  *          agree exactly - that is what the tests check.
  *   max_chunk_frames: frames advanced per internal step (latency / efficiency trade-off, default 16).
- * Supported: SE_MODEL_CRN, SE_MODEL_LSTM, SE_MODEL_GCRN, SE_MODEL_DPCRN.  Streams are limited to max_samples of se_config. */
+ * Supported: SE_MODEL_CRN, SE_MODEL_LSTM, SE_MODEL_GCRN, SE_MODEL_DPCRN, SE_MODEL_DCCRN (whose decoder looks six frames ahead:
+ * its output is final six frames later than the others').  Streams are limited to max_samples of se_config. */
 int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, void* stream);
 int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_new, float* out_dev, int64_t out_pitch,
                    int32_t* n_out, void* stream);

@@ -353,24 +353,29 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
 }
 
 // frames [e->strm.t_done, t_end) of the stream through the network, then every output sample they complete (all of them up to
-// n_final when `last`); returns the number of samples appended to out row b at out_dev[b * out_pitch + *written ...]
+// the end when `last`); the samples are appended to out row b at out_dev[b * out_pitch + *written ...]
 static void stream_process(se_engine* e, int t_end, bool last, float* out_dev, int64_t out_pitch, int* written, hipStream_t st) {
     se_engine::Stream& S = e->strm;
     const StftGeom& g = e->ctx.geom;
-    const int HC = Model::STREAM_HC, B = S.batch;
+    const int HC = e->model->stream_hc(), LAG = e->model->stream_lag(), B = S.batch;
+    // a frame that is transformed before the end of the stream never touches the end reflection / the tail padding
+    // (se_stream_push only releases frames whose last sample has arrived); at the end the decode script's padded length
+    const int Lpad = last ? e->model->padded_samples(S.n_total) : S.n_total;
+    const int n_final = last ? (int)e->model->output_samples(S.n_total) : S.n_total;
     while (S.t_done < t_end) {
         const int t0 = S.t_done, n = std::min(S.max_chunk, t_end - t0), Tw = HC + n;
         float *spec = nullptr, *mag = nullptr, *est = nullptr;
         e->model->stream_bufs(B, n, &spec, &mag, &est);
-        // a frame that is transformed before the end of the stream never touches the end reflection (se_stream_push only
-        // releases frames whose last sample has arrived), so L = Lpad = samples received is exact for both cases
-        launch_stft(g, S.wav, e->ctx.max_samples, B, S.n_total, S.n_total, S.c, e->ctx.p_in, spec, mag, t0 + n, Tw, st, t0, HC);
+        launch_stft(g, S.wav, e->ctx.max_samples, B, S.n_total, Lpad, S.c, e->ctx.p_in, spec, mag, t0 + n, Tw, st, t0, HC);
         e->model->stream_chunk(B, t0, n, st);
         S.t_done = t0 + n;
-        // samples whose every covering frame exists: positions below t_done * hop (all the rest once the stream has ended)
-        const int o_hi = (last && S.t_done == t_end) ? S.n_total : std::min(S.n_total, S.t_done * g.hop - g.n_fft / 2);
+        const bool end = last && S.t_done == t_end;
+        // estimate frames below t_fin are final (a model that looks ahead finalises LAG frames late); samples whose every
+        // covering frame is final: positions below t_fin * hop - and everything once the stream has ended
+        const int t_fin = end ? S.t_done : S.t_done - LAG;
+        const int o_hi = end ? n_final : std::min(S.n_total, t_fin * g.hop - g.n_fft / 2);
         if (o_hi > S.o_done) {
-            launch_istft(g, est, B, S.t_done, Tw, nullptr, S.c, out_dev + *written, out_pitch, o_hi, st, t0 - HC,
+            launch_istft(g, est, B, t_fin, Tw, nullptr, S.c, out_dev + *written, out_pitch, o_hi, st, t0 - HC,
                          std::max(0, t0 - HC), S.o_done);
             *written += o_hi - S.o_done;
             S.o_done = o_hi;
@@ -382,15 +387,15 @@ int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
-        SE_CHECK(e->model->stream_supported(), "this model has no frame-online mode (CRN, LSTM, GCRN and DPCRN have)");
+        SE_CHECK(e->model->stream_supported(), "this model has no frame-online mode (CRN, LSTM, GCRN, DPCRN and DCCRN have)");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         const StftGeom& g = e->ctx.geom;
-        SE_CHECK((g.n_fft + g.hop - 1) / g.hop - 1 <= Model::STREAM_HC, "front end overlaps more frames than the history holds");
-        SE_CHECK(e->model->padded_samples(12345) == 12345, "streaming needs a decode script without tail padding");
+        SE_CHECK((g.n_fft + g.hop - 1) / g.hop - 1 + e->model->stream_lag() <= e->model->stream_hc(),
+                 "front end overlap + look-ahead exceed the history the model keeps");
         hipStream_t st = static_cast<hipStream_t>(stream);
         se_engine::Stream& S = e->strm;
         const int tmax = e->model->num_frames(e->ctx.max_samples);
-        S.max_chunk = std::max(1, std::min(max_chunk_frames > 0 ? max_chunk_frames : 16, tmax - Model::STREAM_HC));
+        S.max_chunk = std::max(1, std::min(max_chunk_frames > 0 ? max_chunk_frames : 16, tmax - e->model->stream_hc()));
         if (!S.wav) {
             SE_HIP(hipMalloc(&S.wav, (size_t)e->ctx.max_batch * e->ctx.max_samples * sizeof(float)));
             SE_HIP(hipMalloc(&S.c, (size_t)e->ctx.max_batch * sizeof(float)));
@@ -423,7 +428,7 @@ int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_
         // left half needs sample n_fft / 2 as well)
         const int t_avail = S.n_total > g.n_fft / 2 ? (S.n_total - g.n_fft / 2 - 1) / g.hop + 1 : 0;
         int written = 0;
-        const int will = std::max(0, std::min(S.n_total, t_avail * g.hop - g.n_fft / 2) - S.o_done);
+        const int will = std::max(0, std::min(S.n_total, (t_avail - e->model->stream_lag()) * g.hop - g.n_fft / 2) - S.o_done);
         SE_CHECK(out_pitch >= will, "output row pitch too small for the samples this push completes");
         e->ctx.prof_reset();
         stream_process(e, std::max(t_avail, S.t_done), false, out_dev, out_pitch, &written, st);
@@ -438,7 +443,7 @@ int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_
         SE_CHECK(S.active, "se_stream_flush without se_stream_begin");
         SE_CHECK(out_dev && n_out, "bad argument");
         SE_CHECK(S.n_total >= e->ctx.geom.n_fft, "stream shorter than one FFT frame");
-        SE_CHECK(out_pitch >= S.n_total - S.o_done, "output row pitch too small for the rest of the stream");
+        SE_CHECK(out_pitch >= e->model->output_samples(S.n_total) - S.o_done, "output row pitch too small for the rest of the stream");
         int written = 0;
         e->ctx.prof_reset();
         stream_process(e, e->model->num_frames(S.n_total), true, out_dev, out_pitch, &written, static_cast<hipStream_t>(stream));

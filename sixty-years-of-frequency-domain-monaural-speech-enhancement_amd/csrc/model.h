@@ -92,6 +92,12 @@ class Model {
     // [t0, t0 + n) of B parallel streams: the engine has written their STFT into columns [STREAM_HC, STREAM_HC + n) of
     // stream_spec() / stream_mag() (row pitch STREAM_HC + n) and reads the estimate from stream_est() in the same layout.
     static constexpr int STREAM_HC = 2;     // history columns in front of every chunk tensor (convs look back 1 frame, the iSTFT 1)
+    // models whose front end overlaps more frames, or whose network looks a bounded number of frames AHEAD (DCCRN's decoder:
+    // one frame per transposed conv), keep more history and finalise their estimate `stream_lag()` frames late: the chunk
+    // tensors then start stream_hc() frames before the new ones and the last stream_lag() estimate frames of a chunk are
+    // provisional (recomputed by the next chunk; final at the end of the stream, where "no future" is the truth)
+    virtual int stream_hc() const { return STREAM_HC; }
+    virtual int stream_lag() const { return 0; }
     virtual bool stream_supported() const { return false; }
     virtual void stream_begin(int B, int max_chunk, hipStream_t st) { SE_CHECK(false, "this model has no streaming mode"); }
     virtual void stream_bufs(int B, int n, float** spec, float** mag, float** est) { SE_CHECK(false, "no streaming mode"); }

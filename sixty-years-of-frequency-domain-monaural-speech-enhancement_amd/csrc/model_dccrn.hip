@@ -16,7 +16,7 @@
 //     time-major [T][feature][sequence] layout, the recurrence is one fused MFMA GEMM + LSTM-cell epilogue per
 //     frame covering both LSTMs (blockIdx.z) and all 2B sequences; r-i / r+i combinations are folded into the
 //     next layer's weights ([W,-W] / [W,W] two-source GEMMs).
-#include "model.h"
+#include "rnn.h"
 #include "../../include/se_engine.h"
 
 namespace se {
@@ -189,7 +189,104 @@ class Dccrn final : public Model {
         bufs(B, T);
     }
 
+    // ---- frame-online mode (model.h).  The encoder convs look back one frame (causal time pad, :66-72) and the complex LSTM
+    // carries (h, c); the DECODER looks one frame AHEAD per transposed conv (`out[..., 1:]`, :199), six frames in all.  A
+    // chunk therefore keeps the last DHC = 10 final frames of the decoder's inputs (encoder outputs, LSTM output, spectrum)
+    // in front of the n new ones and runs the decoder over the whole window: its last six output frames saw zeros where
+    // their future will be and are provisional - the next chunk recomputes them (the engine finalises the estimate six frames
+    // late) - except at the end of the stream, where zeros past the last frame are what the offline decode sees too.
+    static constexpr int DHC = 10;          // 6 look-ahead + 3 frames of iSTFT overlap (512 / 128), rounded up to even
+    int stream_hc() const override { return DHC; }
+    int stream_lag() const override { return NL; }
+    bool stream_supported() const override { return true; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        ss.release();
+        ss.B = B;
+        ss.first = true;
+        for (long rows : stream_rows()) ss.hist.push_back(zeros((size_t)B * rows * DHC, st));
+        for (int l = 0; l < 2; ++l) {           // [2 real LSTMs][128][2B]
+            ss.h[l] = zeros((size_t)2 * 128 * 2 * B, st);
+            ss.c[l] = zeros((size_t)2 * 128 * 2 * B, st);
+        }
+        (void)max_chunk;
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, DHC + n);
+        *spec = b.spec;
+        *mag = nullptr;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+        SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
+        const int Tw = DHC + n;
+        Bufs& b = bufs(B, Tw);
+        Profiler* pf = &ctx.prof;
+        const std::vector<long> rows = stream_rows();
+        float* tens[8] = {b.spec, b.E[0], b.E[1], b.E[2], b.E[3], b.E[4], b.E[5], b.D[0]};
+        auto restore = [&](int k) { launch_hist_restore(tens[k], ss.hist[k], B, rows[k], Tw, DHC, st); };
+        restore(0);
+        Act4 x{b.spec + Tw, 2, 256, 2L * NBIN * Tw, (long)NBIN * Tw, (long)Tw};
+        int F = 256;
+        for (int k = 0; k < NL; ++k) {
+            run_conv(enc[k], x, nullptr, b.E[k], KN[k + 1], F / 2, B, Tw, Tw, st, pf);
+            restore(1 + k);                      // column 0 was recomputed without its own history
+            F /= 2;
+            x = act4(b.E[k], KN[k + 1], F, Tw);
+        }
+        // complex LSTM over the n new frames, continuing from the carried state
+        const int S = 2 * B;
+        for (int part = 0; part < 2; ++part)
+            launch_transpose_akt(b.E[NL - 1] + (size_t)part * 512 * Tw + DHC, b.X1 + (size_t)part * B, B, 512, n, 1024L * Tw, Tw,
+                                 512L * S, S, st);
+        {
+            GCParams p = g1.p;
+            p.src0 = b.X1; p.s0_b = 512L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 512; p.C1 = 0;
+            p.Fin = 1; p.Tin = S; p.B = n; p.Q = 1; p.Tout = S;
+            p.dst = b.G; p.d_b = 1024L * S; p.d_c = S; p.d_f = 0;
+            gc_launch_prof(g1, p, st, pf);
+        }
+        lstm_steps(whh1, b.H1, b.G, n, S, st, ss.h[0], ss.c[0]);
+        {
+            GCParams p = g2.p;
+            p.src0 = b.H1; p.src0_z = B; p.s0_b = 256L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 128;
+            p.src1 = b.H1 + 128L * S + B; p.src1_z = -(long)B; p.s1_b = 256L * S; p.s1_c = S; p.s1_f = 0; p.C1 = 128;
+            p.Fin = 1; p.Tin = B; p.B = n; p.Q = 1; p.Tout = B;
+            p.dst = b.G; p.dst_z = B; p.d_b = 1024L * S; p.d_c = S; p.d_f = 0;
+            gc_launch_prof(g2, p, st, pf);
+        }
+        lstm_steps(whh2, b.H2, b.G, n, S, st, ss.h[1], ss.c[1]);
+        {
+            GCParams p = proj.p;
+            p.src0 = b.H2; p.src0_z = B; p.s0_b = 256L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 128;
+            p.src1 = b.H2 + 128L * S + B; p.src1_z = -(long)B; p.s1_b = 256L * S; p.s1_c = S; p.s1_f = 0; p.C1 = 128;
+            p.Fin = 1; p.Tin = B; p.B = n; p.Q = 1; p.Tout = B;
+            p.dst = b.P; p.dst_z = 512L * B; p.d_b = 1024L * B; p.d_c = B; p.d_f = 0;
+            gc_launch_prof(proj, p, st, pf);
+        }
+        for (int part = 0; part < 2; ++part)
+            launch_transpose_akt(b.P + (size_t)part * 512 * B, b.D[0] + (size_t)part * 512 * Tw + DHC, n, 512, B, 1024L * B, B,
+                                 1024L * Tw, Tw, st);
+        restore(7);
+        // decoder over the whole window (no look-back: every column is exact given its own and the next input column)
+        F = 4;
+        for (int k = 0; k < NL; ++k) {
+            const int cin = KN[NL - k];
+            Act4 a0 = act4(b.D[k], cin, F, Tw);
+            Act4 a1 = act4(b.E[NL - 1 - k], cin, F, Tw);
+            run_deconv(dec[k], a0, &a1, b.D[k + 1], KN[NL - k - 1], 2 * F, B, Tw, Tw, st, pf);
+            F *= 2;
+        }
+        launch_dccrn_mask(b.D[NL], b.spec, b.est, B, NBIN, Tw, Tw, ctx.p_out, st);
+        for (int k = 0; k < 8; ++k) launch_hist_save(tens[k], ss.hist[k], B, rows[k], Tw, DHC, st);
+        ss.first = false;
+        (void)t0;
+    }
+
   private:
+    StreamState ss;
+    static std::vector<long> stream_rows() {      // rows (C * F) of spec, E[0..5], D[0]
+        return {2L * NBIN, 32L * 128, 64L * 64, 128L * 32, 256L * 16, 256L * 8, 256L * 4, 1024L};
+    }
     GCPlan enc[NL], g1, g2, proj;
     float *whh1 = nullptr, *whh2 = nullptr;
     DeconvPlan dec[NL];
@@ -231,8 +328,12 @@ class Dccrn final : public Model {
     }
 
     // both real LSTMs (z) x all 2B sequences, all T steps in one persistent launch (k_lstm.hip)
-    void lstm_steps(const float* whh, float* H, const float* G, int T, int S, hipStream_t st) {
+    void lstm_steps(const float* whh, float* H, const float* G, int T, int S, hipStream_t st, float* st_h = nullptr,
+                    float* st_c = nullptr) {
         LstmPersistArgs a{};
+        a.st_h = st_h;          // frame-online mode: continue from / leave the carried state ([2][128][S])
+        a.st_c = st_c;
+        a.st_z = 128L * S;
         a.gx = G; a.whh = whh; a.out = H;
         a.gx_o = 0; a.gx_z = 512L * S; a.gx_t = 1024L * S; a.gx_row = S;
         a.whh_z = 512L * 128;

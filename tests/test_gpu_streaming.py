@@ -1,7 +1,8 @@
 """GPU: frame-online decoding (se_stream_*) - the causal models fed piecewise, with the engine
 carrying one history frame per conv layer, the LSTM (h, c) and the iSTFT overlap, must reproduce the offline decode of the
 whole signal sample for sample (CRN/CRN.py:38,112-117 causal pad + Chomp_T; LSTM/LSTM.py:24-28 unidirectional LSTMs;
-GCRN/GCRN_noncprs.py:5-39 grouped LSTMs between convs without any extent in time).
+GCRN/GCRN_noncprs.py:5-39 grouped LSTMs between convs without any extent in time; DCCRN/DCCRN_cprs.py:199 - its
+decoder looks one frame ahead per layer, so its estimate is final six frames late).
 The utterance scale c is handed over from the offline path (it is not causal: c = sqrt(L / sum x^2))."""
 import numpy as np
 import pytest
@@ -11,7 +12,9 @@ from se_amd import synth
 from conftest import rms
 
 pytestmark = pytest.mark.gpu
-SEEDS = {'crn': 12, 'lstm': 11, 'gcrn': 16, 'dpcrn': 13}
+SEEDS = {'crn': 12, 'lstm': 11, 'gcrn': 16, 'dpcrn': 13, 'dccrn': 14}
+# (n_fft, hop, frames of look-ahead): the algorithmic latency is n_fft / 2 + 1 samples + (look-ahead + 1) hops
+GEOM = {'crn': (320, 160, 0), 'lstm': (320, 160, 0), 'gcrn': (320, 160, 0), 'dpcrn': (320, 160, 0), 'dccrn': (512, 128, 6)}
 
 
 def _offline_and_streamed(name, L, pieces, chunk, B=2, p=(1.0, 1.0)):
@@ -39,7 +42,7 @@ def _offline_and_streamed(name, L, pieces, chunk, B=2, p=(1.0, 1.0)):
     return ref, np.concatenate(outs, axis=1), outs
 
 
-@pytest.mark.parametrize('name', ['crn', 'lstm', 'gcrn', 'dpcrn'])
+@pytest.mark.parametrize('name', ['crn', 'lstm', 'gcrn', 'dpcrn', 'dccrn'])
 @pytest.mark.parametrize('pieces,chunk', [([160], 1), ([37, 1000, 3, 481, 2000], 4), ([4000], 16), ([7777, 160], 5)])
 def test_streamed_output_equals_offline(name, pieces, chunk):
     L = 12000
@@ -54,12 +57,15 @@ def test_streamed_output_equals_offline(name, pieces, chunk):
     for n, o in zip(pieces, outs):
         fed += min(n, L - fed)
         emitted += o.shape[1]
-        assert emitted >= fed - (160 + 161) - 160 or fed < 321, (fed, emitted)
+        n_fft, hop, la = GEOM[name]
+        assert emitted >= fed - (n_fft // 2 + 1) - (la + 2) * hop or fed < n_fft, (fed, emitted)
 
 
-def test_streaming_compressed_exponents_and_ragged_end():
-    """cprs exponents 0.5 / 2.0 and a length that is not a hop multiple (the last frames see the reflected right edge)."""
-    ref, got, _ = _offline_and_streamed('crn', 9001, [1234], 8, B=3, p=(0.5, 2.0))
+@pytest.mark.parametrize('name', ['crn', 'dccrn'])
+def test_streaming_compressed_exponents_and_ragged_end(name):
+    """cprs exponents 0.5 / 2.0 and a length that is not a hop multiple (the last frames see the reflected right edge; DCCRN's
+    script zero-pads the tail to a hop multiple first and returns the padded length, dccrn_decode_vb.py:32-35,59-64)."""
+    ref, got, _ = _offline_and_streamed(name, 9001, [1234], 8, B=3, p=(0.5, 2.0))
     assert got.shape == ref.shape and rms(got - ref) < 1e-6 + 2e-5 * rms(ref)
 
 

@@ -107,7 +107,8 @@ int64_t se_output_samples(const se_engine* e, int32_t n_samples);
  * se_output_samples(e, max lengths).  Each row gets exactly the result of decoding it alone: its own unit-RMS scale, its
  * own reflect padding and frame count in the STFT / iSTFT, and utterance-wide statistics (InstanceNorm - CTSNet, G2Net,
  * TaylorSENet, e.g. CTSNet/Step1_network.py:121-145; FullSubNet's offline_laplace_norm, base_model.py:197-209) taken over
- * its own frames only.  Fails for models that look ahead in time without a bound (Uformer): batch those by equal length. */
+ * its own frames only; operators that look ahead in time (DCCRN's decoder, Uformer's symmetric dilated convs and its
+ * attention over time) see zeros / masked keys past a clip's own last frame, as they do when the clip is decoded alone. */
 int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, int32_t batch, const int32_t* lengths,
                       float* wav_out_dev, int64_t out_pitch, void* stream);
 

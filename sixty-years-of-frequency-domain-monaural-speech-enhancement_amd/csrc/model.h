@@ -84,8 +84,9 @@ class Model {
     // samples the STFT sees (decode scripts that tail-pad to a hop multiple)
     virtual int padded_samples(int L) const { return L; }
     int num_frames(int L) const { return 1 + padded_samples(L) / ctx.geom.hop; }
-    // false: the model has operators that look ahead in time beyond a fixed, zero-padded look-ahead (Uformer: non-causal
-    // dilated convolutions and full self-attention over time), so rows of different lengths cannot share a call
+    // false: the model has operators that look ahead in time and does not zero / mask what lies past a row's own last frame,
+    // so rows of different lengths cannot share a call (every model of the zoo does: DCCRN and Uformer through
+    // launch_zero_tail / key masks)
     virtual bool ragged_supported() const { return true; }
     // ---- frame-online decoding (se_stream_*): the causal models carry their state (one history frame per conv layer,
     // LSTM (h, c), the iSTFT's overlap) across calls instead of seeing the whole utterance.  stream_chunk() handles frames

@@ -66,11 +66,12 @@ __global__ __launch_bounds__(256) void uf_fusion_kernel(float* __restrict__ cplx
 // One block = 256 queries of one (b, f); per head K/V [16][T] go through LDS; online softmax; heads are combined with
 // signs into out [B][nout*16][F][T] (complex: heads 0-3 -> real (+,-,-,-), heads 4-7 -> imag (+,+,+,-); real: 1 head).
 __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__ pq, float* __restrict__ out, int F, int T,
-                                                       int nh) {
+                                                       int nh, const int* __restrict__ tlen) {
     extern __shared__ float kv[];          // K [T][16], V [T][16]
     float* Ks = kv;
     float* Vs = kv + HD * T;
     const int f = blockIdx.x % F, b = blockIdx.x / F;
+    const int Tkeys = tlen ? tlen[b] : T;  // ragged batch: a clip attends to its own frames only
     const int t = blockIdx.y * 256 + threadIdx.x;
     const long P = (long)F * T;
     const float* base = pq + (long)b * nh * 48 * P + (long)f * T;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
             // online softmax over chunks of 8 keys: one running-maximum update (one rescale of the 16 accumulators) per
             // chunk instead of per key, hardware exp (v_exp_f32, ~1 ulp: the weights are normalised by their own sum)
             float mx = -3.0e38f, l = 0.f;
-            for (int s0 = 0; s0 < T; s0 += 8) {
+            for (int s0 = 0; s0 < Tkeys; s0 += 8) {
                 float e[8];
                 float cm = -3.0e38f;
 #pragma unroll
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
                         a = fmaf(q[4 * d4 + 2], kk.z, a);
                         a = fmaf(q[4 * d4 + 3], kk.w, a);
                     }
-                    e[k] = (s0 + k < T) ? a : -3.0e38f;
+                    e[k] = (s0 + k < Tkeys) ? a : -3.0e38f;
                     cm = fmaxf(cm, e[k]);
                 }
                 const float mn = fmaxf(mx, cm);
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
 typedef float uf_x4 __attribute__((ext_vector_type(4)));
 constexpr int UF_QT = 2;
 __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restrict__ pq, float* __restrict__ out, int F,
-                                                            int T, int nh, int Tk) {
+                                                            int T, int nh, int Tk, const int* __restrict__ tlen) {
     extern __shared__ float kv[];
     float* Ks = kv;                        // [16][Tk], Tk % 32 == 16: the four dim rows of an A fragment hit distinct banks
     float* Vs = kv + HD * Tk;              // [Tk][17]
@@ -182,7 +183,9 @@ __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restr
     const int q0 = blockIdx.y * (64 * UF_QT) + wave * (16 * UF_QT);
     const long P = (long)F * T;
     const float* base = pq + (long)b * nh * 48 * P + (long)f * T;
-    const int nkt = (T + 15) >> 4;
+    const int Tkeys = tlen ? tlen[b] : T;          // ragged batch: a clip attends to its own frames only
+    const int nkt = (Tkeys + 15) >> 4;
+    const int nks = (T + 15) >> 4;                 // key tiles staged (LDS layout is per launch, not per row)
     uf_x4 accr[UF_QT], acci[UF_QT];
 #pragma unroll
     for (int qt = 0; qt < UF_QT; ++qt) accr[qt] = acci[qt] = uf_x4{0.f, 0.f, 0.f, 0.f};
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restr
             const int d = i / Tk, s = i - d * Tk;
             Ks[i] = s < T ? hq[(long)(HD + d) * P + s] : 0.f;
         }
-        for (int i = tid; i < HD * (nkt * 16); i += 256) {
-            const int d = i / (nkt * 16), s = i - d * (nkt * 16);
+        for (int i = tid; i < HD * (nks * 16); i += 256) {
+            const int d = i / (nks * 16), s = i - d * (nks * 16);
             Vs[s * 17 + d] = s < T ? hq[(long)(2 * HD + d) * P + s] : 0.f;
         }
         __syncthreads();
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restr
                 float cm = -3.0e38f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (key0 + 4 * g + i >= T) sc[i] = -3.0e38f;
+                    if (key0 + 4 * g + i >= Tkeys) sc[i] = -3.0e38f;
                     cm = fmaxf(cm, sc[i]);
                 }
                 cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
@@ -492,7 +495,6 @@ class Uformer final : public Model {
         lnC.free();
         lnR.free();
     }
-    bool ragged_supported() const override { return false; }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, WIN}; }
     int64_t output_samples(int L) const override { return (int64_t)HOP * (L / HOP); }   // istft without length (:276)
 
@@ -666,11 +668,12 @@ class Uformer final : public Model {
                     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(uf_att_t_mfma_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 hipLaunchKernelGGL(uf_att_t_mfma_kernel, dim3(B * F, (T + 64 * UF_QT - 1) / (64 * UF_QT)), dim3(256), lds, st,
-                                   b.pq, b.t2, F, T, a.nh, Tk);
+                                   b.pq, b.t2, F, T, a.nh, Tk, ragged_ctx() ? ragged_ctx()->tlen : nullptr);
             } else {
                 const size_t lds = (size_t)2 * HD * T * sizeof(float);
                 SE_CHECK(lds <= 64 * 1024, "utterance too long for the LDS-resident T-attention K/V tiles");
-                hipLaunchKernelGGL(uf_att_t_kernel, dim3(B * F, (T + 255) / 256), dim3(256), lds, st, b.pq, b.t2, F, T, a.nh);
+                hipLaunchKernelGGL(uf_att_t_kernel, dim3(B * F, (T + 255) / 256), dim3(256), lds, st, b.pq, b.t2, F, T, a.nh,
+                                   ragged_ctx() ? ragged_ctx()->tlen : nullptr);
             }
         } else {
             SE_CHECK(F <= 8, "F-attention kernel is built for the 4-bin bottleneck");
@@ -686,6 +689,9 @@ class Uformer final : public Model {
         Profiler* pf = &ctx.prof;
         ln(d.ln1, x, b.t1, m * B, CC, P, st);
         run_conv(d.c1, act4(b.t1, m * CC, F, T), nullptr, b.t2, m * 32, F, B, T, T, st, pf);
+        // ragged batch: the two dilated convs pad symmetrically in time (dsconv2d_cplx.py:29-36) - a clip decoded alone has
+        // zeros past its last frame there
+        launch_zero_tail(b.t2, B, (long)m * 32 * F, T, st);
         run_conv(d.d2, act4(b.t2, m * 32, F, T), nullptr, b.t3, m * 32, F, B, T, T, st, pf);
         {
             GCParams p = d.d1.p;

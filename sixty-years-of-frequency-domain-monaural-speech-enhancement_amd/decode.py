@@ -58,14 +58,14 @@ def _build(model, checkpoint, state_dict, **kw):
     return net
 
 
-RAGGED_MODELS = frozenset(MODELS) - {'uformer'}     # Uformer looks ahead in time without a bound: equal lengths only
+RAGGED_MODELS = frozenset(MODELS)        # every model takes clips of different lengths in one call
 
 
 def plan_batches(lengths, max_batch, batch_samples, ragged):
     """Group clip indices into engine calls.  ragged: clips sorted by length, consecutive runs of up to `max_batch` clips
     whose padded size (count x longest) stays within `batch_samples` - the padding a call carries is the spread of
     lengths inside one run, a few percent on a corpus like VoiceBank+DEMAND (824 clips, ~700 distinct lengths).
-    Not ragged (Uformer): only clips of exactly equal length share a call, as in round 1."""
+    Not ragged: only clips of exactly equal length share a call, as in round 1."""
     order = sorted(range(len(lengths)), key=lambda i: (lengths[i], i))
     batches, cur = [], []
     for i in order:

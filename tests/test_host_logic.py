@@ -120,7 +120,7 @@ def test_decode_driver_batch_plan():
     assert all(len(g) * max(lens[i] for i in g) <= 10002 for g in b)
     b = plan_batches([70000], 4, 64000, True)                    # a clip longer than the budget still gets its own call
     assert b == [[0]]
-    b = plan_batches(lens, 8, 10 ** 9, False)                    # Uformer: only exactly equal lengths share a call
+    b = plan_batches(lens, 8, 10 ** 9, False)                    # non-ragged plan: only exactly equal lengths share a call
     assert sorted(map(sorted, b)) == sorted([[1, 7], [0], [2], [3], [4], [5], [6]])
 
 

@@ -91,7 +91,11 @@ def main():
     B = args.batch
     base = synth.synth_batch(8, 'speech', 64000, seed0=100)
     wav = torch.from_numpy(np.tile(base, ((B + 7) // 8, 1))[:B].copy()).cuda()
+    B0 = B
     for name in args.models.split(','):
+        B = min(B0, 128) if name == 'fullsubnet' else B0       # 257 * B sub-band sequences: 256 clips do not fit 288 GB
+        if B != wav.shape[0]:
+            wav = torch.from_numpy(np.tile(base, ((B + 7) // 8, 1))[:B].copy()).cuda()
         m = build(name, B)
         eng = m.engine
         out = torch.empty((B, eng.output_samples(64000)), dtype=torch.float32, device='cuda')

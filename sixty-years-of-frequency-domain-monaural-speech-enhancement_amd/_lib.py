@@ -40,6 +40,14 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP engine is not built (run __graft_entry__.build() or "
             f"`make -C {os.path.join(_HERE, 'csrc')}`). There is no CPU fallback for the decode path.")
+    # One HIP runtime per process: the engine shares device memory and streams with torch, so torch's bundled libamdhip64
+    # has to be the copy the engine library binds to.  Loading the engine first would pull in /opt/rocm's runtime, torch
+    # would then bring its own, and the second one to initialise finds "no ROCm-capable device" (seen with
+    # `python __graft_entry__.py smoke`, where build() loads the library before smoke() imports torch).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.se_abi_version.restype = i32

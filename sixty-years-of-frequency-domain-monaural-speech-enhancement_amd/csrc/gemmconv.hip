@@ -136,6 +136,8 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     const int npatch = rows * p.Wp;                  // floats of one staged activation patch
     const int bit = (npatch + 255) >> 8;             // patch elements per thread (uniform)
     const bool pw4 = p.pw4 != 0;                     // the patch is staged in 16 B groups (decided per launch, gc_launch)
+    // 16 B groups under taps that look ahead in time, rows that are not whole groups: see GC_TRIM_TAIL (block-uniform)
+    const bool fixt = p.trim != 0;
     const int bit4 = (npatch / 4 + 255) >> 8;
     const int nA4 = p.KCp * (BM / 4);
     const int ait = (nA4 + 255) >> 8;                // float4 groups of the weight chunk per thread (uniform)
@@ -280,6 +282,22 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             boff[e] = staged ? (unsigned)cc * sc32 + (unsigned)fc * sf32 + (unsigned)tc : 0u;      \
             /* pw4: the slot is a group of 4 frames; never straddles frame 0, may straddle Tin (see gc_launch)   */ \
             vbits |= (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? (1u << e) : 0u; \
+            /* non-causal taps: a 16 B group that straddles the end of its row is trimmed in LDS after it lands (bits 16..) */ \
+            if (fixt) vbits |= (staged && (t < p.Tin) && (t + 4 > p.Tin)) ? (0x10000u << e) : 0u;   \
+        });                                                                                        \
+    }
+// the frames >= Tin of a straddling group hold the head of the next row: the thread that staged the group zeroes them once
+// its own DMAs have landed (behind GC_WAIT_CHUNK, before the barrier that publishes the buffer)
+#define GC_TRIM_TAIL(BUF)                                                                          \
+    if (fixt && (vbits >> 16)) {                                                                   \
+        float* fb_ = Bs + (BUF) * Bs_sz + 4 * tid;                                                 \
+        const int nv_ = p.Tin & 3;                                                                 \
+        static_for<NB>([&](auto E) {                                                               \
+            constexpr int e = decltype(E)::value;                                                  \
+            if (vbits & (0x10000u << e)) {                                                         \
+                _Pragma("unroll") for (int k = 1; k < 4; ++k)                                      \
+                    if (k >= nv_) fb_[1024 * e + k] = 0.f;                                         \
+            }                                                                                      \
         });                                                                                        \
     }
 #define GC_LOAD_CHUNK(CH, BUF)                                                                     \
@@ -326,6 +344,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         GC_LOAD_CHUNK(0, buf);           // `buf` is free: the previous segment's last chunk was read from buf ^ 1
         GC_T(1);
         GC_WAIT_CHUNK();
+        GC_TRIM_TAIL(buf);
         GC_T(3);
         __syncthreads();
         GC_T(4);
@@ -385,6 +404,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
 #undef GC_MMA
             GC_T(2);
             GC_WAIT_CHUNK();
+            GC_TRIM_TAIL(buf ^ 1);
             GC_T(3);
             __syncthreads();
             GC_T(4);
@@ -395,6 +415,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
 #undef GC_MAKE_DESC
 #undef GC_LOAD_CHUNK
 #undef GC_WAIT_CHUNK
+#undef GC_TRIM_TAIL
 
     // ---------------------------------------------------------------- epilogue
     if (p.dbg & 8) return;
@@ -1098,7 +1119,11 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     static const int pw4_env = getenv("SE_GC_PW4") ? atoi(getenv("SE_GC_PW4")) : 1;
     // 16 B staging groups: exact when no group straddles the end of a row (Tin % 4 == 0); for causal tap sets a straddling
     // group only feeds output frames >= Tin, which are never stored - then it merely has to stay inside mapped memory
-    p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || (p.causal && gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
+    // (a tap set that looks ahead would read the straddling group's foreign frames into stored outputs: the kernel trims
+    // them in LDS, GC_TRIM_TAIL)
+    static const int trim_env = getenv("SE_GC_TRIM") ? atoi(getenv("SE_GC_TRIM")) : 1;
+    p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || ((p.causal || trim_env) && gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
+    p.trim = (p.pw4 && !p.causal && p.Tin % 4 != 0) ? 1 : 0;
     SE_CHECK(!p.stats || gc_stats_supported(pl), "gc_launch: this tile configuration has no statistics epilogue");
     SE_CHECK(p.pw4 || p.CI_C * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256,
              "pointwise layer with a row length that is not a multiple of 4 needs its sources inside the engine arena");

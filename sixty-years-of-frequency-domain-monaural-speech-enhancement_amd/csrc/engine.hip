@@ -13,6 +13,7 @@ struct se_engine {
     StateDict sd;
     std::unique_ptr<Model> model;
     bool finalized = false;
+    int plan_frames = 0;     // frames the workspace was sized for (>= frames of max_samples; frame-online windows may be longer)
     std::string err;
     // hipGraph replay of se_enhance_batch (SE_CFG_GRAPHS): one instantiated graph per (batch, samples) shape, captured
     // on the second call of a shape (the first, eager call sets kernel attributes and grows the lazy scratch buffers);
@@ -201,8 +202,11 @@ int se_engine_finalize(se_engine* e) {
         tsd.check_all_used();
         // size the workspace for (max_batch, frames of max_samples)
         const int T = e->model->num_frames(e->ctx.max_samples);
+        // (a frame-online window is the model's history columns + the chunk: models that keep a long history - CTSNet_new's
+        // dilated convs reach 128 frames back - must be able to stream through an engine created for short clips)
+        e->plan_frames = e->model->stream_supported() ? std::max(T, e->model->stream_hc() + 16) : T;
         e->ctx.arena.measure_begin();
-        e->model->plan_buffers(e->ctx.max_batch, T);
+        e->model->plan_buffers(e->ctx.max_batch, e->plan_frames);
         const size_t need = e->ctx.arena.measure_end();
         e->ctx.arena.reserve(need + (1 << 20));
         gc_register_overread_range(e->ctx.arena.base(), e->ctx.arena.capacity());
@@ -394,8 +398,7 @@ int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const
                  "front end overlap + look-ahead exceed the history the model keeps");
         hipStream_t st = static_cast<hipStream_t>(stream);
         se_engine::Stream& S = e->strm;
-        const int tmax = e->model->num_frames(e->ctx.max_samples);
-        S.max_chunk = std::max(1, std::min(max_chunk_frames > 0 ? max_chunk_frames : 16, tmax - e->model->stream_hc()));
+        S.max_chunk = std::max(1, std::min(max_chunk_frames > 0 ? max_chunk_frames : 16, e->plan_frames - e->model->stream_hc()));
         if (!S.wav) {
             SE_HIP(hipMalloc(&S.wav, (size_t)e->ctx.max_batch * e->ctx.max_samples * sizeof(float)));
             SE_HIP(hipMalloc(&S.c, (size_t)e->ctx.max_batch * sizeof(float)));

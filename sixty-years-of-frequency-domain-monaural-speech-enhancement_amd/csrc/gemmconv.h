@@ -102,13 +102,14 @@ struct GCSmallGeom {
 struct GCPlan {
     GCParams p{};            // static part (taps, chunking, weights); pointers for activations filled per launch
     int BM = 128, BN = 128;  // tile config
+    int lookback = 0;        // frames of history the taps reach back (max -dt)
     float* dA = nullptr;     // device copies owned by the plan
     float* dWs = nullptr;
     unsigned* dDesc = nullptr;
     unsigned* dDesc4 = nullptr;
     GCSmallGeom small;       // direct path only
     bool tail_split = false; // tail[0] may be used as a separate launch for the last time tile
-    GCTail tail[2];          // [0]: 32-column geometry for a mostly empty last time tile; [1]: 64-column geometry of the whole layer for small launches
+    GCTail tail[3];          // [0]: 32-column geometry for a mostly empty last time tile; [1]: 64-column geometry of the whole layer for small launches; [2]: 256-column geometry of a 64-row layer for big launches
     float* dBias = nullptr;
     float* dSlope = nullptr;
     int* dTab = nullptr;

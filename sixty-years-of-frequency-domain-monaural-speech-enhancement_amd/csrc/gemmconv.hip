@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     // global-load latency under the matrix work
     constexpr int KCP_MAX = gc_kcp_max(BM);
     constexpr int A_IT = (KCP_MAX * BM / 4 + 255) / 256;
-    constexpr int NB = gc_bld_max(BM);     // patch elements staged per thread (flat index e = tid + 256 * i)
+    // patch slots staged per thread (flat index e = tid + 256 * i); the 256-column tile is only launched with 16 B groups
+    constexpr int NB = BN >= 256 ? 5 : gc_bld_max(BM);
     static_assert(WM * WN == 4, "4 waves");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     // k-pair kp.  They live in registers indexed at compile time (the MFMA loop is fully unrolled over k-pairs), so no
     // operand address depends on an LDS read or a v_readlane (both measured slower, tools/mfmabench.cpp).
     constexpr int NPAIR = KCP_MAX / 2;
-    constexpr bool KOFF_REGS = (BM >= 128);      // small-M tiles keep the table in LDS: registers buy occupancy there
+    constexpr bool KOFF_REGS = (BM >= 128 || TM * TN >= 4);      // small tiles keep the table in LDS: registers buy occupancy there
     int koffv[KOFF_REGS ? NPAIR : 1];
     // the whole device table (frequency rows, taps, per-K-row patch offsets) is staged once into LDS: every later
     // lookup is a short LDS read instead of a dependent global load in the block prologue
@@ -890,6 +891,7 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     // patch geometry: the staged time window starts a multiple of 4 frames before the tile (origin t0 - pad4) so that it
     // decomposes into 16 B groups that never straddle frame 0 (t0 is a multiple of BN): LDS column w <-> frame t0 + dtmin + w
     p.causal = dtmax <= 0;
+    pl.lookback = std::max(-dtmin, 0);                      // frames of history the taps reach back (frame-online mode)
     dtmin = -((std::max(-dtmin, 0) + 3) & ~3);
     dtmax = (std::max(dtmax, 0) + 3) & ~3;
     p.dtmin = dtmin;
@@ -946,6 +948,14 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
         }
         // 64-column geometry of the whole layer (tail[1]) for launches that would not fill the chip with 128-column
         // tiles: the batch is only known at launch time, gc_launch picks
+        // 256-column geometry of a 64-row layer (tail[2]): 1 x 4 waves of 64 x 64 do the 128 x 128 tile's matrix work per
+        // staged K row (the 64 x 128 tile does half of it), for big launches whose rows fill the wide tiles (T = 501: 98 %)
+        static const int wide_env = getenv("SE_GC_WIDE") ? atoi(getenv("SE_GC_WIDE")) : 1;
+        if (wide_env && pl.BN == 128 && pl.BM == 64 && epi != EPI_LSTM && taps.ntaps > 1) {
+            pl.tail[2].BN = 256;
+            pl.tail[2].Wp = 256 + (dtmax - dtmin);
+            pl.tail[2].g = gc_build_geom(taps, rows, dtmin, p.nrows, pl.tail[2].Wp, cic, p.KC, gc_bld_max(pl.BM));
+        }
         if (pl.BN == 128 && (pl.BM == 64 || pl.BM == 128) && epi != EPI_LSTM) {
             pl.tail[1].BN = 64;
             pl.tail[1].Wp = 64 + (dtmax - dtmin);
@@ -1108,7 +1118,12 @@ bool gc_stats_supported(const GCPlan& pl) {
 }
 
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
-    p.n_ttiles = (p.Tout + pl.BN - 1) / pl.BN;
+    // p.t_base (default 0): first output frame of the launch - frame-online chunks only produce the frames behind their
+    // history columns.  A multiple of 4, so that the 16 B staging groups keep their alignment to frame 0.
+    const int tb = p.t_base, Tspan = p.Tout - tb;
+    SE_CHECK(tb >= 0 && (tb & 3) == 0 && Tspan > 0, "gc_launch: first output frame must be a multiple of 4 below Tout");
+    SE_CHECK(tb == 0 || !p.stats, "gc_launch: the statistics epilogue needs whole rows");
+    p.n_ttiles = (Tspan + pl.BN - 1) / pl.BN;
     static const int dbg_env = getenv("SE_GC_DBG") ? atoi(getenv("SE_GC_DBG")) : 0;
     p.dbg = dbg_env;
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
@@ -1144,8 +1159,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
         static const int alt_n64 = getenv("SE_GC_ALT_N64") ? atoi(getenv("SE_GC_ALT_N64")) : 4096;
         if (alt_env && alt.BN == 64 && nblk < (pl.BM == 64 ? alt_n64 : 256)) {
             GCParams pa = p;
-            pa.t_base = 0;
-            pa.n_ttiles = (p.Tout + 63) / 64;
+            pa.n_ttiles = (Tspan + 63) / 64;
             pa.Wp = alt.Wp;
             pa.tab = alt.g.tab;
             pa.desc = alt.g.desc;
@@ -1153,7 +1167,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
             static const int alt32_env = getenv("SE_GC_ALT32") ? atoi(getenv("SE_GC_ALT32")) : 512;
             const long nblk64 = (long)p.Z * p.B * p.Q * pa.n_ttiles * p.n_mtiles;
             if (pl.BM == 128 && pl.tail[0].BN == 32 && nblk64 < alt32_env) {       // tiny launches: 32 columns
-                pa.n_ttiles = (p.Tout + 31) / 32;
+                pa.n_ttiles = (Tspan + 31) / 32;
                 pa.Wp = pl.tail[0].Wp;
                 pa.tab = pl.tail[0].g.tab;
                 pa.desc = pl.tail[0].g.desc;
@@ -1166,13 +1180,32 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
             return;
         }
     }
+    // big launches of a 64-row layer: 64 x 256 tiles when the patch goes in 16 B groups (4 x fewer slots), the rows fill the
+    // wide tiles and the staging buffers leave room for 3 workgroups per CU
+    {
+        const GCTail& wd = pl.tail[2];
+        static const long wide_min = getenv("SE_GC_WIDE_MIN") ? atol(getenv("SE_GC_WIDE_MIN")) : 6144;
+        const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
+        const int nt = (Tspan + 255) / 256;
+        if (wd.BN == 256 && pl.BM == 64 && p.pw4 && nblk >= wide_min && Tspan * 10 >= nt * 256 * 9 &&
+            (long)p.CI_C * p.nrows * wd.Wp <= 4608 /* 5 x 256 groups, 3 workgroups' LDS */) {
+            GCParams pa = p;
+            pa.n_ttiles = nt;
+            pa.Wp = wd.Wp;
+            pa.tab = wd.g.tab;
+            pa.desc = wd.g.desc;
+            pa.desc4 = wd.g.desc4;
+            gc_launch_t<64, 256, 1, 4>(pa, stream);
+            return;
+        }
+    }
     // the last time tile of a row, when it is at most half full, goes to a narrower kernel (own launch, same weights)
-    const int full = p.Tout / pl.BN, rem = p.Tout - full * pl.BN;
+    const int full = Tspan / pl.BN, rem = Tspan - full * pl.BN;
     const GCTail* tl = nullptr;
     if (pl.tail_split && full >= 1 && rem > 0 && pl.tail[0].BN && rem <= pl.tail[0].BN) tl = &pl.tail[0];
     if (tl) {
         GCParams pt = p;
-        pt.t_base = full * pl.BN;
+        pt.t_base = tb + full * pl.BN;
         pt.n_ttiles = 1;
         pt.Wp = tl->Wp;
         pt.tab = tl->g.tab;

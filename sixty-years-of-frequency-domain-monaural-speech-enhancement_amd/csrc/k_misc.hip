@@ -474,11 +474,14 @@ void launch_tcm_head(const float* x, float* y, const float* slope, const float* 
 // Frame t is normalised with the mean / variance of ALL rows of frames 0..t (CTSNet_new/Step1_network.py:213-286).
 // x [B][R][T] with R = C * F rows (F = 1 for the 1-D flavour); three passes: per-frame sums over the rows, an
 // in-LDS prefix scan per utterance, then normalise + affine (+ PReLU before / after, + the TCM branch FIR).
+// Frame-online chunks (c0 > 0 / carry): only columns [c0, T) of the window are summed and scanned, the scan starts from
+// the carried totals of the frames before column c0 (`tg0` = stream index of column 0; columns before the start of the
+// stream do not count) and leaves the totals up to column c0 + n - 1 - the frames before the next window's column c0.
 __global__ __launch_bounds__(256) void cln_stats_kernel(const float* __restrict__ x, const float* __restrict__ pre_slope,
                                                         double* __restrict__ sum, double* __restrict__ sq, int R, int F,
-                                                        int T) {
+                                                        int T, int c0) {
     __shared__ double sh[2][4][64];
-    const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6, t = blockIdx.x * 64 + tl, b = blockIdx.y;
+    const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6, t = c0 + blockIdx.x * 64 + tl, b = blockIdx.y;
     double s = 0.0, q = 0.0;
     if (t < T) {
         const float* xp = x + (long)b * R * T + t;
@@ -507,26 +510,32 @@ __global__ __launch_bounds__(256) void cln_stats_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void cln_scan_kernel(const double* __restrict__ sum, const double* __restrict__ sq,
-                                                       float* __restrict__ mean, float* __restrict__ rstd, int R, int T) {
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int R, int T,
+                                                       int c0, long tg0, int n_new, double* __restrict__ carry) {
     extern __shared__ double sc[];       // [2][T]
     const int b = blockIdx.x;
-    for (int t = threadIdx.x; t < T; t += 256) {
-        sc[t] = sum[(long)b * T + t];
-        sc[T + t] = sq[(long)b * T + t];
+    for (int t = c0 + threadIdx.x; t < T; t += 256) {
+        const bool live = tg0 + t >= 0;
+        sc[t] = live ? sum[(long)b * T + t] : 0.0;
+        sc[T + t] = live ? sq[(long)b * T + t] : 0.0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = 0.0, q = 0.0;
-        for (int t = 0; t < T; ++t) {
+        double a = carry ? carry[2 * b] : 0.0, q = carry ? carry[2 * b + 1] : 0.0;
+        for (int t = c0; t < T; ++t) {
             a += sc[t];
             q += sc[T + t];
             sc[t] = a;
             sc[T + t] = q;
+            if (carry && t == c0 + n_new - 1) {
+                carry[2 * b] = a;
+                carry[2 * b + 1] = q;
+            }
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {
-        const double cnt = (double)R * (t + 1), mu = sc[t] / cnt;
+    for (int t = c0 + threadIdx.x; t < T; t += 256) {
+        const double cnt = (double)R * (double)(tg0 + t >= 0 ? tg0 + t + 1 : 1), mu = sc[t] / cnt;
         const double var = (sc[T + t] - 2.0 * mu * sc[t]) / cnt + mu * mu;
         mean[(long)b * T + t] = (float)mu;
         rstd[(long)b * T + t] = (float)(1.0 / sqrt(var + 1e-5));
@@ -538,8 +547,8 @@ __global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict_
                                                         const float* __restrict__ gain, const float* __restrict__ bias,
                                                         const float* __restrict__ pre_slope,
                                                         const float* __restrict__ post_slope, const float* __restrict__ fir,
-                                                        int K, int R, int F, int T) {
-    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
+                                                        int K, int R, int F, int T, int t_first, long tg0) {
+    const int t = t_first + blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
     if (t >= T) return;
     const float* mu = mean + (long)b * T;
     const float* rs = rstd + (long)b * T;
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict_
             o = 0.f;
             for (int k = 0; k < K; ++k) {
                 const int ti = t - (K - 1) + k;
-                if (ti >= 0) o += fir[k] * nrm(ti);
+                if (tg0 + ti >= 0) o += fir[k] * nrm(ti);
             }
         }
         y[((long)b * R + r) * T + t] = o;
@@ -579,10 +588,28 @@ void launch_cln(const float* x, float* y, const float* gain, const float* bias, 
     float* mean = (float*)(sq + (size_t)B * T);
     float* rstd = mean + (size_t)B * T;
     const int R = C * F;
-    hipLaunchKernelGGL(cln_stats_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T);
-    hipLaunchKernelGGL(cln_scan_kernel, dim3(B), dim3(256), (size_t)T * 16, s, sum, sq, mean, rstd, R, T);
+    if (StreamCtx* cx = stream_ctx()) {
+        // frame-online chunk: the FIR reaches K - 1 frames back into the history columns of x (brought in here), whose
+        // statistics are re-accumulated from the carried totals in the order of the whole-utterance scan
+        SE_CHECK(T == cx->H + cx->n && B == cx->B, "cLN: tensor is not a window of the current chunk");
+        const int back = K > 0 ? K - 1 : 0, c0 = cx->H - back;
+        SE_CHECK(back <= cx->H, "cLN FIR longer than the window's history");
+        if (back > 0) stream_exchange(const_cast<float*>(x), (long)R * T, (long)F * T, T, B, C, F, back, s);
+        cx->memo_src = nullptr;
+        double* carry = static_cast<double*>(cx->slot((size_t)B * 2 * sizeof(double), s));
+        const long tg0 = cx->t0 - cx->H;
+        hipLaunchKernelGGL(cln_stats_kernel, dim3((T - c0 + 63) / 64, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T, c0);
+        hipLaunchKernelGGL(cln_scan_kernel, dim3(B), dim3(256), (size_t)T * 16, s, sum, sq, mean, rstd, R, T, c0, tg0, cx->n,
+                           carry);
+        hipLaunchKernelGGL(cln_apply_kernel, dim3((cx->n + 255) / 256, (R + 7) / 8, B), dim3(256), 0, s, x, y, mean, rstd, gain,
+                           bias, pre_slope, post_slope, fir, K, R, F, T, cx->H, tg0);
+        SE_HIP(hipGetLastError());
+        return;
+    }
+    hipLaunchKernelGGL(cln_stats_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T, 0);
+    hipLaunchKernelGGL(cln_scan_kernel, dim3(B), dim3(256), (size_t)T * 16, s, sum, sq, mean, rstd, R, T, 0, 0L, 0, nullptr);
     hipLaunchKernelGGL(cln_apply_kernel, dim3((T + 255) / 256, (R + 7) / 8, B), dim3(256), 0, s, x, y, mean, rstd, gain,
-                       bias, pre_slope, post_slope, fir, K, R, F, T);
+                       bias, pre_slope, post_slope, fir, K, R, F, T, 0, 0L);
     SE_HIP(hipGetLastError());
 }
 
@@ -637,6 +664,48 @@ void launch_hist_save(const float* buf, float* state, int B, long rows, int Tw, 
     const long n = (long)B * rows * hc;
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, const_cast<float*>(buf), state,
                        (long)B * rows, Tw, hc, 1);
+    SE_HIP(hipGetLastError());
+}
+
+// ---- frame-online context of the block-built models (kernels.h: StreamCtx) -------------------------------------------
+static thread_local StreamCtx* g_stream_ctx = nullptr;
+StreamCtx* stream_ctx() { return g_stream_ctx; }
+void set_stream_ctx(StreamCtx* c) { g_stream_ctx = c; }
+void* StreamCtx::slot(size_t bytes, hipStream_t st) {
+    SE_CHECK(slots, "stream context without state");
+    if (cursor == slots->size()) {
+        void* d = nullptr;
+        SE_HIP(hipMalloc(&d, bytes));
+        SE_HIP(hipMemsetAsync(d, 0, bytes, st));
+        slots->emplace_back(d, bytes);
+    }
+    SE_CHECK((*slots)[cursor].second == bytes, "frame-online state: launch order differs from the first chunk");
+    return (*slots)[cursor++].first;
+}
+// mode 0: x[.., c0 + k] = state[.., k]; mode 1: state[.., k] = x[.., c0 + k]   (k < need)
+__global__ __launch_bounds__(256) void stream_hist_kernel(float* __restrict__ x, float* __restrict__ state, long sb, long sc,
+                                                          long sf, int C, int F, int need, int c0, long total, int mode) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % need);
+    long r = i / need;
+    const int f = (int)(r % F);
+    r /= F;
+    const int c = (int)(r % C);
+    const long b = r / C;
+    float* xp = x + b * sb + c * sc + f * sf + c0 + k;
+    if (mode) state[i] = *xp;
+    else *xp = state[i];
+}
+void stream_exchange(float* x, long sb, long sc, long sf, int B, int C, int F, int need, hipStream_t st) {
+    StreamCtx* cx = stream_ctx();
+    SE_CHECK(cx && need > 0 && need <= cx->H, "stream_exchange: history deeper than the window keeps");
+    const long total = (long)B * C * F * need;
+    float* state = static_cast<float*>(cx->slot((size_t)total * sizeof(float), st));
+    const unsigned g = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(stream_hist_kernel, dim3(g), dim3(256), 0, st, x, state, sb, sc, sf, C, F, need, cx->H - need, total, 0);
+    hipLaunchKernelGGL(stream_hist_kernel, dim3(g), dim3(256), 0, st, x, state, sb, sc, sf, C, F, need, cx->H + cx->n - need,
+                       total, 1);
     SE_HIP(hipGetLastError());
 }
 

@@ -2,7 +2,9 @@
 // Engine-internal spectrogram layout: [B][C][F][Tp] with T contiguous, Tp = row pitch (>= T).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <vector>
+#include "common.h"
 
 namespace se {
 
@@ -74,6 +76,57 @@ void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, 
 void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* frames_scratch,
                   const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s, int t_off = 0, int t_lo = 0,
                   int o_lo = 0);
+
+// Frame-online context of the models that are built from shared blocks (blocks.h / unet.h: the cLN `_new` variants).
+// While a chunk is decoded the model publishes it thread-locally; every activation of the chunk is a window of H history
+// columns + n new frames (row pitch H + n), and the shared launch helpers then
+//   * produce only the new frames (gc_launch's first output frame = H),
+//   * bring the history columns their taps / FIRs reach back to into the source tensor before they read it, from a state
+//     slot that belongs to the call site (slots are taken in call order, which is the same for every chunk), and leave the
+//     last columns of the window there for the next chunk,
+//   * carry the cumulative LayerNorm sums across chunks.
+// Zero-initialised slots are the zero padding of the causal convs; frames before the start of the stream never count.
+struct StreamCtx {
+    int H = 0, n = 0;        // window = H history columns + n new frames
+    long t0 = 0;             // index of the first new frame in the stream
+    int B = 0;
+    std::vector<std::pair<void*, size_t>>* slots = nullptr;     // device state, owned by the model
+    size_t cursor = 0;
+    const void* memo_src = nullptr;     // source whose history the previous launch restored (parity classes of one deconv)
+    int memo_need = 0;
+    void* slot(size_t bytes, hipStream_t st);      // next state slot (allocated zeroed on the first chunk)
+};
+StreamCtx* stream_ctx();                 // nullptr outside frame-online chunks
+void set_stream_ctx(StreamCtx* c);
+// x [B][C][F][H + n] (strides in floats, frames contiguous): columns [H - need, H) <- slot, then slot <- the last `need`
+// columns of the window
+void stream_exchange(float* x, long sb, long sc, long sf, int B, int C, int F, int need, hipStream_t st);
+
+// Model-side owner of the state slots and RAII publisher of one chunk's context
+struct StreamSlots {
+    std::vector<std::pair<void*, size_t>> v;
+    int B = 0;
+    void begin(int B_, hipStream_t st) {       // new stream: zero state (= zero padding before the first frame)
+        if (B_ != B) clear();
+        for (auto& s : v) SE_HIP(hipMemsetAsync(s.first, 0, s.second, st));
+        B = B_;
+    }
+    void clear() {
+        for (auto& s : v) (void)hipFree(s.first);
+        v.clear();
+    }
+    ~StreamSlots() { clear(); }
+};
+struct StreamScope {
+    StreamCtx cx;
+    StreamScope(StreamSlots& sl, int H, int n, long t0, int B) {
+        cx.H = H; cx.n = n; cx.t0 = t0; cx.B = B; cx.slots = &sl.v;
+        set_stream_ctx(&cx);
+    }
+    ~StreamScope() { set_stream_ctx(nullptr); }
+    StreamScope(const StreamScope&) = delete;
+    StreamScope& operator=(const StreamScope&) = delete;
+};
 
 // Streaming history columns of a [B][rows][Tw] activation: restore the first `hc` columns from state [B][rows][hc] (the
 // producing kernel recomputed them without their own history), or save the last `hc` columns into it.

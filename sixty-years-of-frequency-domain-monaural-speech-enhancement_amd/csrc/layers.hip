@@ -1,4 +1,5 @@
 #include "layers.h"
+#include "kernels.h"
 #include <algorithm>
 #include <cmath>
 
@@ -307,7 +308,29 @@ Profiler::~Profiler() {
     for (auto e : ev) (void)hipEventDestroy(e);
 }
 
+// Frame-online chunk (kernels.h: StreamCtx): bring the history columns the taps reach back to into the sources, then
+// produce only the new frames.
+static void gc_launch_stream(StreamCtx& cx, const GCPlan& pl, GCParams p, hipStream_t st) {
+    SE_CHECK(pl.p.causal && p.Z <= 1 && p.epi != EPI_LSTM && !p.stats, "frame-online mode: layer is not a causal feed-forward conv");
+    SE_CHECK(p.Tin == cx.H + cx.n && p.Tout == p.Tin && p.B == cx.B, "frame-online mode: tensor is not a window of the current chunk");
+    const int need = pl.lookback;
+    if (need > 0 && !(cx.memo_src == p.src0 && cx.memo_need == need)) {
+        // (the parity classes of one transposed conv read the same sources: one exchange serves both launches)
+        stream_exchange(const_cast<float*>(p.src0), p.s0_b, p.s0_c, p.s0_f, p.B, p.C0, p.s0_f ? p.Fin : 1, need, st);
+        if (p.src1 && p.C1 > 0)
+            stream_exchange(const_cast<float*>(p.src1), p.s1_b, p.s1_c, p.s1_f, p.B, p.C1, p.s1_f ? p.Fin : 1, need, st);
+    }
+    cx.memo_src = need > 0 ? p.src0 : nullptr;
+    cx.memo_need = need;
+    p.t_base = cx.H;
+    gc_launch(pl, p, st);
+}
+
 void gc_launch_prof(const GCPlan& pl, const GCParams& p, hipStream_t st, Profiler* prof) {
+    if (StreamCtx* cx = stream_ctx()) {
+        gc_launch_stream(*cx, pl, p, st);
+        return;
+    }
     if (prof && prof->on) {
         prof->begin(st);
         gc_launch(pl, p, st);

@@ -114,6 +114,7 @@ class CtsNet final : public Model {
                     tcm2[r * 6 + i].load(sd, "step2.tcm_list." + std::to_string(r) + ".glu_list." + std::to_string(i) + ".", 1 << i,
                                          "ori_conv", "att_ori", 4, 2 * (1 << i) - 1, 5);
         }
+        cum = (has1 ? en1.na[0].cum : true) && (has2 ? en2.na[0].cum : true);
     }
 
     void plan_buffers(int B, int T) override {
@@ -157,7 +158,38 @@ class CtsNet final : public Model {
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :93-96 ([:wav_len])
     }
 
+    // ---- frame-online mode (CTSNet_new: every norm is a cumulative LayerNorm, so the whole network is causal).  The chunk
+    // runs the same launch sequence as enhance() on windows of SH history columns + n new frames; the shared helpers keep
+    // the per-layer history and the cLN sums (kernels.h: StreamCtx).  SH = the deepest look-back: (5 - 1) * 32 frames of
+    // the last dilated conv of a TCM group (its ShareSepConv reaches 62 back).
+    static constexpr int SH = 128;
+    bool stream_supported() const override { return has1 && has2 && cum; }
+    int stream_hc() const override { return SH; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        SE_CHECK(stream_supported(), "frame-online CTSNet needs the cumulative-LayerNorm (`_new`) weights of both stages");
+        slots.begin(B, st);
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, SH + n);
+        *spec = b.spec;
+        *mag = b.mag;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+        Bufs& b = bufs(B, SH + n);
+        const int T = b.T;
+        StreamScope sc(slots, SH, n, t0, B);
+        step1(b, b.mag, b.est1, st);
+        launch_mag_phase(b.est1, b.spec, b.s1, B, NBIN, T, 1.f, st);
+        step2(b, b.spec, b.s1, b.est, st);
+        launch_add(b.est, b.s1, b.est, (long)B * 2 * NBIN * T, st);
+        launch_polar_pow(b.est, b.est, B, NBIN, T, ctx.p_out, st);
+        stream_exchange(b.est, 2L * NBIN * T, (long)NBIN * T, T, B, 2, NBIN, 2, st);      // the iSTFT overlaps one frame back
+    }
+
   private:
+    StreamSlots slots;
+    bool cum = false;
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *mag, *est1, *s1, *est, *frames, *E[5], *D[5], *X[2], *acc;

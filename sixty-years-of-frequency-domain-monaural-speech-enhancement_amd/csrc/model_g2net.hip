@@ -99,6 +99,7 @@ class G2Net final : public Model {
     void finalize(const TrackedSD& sd) override {
         en.load(sd, "en.", 2, UNET_G2NET, 2);
         for (int s = 0; s < NSTAGE; ++s) st_[s].load(sd, "gafs." + std::to_string(s) + ".");
+        cum = en.last.na.cum;
     }
 
     void plan_buffers(int B, int T) override {
@@ -126,7 +127,34 @@ class G2Net final : public Model {
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :86-88
     }
 
+    // ---- frame-online mode (G2Net_new: cumulative LayerNorms only).  Windows of SH history columns + n new frames through
+    // the same launch sequence; history / cLN sums are kept by the shared helpers (kernels.h: StreamCtx).  SH covers the
+    // deepest look-back, (3 - 1) * 9 frames of the widest dilated conv.
+    static constexpr int SH = 20;
+    bool stream_supported() const override { return cum; }
+    int stream_hc() const override { return SH; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        SE_CHECK(cum, "frame-online G2Net needs the cumulative-LayerNorm (`_new`) weights");
+        slots.begin(B, st);
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, SH + n);
+        *spec = b.spec;
+        *mag = nullptr;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+        Bufs& b = bufs(B, SH + n);
+        const int T = b.T;
+        StreamScope sc(slots, SH, n, t0, B);
+        const float* y = network(b, st);
+        launch_polar_pow(y, b.est, B, NBIN, T, ctx.p_out, st);
+        stream_exchange(b.est, 2L * NBIN * T, (long)NBIN * T, T, B, 2, NBIN, 2, st);      // the iSTFT overlaps one frame back
+    }
+
   private:
+    StreamSlots slots;
+    bool cum = false;
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *est, *frames, *ens[5], *pre[2], *gain, *resi, *hx, *X[2];

@@ -106,6 +106,7 @@ class TaylorSENet final : public Model {
                                            ACT_NONE, {}, 401);
             htcm[k].load(sd, p);
         }
+        cum = zen.last.na.cum;
     }
 
     void plan_buffers(int B, int T) override {
@@ -132,7 +133,33 @@ class TaylorSENet final : public Model {
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :48-51
     }
 
+    // ---- frame-online mode (TaylorSENet_new: cumulative LayerNorms only).  Windows of SH history columns + n new frames
+    // through the same launch sequence; history / cLN sums are kept by the shared helpers (kernels.h: StreamCtx).  SH is the
+    // deepest look-back, (5 - 1) * 9 frames of the widest dilated conv.
+    static constexpr int SH = 36;
+    bool stream_supported() const override { return cum; }
+    int stream_hc() const override { return SH; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        SE_CHECK(cum, "frame-online TaylorSENet needs the cumulative-LayerNorm (`_new`) weights");
+        slots.begin(B, st);
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, SH + n);
+        *spec = b.spec;
+        *mag = nullptr;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+        Bufs& b = bufs(B, SH + n);
+        StreamScope sc(slots, SH, n, t0, B);
+        network(b, st);
+        launch_polar_pow(b.est, b.est, B, NBIN, b.T, ctx.p_out, st);
+        stream_exchange(b.est, 2L * NBIN * b.T, (long)NBIN * b.T, b.T, B, 2, NBIN, 2, st);   // the iSTFT overlaps one frame back
+    }
+
   private:
+    StreamSlots slots;
+    bool cum = false;
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *est, *frames, *ens[5], *sens[5], *dx[4], *dlast, *gain, *zero, *hx, *hob, *X[2];

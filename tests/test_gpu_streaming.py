@@ -91,6 +91,57 @@ def test_dpcrn_real_checkpoint_streams_like_offline():
     assert e < 1e-4 and e < 5e-4 * rms(G['enh_real'])
 
 
+def _new_variant(name, B, L):
+    from se_amd import models_new
+    from se_amd.models import MODEL_CLASSES
+    if name == 'ctsnet_new':
+        return models_new.CTSNet(max_batch=B, max_samples=L).load_synthetic(17, 18)
+    return MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic({'taylorsenet_new': 19, 'g2net_new': 20}[name])
+
+
+@pytest.mark.parametrize('name', ['ctsnet_new', 'taylorsenet_new', 'g2net_new'])
+@pytest.mark.parametrize('pieces,chunk', [([160], 1), ([37, 1000, 3, 481, 2000], 4), ([4000], 16), ([7777, 160], 40)])
+def test_cln_variants_stream_like_offline(name, pieces, chunk):
+    """The `_new` directories replace every InstanceNorm by a cumulative LayerNorm (CTSNet_new/Step1_network.py:213-286), which
+    makes the whole network causal: fed piecewise - per-layer history columns (up to 128 frames for CTSNet's dilated convs,
+    62 for its ShareSepConv FIRs) and the running cLN sums carried between chunks - the engine must reproduce its offline
+    decode, which tests/test_gpu_new_variants.py pins to the reference's output."""
+    import torch
+    L, B = 16000, 2
+    m = _new_variant(name, B, L)
+    x = np.stack([synth.synth_clip(820 + b, 'speech' if b % 2 == 0 else 'white', L) for b in range(B)])
+    xt = torch.from_numpy(x).cuda()
+    ref = m.enhance_batch(xt).cpu().numpy()
+    eng = m.engine
+    eng.stream_begin(B, c=eng.rms_scale(xt), max_chunk_frames=chunk)
+    outs, pos, k = [], 0, 0
+    while pos < L:
+        n = min(pieces[min(k, len(pieces) - 1)], L - pos)
+        outs.append(eng.stream_push(xt[:, pos:pos + n].contiguous()).cpu().numpy())
+        pos += n
+        k += 1
+    outs.append(eng.stream_flush().cpu().numpy())
+    got = np.concatenate(outs, axis=1)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    e = rms(got - ref)
+    print(name, pieces, chunk, 'streamed vs offline rms err', e, 'rms ref', rms(ref))
+    assert e < 1e-6 + 2e-5 * rms(ref), (name, e, rms(ref))
+    # a second stream on the same engine starts from zero state again
+    eng.stream_begin(B, c=eng.rms_scale(xt), max_chunk_frames=chunk)
+    o2 = [eng.stream_push(xt[:, :8000].contiguous()).cpu().numpy(), eng.stream_push(xt[:, 8000:].contiguous()).cpu().numpy(),
+          eng.stream_flush().cpu().numpy()]
+    assert rms(np.concatenate(o2, axis=1) - ref) < 1e-6 + 2e-5 * rms(ref)
+
+
+def test_instance_norm_variants_refuse_streaming():
+    """The base directories' InstanceNorms need the whole utterance: only the cLN weights unlock the frame-online mode."""
+    from se_amd.models import MODEL_CLASSES
+    from se_amd.engine import EngineError
+    m = MODEL_CLASSES['g2net'](max_batch=1, max_samples=4000).load_synthetic(20)
+    with pytest.raises(EngineError):
+        m.engine.stream_begin(1)
+
+
 def test_streaming_is_refused_where_the_model_is_not_causal():
     import torch
     from se_amd.models import MODEL_CLASSES

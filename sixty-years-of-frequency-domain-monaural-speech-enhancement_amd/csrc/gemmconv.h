@@ -72,6 +72,8 @@ struct GCParams {
     int t_base;              // first frame of time tile 0 of this launch (tail launches start at the last tile)
     int pw4;                 // per launch: 1 -> stage the patch in 16 B groups
     int causal;              // no tap looks ahead in time (dt <= 0 for every tap)
+    short tdf[GC_MAX_TAPS], tdt[GC_MAX_TAPS];     // tap offsets (frequency rows, frames) by value, for the thin kernel
+    int nbuf;                // per launch (resident-K form of the kernel): staging buffers = chunks of the longer source
     int trim;                // per launch: 1 -> 16 B groups that straddle the end of a row are cut back to Tin in LDS
     const unsigned* desc;    // host-built patch-slot descriptors [NB][256]: w | r << 12 | cil << 16 | staged << 31
     const int* tab;          // device table: row_df[GC_MAX_ROWS], tap_row[GC_MAX_TAPS], tap_dt[GC_MAX_TAPS], koff[GC_MAX_KCP + 8]    // optional (EPI_ACT on 64-row tiles, EPI_GLU): per (b, output channel, output frequency row, group of 32 frames)

@@ -116,8 +116,11 @@ __device__ __forceinline__ float dpp_add8(float x) {
     return x;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {
+// RES (tiny launches, e.g. the few-frame chunks of the frame-online mode): every K chunk of a source has its own staging
+// buffer, all are requested at once and waited for once - the block's life is then 1-2 memory round trips instead of one
+// per chunk (16 for a 64 x 320 TCM conv, whose matrix work is a few hundred cycles).
+template <int BM, int BN, int WM, int WN, int EPI, bool RES = false>
+__global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {
 #ifdef GC_TIMING
     unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
     const int ait = (nA4 + 255) >> 8;                // float4 groups of the weight chunk per thread (uniform)
     const int As_sz = ait * 1024;                    // padded so that every thread stores unconditionally
     const int Bs_sz = bit * 256;                     // padded: every thread stores unconditionally
-    constexpr int nbuf = 2;                          // double-buffered staging
+    const int nbuf = RES ? p.nbuf : 2;               // double-buffered staging (RES: one buffer per chunk of a source)
     float* As = smem;
     float* Bs = smem + nbuf * As_sz;
 
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
             epv[3] = p.post_scale ? p.post_shift[oc] : 0.f;
         }
     }
-    for (int i = tid; i < 2 * Bs_sz / 4; i += 256) reinterpret_cast<floatx4*>(Bs)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < nbuf * Bs_sz / 4; i += 256) reinterpret_cast<floatx4*>(Bs)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     if (tid < GC_TAB_KOFF + KCP_MAX + 8) tabl[tid] = tabv;
     if (EPI != EPI_LSTM && tid < BM) {
         ep[tid] = epv[0];
@@ -342,7 +345,15 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         GC_T(9);      /* Bs zero + sync */
         GC_MAKE_DESC(nch > 1 ? p.CI_C : tail);
         GC_T(10);     /* descriptors */
-        GC_LOAD_CHUNK(0, buf);           // `buf` is free: the previous segment's last chunk was read from buf ^ 1
+        if constexpr (RES) {
+            buf = 0;
+            for (int c2 = 0; c2 < min(nch, nbuf); ++c2) {
+                if (c2 + 1 == nch && nch > 1 && tail != p.CI_C) GC_MAKE_DESC(tail);
+                GC_LOAD_CHUNK(c2, c2);
+            }
+        } else {
+            GC_LOAD_CHUNK(0, buf);       // `buf` is free: the previous segment's last chunk was read from buf ^ 1
+        }
         GC_T(1);
         GC_WAIT_CHUNK();
         GC_TRIM_TAIL(buf);
@@ -351,7 +362,19 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
         GC_T(4);
 
         for (int c = 0; c < nch; ++c) {
-            if (c + 1 < nch && !(p.dbg & 1)) {
+            if constexpr (RES) {
+                if (c > 0 && buf == nbuf) {      // next group of resident chunks
+                    __syncthreads();
+                    for (int c2 = c; c2 < min(nch, c + nbuf); ++c2) {
+                        if (c2 + 1 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
+                        GC_LOAD_CHUNK(c2, c2 - c);
+                    }
+                    GC_WAIT_CHUNK();
+                    __syncthreads();
+                    buf = 0;
+                }
+            }
+            if (!RES && c + 1 < nch && !(p.dbg & 1)) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
                 GC_LOAD_CHUNK(c + 1, buf ^ 1);
             }
@@ -404,13 +427,18 @@ __global__ __launch_bounds__(256, gc_blocks_per_cu(BM)) void gc_kernel(const GCP
 #undef GC_FETCH
 #undef GC_MMA
             GC_T(2);
-            GC_WAIT_CHUNK();
-            GC_TRIM_TAIL(buf ^ 1);
-            GC_T(3);
-            __syncthreads();
-            GC_T(4);
-            buf ^= 1;
+            if constexpr (RES) {
+                buf += 1;
+            } else {
+                GC_WAIT_CHUNK();
+                GC_TRIM_TAIL(buf ^ 1);
+                GC_T(3);
+                __syncthreads();
+                GC_T(4);
+                buf ^= 1;
+            }
         }
+        if constexpr (RES) __syncthreads();      // every chunk has been read: the next source (or the epilogue strips) may overwrite
         gchunk += nch;
     }
 #undef GC_MAKE_DESC
@@ -771,6 +799,133 @@ __global__ __launch_bounds__(256) void gc_small_lds_kernel(const GCParams p, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Thin path: launches that produce at most 8 frames per row (the chunks of the frame-online mode).  A 64-column MFMA tile
+// would spend its whole matrix time on padding (a 64 x 320 TCM conv: 5 us of MFMAs for one useful column); here the layer is
+// a handful of dot products.  A workgroup owns 16 output rows of one (b, q): thread (mi, kg) walks every 16th K row
+// (ci, tap) of the packed weight matrix - 16 lanes read 64 B of one K row, the activation is the same address for all of
+// them - with up to 8 frame accumulators, the 16 partial sums per output are folded through LDS, and the epilogues of the
+// MFMA kernel follow.
+// ------------------------------------------------------------------------------------------------
+constexpr int GC_THIN_NT = 8;
+// NT = frames per row (1, 2, 4, 8: no masked loads for the frames a short chunk does not have).  A thread's whole K walk is
+// issued in batches of 8 independent (weight, activation) loads - a block lives for 2-3 memory round trips - and the tap
+// table travels in the kernel arguments (GCParams::tdf / tdt), so that no address waits for a table fetch.
+template <int EPI, int NT>
+__global__ __launch_bounds__(256) void gc_thin_kernel(const GCParams p) {
+    constexpr int RB = 8, KG = 32, UN = 8;          // rows per workgroup, K groups, loads in flight per thread
+    __shared__ float part[KG][RB][NT + 1];
+    __shared__ int s_df[GC_MAX_TAPS], s_dt[GC_MAX_TAPS];
+    const int tid = threadIdx.x, mi = tid & (RB - 1), kg = tid / RB;
+#pragma unroll
+    for (int j = 0; j < GC_MAX_TAPS; ++j)       // constant indices: scalar loads from the argument segment
+        if (tid == j) {
+            s_df[j] = p.tdf[j];
+            s_dt[j] = p.tdt[j];
+        }
+    __syncthreads();
+    const int nm = p.Mp / RB;
+    const int mt = blockIdx.x % nm;
+    const int rest = blockIdx.x / nm;
+    const int q = rest % p.Q, b = rest / p.Q;
+    const int m = mt * RB + mi, t0 = p.t_base, n = p.Tout - p.t_base;
+    const int ntaps = p.ntaps, Ktot = (p.C0 + p.C1) * ntaps;
+    const int nch0 = p.C0 > 0 ? (p.C0 + p.CI_C - 1) / p.CI_C : 0;
+    float acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    for (int k0 = kg; k0 < Ktot; k0 += KG * UN) {
+        float w[UN], xv[UN][NT];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kk = k0 + u * KG;
+            const bool kok = kk < Ktot;
+            const int kc = kok ? kk : 0;
+            const int ci = kc / ntaps, j = kc - ci * ntaps;
+            const bool seg = ci >= p.C0;
+            const int cs = seg ? ci - p.C0 : ci;
+            const int chunk = (seg ? nch0 : 0) + cs / p.CI_C, cil = cs % p.CI_C;
+            const float wv = p.A[((long)chunk * p.KCp + cil * ntaps + j) * p.Mp + m];
+            const int f = q * p.si + s_df[j];
+            const bool fok = kok && f >= 0 && f < p.Fin;
+            const int fc = fok ? f : 0;
+            const float* __restrict__ src = seg ? p.src1 + (long)b * p.s1_b + (long)cs * p.s1_c + (long)fc * p.s1_f
+                                                : p.src0 + (long)b * p.s0_b + (long)cs * p.s0_c + (long)fc * p.s0_f;
+            const int tb = t0 + s_dt[j];
+            w[u] = fok ? wv : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ti = tb + t;
+                const bool ok = t < n && ti >= 0 && ti < p.Tin;
+                const float x = src[ok ? ti : 0];
+                xv[u][t] = ok ? x : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = fmaf(w[u], xv[u][t], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) part[kg][mi][t] = acc[t];
+    __syncthreads();
+    const bool fold = tid < RB * NT;
+    const int r = tid & (RB - 1), t = (tid / RB) & (NT - 1);
+    float tot = 0.f;
+    if (fold) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) tot += part[g][r][t];
+    }
+    __syncthreads();
+    if (fold) part[0][r][t] = tot;      // row pairs of the GLU epilogue read their neighbour's total
+    __syncthreads();
+    if (!fold || t >= n) return;
+    const int fo = q * p.so + p.po, mr = mt * RB + r;
+    const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : p.bias;
+    float* __restrict__ dst = p.dst + (long)b * p.d_b + (long)fo * p.d_f + t0 + t;
+    if (EPI == EPI_GLU) {
+        if ((r & 1) || mr + 1 >= p.M) return;
+        const int oc = mr >> 1;
+        const float a = part[0][r][t] + (bias ? bias[mr] : 0.f), g = part[0][r + 1][t] + (bias ? bias[mr + 1] : 0.f);
+        float v = a * fsig_(g);
+        if (p.post_scale) v = v * p.post_scale[oc] + p.post_shift[oc];
+        dst[(long)oc * p.d_c] = act_apply(v, p.act, p.slope ? p.slope[oc] : 0.f);
+    } else {
+        if (mr >= p.M) return;
+        float v = part[0][r][t] + (bias ? bias[mr] : 0.f);
+        v = act_apply(v, p.act, p.slope ? p.slope[mr] : 0.f);
+        if (EPI == EPI_ADD || EPI == EPI_MUL) {
+            const float rv = p.aux[(long)b * p.x_b + (long)fo * p.x_f + (long)mr * p.x_c + t0 + t];
+            v = (EPI == EPI_ADD) ? v + rv : v * rv;
+        }
+        dst[(long)mr * p.d_c] = v;
+    }
+}
+template <int EPI>
+static void gc_thin_launch_n(const GCParams& p, dim3 grid, int n, hipStream_t stream) {
+    if (n <= 1) hipLaunchKernelGGL((gc_thin_kernel<EPI, 1>), grid, dim3(256), 0, stream, p);
+    else if (n <= 2) hipLaunchKernelGGL((gc_thin_kernel<EPI, 2>), grid, dim3(256), 0, stream, p);
+    else if (n <= 4) hipLaunchKernelGGL((gc_thin_kernel<EPI, 4>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gc_thin_kernel<EPI, 8>), grid, dim3(256), 0, stream, p);
+}
+static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
+    static const int thin_env = getenv("SE_GC_THIN") ? atoi(getenv("SE_GC_THIN")) : 1;
+    const int n = p.Tout - p.t_base;
+    if (!thin_env || p.Ws || n > GC_THIN_NT || p.Z > 1 || p.epi == EPI_LSTM || p.stats) return false;
+    const long nblk = (long)(p.Mp >> 3) * p.Q * p.B;
+    if (nblk >= (1L << 31)) return false;
+    dim3 grid((unsigned)nblk);
+    switch (p.epi) {
+        case EPI_ACT: gc_thin_launch_n<EPI_ACT>(p, grid, n, stream); break;
+        case EPI_ADD: gc_thin_launch_n<EPI_ADD>(p, grid, n, stream); break;
+        case EPI_MUL: gc_thin_launch_n<EPI_MUL>(p, grid, n, stream); break;
+        case EPI_GLU: gc_thin_launch_n<EPI_GLU>(p, grid, n, stream); break;
+        default: return false;
+    }
+    SE_HIP(hipGetLastError());
+    return true;
+}
+
 template <int MM, int EPI>
 static void gc_small_lds_launch(const GCParams& p, dim3 grid, size_t shm, int CC, int NR, const GCSmallGeom& sg, hipStream_t stream) {
     if (p.si == 1) hipLaunchKernelGGL((gc_small_lds_kernel<MM, EPI, 1>), grid, dim3(256), shm, stream, p, CC, NR, sg.dfmin, sg.dtmin);
@@ -822,9 +977,9 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes) {
+static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes, int nbuf = 2) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
-    return std::max(2 * (as + bs) * 4, epi_bytes) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64;
+    return std::max((size_t)nbuf * (as + bs) * 4, epi_bytes) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64;
 }
 
 // Device tables of one patch geometry (row stride Wp): frequency rows / tap table / K-row patch offsets, and the
@@ -888,6 +1043,11 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     SE_CHECK((int)rows.size() <= GC_MAX_ROWS, "too many distinct frequency rows");
     p.ntaps = taps.ntaps;
     p.nrows = (int)rows.size();
+    for (int j = 0; j < taps.ntaps; ++j) {       // the thin kernel reads the taps from its arguments
+        SE_CHECK(taps.df[j] >= -32768 && taps.df[j] <= 32767 && taps.dt[j] >= -32768 && taps.dt[j] <= 32767, "tap offset range");
+        p.tdf[j] = (short)taps.df[j];
+        p.tdt[j] = (short)taps.dt[j];
+    }
     // patch geometry: the staged time window starts a multiple of 4 frames before the tile (origin t0 - pad4) so that it
     // decomposes into 16 B groups that never straddle frame 0 (t0 is a multiple of BN): LDS column w <-> frame t0 + dtmin + w
     p.causal = dtmax <= 0;
@@ -1085,32 +1245,50 @@ void gc_free_plan(GCPlan& pl) {
     pl.dA = pl.dBias = pl.dSlope = nullptr;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool RES = false>
 static void gc_launch_e(const GCParams& p, hipStream_t stream) {
     // epilogue: 4*BM row parameters + one transposition strip per wave (rows x (cols + 4))
     const size_t epi = (size_t)(4 * (BM / WM) * 36) * sizeof(float);
-    const size_t lds = gc_lds_bytes(p, BM, epi);
+    const size_t lds = gc_lds_bytes(p, BM, epi, RES ? p.nbuf : 2);
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {
-        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI>),
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI, RES>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
-    hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN, EPI>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN, EPI, RES>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
     SE_HIP(hipGetLastError());
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool RES = false>
 static void gc_launch_t(const GCParams& p, hipStream_t stream) {
     switch (p.epi) {
-        case EPI_ACT: gc_launch_e<BM, BN, WM, WN, EPI_ACT>(p, stream); break;
-        case EPI_ADD: gc_launch_e<BM, BN, WM, WN, EPI_ADD>(p, stream); break;
-        case EPI_MUL: gc_launch_e<BM, BN, WM, WN, EPI_MUL>(p, stream); break;
-        case EPI_GLU: gc_launch_e<BM, BN, WM, WN, EPI_GLU>(p, stream); break;
-        case EPI_LSTM: gc_launch_e<BM, BN, WM, WN, EPI_LSTM>(p, stream); break;
+        case EPI_ACT: gc_launch_e<BM, BN, WM, WN, EPI_ACT, RES>(p, stream); break;
+        case EPI_ADD: gc_launch_e<BM, BN, WM, WN, EPI_ADD, RES>(p, stream); break;
+        case EPI_MUL: gc_launch_e<BM, BN, WM, WN, EPI_MUL, RES>(p, stream); break;
+        case EPI_GLU: gc_launch_e<BM, BN, WM, WN, EPI_GLU, RES>(p, stream); break;
+        case EPI_LSTM:
+            if constexpr (!RES) gc_launch_e<BM, BN, WM, WN, EPI_LSTM>(p, stream);
+            else SE_CHECK(false, "no resident-K form of the LSTM step");
+            break;
         default: SE_CHECK(false, "unknown epilogue");
     }
+}
+// all chunks of a source resident in LDS at once (gc_kernel RES): launches of at most one workgroup per CU whose staging fits
+static bool gc_resident_fits(GCParams& p, int BM, int BM_div_WM) {
+    static const int res_env = getenv("SE_GC_RES") ? atoi(getenv("SE_GC_RES")) : 1;
+    if (!res_env || p.trim || p.epi == EPI_LSTM) return false;
+    const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
+    const int nch0 = p.C0 > 0 ? (p.C0 + p.CI_C - 1) / p.CI_C : 0, nch1 = p.C1 > 0 ? (p.C1 + p.CI_C - 1) / p.CI_C : 0;
+    int nb = std::max(std::max(nch0, nch1), 1);
+    if (nblk > 256 || nb <= 2) return false;
+    // as many chunks per round trip as the LDS holds (a longer source goes in groups)
+    const size_t epi = (size_t)(4 * BM_div_WM * 36) * sizeof(float);
+    while (nb > 2 && gc_lds_bytes(p, BM, epi, nb) > 158 * 1024) --nb;
+    if (nb <= 2) return false;
+    p.nbuf = nb;
+    return true;
 }
 
 bool gc_stats_supported(const GCPlan& pl) {
@@ -1142,6 +1320,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     SE_CHECK(!p.stats || gc_stats_supported(pl), "gc_launch: this tile configuration has no statistics epilogue");
     SE_CHECK(p.pw4 || p.CI_C * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256,
              "pointwise layer with a row length that is not a multiple of 4 needs its sources inside the engine arena");
+    if (gc_thin_launch(p, stream)) return;
     if (p.Ws) {
         if (p.M <= 1) gc_small_launch<1>(p, pl.small, stream);
         else if (p.M <= 2) gc_small_launch<2>(p, pl.small, stream);
@@ -1172,11 +1351,16 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
                 pa.tab = pl.tail[0].g.tab;
                 pa.desc = pl.tail[0].g.desc;
                 pa.desc4 = pl.tail[0].g.desc4;
-                gc_launch_t<128, 32, 4, 1>(pa, stream);
+                if (gc_resident_fits(pa, 128, 32)) gc_launch_t<128, 32, 4, 1, true>(pa, stream);
+                else gc_launch_t<128, 32, 4, 1>(pa, stream);
                 return;
             }
-            if (pl.BM == 64) gc_launch_t<64, 64, 2, 2>(pa, stream);
-            else gc_launch_t<128, 64, 4, 1>(pa, stream);
+            if (pl.BM == 64) {
+                if (gc_resident_fits(pa, 64, 32)) gc_launch_t<64, 64, 2, 2, true>(pa, stream);
+                else gc_launch_t<64, 64, 2, 2>(pa, stream);
+            } else {
+                gc_launch_t<128, 64, 4, 1>(pa, stream);
+            }
             return;
         }
     }

@@ -479,9 +479,11 @@ void launch_tcm_head(const float* x, float* y, const float* slope, const float* 
 // stream do not count) and leaves the totals up to column c0 + n - 1 - the frames before the next window's column c0.
 __global__ __launch_bounds__(256) void cln_stats_kernel(const float* __restrict__ x, const float* __restrict__ pre_slope,
                                                         double* __restrict__ sum, double* __restrict__ sq, int R, int F,
-                                                        int T, int c0) {
-    __shared__ double sh[2][4][64];
-    const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6, t = c0 + blockIdx.x * 64 + tl, b = blockIdx.y;
+                                                        int T, int c0, int WP) {
+    // WP columns per workgroup, 256 / WP threads share a column's rows (whole utterances: 64 x 4; narrow frame-online
+    // windows put more threads on each column)
+    __shared__ double sh[2][256];
+    const int NL = 256 / WP, tl = threadIdx.x % WP, rg = threadIdx.x / WP, t = c0 + blockIdx.x * WP + tl, b = blockIdx.y;
     double s = 0.0, q = 0.0;
     if (t < T) {
         const float* xp = x + (long)b * R * T + t;
@@ -491,21 +493,26 @@ __global__ __launch_bounds__(256) void cln_stats_kernel(const float* __restrict_
             q += (double)v * v;
         };
         int r = rg;
-        for (; r + 4 * (NU - 1) < R; r += 4 * NU) {         // NU rows in flight per thread, summed in row order
+        for (; r + NL * (NU - 1) < R; r += NL * NU) {         // NU rows in flight per thread, summed in row order
             float xr[NU];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) xr[u] = xp[(long)(r + 4 * u) * T];
+            for (int u = 0; u < NU; ++u) xr[u] = xp[(long)(r + NL * u) * T];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) take(r + 4 * u, xr[u]);
+            for (int u = 0; u < NU; ++u) take(r + NL * u, xr[u]);
         }
-        for (; r < R; r += 4) take(r, xp[(long)r * T]);
+        for (; r < R; r += NL) take(r, xp[(long)r * T]);
     }
-    sh[0][rg][tl] = s;
-    sh[1][rg][tl] = q;
+    sh[0][rg * WP + tl] = s;
+    sh[1][rg * WP + tl] = q;
     __syncthreads();
     if (rg == 0 && t < T) {
-        sum[(long)b * T + t] = sh[0][0][tl] + sh[0][1][tl] + sh[0][2][tl] + sh[0][3][tl];
-        sq[(long)b * T + t] = sh[1][0][tl] + sh[1][1][tl] + sh[1][2][tl] + sh[1][3][tl];
+        double a = sh[0][tl], c = sh[1][tl];
+        for (int l = 1; l < NL; ++l) {
+            a += sh[0][l * WP + tl];
+            c += sh[1][l * WP + tl];
+        }
+        sum[(long)b * T + t] = a;
+        sq[(long)b * T + t] = c;
     }
 }
 
@@ -576,6 +583,112 @@ __global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict_
     }
 }
 
+// Frame-online windows are a few columns wide: one workgroup per utterance does the three passes in one launch (sums in
+// double precision like the kernels above, the same serial scan; the order inside a column's row sum differs).
+__global__ __launch_bounds__(256) void cln_window_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         const float* __restrict__ gain, const float* __restrict__ bias,
+                                                         const float* __restrict__ pre_slope,
+                                                         const float* __restrict__ post_slope, const float* __restrict__ fir,
+                                                         int K, int R, int F, int T, int c0, int t_first, long tg0, int n_new,
+                                                         double* __restrict__ carry) {
+    extern __shared__ double sc[];       // [2][T] totals, then [2][T] floats mean / rstd behind them
+    __shared__ double sh[2][256];
+    const int b = blockIdx.x;
+    float* mu = reinterpret_cast<float*>(sc + 2 * T);
+    float* rs = mu + T;
+    // per-column sums over the rows: WP columns at a time (WP = the window width rounded up to a power of two, at most 64),
+    // 256 / WP threads share one column's rows and are folded by a tree in double precision
+    int WP = 1;
+    while (WP < T - c0 && WP < 64) WP <<= 1;
+    const int NL = 256 / WP, col = threadIdx.x % WP, ln = threadIdx.x / WP;
+    for (int tb = c0; tb < T; tb += WP) {
+        const int t = tb + col;
+        double s = 0.0, q = 0.0;
+        if (t < T) {
+            const float* xp = x + (long)b * R * T + t;
+            auto take = [&](int r, float v) {
+                if (pre_slope) v = v >= 0.f ? v : pre_slope[r / F] * v;
+                s += v;
+                q += (double)v * v;
+            };
+            int r = ln;
+            for (; r + NL * 3 < R; r += NL * 4) {
+                float xr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xr[u] = xp[(long)(r + NL * u) * T];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) take(r + NL * u, xr[u]);
+            }
+            for (; r < R; r += NL) take(r, xp[(long)r * T]);
+        }
+        sh[0][threadIdx.x] = s;
+        sh[1][threadIdx.x] = q;
+        __syncthreads();
+        for (int h = NL >> 1; h >= 1; h >>= 1) {
+            if (ln < h) {
+                sh[0][threadIdx.x] += sh[0][threadIdx.x + h * WP];
+                sh[1][threadIdx.x] += sh[1][threadIdx.x + h * WP];
+            }
+            __syncthreads();
+        }
+        if (ln == 0 && t < T) {
+            const bool live = tg0 + t >= 0;
+            sc[t] = live ? sh[0][col] : 0.0;
+            sc[T + t] = live ? sh[1][col] : 0.0;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double a = carry[2 * b], q = carry[2 * b + 1];
+        for (int t = c0; t < T; ++t) {
+            a += sc[t];
+            q += sc[T + t];
+            sc[t] = a;
+            sc[T + t] = q;
+            if (t == c0 + n_new - 1) {
+                carry[2 * b] = a;
+                carry[2 * b + 1] = q;
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = c0 + threadIdx.x; t < T; t += 256) {
+        const double cnt = (double)R * (double)(tg0 + t >= 0 ? tg0 + t + 1 : 1), m = sc[t] / cnt;
+        const double var = (sc[T + t] - 2.0 * m * sc[t]) / cnt + m * m;
+        mu[t] = (float)m;
+        rs[t] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const int nn = T - t_first, W = T - c0;
+    float* nw = rs + T;                  // [R][W] normalised window (FIR flavour only: the launcher sizes the LDS for it)
+    if (K > 0) {
+        for (long i = threadIdx.x; i < (long)R * W; i += 256) {
+            const int r = (int)(i / W), ti = c0 + (int)(i - (long)r * W), c = r / F;
+            float v = x[((long)b * R + r) * T + ti];
+            v = v >= 0.f ? v : (pre_slope ? pre_slope[c] : 1.f) * v;
+            nw[i] = (tg0 + ti >= 0) ? (v - mu[ti]) * rs[ti] * gain[c] + bias[c] : 0.f;
+        }
+        __syncthreads();
+    }
+    for (long i = threadIdx.x; i < (long)R * nn; i += 256) {
+        const int r = (int)(i / nn), t = t_first + (int)(i - (long)r * nn), c = r / F;
+        float o;
+        if (K <= 0) {
+            float v = x[((long)b * R + r) * T + t];
+            v = v >= 0.f ? v : (pre_slope ? pre_slope[c] : 1.f) * v;
+            o = (v - mu[t]) * rs[t] * gain[c] + bias[c];
+            if (post_slope) o = o >= 0.f ? o : post_slope[c] * o;
+        } else {
+            o = 0.f;
+            const float* wp = nw + (long)r * W + (t - c0) - (K - 1);
+            for (int k = 0; k < K; ++k) {
+                if (tg0 + t - (K - 1) + k >= 0) o += fir[k] * wp[k];
+            }
+        }
+        y[((long)b * R + r) * T + t] = o;
+    }
+}
+
 void launch_cln(const float* x, float* y, const float* gain, const float* bias, const float* pre_slope,
                 const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s) {
     // per-(b, t) statistics live in a small engine-lifetime buffer (grown on first use, never on the steady-state path)
@@ -598,7 +711,17 @@ void launch_cln(const float* x, float* y, const float* gain, const float* bias, 
         cx->memo_src = nullptr;
         double* carry = static_cast<double*>(cx->slot((size_t)B * 2 * sizeof(double), s));
         const long tg0 = cx->t0 - cx->H;
-        hipLaunchKernelGGL(cln_stats_kernel, dim3((T - c0 + 63) / 64, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T, c0);
+        if ((long)R * (T - c0) <= 32768 && (K <= 0 || (size_t)R * (T - c0) * 4 + (size_t)T * 24 <= 60000)) {   // small windows: one launch
+            const size_t lds = (size_t)T * 24 + (K > 0 ? (size_t)R * (T - c0) * 4 : 0);
+            hipLaunchKernelGGL(cln_window_kernel, dim3(B), dim3(256), lds, s, x, y, gain, bias, pre_slope, post_slope,
+                               fir, K, R, F, T, c0, cx->H, tg0, cx->n, carry);
+            SE_HIP(hipGetLastError());
+            return;
+        }
+        int WP = 1;
+        while (WP < T - c0 && WP < 64) WP <<= 1;
+        hipLaunchKernelGGL(cln_stats_kernel, dim3((T - c0 + WP - 1) / WP, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T, c0,
+                           WP);
         hipLaunchKernelGGL(cln_scan_kernel, dim3(B), dim3(256), (size_t)T * 16, s, sum, sq, mean, rstd, R, T, c0, tg0, cx->n,
                            carry);
         hipLaunchKernelGGL(cln_apply_kernel, dim3((cx->n + 255) / 256, (R + 7) / 8, B), dim3(256), 0, s, x, y, mean, rstd, gain,
@@ -606,7 +729,7 @@ void launch_cln(const float* x, float* y, const float* gain, const float* bias, 
         SE_HIP(hipGetLastError());
         return;
     }
-    hipLaunchKernelGGL(cln_stats_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T, 0);
+    hipLaunchKernelGGL(cln_stats_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T, 0, 64);
     hipLaunchKernelGGL(cln_scan_kernel, dim3(B), dim3(256), (size_t)T * 16, s, sum, sq, mean, rstd, R, T, 0, 0L, 0, nullptr);
     hipLaunchKernelGGL(cln_apply_kernel, dim3((T + 255) / 256, (R + 7) / 8, B), dim3(256), 0, s, x, y, mean, rstd, gain,
                        bias, pre_slope, post_slope, fir, K, R, F, T, 0, 0L);
@@ -682,30 +805,44 @@ void* StreamCtx::slot(size_t bytes, hipStream_t st) {
     SE_CHECK((*slots)[cursor].second == bytes, "frame-online state: launch order differs from the first chunk");
     return (*slots)[cursor++].first;
 }
-// mode 0: x[.., c0 + k] = state[.., k]; mode 1: state[.., k] = x[.., c0 + k]   (k < need)
+// Columns [H - need, H) of x <- state, then state <- the last `need` columns of the window [H + n - need, H + n).  For
+// n < need the new state starts with the tail of the old one: a workgroup owns whole rows (KP = need rounded up to a
+// power of two <= 256 threads per row), reads everything it needs, and only then writes.
 __global__ __launch_bounds__(256) void stream_hist_kernel(float* __restrict__ x, float* __restrict__ state, long sb, long sc,
-                                                          long sf, int C, int F, int need, int c0, long total, int mode) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int k = (int)(i % need);
-    long r = i / need;
-    const int f = (int)(r % F);
-    r /= F;
-    const int c = (int)(r % C);
-    const long b = r / C;
-    float* xp = x + b * sb + c * sc + f * sf + c0 + k;
-    if (mode) state[i] = *xp;
-    else *xp = state[i];
+                                                          long sf, int C, int F, int need, int KP, int H, int n, long rows) {
+    const int k = threadIdx.x % KP;
+    const long r = (long)blockIdx.x * (256 / KP) + threadIdx.x / KP;
+    const bool on = r < rows && k < need;
+    float old = 0.f, nxt = 0.f;
+    float* xp = nullptr;
+    float* sp = nullptr;
+    if (on) {
+        const int f = (int)(r % F);
+        const long q = r / F;
+        const int c = (int)(q % C);
+        const long b = q / C;
+        xp = x + b * sb + c * sc + f * sf;
+        sp = state + r * need;
+        old = sp[k];
+        nxt = (k + n < need) ? sp[k + n] : xp[H + n - need + k];
+    }
+    __syncthreads();
+    if (on) {
+        xp[H - need + k] = old;
+        sp[k] = nxt;
+    }
 }
 void stream_exchange(float* x, long sb, long sc, long sf, int B, int C, int F, int need, hipStream_t st) {
     StreamCtx* cx = stream_ctx();
     SE_CHECK(cx && need > 0 && need <= cx->H, "stream_exchange: history deeper than the window keeps");
-    const long total = (long)B * C * F * need;
-    float* state = static_cast<float*>(cx->slot((size_t)total * sizeof(float), st));
-    const unsigned g = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(stream_hist_kernel, dim3(g), dim3(256), 0, st, x, state, sb, sc, sf, C, F, need, cx->H - need, total, 0);
-    hipLaunchKernelGGL(stream_hist_kernel, dim3(g), dim3(256), 0, st, x, state, sb, sc, sf, C, F, need, cx->H + cx->n - need,
-                       total, 1);
+    const long rows = (long)B * C * F;
+    float* state = static_cast<float*>(cx->slot((size_t)rows * need * sizeof(float), st));
+    SE_CHECK(need <= 256, "stream_exchange: more than 256 history columns");
+    int KP = 1;
+    while (KP < need) KP <<= 1;
+    const int rpb = 256 / KP;
+    hipLaunchKernelGGL(stream_hist_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, x, state, sb, sc, sf, C,
+                       F, need, KP, cx->H, cx->n, rows);
     SE_HIP(hipGetLastError());
 }
 

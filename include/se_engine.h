@@ -127,7 +127,11 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
  *          agree exactly - that is what the tests check.
  *   max_chunk_frames: frames advanced per internal step (latency / efficiency trade-off, default 16).
  * Supported: SE_MODEL_CRN, SE_MODEL_LSTM, SE_MODEL_GCRN, SE_MODEL_DPCRN, SE_MODEL_DCCRN (whose decoder looks six frames ahead:
- * its output is final six frames later than the others').  Streams are limited to max_samples of se_config. */
+ * its output is final six frames later than the others'), and SE_MODEL_CTSNET / SE_MODEL_TAYLORSENET / SE_MODEL_G2NET when
+ * loaded with the cumulative-LayerNorm weights of the `_new` directories (CTSNet_new/Step1_network.py:213-286 - with the
+ * InstanceNorm weights of the base directories the network needs the whole utterance and se_stream_begin fails; the engine
+ * then carries up to 128 history frames per dilated conv and the running cLN sums).  Streams are limited to max_samples
+ * of se_config. */
 int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, void* stream);
 int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_new, float* out_dev, int64_t out_pitch,
                    int32_t* n_out, void* stream);

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libse_engine.so")
+LIB_PATH = os.environ.get("SE_ENGINE_LIB") or os.path.join(_HERE, "libse_engine.so")      # SE_ENGINE_LIB: A/B another build
 
 MODEL_IDS = {
     'lstm': 1, 'crn': 2, 'gcrn': 3, 'dpcrn': 4, 'dccrn': 5, 'fullsubnet': 6, 'ctsnet': 7, 'g2net': 8,

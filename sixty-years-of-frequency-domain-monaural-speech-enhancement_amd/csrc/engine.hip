@@ -391,7 +391,7 @@ int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
-        SE_CHECK(e->model->stream_supported(), "this model has no frame-online mode (CRN, LSTM, GCRN, DPCRN and DCCRN have)");
+        SE_CHECK(e->model->stream_supported(), "this model has no frame-online mode (CRN, LSTM, GCRN, DPCRN, DCCRN and the cLN `_new` weights of CTSNet / TaylorSENet / G2Net have)");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         const StftGeom& g = e->ctx.geom;
         SE_CHECK((g.n_fft + g.hop - 1) / g.hop - 1 + e->model->stream_lag() <= e->model->stream_hc(),

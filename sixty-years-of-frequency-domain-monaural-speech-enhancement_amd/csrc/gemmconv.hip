@@ -119,7 +119,9 @@ __device__ __forceinline__ float dpp_add8(float x) {
 // RES (tiny launches, e.g. the few-frame chunks of the frame-online mode): every K chunk of a source has its own staging
 // buffer, all are requested at once and waited for once - the block's life is then 1-2 memory round trips instead of one
 // per chunk (16 for a 64 x 320 TCM conv, whose matrix work is a few hundred cycles).
-template <int BM, int BN, int WM, int WN, int EPI, bool RES = false>
+// TRIM: the launch stages 16 B groups under taps that look ahead in time (GC_TRIM_TAIL).  A variant of its own: the mere
+// presence of the LDS stores in the K loop costs the other launches 2-10 % (gcbench, 32- / 64-row tiles most).
+template <int BM, int BN, int WM, int WN, int EPI, bool RES = false, bool TRIM = false>
 __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {
 #ifdef GC_TIMING
     unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
     const int bit = (npatch + 255) >> 8;             // patch elements per thread (uniform)
     const bool pw4 = p.pw4 != 0;                     // the patch is staged in 16 B groups (decided per launch, gc_launch)
     // 16 B groups under taps that look ahead in time, rows that are not whole groups: see GC_TRIM_TAIL (block-uniform)
-    const bool fixt = p.trim != 0;
+    constexpr bool fixt = TRIM;
     const int bit4 = (npatch / 4 + 255) >> 8;
     const int nA4 = p.KCp * (BM / 4);
     const int ait = (nA4 + 255) >> 8;                // float4 groups of the weight chunk per thread (uniform)
@@ -249,7 +251,9 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wm = wave / WN, wn = wave % WN;
+    // 64 x 256 tile: the wave -> column-strip assignment rotates with the time tile, so that the idle waves of a partly
+    // filled last tile (T = 401: 145 of 256 columns) sit on a different SIMD in every workgroup of a CU instead of all on SIMD 3
+    const int wm = wave / WN, wn = (WN == 4 && BN >= 256) ? ((wave + ttile) & 3) : wave % WN;
     const int am = wm * (TM * 32) + l31;      // A column base inside the tile
     const int bn = wn * (TN * 32) + l31;      // B column base inside the tile
     // 32-column sub-tiles of this wave with a frame below Tout (wave-uniform)
@@ -1257,6 +1261,19 @@ static void gc_launch_e(const GCParams& p, hipStream_t stream) {
     }
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
+    if constexpr (EPI == EPI_ACT && !RES) {
+        if (p.trim) {
+            static bool attr_trim[64] = {};
+            if (first_on_device(attr_trim)) {
+                SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN, EPI, false, true>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
+            SE_HIP(hipGetLastError());
+            return;
+        }
+    }
+    SE_CHECK(!p.trim, "gc_launch: no trimming variant of this kernel");
     hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN, EPI, RES>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
     SE_HIP(hipGetLastError());
 }
@@ -1315,7 +1332,8 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     // (a tap set that looks ahead would read the straddling group's foreign frames into stored outputs: the kernel trims
     // them in LDS, GC_TRIM_TAIL)
     static const int trim_env = getenv("SE_GC_TRIM") ? atoi(getenv("SE_GC_TRIM")) : 1;
-    p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || ((p.causal || trim_env) && gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
+    const bool trim_ok = trim_env && p.epi == EPI_ACT;       // the trimming variant exists for the plain epilogue (DCCRN's decoder)
+    p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || ((p.causal || trim_ok) && gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
     p.trim = (p.pw4 && !p.causal && p.Tin % 4 != 0) ? 1 : 0;
     SE_CHECK(!p.stats || gc_stats_supported(pl), "gc_launch: this tile configuration has no statistics epilogue");
     SE_CHECK(p.pw4 || p.CI_C * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256,
@@ -1371,7 +1389,8 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
         static const long wide_min = getenv("SE_GC_WIDE_MIN") ? atol(getenv("SE_GC_WIDE_MIN")) : 6144;
         const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
         const int nt = (Tspan + 255) / 256;
-        if (wd.BN == 256 && pl.BM == 64 && p.pw4 && nblk >= wide_min && Tspan * 10 >= nt * 256 * 9 &&
+        static const int wide_fill = getenv("SE_GC_WIDE_FILL") ? atoi(getenv("SE_GC_WIDE_FILL")) : 75;
+        if (wd.BN == 256 && pl.BM == 64 && p.pw4 && nblk >= wide_min && Tspan * 100 >= nt * 256 * wide_fill &&
             (long)p.CI_C * p.nrows * wd.Wp <= 4608 /* 5 x 256 groups, 3 workgroups' LDS */) {
             GCParams pa = p;
             pa.n_ttiles = nt;

@@ -72,6 +72,7 @@ struct GCParams {
     int t_base;              // first frame of time tile 0 of this launch (tail launches start at the last tile)
     int pw4;                 // per launch: 1 -> stage the patch in 16 B groups
     int causal;              // no tap looks ahead in time (dt <= 0 for every tap)
+    int pair, po2, fo_lim;   // direct path: both parity classes of a transposed conv as 2 * pair virtual output channels (0 = off)
     short tdf[GC_MAX_TAPS], tdt[GC_MAX_TAPS];     // tap offsets (frequency rows, frames) by value, for the thin kernel
     int nbuf;                // per launch (resident-K form of the kernel): staging buffers = chunks of the longer source
     int trim;                // per launch: 1 -> 16 B groups that straddle the end of a row are cut back to Tin in LDS
@@ -105,6 +106,7 @@ struct GCPlan {
     GCParams p{};            // static part (taps, chunking, weights); pointers for activations filled per launch
     int BM = 128, BN = 128;  // tile config
     int lookback = 0;        // frames of history the taps reach back (max -dt)
+    double flop_scale = 1.0; // algorithmic / executed multiply-adds (fused parity pairs carry zero-weight taps)
     float* dA = nullptr;     // device copies owned by the plan
     float* dWs = nullptr;
     unsigned* dDesc = nullptr;

@@ -683,6 +683,12 @@ __global__ __launch_bounds__(256) void gc_small_kernel(const GCParams p) {
             v = act_apply(v, p.act, p.slope ? p.slope[m] : 0.f);
             if (EPI == EPI_ADD) v += res[(long)m * p.x_c + t];
             if (EPI == EPI_MUL) v *= res[(long)m * p.x_c + t];
+            if (EPI == EPI_ACT && p.pair) {
+                // both parity classes of a transposed conv in one launch: rows [cls * pair, (cls + 1) * pair) are class cls
+                const int cls = m / p.pair, fo2 = q * p.so + (cls ? p.po2 : p.po);
+                if (fo2 < p.fo_lim) dst[(long)(fo2 - fo) * p.d_f + (long)(m - cls * p.pair) * p.d_c + t] = v;
+                continue;
+            }
             dst[(long)m * p.d_c + t] = v;
         }
     }
@@ -797,6 +803,11 @@ __global__ __launch_bounds__(256) void gc_small_lds_kernel(const GCParams p, con
                 v = act_apply(v, p.act, p.slope ? p.slope[m] : 0.f);
                 if (EPI == EPI_ADD) v += res[(long)m * p.x_c + t];
                 if (EPI == EPI_MUL) v *= res[(long)m * p.x_c + t];
+                if (EPI == EPI_ACT && p.pair) {      // see gc_small_kernel
+                    const int cls = m / p.pair, fo2 = (q0 + qq) * p.so + (cls ? p.po2 : p.po);
+                    if (fo2 < p.fo_lim) dst[(long)(fo2 - fo) * p.d_f + (long)(m - cls * p.pair) * p.d_c + t] = v;
+                    continue;
+                }
                 dst[(long)m * p.d_c + t] = v;
             }
         }

@@ -60,6 +60,11 @@ GCPlan make_conv_plan(const DenseW& d, int sf, int pf, int pt_left, int dil_f, i
 struct DeconvPlan {
     std::vector<GCPlan> par;   // one per parity class (classes with no taps are dropped -> bias-only rows unsupported)
     int sf = 1;
+    // layers back to <= 2 channels (DCCRN's last transposed conv, 64 -> 2): both parity classes as ONE launch of the direct
+    // path - 2 x M virtual output channels over the union of the classes' taps (a tap a class does not have gets zero
+    // weights), so the input plane is read once instead of once per class
+    GCPlan pair;
+    bool has_pair = false;
 };
 DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, const std::vector<float>& slope,
                             int tout_hint, int C0split = -1, const std::vector<float>* bias_pad = nullptr,

@@ -239,6 +239,8 @@ DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, 
     SE_CHECK(pf >= 0 || bias_pad, "a left frequency pad needs the bias of the padded rows");
     DeconvPlan out;
     out.sf = sf;
+    std::vector<TapSpec> cls_taps;
+    std::vector<std::vector<float>> cls_w;
     for (int par = 0; par < sf; ++par) {
         TapSpec ts;
         std::vector<int> sel;
@@ -260,11 +262,50 @@ DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, 
                 for (int j = 0; j < ts.ntaps; ++j)
                     w[((size_t)m * d.Cin + c) * ts.ntaps + j] = d.w[((size_t)m * d.Cin + c) * d.ntaps() + sel[j]];
         out.par.push_back(gc_make_plan(d.M, d.Cin, ts, w, d.bias, slope, act, epi, 1, sf, par, tout_hint, 1, C0split));
+        cls_taps.push_back(ts);
+        cls_w.push_back(w);
         if (pf < 0) {
             GCPlan& g = out.par.back();
             g.dBiasPad = to_device(*bias_pad);
             g.p.bias_pad = g.dBiasPad;
             g.p.pad_lo = -pf;
+        }
+    }
+    static const bool pair_env = !(getenv("SE_GC_PAIR") && atoi(getenv("SE_GC_PAIR")) == 0);
+    if (pair_env && sf == 2 && d.M <= 2 && epi == EPI_ACT && pf >= 0 && out.par.size() == 2 && out.par[0].p.Ws && out.par[1].p.Ws) {
+        TapSpec un;
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < cls_taps[c].ntaps; ++j) {
+                bool have = false;
+                for (int u = 0; u < un.ntaps; ++u) have = have || (un.df[u] == cls_taps[c].df[j] && un.dt[u] == cls_taps[c].dt[j]);
+                if (!have && un.ntaps < GC_MAX_TAPS) {
+                    un.df[un.ntaps] = cls_taps[c].df[j];
+                    un.dt[un.ntaps] = cls_taps[c].dt[j];
+                    un.ntaps++;
+                }
+            }
+        const int M2 = 2 * d.M;
+        std::vector<float> w((size_t)M2 * d.Cin * un.ntaps, 0.f), bias, sl;
+        for (int c = 0; c < 2; ++c)
+            for (int m = 0; m < d.M; ++m)
+                for (int ci = 0; ci < d.Cin; ++ci)
+                    for (int j = 0; j < cls_taps[c].ntaps; ++j)
+                        for (int u = 0; u < un.ntaps; ++u)
+                            if (un.df[u] == cls_taps[c].df[j] && un.dt[u] == cls_taps[c].dt[j])
+                                w[((size_t)(c * d.M + m) * d.Cin + ci) * un.ntaps + u] =
+                                    cls_w[c][((size_t)m * d.Cin + ci) * cls_taps[c].ntaps + j];
+        for (int c = 0; c < 2; ++c) {
+            bias.insert(bias.end(), d.bias.begin(), d.bias.end());
+            sl.insert(sl.end(), slope.begin(), slope.end());
+        }
+        out.pair = gc_make_plan(M2, d.Cin, un, w, bias, sl, act, EPI_ACT, 1, sf, 0, tout_hint, 1, C0split);
+        out.has_pair = out.pair.p.Ws != nullptr;
+        if (out.has_pair) {
+            out.pair.p.pair = d.M;
+            out.pair.p.po2 = 1;
+            out.pair.flop_scale = (double)(cls_taps[0].ntaps + cls_taps[1].ntaps) / (2.0 * un.ntaps);
+        } else {
+            gc_free_plan(out.pair);
         }
     }
     return out;
@@ -273,6 +314,8 @@ DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, 
 void free_deconv_plan(DeconvPlan& p) {
     for (auto& g : p.par) gc_free_plan(g);
     p.par.clear();
+    if (p.has_pair) gc_free_plan(p.pair);
+    p.has_pair = false;
 }
 
 // ------------------------------------------------------------------------------------------------ profiler
@@ -335,7 +378,7 @@ void gc_launch_prof(const GCPlan& pl, const GCParams& p, hipStream_t st, Profile
         prof->begin(st);
         gc_launch(pl, p, st);
         const double nch = (p.epi == EPI_LSTM && p.first_step) ? 0.0 : (double)(p.C0 + p.C1);
-        prof->end(st, 2.0 * p.M * nch * p.ntaps * (double)p.Z * p.B * p.Q * p.Tout);
+        prof->end(st, pl.flop_scale * 2.0 * p.M * nch * p.ntaps * (double)p.Z * p.B * p.Q * p.Tout);
     } else {
         gc_launch(pl, p, st);
     }
@@ -393,6 +436,22 @@ void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int 
 
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
                 int Tp, hipStream_t st, Profiler* prof, float* stats) {
+    if (pl.has_pair && !stats) {
+        GCParams p = pl.pair.p;
+        fill_src(p, s0, s1);
+        p.Fin = s0.F;
+        p.Tin = T;
+        p.B = B;
+        p.Q = (Fout + p.so - 1) / p.so;
+        p.fo_lim = Fout;
+        p.Tout = T;
+        p.dst = dst;
+        p.d_b = (long)dstC * Fout * Tp;
+        p.d_c = (long)Fout * Tp;
+        p.d_f = Tp;
+        gc_launch_prof(pl.pair, p, st, prof);
+        return;
+    }
     for (const auto& g : pl.par) {
         GCParams p = g.p;
         if (stats) set_stats(p, stats, dstC, Fout, T);

@@ -72,6 +72,7 @@ struct GCParams {
     int t_base;              // first frame of time tile 0 of this launch (tail launches start at the last tile)
     int pw4;                 // per launch: 1 -> stage the patch in 16 B groups
     int causal;              // no tap looks ahead in time (dt <= 0 for every tap)
+    int qt2, qq_off, Qt;     // per launch: two-row tiles (LDS offset of the second row's patch rows; row tiles per plane)
     int pair, po2, fo_lim;   // direct path: both parity classes of a transposed conv as 2 * pair virtual output channels (0 = off)
     short tdf[GC_MAX_TAPS], tdt[GC_MAX_TAPS];     // tap offsets (frequency rows, frames) by value, for the thin kernel
     int nbuf;                // per launch (resident-K form of the kernel): staging buffers = chunks of the longer source
@@ -114,6 +115,8 @@ struct GCPlan {
     GCSmallGeom small;       // direct path only
     bool tail_split = false; // tail[0] may be used as a separate launch for the last time tile
     GCTail tail[3];          // [0]: 32-column geometry for a mostly empty last time tile; [1]: 64-column geometry of the whole layer for small launches; [2]: 256-column geometry of a 64-row layer for big launches
+    GCTail qt2;              // two-row geometry: 2 output rows x 64 frames per tile (BN = 0: unused)
+    int qt2_nrows = 0, qt2_qoff = 0;
     float* dBias = nullptr;
     float* dSlope = nullptr;
     int* dTab = nullptr;

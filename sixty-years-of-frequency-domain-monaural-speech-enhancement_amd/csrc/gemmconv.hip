@@ -171,11 +171,15 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
     int rest = lid / p.n_mtiles;
     const int ttile = rest % p.n_ttiles;
     rest /= p.n_ttiles;
-    const int q = rest % p.Q;
-    rest /= p.Q;
+    // two-row tiles (p.qt2, gc_launch): the tile's columns are 2 output rows x BN / 2 frames - neighbouring output rows share
+    // most of their input rows (5 taps at stride 2: 7 staged rows instead of 10), so a chunk stages ~30 % fewer bytes for the
+    // same matrix work.  The waves of the upper column half take the second row; only block-level scalars differ.
+    const bool qt2 = p.qt2 != 0;
+    const int q = (rest % p.Qt) << (qt2 ? 1 : 0);
+    rest /= p.Qt;
     const int b = rest % p.B;
     const int z = rest / p.B;
-    const int t0 = p.t_base + ttile * BN;
+    const int t0 = p.t_base + ttile * (qt2 ? BN / 2 : BN);
     const int m0 = mt * BM;
 
     const float* __restrict__ Ag = p.A + (long)z * p.A_z + m0;
@@ -254,10 +258,13 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
     // 64 x 256 tile: the wave -> column-strip assignment rotates with the time tile, so that the idle waves of a partly
     // filled last tile (T = 401: 145 of 256 columns) sit on a different SIMD in every workgroup of a CU instead of all on SIMD 3
     const int wm = wave / WN, wn = (WN == 4 && BN >= 256) ? ((wave + ttile) & 3) : wave % WN;
+    constexpr int WNT = WN >= 2 ? WN / 2 : 1;          // waves per output row of a two-row tile
+    const int wq = (qt2 && WN >= 2) ? wn / WNT : 0;     // output row of this wave inside the tile
+    const int wt = (qt2 && WN >= 2) ? wn % WNT : wn;    // its 32 * TN-frame strip inside the row
     const int am = wm * (TM * 32) + l31;      // A column base inside the tile
-    const int bn = wn * (TN * 32) + l31;      // B column base inside the tile
+    const int bn = wq * p.qq_off + wt * (TN * 32) + l31;      // B column base inside the staged patch
     // 32-column sub-tiles of this wave with a frame below Tout (wave-uniform)
-    const int jact = max(0, min(TN, (p.Tout - t0 - wn * (TN * 32) + 31) >> 5));
+    const int jact = (q + wq >= p.Q) ? 0 : max(0, min(TN, (p.Tout - t0 - wt * (TN * 32) + 31) >> 5));
 
     int gchunk = 0;          // global chunk counter (weights are packed segment after segment)
     int buf = 0;
@@ -453,7 +460,8 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
     // ---------------------------------------------------------------- epilogue
     if (p.dbg & 8) return;
     GC_T(0);
-    float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fo * p.d_f;
+    const int fow = fo + wq * p.so;      // output row of this wave (two-row tiles)
+    float* __restrict__ dst = p.dst + (long)z * p.dst_z + (long)b * p.d_b + (long)fow * p.d_f;
 
     // The activated tile is transposed through LDS inside each wave so that a lane stores 16 B runs along t (4x fewer,
     // 4x wider stores than the MFMA accumulator layout gives).  The strips alias the staging buffers (the K loop's last
@@ -470,9 +478,10 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
         const int mw = wm * (TM * 32) + 4 * hi;                 // first tile row of this lane
         const int lr = lane >> 3, lc = (lane & 7) * 4;           // read-back role: (row within 8, 4 consecutive t)
         const int mo0 = (EPI == EPI_GLU ? (m0 >> 1) : m0) + wm * OROWS;      // first output row of the strip
-        const int Mo = (EPI == EPI_GLU) ? (p.M >> 1) : p.M;
+        // (an odd row count leaves the second row of the last two-row tile outside the plane: nothing of it is stored)
+        const int Mo = (q + wq < p.Q) ? ((EPI == EPI_GLU) ? (p.M >> 1) : p.M) : 0;
         const float* __restrict__ res =
-            (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : nullptr;
+            (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fow * p.x_f : nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (j > 0) GC_WAVE_FENCE();                          // the previous column tile has been read back
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
             }
             GC_WAVE_FENCE();
             // read back as rows: 8 lanes x 16 B cover the 32 columns of one row, 8 rows per wave instruction
-            const int tg = t0 + wn * (TN * 32) + j * 32 + lc;
+            const int tg = t0 + wt * (TN * 32) + j * 32 + lc;
 #pragma unroll
             for (int it = 0; it < OROWS / 8; ++it) {
                 const int row = it * 8 + lr, m = mo0 + row;
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
                         q = dpp_add8(q);
                         const int tb = tg - lc;                  // first frame of the sub-tile
                         if ((lane & 7) == 0 && m < Mo && tb < p.Tout) {
-                            float* sp = p.stats + (long)b * p.st_b + (long)m * p.st_c + (long)fo * p.st_f + (tb >> 5) * 2;
+                            float* sp = p.stats + (long)b * p.st_b + (long)m * p.st_c + (long)fow * p.st_f + (tb >> 5) * 2;
                             sp[0] = s;
                             sp[1] = q;
                         }
@@ -1123,6 +1132,24 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
         }
         // 64-column geometry of the whole layer (tail[1]) for launches that would not fill the chip with 128-column
         // tiles: the batch is only known at launch time, gc_launch picks
+        // two-row geometry (gc_kernel: qt2): rows of the patch = union of the input rows of two neighbouring output rows,
+        // when that union is an interval and smaller than twice the single-row set
+        if (pl.BN == 128 && epi != EPI_LSTM && taps.ntaps > 1) {
+            std::vector<int> r2 = rows;
+            for (int r : rows)
+                if (std::find(r2.begin(), r2.end(), r + si) == r2.end()) r2.push_back(r + si);
+            std::sort(r2.begin(), r2.end());
+            const bool interval = r2.back() - r2.front() + 1 == (int)r2.size();
+            const int wp2 = 64 + (dtmax - dtmin);
+            if (interval && (int)r2.size() <= GC_MAX_ROWS && (int)r2.size() < 2 * p.nrows &&
+                cic * (int)r2.size() * wp2 <= gc_bld_max(pl.BM) * 256) {
+                pl.qt2.BN = 64;
+                pl.qt2.Wp = wp2;
+                pl.qt2.g = gc_build_geom(taps, r2, dtmin, (int)r2.size(), wp2, cic, p.KC, gc_bld_max(pl.BM));
+                pl.qt2_nrows = (int)r2.size();
+                pl.qt2_qoff = si * wp2;
+            }
+        }
         // 256-column geometry of a 64-row layer (tail[2]): 1 x 4 waves of 64 x 64 do the 128 x 128 tile's matrix work per
         // staged K row (the 64 x 128 tile does half of it), for big launches whose rows fill the wide tiles (T = 501: 98 %)
         static const int wide_env = getenv("SE_GC_WIDE") ? atoi(getenv("SE_GC_WIDE")) : 1;
@@ -1240,6 +1267,10 @@ void gc_free_plan(GCPlan& pl) {
     if (pl.dDesc) (void)hipFree(pl.dDesc);
     if (pl.dDesc4) (void)hipFree(pl.dDesc4);
     pl.dDesc4 = nullptr;
+    if (pl.qt2.g.tab) (void)hipFree(pl.qt2.g.tab);
+    if (pl.qt2.g.desc) (void)hipFree(pl.qt2.g.desc);
+    if (pl.qt2.g.desc4) (void)hipFree(pl.qt2.g.desc4);
+    pl.qt2 = GCTail{};
     for (auto& t : pl.tail) {
         if (t.g.tab) (void)hipFree(t.g.tab);
         if (t.g.desc) (void)hipFree(t.g.desc);
@@ -1270,7 +1301,7 @@ static void gc_launch_e(const GCParams& p, hipStream_t stream) {
         SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI, RES>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
+    const long nblk = (long)p.Z * p.B * p.Qt * p.n_ttiles * p.n_mtiles;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
     if constexpr (EPI == EPI_ACT && !RES) {
         if (p.trim) {
@@ -1330,6 +1361,9 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     SE_CHECK(tb >= 0 && (tb & 3) == 0 && Tspan > 0, "gc_launch: first output frame must be a multiple of 4 below Tout");
     SE_CHECK(tb == 0 || !p.stats, "gc_launch: the statistics epilogue needs whole rows");
     p.n_ttiles = (Tspan + pl.BN - 1) / pl.BN;
+    p.Qt = p.Q;
+    p.qt2 = 0;
+    p.qq_off = 0;
     static const int dbg_env = getenv("SE_GC_DBG") ? atoi(getenv("SE_GC_DBG")) : 0;
     p.dbg = dbg_env;
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
@@ -1410,6 +1444,29 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
             pa.desc = wd.g.desc;
             pa.desc4 = wd.g.desc4;
             gc_launch_t<64, 256, 1, 4>(pa, stream);
+            return;
+        }
+    }
+    // big launches of layers whose neighbouring output rows share input rows: two-row tiles (2 x 64 frames)
+    {
+        static const int qt2_env = getenv("SE_GC_QT2") ? atoi(getenv("SE_GC_QT2")) : 1;
+        static const long qt2_min = getenv("SE_GC_QT2_MIN") ? atol(getenv("SE_GC_QT2_MIN")) : 4096;
+        const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
+        if (qt2_env && pl.qt2.BN == 64 && pl.BN == 128 && p.Q >= 2 && !p.stats && p.pad_lo == 0 && p.epi != EPI_LSTM &&
+            nblk >= qt2_min) {
+            GCParams pa = p;
+            pa.qt2 = 1;
+            pa.qq_off = pl.qt2_qoff;
+            pa.nrows = pl.qt2_nrows;
+            pa.Qt = (p.Q + 1) / 2;
+            pa.n_ttiles = (Tspan + 63) / 64;
+            pa.Wp = pl.qt2.Wp;
+            pa.tab = pl.qt2.g.tab;
+            pa.desc = pl.qt2.g.desc;
+            pa.desc4 = pl.qt2.g.desc4;
+            if (pl.BM == 128) gc_launch_t<128, 128, 2, 2>(pa, stream);
+            else if (pl.BM == 64) gc_launch_t<64, 128, 2, 2>(pa, stream);
+            else gc_launch_t<32, 128, 1, 4>(pa, stream);
             return;
         }
     }

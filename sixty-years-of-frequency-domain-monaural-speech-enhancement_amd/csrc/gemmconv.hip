@@ -937,7 +937,10 @@ static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
     const int n = p.Tout - p.t_base;
     if (!thin_env || p.Ws || n > GC_THIN_NT || p.Z > 1 || p.epi == EPI_LSTM || p.stats) return false;
     const long nblk = (long)(p.Mp >> 3) * p.Q * p.B;
-    if (nblk >= (1L << 31)) return false;
+    // (a few frames per row is not yet a small launch: the LSTM input projections of a batch-1 decode are 1 "frame" wide
+    // and 401 rows high with K = 1024 - matrix work)
+    static const long thin_max = getenv("SE_GC_THIN_MAX") ? atol(getenv("SE_GC_THIN_MAX")) : 8192;
+    if (nblk > thin_max) return false;
     dim3 grid((unsigned)nblk);
     switch (p.epi) {
         case EPI_ACT: gc_thin_launch_n<EPI_ACT>(p, grid, n, stream); break;
@@ -1341,7 +1344,9 @@ static bool gc_resident_fits(GCParams& p, int BM, int BM_div_WM) {
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     const int nch0 = p.C0 > 0 ? (p.C0 + p.CI_C - 1) / p.CI_C : 0, nch1 = p.C1 > 0 ? (p.C1 + p.CI_C - 1) / p.CI_C : 0;
     int nb = std::max(std::max(nch0, nch1), 1);
-    if (nblk > 256 || nb <= 2) return false;
+    // (few frames per row: the chunks of the frame-online mode.  A batch-1 offline decode has as few workgroups, but 64
+    // frames of matrix work per chunk to hide the next load under - the double-buffered loop is 1-3 % faster there)
+    if (nblk > 256 || nb <= 2 || p.Tout - p.t_base > 64) return false;
     // as many chunks per round trip as the LDS holds (a longer source goes in groups)
     const size_t epi = (size_t)(4 * BM_div_WM * 36) * sizeof(float);
     while (nb > 2 && gc_lds_bytes(p, BM, epi, nb) > 158 * 1024) --nb;
@@ -1377,7 +1382,10 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     // (a tap set that looks ahead would read the straddling group's foreign frames into stored outputs: the kernel trims
     // them in LDS, GC_TRIM_TAIL)
     static const int trim_env = getenv("SE_GC_TRIM") ? atoi(getenv("SE_GC_TRIM")) : 1;
-    const bool trim_ok = trim_env && p.epi == EPI_ACT;       // the trimming variant exists for the plain epilogue (DCCRN's decoder)
+    // the trimming variant exists for the plain epilogue (DCCRN's decoder); it pays from a few thousand workgroups on - small
+    // launches are latency-bound and the extra LDS stores per chunk cost them 3 % (batch 1)
+    static const long trim_min = getenv("SE_GC_TRIM_MIN") ? atol(getenv("SE_GC_TRIM_MIN")) : 8192;
+    const bool trim_ok = trim_env && p.epi == EPI_ACT && (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles >= trim_min;
     p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || ((p.causal || trim_ok) && gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
     p.trim = (p.pw4 && !p.causal && p.Tin % 4 != 0) ? 1 : 0;
     SE_CHECK(!p.stats || gc_stats_supported(pl), "gc_launch: this tile configuration has no statistics epilogue");

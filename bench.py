@@ -34,14 +34,15 @@ DCCRN_GFLOP_PER_UTT = 53.4    # algorithmic 2*MAC per 4 s uttera
 
 
 def dccrn_conv_bytes(B, T=501):
-    """Algorithmic HBM bytes of the 21 tap-table GEMM launches of one DCCRN step (DESIGN.md 'Measurement'): every
+    """Algorithmic HBM bytes of the 20 tap-table GEMM launches of one DCCRN step (DESIGN.md 'Measurement'): every
     launch reads its input activations once and writes its output once (fp32; weights are < 0.1 %).  Encoder: 6 convs;
-    decoder: 6 transposed convs = 2 frequency-parity launches each, both reading the (previous, skip) pair; LSTM input /
-    output projections: 3 launches.  Channels are real counts (complex = 2 x)."""
+    decoder: 5 transposed convs = 2 frequency-parity launches each, both reading the (previous, skip) pair, and the last
+    one (64 -> 2 channels) as one launch for both classes; LSTM input / output projections: 3 launches.  Channels are real
+    counts (complex = 2 x)."""
     ch = [2, 32, 64, 128, 256, 256, 256]
     F = [257, 129, 65, 33, 17, 9, 5]
     act = [ch[i] * F[i] * T for i in range(7)]                 # floats per utterance at each encoder level
-    rd = sum(act[0:6]) + 2 * sum(2 * act[i] for i in range(1, 7))
+    rd = sum(act[0:6]) + 2 * sum(2 * act[i] for i in range(2, 7)) + 2 * act[1]
     wr = sum(act[1:7]) + sum(act[0:6])
     lstm = 2 * (256 * 5 * T) + 2 * (4 * 256 * T) * 2 + 2 * (256 * 5 * T)    # in-proj, 2 x (gates), out-proj
     return 4.0 * B * (rd + lstm), 4.0 * B * (wr + lstm)

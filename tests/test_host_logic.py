@@ -137,6 +137,7 @@ def test_bench_roofline_inputs():
     assert rd > wr > 0
     pmc = bench.pmc_traffic()
     assert pmc is not None and pmc["launches_per_step"] == 20.0
-    # measured traffic can only exceed the algorithmic bytes, and by less than 1.3x since the LDS-tiled direct kernel
-    assert per_launch <= pmc['traffic_GB_per_launch'] < 1.3 * per_launch
+    # measured traffic can only exceed the algorithmic bytes; 1.33x since the decoder stages 16 B groups (its 256-row layers
+    # stream a 3 MB weight matrix through a 4 MB L2 next to the activations: DESIGN.md 5)
+    assert per_launch <= pmc['traffic_GB_per_launch'] < 1.4 * per_launch
     assert bench.DCCRN_GFLOP_PER_UTT == 53.4 and bench.F32_MFMA_PEAK_TFLOPS == 157.3

@@ -680,7 +680,13 @@ __global__ __launch_bounds__(256) void gc_small_kernel(const GCParams p) {
                 const float a = acc[2 * j] + (bias ? bias[2 * j] : 0.f), g = acc[2 * j + 1] + (bias ? bias[2 * j + 1] : 0.f);
                 float v = a * fsig_(g);
                 if (p.post_scale) v = v * p.post_scale[j] + p.post_shift[j];
-                dst[(long)j * p.d_c + t] = act_apply(v, p.act, p.slope ? p.slope[j] : 0.f);
+                v = act_apply(v, p.act, p.slope ? p.slope[j] : 0.f);
+                if (p.pair) {       // parity classes as virtual row groups: (value, gate) pairs [cls * pair / 2, ...) belong to class cls
+                    const int cls = (2 * j) / p.pair, fo2 = q * p.so + (cls ? p.po2 : p.po);
+                    if (fo2 < p.fo_lim) dst[(long)(fo2 - fo) * p.d_f + (long)(j - cls * (p.pair >> 1)) * p.d_c + t] = v;
+                } else {
+                    dst[(long)j * p.d_c + t] = v;
+                }
             }
         }
         return;
@@ -800,7 +806,13 @@ __global__ __launch_bounds__(256) void gc_small_lds_kernel(const GCParams p, con
                     const float a = acc[qq][2 * j] + (bias ? bias[2 * j] : 0.f), g = acc[qq][2 * j + 1] + (bias ? bias[2 * j + 1] : 0.f);
                     float v = a * fsig_(g);
                     if (p.post_scale) v = v * p.post_scale[j] + p.post_shift[j];
-                    dst[(long)j * p.d_c + t] = act_apply(v, p.act, p.slope ? p.slope[j] : 0.f);
+                    v = act_apply(v, p.act, p.slope ? p.slope[j] : 0.f);
+                    if (p.pair) {       // see gc_small_kernel
+                        const int cls = (2 * j) / p.pair, fo2 = (q0 + qq) * p.so + (cls ? p.po2 : p.po);
+                        if (fo2 < p.fo_lim) dst[(long)(fo2 - fo) * p.d_f + (long)(j - cls * (p.pair >> 1)) * p.d_c + t] = v;
+                    } else {
+                        dst[(long)j * p.d_c + t] = v;
+                    }
                 }
             }
             continue;

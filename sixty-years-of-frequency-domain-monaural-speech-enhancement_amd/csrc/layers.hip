@@ -272,7 +272,8 @@ DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, 
         }
     }
     static const bool pair_env = !(getenv("SE_GC_PAIR") && atoi(getenv("SE_GC_PAIR")) == 0);
-    if (pair_env && sf == 2 && d.M <= 2 && epi == EPI_ACT && pf >= 0 && out.par.size() == 2 && out.par[0].p.Ws && out.par[1].p.Ws) {
+    const bool pair_epi = epi == EPI_ACT || (epi == EPI_GLU && d.M == 2 && slope.empty());     // one gated output channel: rows (value, gate)
+    if (pair_env && sf == 2 && d.M <= 2 && pair_epi && pf >= 0 && out.par.size() == 2 && out.par[0].p.Ws && out.par[1].p.Ws) {
         TapSpec un;
         for (int c = 0; c < 2; ++c)
             for (int j = 0; j < cls_taps[c].ntaps; ++j) {
@@ -298,7 +299,7 @@ DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, 
             bias.insert(bias.end(), d.bias.begin(), d.bias.end());
             sl.insert(sl.end(), slope.begin(), slope.end());
         }
-        out.pair = gc_make_plan(M2, d.Cin, un, w, bias, sl, act, EPI_ACT, 1, sf, 0, tout_hint, 1, C0split);
+        out.pair = gc_make_plan(M2, d.Cin, un, w, bias, sl, act, epi, 1, sf, 0, tout_hint, 1, C0split);
         out.has_pair = out.pair.p.Ws != nullptr;
         if (out.has_pair) {
             out.pair.p.pair = d.M;
@@ -436,7 +437,7 @@ void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int 
 
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
                 int Tp, hipStream_t st, Profiler* prof, float* stats) {
-    if (pl.has_pair && !stats) {
+    if (pl.has_pair && !stats && !pl.par[0].p.post_scale) {      // (a BatchNorm attached to the class plans later is not in the pair)
         GCParams p = pl.pair.p;
         fill_src(p, s0, s1);
         p.Fin = s0.F;

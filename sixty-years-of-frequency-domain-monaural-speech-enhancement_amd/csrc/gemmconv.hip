@@ -1102,6 +1102,7 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     // chunk = CI_C input channels x all taps.  Among the sizes that fit the staging budgets take the one that wastes the
     // fewest K rows on padding to a multiple of 4 (rows of zeros cost full MFMAs), then the largest: measured on the DCCRN
     // bench, 20 exact rows per barrier beat 30 rows padded to 32 (taps = 10), 24 beat 30 / 32 (taps = 6)
+    static const bool wide_chunk_env = !(getenv("SE_GC_WIDE_CHUNK") && atoi(getenv("SE_GC_WIDE_CHUNK")) == 0);
     int cic = 1;
     double best = -1.0;
     for (int c = 1; c <= std::max(std::max(C0, Cin - C0), 1); ++c) {
@@ -1111,6 +1112,12 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
         const int kmax = pw ? (pl.BM >= 128 ? 24 : 32) : gc_kcp_max(pl.BM);
         const int cap = gc_bld_max(pl.BM) * 256 * (pw ? 4 : 1);
         if (kcp > std::min(kmax, kcp_cap) || c * p.nrows * p.Wp > cap) continue;
+        // 64-row layers: keep the chunk small enough for the 64 x 256 tile's patch (3 workgroups per CU) when that still
+        // leaves >= 12 K rows per barrier - G2Net's 3-tap convs would stage 8 channels x 3 rows and fall back to 64 x 128
+        // tiles (measured: + 4 % for the whole model at batch 256 with 4-channel chunks)
+        if (wide_chunk_env && pl.BM == 64 && pl.BN == 128 && taps.ntaps > 1 && epi != EPI_LSTM && kc > 12 &&
+            (long)c * p.nrows * (256 + (dtmax - dtmin)) > 4608)
+            continue;
         const double score = (double)kc / kcp + 1e-4 * kc;       // padding efficiency first, size second
         if (score > best) {
             best = score;

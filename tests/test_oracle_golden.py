@@ -157,3 +157,30 @@ def test_ctsnet_new_matches_reference():
     assert rms(M.cts_step2_forward(sd2, G['x2']) - G['y2']) < 5e-6 * max(rms(G['y2']), 1.0)
     e = D.enhance_ctsnet(sd1, sd2, G['wav'], 0.5, 2.0)
     assert rms(e - G['enh_cprs']) < 1e-5 * max(rms(G['enh_cprs']), 1e-3)
+
+
+@pytest.mark.parametrize('name', ['taylorsenet', 'g2net', 'cts_step1'])
+def test_cln_variants_are_causal_and_instance_norm_bases_are_not(name):
+    """What the frame-online mode (se_stream_*, tests/test_gpu_streaming.py) rests on, checked on the oracle - which the tests
+    above pin to the reference's modules: with the cumulative LayerNorm of the `_new` directories (CTSNet_new/
+    Step1_network.py:213-286) the first t frames of the output depend on the first t frames of the input only; with the
+    InstanceNorm of the base directories they do not (utterance statistics)."""
+    G = load_golden({'cts_step1': 'ctsnet_new'}.get(name, name + '_new'))
+    x = G['x1'] if name == 'cts_step1' else G['x']
+    fwd = {'taylorsenet': M.taylorsenet_forward, 'g2net': lambda sd, v: M.g2net_forward(sd, v)[-1],
+           'cts_step1': M.cts_step1_forward}[name]
+    t_axis = 1 if name == 'cts_step1' else 2                 # [B,T,F] / [B,2,T,F]
+    T = x.shape[t_axis]
+    cut = T // 2
+    head = np.take(x, np.arange(cut), axis=t_axis)
+
+    def out_frames(y, n):                                     # the networks return [B,T,F], [B,2,T,F] or [B,2,F,T]
+        ax = [a for a in range(y.ndim) if y.shape[a] in (T, cut)][0 if name != 'g2net' else -1]
+        return np.take(y, np.arange(n), axis=ax)
+
+    for variant, causal in ((name + '_new', True), (name, False)):
+        seed = {'taylorsenet': 19, 'g2net': 20, 'cts_step1': 17}[name]
+        sd = _sd(variant, seed)
+        full, part = fwd(sd, x), fwd(sd, head)
+        err = rms(out_frames(full, cut) - out_frames(part, cut)) / max(rms(full), 1e-9)
+        assert (err < 1e-7) if causal else (err > 1e-4), (variant, err)      # (sums in another order: ~1e-9)

@@ -24,10 +24,12 @@ constexpr int GC_MAX_KCP = 48;
 constexpr int GC_TAB_KOFF = GC_MAX_ROWS + 2 * GC_MAX_TAPS;   // start of the per-K-row patch offsets in GCParams::tab
 // K rows of one staged chunk and patch elements staged per thread, by output-channel tile
 constexpr int gc_kcp_max(int BM) { return 32; }
-constexpr int gc_bld_max(int BM) { return BM >= 128 ? 9 : 13; }
+constexpr int gc_bld_max(int BM) { return (BM >= 128 || BM <= 32) ? 9 : 13; }
 // resident blocks per CU the kernel is register-budgeted for: small-M tiles do little matrix work per staged K row and
 // hide the global-load latency with occupancy instead
-constexpr int gc_blocks_per_cu(int BM) { return 3; }
+// (the 32-row tile keeps one accumulator tile per wave: with 9 patch slots it fits 78 VGPRs, i.e. 6 workgroups per CU - its
+// chunks are short, 10 MFMAs per wave and barrier, and more resident workgroups fill the gaps: DPCRN / Uformer + 1.5 %)
+constexpr int gc_blocks_per_cu(int BM) { return BM <= 32 ? 6 : 3; }
 
 enum Act : int { ACT_NONE = 0, ACT_PRELU = 1, ACT_ELU = 2, ACT_SOFTPLUS = 3, ACT_SIGMOID = 4, ACT_TANH = 5, ACT_RELU = 6 };
 enum Epi : int {

@@ -204,7 +204,8 @@ int se_engine_finalize(se_engine* e) {
         const int T = e->model->num_frames(e->ctx.max_samples);
         // (a frame-online window is the model's history columns + the chunk: models that keep a long history - CTSNet_new's
         // dilated convs reach 128 frames back - must be able to stream through an engine created for short clips)
-        e->plan_frames = e->model->stream_supported() ? std::max(T, e->model->stream_hc() + 16) : T;
+        // (models that look ahead run with the frame count rounded up to whole 16 B groups: model.h PadFrames)
+        e->plan_frames = e->model->stream_supported() ? std::max((T + 3) & ~3, e->model->stream_hc() + 16) : (T + 3) & ~3;
         e->ctx.arena.measure_begin();
         e->model->plan_buffers(e->ctx.max_batch, e->plan_frames);
         const size_t need = e->ctx.arena.measure_end();

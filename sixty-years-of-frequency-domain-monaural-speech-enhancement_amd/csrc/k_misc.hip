@@ -846,6 +846,19 @@ void stream_exchange(float* x, long sb, long sc, long sf, int B, int C, int F, i
     SE_HIP(hipGetLastError());
 }
 
+__global__ void fill_rows_kernel(int* d, int MB, int B, int len, int lpad, int tlen, int olen) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    d[b] = len;
+    d[MB + b] = lpad;
+    d[2 * MB + b] = tlen;
+    d[3 * MB + b] = olen;
+}
+void launch_fill_rows(int* d, int MB, int B, int len, int lpad, int tlen, int olen, hipStream_t s) {
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d, MB, B, len, lpad, tlen, olen);
+    SE_HIP(hipGetLastError());
+}
+
 __global__ void fill_kernel(float* p, long n, float v) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;

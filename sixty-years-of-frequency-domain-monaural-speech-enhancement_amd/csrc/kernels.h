@@ -20,6 +20,8 @@ struct Ragged {
     const int* olen = nullptr;   // device [B]: output samples of row b
 };
 const Ragged* ragged_ctx();              // nullptr: equal-length batch
+// d [4][MB] <- (len, lpad, tlen, olen) for rows 0..B-1 (an equal-length batch as ragged rows: model.h PadFrames)
+void launch_fill_rows(int* d, int MB, int B, int len, int lpad, int tlen, int olen, hipStream_t s);
 void set_ragged_ctx(const Ragged* r);    // thread-local (a handle is driven by one thread at a time)
 
 // HIP-event timing of the HBM-bound front / back-end kernels (se_get_stage_profile): every launcher below brackets its

@@ -39,7 +39,9 @@ struct EngineCtx {
         }
         return aux[i];
     }
+    int* eq_rows = nullptr;     // device [4][max_batch]: per-row sizes of an equal-length batch decoded as ragged rows (PadFrames)
     ~EngineCtx() {
+        if (eq_rows) (void)hipFree(eq_rows);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int i = 0; i < MAX_AUX; ++i)
             if (aux[i]) {
@@ -66,6 +68,34 @@ struct TrackedSD {
             SE_CHECK(nbt || used.count(k), "unexpected key in state dict: '" + k + "'");
         }
     }
+};
+
+// Models with operators that look ahead in time stage 16 B groups only over rows of whole groups (gemmconv: a group that
+// straddles the end of a row would feed the next row's head into stored frames).  Their equal-length batches therefore run
+// with the frame count rounded up to a multiple of 4 and the added frames treated like the tail of a shorter clip in a
+// ragged batch - zeroed in front of every look-ahead operator, masked in attention - by publishing per-row sizes that
+// are all equal (measured against trimming the straddling groups in LDS: DCCRN + 2 %, Uformer + 1.7 % at batch 256).
+struct PadFrames {
+    Ragged rg;
+    bool on = false;
+    int T;                  // frame count (row pitch) to run with
+    PadFrames(EngineCtx& ctx, int B, int L, int Lpad, int T_true, int olen, hipStream_t st) : T(T_true) {
+        static const bool env = !(getenv("SE_PAD_FRAMES") && atoi(getenv("SE_PAD_FRAMES")) == 0);
+        if (!env || (T_true & 3) == 0) return;
+        T = (T_true + 3) & ~3;
+        if (ragged_ctx()) return;          // rows of different lengths already carry their sizes
+        const int MB = ctx.max_batch;
+        if (!ctx.eq_rows) SE_HIP(hipMalloc(reinterpret_cast<void**>(&ctx.eq_rows), sizeof(int) * 4 * MB));
+        launch_fill_rows(ctx.eq_rows, MB, B, L, Lpad, T_true, olen, st);
+        rg = Ragged{ctx.eq_rows, ctx.eq_rows + MB, ctx.eq_rows + 2 * MB, ctx.eq_rows + 3 * MB};
+        set_ragged_ctx(&rg);
+        on = true;
+    }
+    ~PadFrames() {
+        if (on) set_ragged_ctx(nullptr);
+    }
+    PadFrames(const PadFrames&) = delete;
+    PadFrames& operator=(const PadFrames&) = delete;
 };
 
 class Model {

@@ -175,7 +175,8 @@ class Dccrn final : public Model {
 
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int Lpad = padded_samples(L);
-        const int T = 1 + Lpad / HOP;
+        PadFrames pad(ctx, B, L, Lpad, 1 + Lpad / HOP, Lpad, st);       // the decoder looks ahead: rows of whole 16 B groups
+        const int T = pad.T;
         Bufs& b = bufs(B, T);
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                           // :27
         launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, nullptr, T, T, st);   // :28-42

@@ -715,7 +715,9 @@ class Uformer final : public Model {
     }
 
     void run(const float* wav, long pitch, int B, int L, float* out, long out_pitch, bool normalise, hipStream_t st) {
-        const int T = 1 + L / HOP;
+        const int T_true = 1 + L / HOP;
+        PadFrames pad(ctx, B, L, L, T_true, HOP * (T_true - 1), st);      // symmetric dilated convs: rows of whole 16 B groups
+        const int T = pad.T;
         Bufs& b = bufs(B, T);
         Profiler* pf = &ctx.prof;
         if (normalise) launch_rms_scale(wav, B, L, pitch, b.c, st);
@@ -774,7 +776,7 @@ class Uformer final : public Model {
         }
         hipLaunchKernelGGL(uf_post_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, c, m, b.mag0, b.ph0, b.est, T, ctx.p_out);
         SE_HIP(hipGetLastError());
-        launch_istft(ctx.geom, b.est, B, T, T, b.frames, cs, out, out_pitch, HOP * (T - 1), st);  // :276
+        launch_istft(ctx.geom, b.est, B, T, T, b.frames, cs, out, out_pitch, HOP * (T_true - 1), st);  // :276
     }
 };
 

@@ -137,7 +137,7 @@ def test_bench_roofline_inputs():
     assert rd > wr > 0
     pmc = bench.pmc_traffic()
     assert pmc is not None and pmc["launches_per_step"] == 20.0
-    # measured traffic can only exceed the algorithmic bytes; 1.33x since the decoder stages 16 B groups (its 256-row layers
-    # stream a 3 MB weight matrix through a 4 MB L2 next to the activations: DESIGN.md 5)
-    assert per_launch <= pmc['traffic_GB_per_launch'] < 1.4 * per_launch
+    # measured traffic can only exceed the algorithmic bytes, and by less than 1.2x (halo rows / columns of neighbouring tiles;
+    # it was 1.33x while the decoder staged 16 B groups over rows that did not start on 16 B boundaries: DESIGN.md 5)
+    assert per_launch <= pmc['traffic_GB_per_launch'] < 1.2 * per_launch
     assert bench.DCCRN_GFLOP_PER_UTT == 53.4 and bench.F32_MFMA_PEAK_TFLOPS == 157.3

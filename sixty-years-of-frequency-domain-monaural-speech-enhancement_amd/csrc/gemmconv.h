@@ -74,6 +74,7 @@ struct GCParams {
     int t_base;              // first frame of time tile 0 of this launch (tail launches start at the last tile)
     int pw4;                 // per launch: 1 -> stage the patch in 16 B groups
     int causal;              // no tap looks ahead in time (dt <= 0 for every tap)
+    const int* tlen;         // per launch (optional, device [B]): output frames >= tlen[b] are stored as zeros (MFMA path)
     int qt2, qq_off, Qt;     // per launch: two-row tiles (LDS offset of the second row's patch rows; row tiles per plane)
     int pair, po2, fo_lim;   // direct path: both parity classes of a transposed conv as 2 * pair virtual output channels (0 = off)
     short tdf[GC_MAX_TAPS], tdt[GC_MAX_TAPS];     // tap offsets (frequency rows, frames) by value, for the thin kernel

@@ -480,6 +480,8 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
         const int mo0 = (EPI == EPI_GLU ? (m0 >> 1) : m0) + wm * OROWS;      // first output row of the strip
         // (an odd row count leaves the second row of the last two-row tile outside the plane: nothing of it is stored)
         const int Mo = (q + wq < p.Q) ? ((EPI == EPI_GLU) ? (p.M >> 1) : p.M) : 0;
+        // p.tlen (ragged batches, layers in front of operators that look ahead): frames >= tlen[b] of the output are zeros
+        const int tvalid = p.tlen ? p.tlen[b] : 0x7fffffff;
         const float* __restrict__ res =
             (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fow * p.x_f : nullptr;
 #pragma unroll
@@ -544,6 +546,10 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
                             const floatx4 rv = *reinterpret_cast<const floatx4*>(res + (long)m * p.x_c + tg);
                             v = (EPI == EPI_ADD) ? v + rv : v * rv;
                         }
+                        if (tg + 3 >= tvalid) {      // rows of a ragged batch: frames past the row's own end are stored as zeros
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = (tg + k < tvalid) ? v[k] : 0.f;
+                        }
                         *reinterpret_cast<floatx4*>(dp) = v;
                     } else {
 #pragma unroll
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
                                 float o = v[k];
                                 if (EPI == EPI_ADD) o += res[(long)m * p.x_c + tg + k];
                                 if (EPI == EPI_MUL) o *= res[(long)m * p.x_c + tg + k];
-                                dp[k] = o;
+                                dp[k] = (tg + k < tvalid) ? o : 0.f;
                             }
                     }
                 }

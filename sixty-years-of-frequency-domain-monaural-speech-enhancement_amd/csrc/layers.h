@@ -70,6 +70,10 @@ DeconvPlan make_deconv_plan(const DenseW& d, int sf, int pf, int toff, int act, 
                             int tout_hint, int C0split = -1, const std::vector<float>* bias_pad = nullptr,
                             int epi = EPI_ACT);
 void free_deconv_plan(DeconvPlan& p);
+// run_conv / run_deconv of these plans store zeros past a ragged row's own last frame themselves (MFMA path), so the
+// models that need zero tails in front of look-ahead operators can skip their launch_zero_tail
+inline bool conv_zeroes_tail(const GCPlan& pl) { return pl.p.Ws == nullptr; }
+inline bool conv_zeroes_tail(const DeconvPlan& pl) { return !pl.has_pair && !pl.par.empty() && pl.par[0].p.Ws == nullptr; }
 
 // Convenience launcher for [B][C][F][T]-layout tensors (row pitch Tp).
 struct Act4 {          // a view of an activation tensor

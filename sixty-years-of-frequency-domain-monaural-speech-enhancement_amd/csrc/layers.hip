@@ -432,6 +432,7 @@ void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int 
     p.d_b = (long)dstC * Fout * Tp;
     p.d_c = (long)Fout * Tp;
     p.d_f = Tp;
+    if (const Ragged* rg = ragged_ctx()) p.tlen = rg->tlen;       // MFMA path: tails of shorter rows leave as zeros
     gc_launch_prof(pl, p, st, prof);
 }
 
@@ -466,6 +467,7 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
         p.d_b = (long)dstC * Fout * Tp;
         p.d_c = (long)Fout * Tp;
         p.d_f = Tp;
+        if (const Ragged* rg = ragged_ctx()) p.tlen = rg->tlen;
         if (p.Q > 0) gc_launch_prof(g, p, st, prof);
     }
 }

@@ -354,7 +354,7 @@ class Dccrn final : public Model {
             run_conv(enc[k], x, nullptr, b.E[k], KN[k + 1], F / 2, B, T, T, st, pf);
             // ragged batch: the decoder looks one frame ahead per layer (`out[..., 1:]`, :199) into its (previous, skip)
             // inputs, and a clip decoded alone has zeros past its last frame
-            launch_zero_tail(b.E[k], B, (long)KN[k + 1] * (F / 2), T, st);
+            if (!conv_zeroes_tail(enc[k])) launch_zero_tail(b.E[k], B, (long)KN[k + 1] * (F / 2), T, st);
             F /= 2;
             x = act4(b.E[k], KN[k + 1], F, T);
         }
@@ -399,7 +399,7 @@ class Dccrn final : public Model {
             Act4 a0 = act4(b.D[k], cin, F, T);
             Act4 a1 = act4(b.E[NL - 1 - k], cin, F, T);
             run_deconv(dec[k], a0, &a1, b.D[k + 1], KN[NL - k - 1], 2 * F, B, T, T, st, pf);
-            if (k + 1 < NL) launch_zero_tail(b.D[k + 1], B, (long)KN[NL - k - 1] * (2 * F), T, st);
+            if (k + 1 < NL && !conv_zeroes_tail(dec[k])) launch_zero_tail(b.D[k + 1], B, (long)KN[NL - k - 1] * (2 * F), T, st);
             F *= 2;
         }
     }

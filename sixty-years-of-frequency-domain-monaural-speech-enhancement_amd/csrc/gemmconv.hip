@@ -982,7 +982,8 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
     // LDS-tiled form when the launch still fills the chip with 8-row workgroups and the patch of at least 2 channels fits
     static const int lds_env = getenv("SE_GC_SMALL_LDS") ? atoi(getenv("SE_GC_SMALL_LDS")) : 1;
     const int NR = (SQB - 1) * p.si + (sg.dfmax - sg.dfmin) + 1;
-    const int CC = std::min(8, (int)(40 * 1024 / ((size_t)NR * SWT * sizeof(float))));      // <= 8: s_w holds 8 channels
+    static const int small_kb = getenv("SE_GC_SMALL_KB") ? atoi(getenv("SE_GC_SMALL_KB")) : 24;       // LDS budget of the staged patch (KB): 2-channel chunks, 6-7 workgroups per CU (40 KB: DCCRN -0.4 %, CTSNet -1.7 %)
+    const int CC = std::min(8, (int)((size_t)small_kb * 1024 / ((size_t)NR * SWT * sizeof(float))));      // <= 8: s_w holds 8 channels
     const long nblk8 = (long)((p.Tout + 255) / 256) * ((p.Q + SQB - 1) / SQB) * p.B * p.Z;
     // (worth it from three frequency rows per output row on: with one or two the plain kernel's caches do as well - CRN /
     // DPCRN last layers measured 1-3 % slower here, DCCRN's 5-tap deconv 1 % faster with a third of the fetches)

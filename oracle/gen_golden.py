@@ -42,6 +42,23 @@ def _stub(name, **attrs):
     return m
 
 
+# oracle/adopt_complexnn.py sets this to a supplied upstream complexnn.py (huyanxin/DeepComplexCRN); None = the recall
+COMPLEXNN_PATH = None
+
+
+def load_complexnn():
+    """The module DCCRN/DCCRN_cprs.py:6 imports as `complexnn`: the supplied upstream file when COMPLEXNN_PATH is set,
+    else oracle/_complexnn_recall.py (a restatement - DCCRN parity is then unpinned at this boundary)."""
+    if COMPLEXNN_PATH is None:
+        from oracle import _complexnn_recall
+        return _complexnn_recall
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('complexnn', COMPLEXNN_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def install_stubs():
     """Import-time stubs for packages absent here; none is touched by forward."""
     for n in ('librosa', 'soundfile', 'h5py'):
@@ -54,8 +71,7 @@ def install_stubs():
     _stub('ptflops.flops_counter', get_model_complexity_info=None)
     _stub('torch_complex', ComplexTensor=None)
     _stub('show', show_model=lambda *a, **k: None, show_params=lambda *a, **k: None)
-    from oracle import _complexnn_recall
-    sys.modules['complexnn'] = _complexnn_recall
+    sys.modules['complexnn'] = load_complexnn()
     _stub('conv_stft', ConvSTFT=None, ConviSTFT=None)
 
 
@@ -92,14 +108,28 @@ def t_stft(x, n_fft, hop, win):
 
 FULL_ONLY = False      # `python -m oracle.gen_golden --full ...`: write only the full_<name>.npz (4 s clip) fixtures
 FULL_SAMPLES = 64000   # BASELINE's clip: 16 kHz x 4 s
+LONG_ONLY = False      # `python -m oracle.gen_golden --long ...`: write only the long<secs>_<name>.npz fixtures
+# Clips longer than BASELINE's 4 s (VoiceBank+DEMAND reaches ~10-15 s): 10 s = 160 000 samples (T = 1001 / 1251 / 626) and
+# just under 15 s with a length that is no multiple of any hop (239 987 samples: T = 1500 / 1876 / 938) - paths only long
+# clips reach: the fused TCM kernel's T > 416 / T > 512 switches, cLN scans and FIR history past 401 frames, attention
+# over > 1 160 keys, iSTFT windows.  (secs tag, samples, seed offset)
+LONG_CLIPS = (('10', 160000, 1000), ('15', 239987, 2000))
 
 
 def save_full(name, seed, enh_fn, kind='speech'):
     """One reference decode of a full-size (4 s) clip per network: tests/golden/full_<name>.npz holds the clip's synth
     seed and the reference's float32 output (256 kB); the clip itself is regenerated by se_amd.synth."""
+    os.makedirs(GOLD, exist_ok=True)
+    if LONG_ONLY:
+        for tag, n, off in LONG_CLIPS:
+            wav = synth.synth_clip(seed + off, kind, n)
+            enh = np.asarray(enh_fn(wav), dtype=np.float32)
+            path = os.path.join(GOLD, f'long{tag}_{name}.npz')
+            np.savez_compressed(path, seed=np.int64(seed + off), n=np.int64(n), enh_cprs=enh)
+            print(f'wrote {path}  {os.path.getsize(path) / 1024:.0f} kB')
+        return
     wav = synth.synth_clip(seed, kind, FULL_SAMPLES)
     enh = np.asarray(enh_fn(wav), dtype=np.float32)
-    os.makedirs(GOLD, exist_ok=True)
     path = os.path.join(GOLD, f'full_{name}.npz')
     np.savez_compressed(path, seed=np.int64(seed), n=np.int64(FULL_SAMPLES), enh4_cprs=enh)
     print(f'wrote {path}  {os.path.getsize(path) / 1024:.0f} kB')
@@ -216,6 +246,10 @@ def gen_dpcrn():
     enh_real_cprs = _enhance_librosa_family(model, wav4, 'ri', 0.5, 2.0)
     save('dpcrn', x=x, y=y, wav=wav, enh=enh, y_real=y_real, enh_real=enh_real.astype(np.float32),
          enh_real_cprs=enh_real_cprs.astype(np.float32))
+    if LONG_ONLY:           # long clips through the REAL compressed-spectrum checkpoint (loaded above)
+        save_full('dpcrn', 0, lambda w: _enhance_librosa_family(model, w, 'ri', 0.5, 2.0))
+    if FULL_ONLY:
+        return
     # the checkpoints themselves, as data fixtures (fp32, int64 counters dropped -> re-added as zeros)
     for tag, c in (('noncprs', ck), ('cprs', ckc)):
         np.savez_compressed(os.path.join(GOLD, f'ckpt_vb_dpcrn_{tag}.npz'),
@@ -255,6 +289,9 @@ def gen_dccrn():
     wav = synth.synth_clip(6, 'speech', 4000)
     enh, _, _ = _enhance_dccrn(model, wav, 1.0, 1.0)
     enh_c, _, _ = _enhance_dccrn(model, wav, 0.5, 2.0)
+    if LONG_ONLY:
+        save_full('dccrn', 1, lambda w: _enhance_dccrn(model, w, 0.5, 2.0)[0])
+        return
     wav4 = synth.synth_clip(1, 'speech', 64000)
     enh4, _, _ = _enhance_dccrn(model, wav4, 0.5, 2.0)
     save('dccrn', x=x, y=y, wav=wav, enh=enh, enh_cprs=enh_c, enh4_cprs=enh4.astype(np.float32))
@@ -498,6 +535,8 @@ if __name__ == '__main__':
     names = sys.argv[1:]
     if names and names[0] == '--full':
         FULL_ONLY, names = True, names[1:]
+    if names and names[0] == '--long':
+        FULL_ONLY, LONG_ONLY, names = True, True, names[1:]
     names = names or list(GENS)
     for n in names:
         GENS[n]()

@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
 typedef float uf_x4 __attribute__((ext_vector_type(4)));
 constexpr int UF_QT = 2;
 __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restrict__ pq, float* __restrict__ out, int F,
-                                                            int T, int nh, int Tk, const int* __restrict__ tlen) {
+                                                            int T, int nh, int Tk, int KB, const int* __restrict__ tlen) {
     extern __shared__ float kv[];
     float* Ks = kv;                        // [16][Tk], Tk % 32 == 16: the four dim rows of an A fragment hit distinct banks
-    float* Vs = kv + HD * Tk;              // [Tk][17]
+    float* Vs = kv + HD * Tk;              // [KB][17]; Tk = KB (+16): one block of KB keys is resident at a time
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int f = blockIdx.x % F, b = blockIdx.x / F;
@@ -191,16 +191,6 @@ __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restr
     for (int qt = 0; qt < UF_QT; ++qt) accr[qt] = acci[qt] = uf_x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < nh; ++h) {
         const float* hq = base + (long)h * 48 * P;
-        __syncthreads();
-        for (int i = tid; i < HD * Tk; i += 256) {
-            const int d = i / Tk, s = i - d * Tk;
-            Ks[i] = s < T ? hq[(long)(HD + d) * P + s] : 0.f;
-        }
-        for (int i = tid; i < HD * (nks * 16); i += 256) {
-            const int d = i / (nks * 16), s = i - d * (nks * 16);
-            Vs[s * 17 + d] = s < T ? hq[(long)(2 * HD + d) * P + s] : 0.f;
-        }
-        __syncthreads();
         float qf[UF_QT][4], mx[UF_QT], l[UF_QT];
         uf_x4 o[UF_QT];
 #pragma unroll
@@ -212,13 +202,28 @@ __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restr
             l[qt] = 0.f;
             o[qt] = uf_x4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int key0 = kt * 16;
+        // keys stream through LDS in blocks of KB (t_att_cplx.py:25 has no length limit): the online-softmax state
+        // (mx, l, o) lives in registers across blocks; a clip of <= KB frames is one block, as before
+        for (int kb0 = 0; kb0 < nkt * 16; kb0 += KB) {
+        const int kbn = min(KB, nks * 16 - kb0);           // keys staged for this block (whole 16-key tiles)
+        __syncthreads();
+        for (int i = tid; i < HD * Tk; i += 256) {
+            const int d = i / Tk, s = i - d * Tk;
+            Ks[i] = (s < kbn && kb0 + s < T) ? hq[(long)(HD + d) * P + kb0 + s] : 0.f;
+        }
+        for (int i = tid; i < HD * kbn; i += 256) {
+            const int d = i / kbn, s = i - d * kbn;
+            Vs[s * 17 + d] = kb0 + s < T ? hq[(long)(2 * HD + d) * P + kb0 + s] : 0.f;
+        }
+        __syncthreads();
+        const int kte = min(nkt, (kb0 + KB) >> 4);
+        for (int kt = kb0 >> 4; kt < kte; ++kt) {
+            const int key0 = kt * 16, kl = key0 - kb0;
             float ka[4], va[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ka[j] = Ks[(4 * j + g) * Tk + key0 + n];
-                va[j] = Vs[(key0 + 4 * g + j) * 17 + n];
+                ka[j] = Ks[(4 * j + g) * Tk + kl + n];
+                va[j] = Vs[(kl + 4 * g + j) * 17 + n];
             }
 #pragma unroll
             for (int qt = 0; qt < UF_QT; ++qt) {
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[j], pe[j], o[qt], 0, 0, 0);
             }
+        }
         }
         const float sg = (nh == 1) ? 1.f : ((h == 0 || (h >= 4 && h < 7)) ? 1.f : -1.f);
 #pragma unroll
@@ -659,16 +665,19 @@ class Uformer final : public Model {
             // SE_UF_ATT_MFMA=0: the round-1 VALU kernel (kept for the A/B measurement in profiles/)
             static const bool mfma = !(getenv("SE_UF_ATT_MFMA") && atoi(getenv("SE_UF_ATT_MFMA")) == 0);
             if (mfma) {
-                int Tk = (T + 15) / 16 * 16;
+                // key blocks of <= 512 frames (68 KB of K / V per workgroup: two workgroups per CU at any clip length)
+                static const int kbmax = getenv("SE_UF_ATT_KB") ? std::max(16, atoi(getenv("SE_UF_ATT_KB")) / 16 * 16) : 512;
+                const int KB = std::min((T + 15) / 16 * 16, kbmax);
+                int Tk = KB;
                 if (Tk % 32 != 16) Tk += 16;
-                const size_t lds = ((size_t)HD * Tk + (size_t)((T + 15) / 16 * 16) * 17) * sizeof(float);
-                SE_CHECK(lds <= 150 * 1024, "utterance too long for the LDS-resident T-attention K/V tiles");
+                const size_t lds = ((size_t)HD * Tk + (size_t)KB * 17) * sizeof(float);
+                SE_CHECK(lds <= 150 * 1024, "SE_UF_ATT_KB too large for the LDS-resident T-attention K/V block");
                 static bool seen[64] = {};
                 if (first_on_device(seen))
                     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(uf_att_t_mfma_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 hipLaunchKernelGGL(uf_att_t_mfma_kernel, dim3(B * F, (T + 64 * UF_QT - 1) / (64 * UF_QT)), dim3(256), lds, st,
-                                   b.pq, b.t2, F, T, a.nh, Tk, ragged_ctx() ? ragged_ctx()->tlen : nullptr);
+                                   b.pq, b.t2, F, T, a.nh, Tk, KB, ragged_ctx() ? ragged_ctx()->tlen : nullptr);
             } else {
                 const size_t lds = (size_t)2 * HD * T * sizeof(float);
                 SE_CHECK(lds <= 64 * 1024, "utterance too long for the LDS-resident T-attention K/V tiles");

@@ -91,6 +91,17 @@ int se_engine_finalize(se_engine* e);
 int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32_t in_ndim, float* out_dev,
                void* stream);
 
+/* Uformer's full return: `output, src, output_cplx, src_cplx = model(inputs, src)` (Uformer/uformer.py:172-287; the decode
+ * script calls `model(x, x)[0]`, uformer_decode_vb.py:40).  inputs_dev / src_dev: waveforms [batch][n_samples] (dense rows).
+ *   output_dev      [batch][se_output_samples(n)]   enhanced waveform (uformer.py:276) - what se_forward returns
+ *   src_out_dev     [batch][se_output_samples(n)]   istft(stft(src)) (uformer.py:186), NULL = not wanted
+ *   output_cplx_dev [batch][2][257][T]              the RI estimate the waveform is synthesised from (uformer.py:264-286)
+ *   src_cplx_dev    [batch][2][257][T]              |S| e^{j angle S} of the source's STFT (uformer.py:187-194)
+ * T = se_num_frames(e, n_samples); rows of T frames, T contiguous.  src_dev == NULL skips the two source outputs.
+ * Only for engines created with SE_MODEL_UFORMER. */
+int se_uformer_forward(se_engine* e, const float* inputs_dev, const float* src_dev, int32_t batch, int32_t n_samples,
+                       float* output_dev, float* src_out_dev, float* output_cplx_dev, float* src_cplx_dev, void* stream);
+
 /* The per-utterance body of `enhance(args)` for a batch of equal-length clips, device to device:
  * unit-RMS normalise -> (tail pad) -> STFT -> compress -> network (+mask) -> decompress -> iSTFT -> /c.
  * wav_in_dev [B][in_pitch] (first n_samples of each row valid), wav_out_dev [B][out_pitch]; the number of
@@ -175,8 +186,17 @@ int64_t se_resample_samples(int32_t n_in, int32_t sr_in, int32_t sr_out);
 int se_resample(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n_in, int32_t sr_in, int32_t sr_out,
                 float* out_dev, int64_t out_pitch, void* stream);
 
+/* The two ends of `enhance(args)`: `feat_wav, orig_fs = sf.read(path)` hands out int16 / 32768 as floats, and
+ * `sf.write(path, y, fs)` stores PCM_16 (soundfile's default subtype for .wav: round to nearest, clipped) - e.g.
+ * DCCRN/dccrn_decode_vb.py:25,64.  Both conversions are exact in fp32, so they run on the device and the host moves raw
+ * 2-byte samples only.  Stateless; rows of `n` samples, pitches in elements. */
+int se_pcm16_decode(const int16_t* in_dev, int64_t in_pitch, int32_t batch, int32_t n, float* out_dev, int64_t out_pitch,
+                    void* stream);
+int se_pcm16_encode(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n, int16_t* out_dev, int64_t out_pitch,
+                    void* stream);
+
 /* ABI version of this header. */
-int32_t se_abi_version(void);   /* 2: se_enhance_ragged, se_get_stage_profile, se_stream_* */
+int32_t se_abi_version(void);   /* 2: se_enhance_ragged, se_get_stage_profile, se_stream_*; 3: se_uformer_forward, se_pcm16_* */
 
 #ifdef __cplusplus
 }

@@ -198,4 +198,21 @@ def enhance_uformer(sd, wav, net_dtype=np.float32):
     return y / c
 
 
+def uformer_forward4(sd, inputs, src, net_dtype=np.float32):
+    """`output, src, output_cplx, src_cplx = model(inputs, src)` for ONE pair of waveforms (Uformer/uformer.py:172-287):
+    output = istft of the estimate (:276), src = istft(stft(src)) (:186), output_cplx [2,257,T] the RI estimate (:264-286),
+    src_cplx [2,257,T] = |S| e^{j angle S} of the source's STFT with the reference's clamp / EPS (:187-194)."""
+    x = np.asarray(inputs, dtype=net_dtype)
+    spec = S.stft(x, 512, 160, 400)
+    er, ei = M.uformer_core(sd, spec.real.astype(net_dtype)[None], spec.imag.astype(net_dtype)[None])
+    out = S.istft(er[0].astype(np.float64) + 1j * ei[0].astype(np.float64), 512, 160, 400)
+    ss = S.stft(np.asarray(src, dtype=net_dtype), 512, 160, 400)
+    sr, si = ss.real.astype(net_dtype), ss.imag.astype(net_dtype)
+    src_out = S.istft(sr.astype(np.float64) + 1j * si.astype(np.float64), 512, 160, 400)
+    eps = np.float32(np.finfo(np.float32).eps)
+    mag = np.sqrt(np.maximum(sr ** 2 + si ** 2, eps))
+    ph = np.arctan2(si + eps, sr)
+    return out, src_out, np.stack([er[0], ei[0]]), np.stack([mag * np.cos(ph), mag * np.sin(ph)])
+
+
 ENHANCE['uformer'] = enhance_uformer

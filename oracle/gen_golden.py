@@ -500,9 +500,12 @@ def gen_uformer():
         with torch.no_grad():
             out, _, cplx, _ = model(xw[None], xw[None])
         enh = (out[0].numpy() / c)
-        # the spectral core alone on random spectra (B = 2)
-        rng = np.random.default_rng(14)
-        save('uformer', wav=wav, enh=enh, cplx=cplx.numpy())
+        # the full 4-tuple with a source that differs from the input (uformer.py:182-194, :287): src = another clip
+        src = torch.FloatTensor(synth.synth_clip(13, 'speech', 4000).astype(np.float64) * c)
+        with torch.no_grad():
+            out2, src_out, cplx2, src_cplx = model(xw[None], src[None])
+        assert torch.equal(out2, out) and torch.equal(cplx2, cplx)
+        save('uformer', wav=wav, enh=enh, cplx=cplx.numpy(), src_wav=src_out.numpy(), src_cplx=src_cplx.numpy())
 
         def enh_full(w):
             cc = np.sqrt(len(w) / np.sum(w.astype(np.float64) ** 2.0))

@@ -19,6 +19,7 @@ SYMBOLS = [
     'se_engine_finalize', 'se_forward', 'se_enhance_batch', 'se_output_samples', 'se_rms_scale', 'se_stft',
     'se_istft', 'se_num_frames', 'se_num_bins', 'se_set_profiling', 'se_get_profile', 'se_resample',
     'se_resample_samples', 'se_enhance_ragged', 'se_get_stage_profile', 'se_stream_begin', 'se_stream_push', 'se_stream_flush',
+    'se_uformer_forward', 'se_pcm16_decode', 'se_pcm16_encode',
 ]
 
 
@@ -58,6 +59,7 @@ def load():
     lib.se_engine_set_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(i64), i32, i32]
     lib.se_engine_finalize.argtypes = [vp]
     lib.se_forward.argtypes = [vp, vp, C.POINTER(i64), i32, vp, vp]
+    lib.se_uformer_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     lib.se_enhance_batch.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp]
     lib.se_enhance_ragged.argtypes = [vp, vp, i64, i32, C.POINTER(i32), vp, i64, vp]
     lib.se_output_samples.restype = i64
@@ -77,6 +79,8 @@ def load():
     lib.se_stream_flush.argtypes = [vp, vp, i64, C.POINTER(i32), vp]
     lib.se_resample_samples.restype = i64
     lib.se_resample_samples.argtypes = [i32, i32, i32]
+    lib.se_pcm16_decode.argtypes = [vp, i64, i32, i32, vp, i64, vp]
+    lib.se_pcm16_encode.argtypes = [vp, i64, i32, i32, vp, i64, vp]
     lib.se_resample.argtypes = [vp, i64, i32, i32, i32, i32, vp, i64, vp]
     _lib = lib
     return lib

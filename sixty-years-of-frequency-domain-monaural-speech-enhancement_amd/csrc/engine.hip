@@ -88,7 +88,25 @@ int se_resample(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n_
     });
 }
 
-int32_t se_abi_version(void) { return 2; }
+int se_pcm16_decode(const int16_t* in_dev, int64_t in_pitch, int32_t batch, int32_t n, float* out_dev, int64_t out_pitch,
+                    void* stream) {
+    return guard(nullptr, [&] {
+        SE_CHECK(in_dev && out_dev, "null argument");
+        SE_CHECK(batch == 1 || (in_pitch >= n && out_pitch >= n), "row pitch too small");
+        se::launch_pcm16_decode(in_dev, in_pitch, batch, n, out_dev, out_pitch, static_cast<hipStream_t>(stream));
+    });
+}
+
+int se_pcm16_encode(const float* in_dev, int64_t in_pitch, int32_t batch, int32_t n, int16_t* out_dev, int64_t out_pitch,
+                    void* stream) {
+    return guard(nullptr, [&] {
+        SE_CHECK(in_dev && out_dev, "null argument");
+        SE_CHECK(batch == 1 || (in_pitch >= n && out_pitch >= n), "row pitch too small");
+        se::launch_pcm16_encode(in_dev, in_pitch, batch, n, out_dev, out_pitch, static_cast<hipStream_t>(stream));
+    });
+}
+
+int32_t se_abi_version(void) { return 3; }
 
 const char* se_last_error(const se_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 
@@ -226,6 +244,20 @@ int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32
         SE_CHECK(in_dev && out_dev && in_shape, "null argument");
         e->ctx.prof_reset();
         e->model->forward(in_dev, in_shape, in_ndim, out_dev, static_cast<hipStream_t>(stream));
+    });
+}
+
+int se_uformer_forward(se_engine* e, const float* inputs_dev, const float* src_dev, int32_t batch, int32_t n_samples,
+                       float* output_dev, float* src_out_dev, float* output_cplx_dev, float* src_cplx_dev, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(e->finalized, "engine not finalized");
+        SE_CHECK(inputs_dev && output_dev, "null argument");
+        SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
+        SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples, "n_samples outside [n_fft, max_samples]");
+        e->ctx.prof_reset();
+        e->model->forward_uformer(inputs_dev, src_dev, batch, n_samples, output_dev, src_out_dev, output_cplx_dev, src_cplx_dev,
+                                  static_cast<hipStream_t>(stream));
     });
 }
 
@@ -420,6 +452,7 @@ int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_
         se_engine::Stream& S = e->strm;
         SE_CHECK(S.active, "se_stream_push without se_stream_begin");
         SE_CHECK(wav_dev && out_dev && n_out && n_new >= 0, "bad argument");
+        SE_CHECK(S.batch == 1 || pitch >= n_new, "se_stream_push: input row pitch smaller than n_new");
         SE_CHECK(S.n_total + n_new <= e->ctx.max_samples, "stream longer than max_samples given at create");
         hipStream_t st = static_cast<hipStream_t>(stream);
         const StftGeom& g = e->ctx.geom;

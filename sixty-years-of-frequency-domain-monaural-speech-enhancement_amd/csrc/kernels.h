@@ -243,6 +243,9 @@ void launch_lstm_persist(const LstmPersistArgs& a, hipStream_t s);
 long resample_out_samples(int n_in, int sr_in, int sr_out);
 void launch_resample(const float* x, long in_pitch, int batch, int n_in, int sr_in, int sr_out, float* y, long out_pitch,
                      hipStream_t s);
+// PCM_16 <-> float32 rows at the two ends of the decode driver (sf.read / sf.write PCM_16 of every decode script)
+void launch_pcm16_decode(const short* in, long in_pitch, int batch, int n, float* out, long out_pitch, hipStream_t s);
+void launch_pcm16_encode(const float* in, long in_pitch, int batch, int n, short* out, long out_pitch, hipStream_t s);
 
 // Weight-stationary cooperative LSTM recurrence for H = 512 / 1024 (k_lstm_coop.hip): W_hh spread over the register
 // files of all CUs, one launch for all T steps.  Same tensor conventions as LstmPersistArgs (O = 1):

@@ -106,6 +106,11 @@ class Model {
     virtual void finalize(const TrackedSD& sd) = 0;
     // y = model(x) in the reference's tensor layout
     virtual void forward(const float* in, const int64_t* shape, int ndim, float* out, hipStream_t st) = 0;
+    // Uformer only: the full 4-tuple of `model(inputs, src)` (uformer.py:287); any of src / the three extra outputs may be null
+    virtual void forward_uformer(const float* inputs, const float* src, int B, int L, float* output, float* src_out,
+                                 float* output_cplx, float* src_cplx, hipStream_t st) {
+        SE_CHECK(false, "se_uformer_forward: the engine was not created with SE_MODEL_UFORMER");
+    }
     // body of enhance(args) for B equal-length clips
     virtual void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) = 0;
     // carve the activation workspace for (B clips, T frames) out of ctx.arena (also used to size it)

@@ -356,6 +356,23 @@ __global__ __launch_bounds__(256) void uf_post_kernel(const float* __restrict__ 
     est[o + (long)NBIN * T] = em * sinf(ep);
 }
 
+// ---- :182-194  src_cplx = |S| e^{j angle S} of the clean source's STFT with the clamp / EPS of the reference,
+// [B][2][257][T] (spec and out share the row pitch T)
+__global__ __launch_bounds__(256) void uf_src_cplx_kernel(const float* __restrict__ spec, float* __restrict__ out, int T,
+                                                          float p_in) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long plane = (long)NBIN * T;
+    const long o = ((long)b * 2 * NBIN + k) * T + t;
+    const float re = spec[o], im = spec[o + plane];
+    float m = sqrtf(fmaxf(re * re + im * im, UEPS));
+    if (p_in != 1.f) m = powf(m, p_in);
+    const float ph = atan2f(im + UEPS, re);
+    out[o] = m * cosf(ph);
+    out[o + plane] = m * sinf(ph);
+}
+
 // ------------------------------------------------------------------------------------------------ weight helpers
 HostTensor dup2(const HostTensor& t) {         // BatchNorm3d(C) acts on the real and the imaginary planes alike
     HostTensor o = t;
@@ -576,6 +593,22 @@ class Uformer final : public Model {
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         run(wav, pitch, B, L, out, out_pitch, true, st);                  // uformer_decode_vb.py:35-36,62
     }
+    // output, src, output_cplx, src_cplx = model(inputs, src)   (uformer.py:172-287)
+    void forward_uformer(const float* inputs, const float* src, int B, int L, float* output, float* src_out, float* output_cplx,
+                         float* src_cplx, hipStream_t st) override {
+        const long olen = output_samples(L);
+        run(inputs, L, B, L, output, olen, false, st, output_cplx);
+        if (!src || (!src_out && !src_cplx)) return;
+        // :182-194: the clean source only goes through the front end - STFT, waveform round trip, polar re-synthesis
+        const int T = 1 + L / HOP;
+        Bufs& b = bufs(cur.B, cur.T);                 // the buffers of the run above (its spectra are consumed by now)
+        launch_stft(ctx.geom, src, L, B, L, L, nullptr, 1.f, b.spec, nullptr, T, T, st);
+        if (src_out) launch_istft(ctx.geom, b.spec, B, T, T, b.frames, nullptr, src_out, olen, HOP * (T - 1), st);
+        if (src_cplx) {
+            hipLaunchKernelGGL(uf_src_cplx_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, b.spec, src_cplx, T, ctx.p_in);
+            SE_HIP(hipGetLastError());
+        }
+    }
 
   private:
     struct Bufs {
@@ -723,7 +756,8 @@ class Uformer final : public Model {
         }
     }
 
-    void run(const float* wav, long pitch, int B, int L, float* out, long out_pitch, bool normalise, hipStream_t st) {
+    void run(const float* wav, long pitch, int B, int L, float* out, long out_pitch, bool normalise, hipStream_t st,
+             float* out_cplx = nullptr) {
         const int T_true = 1 + L / HOP;
         PadFrames pad(ctx, B, L, L, T_true, HOP * (T_true - 1), st);      // symmetric dilated convs: rows of whole 16 B groups
         const int T = pad.T;
@@ -785,6 +819,15 @@ class Uformer final : public Model {
         }
         hipLaunchKernelGGL(uf_post_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, c, m, b.mag0, b.ph0, b.est, T, ctx.p_out);
         SE_HIP(hipGetLastError());
+        if (out_cplx) {      // :264-286 output_cplx [B][2][257][T_true] (the engine's rows may be padded to whole 16 B groups)
+            const float* oc = b.est;
+            if (ctx.p_out != 1.f) {      // the reference collects it BEFORE the (commented-out) decompression, :273
+                hipLaunchKernelGGL(uf_post_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, c, m, b.mag0, b.ph0, b.spec, T, 1.f);
+                oc = b.spec;             // the input spectrum was consumed by uf_prep_kernel
+            }
+            SE_HIP(hipMemcpy2DAsync(out_cplx, (size_t)T_true * sizeof(float), oc, (size_t)T * sizeof(float),
+                                    (size_t)T_true * sizeof(float), (size_t)B * 2 * NBIN, hipMemcpyDeviceToDevice, st));
+        }
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, cs, out, out_pitch, HOP * (T_true - 1), st);  // :276
     }
 };

@@ -61,79 +61,249 @@ def _build(model, checkpoint, state_dict, **kw):
 RAGGED_MODELS = frozenset(MODELS)        # every model takes clips of different lengths in one call
 
 
-def plan_batches(lengths, max_batch, batch_samples, ragged):
+def plan_batches(lengths, max_batch, batch_samples, ragged, max_pad=0.15):
     """Group clip indices into engine calls.  ragged: clips sorted by length, consecutive runs of up to `max_batch` clips
-    whose padded size (count x longest) stays within `batch_samples` - the padding a call carries is the spread of
-    lengths inside one run, a few percent on a corpus like VoiceBank+DEMAND (824 clips, ~700 distinct lengths).
-    Not ragged: only clips of exactly equal length share a call, as in round 1."""
+    whose padded size (count x longest) stays within `batch_samples` AND whose padding (1 - sum of lengths / padded size)
+    stays within `max_pad` - a run is closed as soon as the next, longer clip would push the rows already in it past that
+    share of wasted frames (without the cap a run of 256 clips of a VoiceBank+DEMAND-like corpus spans 1.2 - 9.8 s and
+    carries 42 % padding).  Not ragged: only clips of exactly equal length share a call."""
     order = sorted(range(len(lengths)), key=lambda i: (lengths[i], i))
-    batches, cur = [], []
+    batches, cur, tot = [], [], 0
     for i in order:
-        same = not cur or lengths[cur[0]] == lengths[i]
-        fits = len(cur) < max_batch and (len(cur) + 1) * lengths[i] <= max(batch_samples, lengths[i])
-        if cur and not (fits and (ragged or same)):
+        n = lengths[i]
+        same = not cur or lengths[cur[0]] == n
+        fits = len(cur) < max_batch and (len(cur) + 1) * n <= max(batch_samples, n)
+        tight = (len(cur) + 1) * n * (1.0 - max_pad) <= tot + n            # padding of the run with this clip in it
+        if cur and not (fits and ((ragged and tight) or same)):
             batches.append(cur)
-            cur = []
+            cur, tot = [], 0
         cur.append(i)
+        tot += n
     if cur:
         batches.append(cur)
     return batches
 
 
-def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_batch=64, state_dict=None,
-            batch_samples=64 * 64000):
-    """p_in / p_out None -> the exponents checked in at the model's decode script (host class defaults).
-    Clips of different lengths are decoded together through se_enhance_ragged (each clip gets exactly its batch-1
-    result); under torch.distributed the list of engine calls is sharded contiguously over the ranks (one GPU each),
-    every rank writing its own output files - the reference's `for file_id in file_list` split across GPUs."""
-    import torch
+def shard_clips(lengths, rank, world):
+    """Clips -> ranks: the length-sorted clip list dealt round-robin (clip k of the sorted order goes to rank k % world), so
+    every rank gets the same number of clips (+-1), the same length distribution and therefore the same number of frames
+    to decode and the same padding in its calls - a contiguous shard of a length-sorted plan would hand rank 0 all the
+    short clips and the last rank all the long ones.  Deterministic: every rank derives its own share from the
+    same file list, nothing is exchanged.  -> this rank's clip indices (ascending length)."""
+    order = sorted(range(len(lengths)), key=lambda i: (lengths[i], i))
+    return order[rank::world]
+
+
+def _rank_world(rank, world):
     import torch.distributed as dist
-    from . import shard
+    if rank is not None and world is not None:
+        return int(rank), int(world)
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+class _Slot:
+    """One stage of the pipeline's ring: pinned host + device staging for a call's input and output."""
+
+    def __init__(self, torch, rows, n_in, n16, n_out, device, raw16):
+        dev = torch.device('cuda', device)
+        self.h_in = torch.empty((rows, n_in), dtype=torch.int16 if raw16 else torch.float32).pin_memory()
+        self.d_in = torch.empty((rows, n_in), dtype=self.h_in.dtype, device=dev)
+        self.d_nat = torch.empty((rows, n_in), dtype=torch.float32, device=dev) if raw16 else self.d_in
+        self.wav = torch.zeros((rows, n16), dtype=torch.float32, device=dev)
+        self.out = torch.empty((rows, n_out), dtype=torch.float32, device=dev)
+        self.d_q = torch.empty((rows, n_out), dtype=torch.int16, device=dev)
+        self.h_q = torch.empty((rows, n_out), dtype=torch.int16).pin_memory()
+        self.ready = torch.cuda.Event()     # input resident on the device
+        self.done = torch.cuda.Event()      # quantised output resident in h_q
+
+
+def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_batch=64, state_dict=None,
+            batch_samples=None, max_pad=0.15, rank=None, world=None, verbose=True, stats=None, readers=4):
+    """The file -> file decode of a directory (`enhance(args)` of every `*_decode_vb.py`), as a pipeline:
+
+      plan     lengths come from the WAV headers only; the length-sorted clip list is dealt round-robin to the ranks and every
+               rank reads, decodes and writes ONLY its own clips (one process per GPU, no collective on the data path);
+               clips of different lengths share calls (se_enhance_ragged: each clip gets exactly its batch-1 result)
+               within a padding cap;
+      reader   threads copy the raw PCM_16 samples of the next call into pinned memory, a side stream uploads them, turns
+               them into floats (se_pcm16_decode) and resamples to 16 kHz where the corpus is not (se_resample,
+               librosa.resample(..., 16000) of e.g. DCCRN/dccrn_decode_vb.py:26) - while the current call decodes;
+      decode   the caller's stream: se_enhance_ragged / se_enhance_batch, then PCM_16 quantisation on the device
+               (se_pcm16_encode) and one asynchronous D2H of 2-byte samples;
+      writer   a thread writes each clip's `<out>/<same file name>` as soon as its call's samples have landed.
+    p_in / p_out None -> the exponents checked in at the model's decode script (host class defaults).  `stats` (a dict)
+    receives the timing of the run (tools/corpus_bench.py)."""
+    import queue
+    import threading
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    import ctypes as C
+    import torch
+    from . import _lib
+    t_begin = time.perf_counter()
     mix, out_dir = args.mix_file_path, getattr(args, 'esti_clean_file_path', None) or args.esti_file_path
     if getattr(args, 'noise_type', None):
         # WSJ0-SI84 grid drivers (`*_decode.py`, e.g. CRN/crn_decode.py:28-32): one (noise, seen/unseen, SNR) cell
         mix = os.path.join(mix, args.noise_type, args.seen, str(args.snr))
         out_dir = os.path.join(out_dir, args.noise_type, args.seen, str(args.snr))
     os.makedirs(out_dir, exist_ok=True)
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    rank, world = _rank_world(rank, world)
     device = torch.cuda.current_device()
     files = sorted(os.listdir(mix)) if world > 1 else os.listdir(mix)     # ranks must agree on the order
-    clips = []
-    for name in files:
-        x, fs = wavio.read_wav(os.path.join(mix, name))
-        if fs != 16000:
-            # librosa.resample(feat_wav, orig_fs, 16000, fix=True, scale=False), e.g. DCCRN/dccrn_decode_vb.py:26
-            x = resample.resample(torch.from_numpy(x.astype(np.float32)).cuda(), fs, 16000).cpu().numpy()
-        clips.append((name, x.astype(np.float32)))
-    if not clips:
+    if not files:
         return 0
-    lengths = [len(x) for _, x in clips]
-    ragged = model in RAGGED_MODELS
-    batches = plan_batches(lengths, max_batch, batch_samples, ragged)
-    lo, hi = shard.shard_range(len(batches), rank, world)
-    batches = batches[lo:hi]
-    if not batches:
+    # ---- plan from the headers
+    info = [wavio.wav_info(os.path.join(mix, f)) for f in files]
+    for f, (_, _, ch, tag, bits, _) in zip(files, info):
+        if ch != 1:
+            raise ValueError(f'{f}: {ch} channels - the decode scripts read mono clips')
+    native = [i[0] for i in info]
+    rates = [i[1] for i in info]
+    lengths = [n if fs == 16000 else resample.resample_samples(n, fs, 16000) for n, fs in zip(native, rates)]
+    raw16 = all(i[3] == 1 and i[4] == 16 for i in info)       # PCM_16 corpus: raw samples to the device, floats made there
+    if batch_samples is None:
+        batch_samples = max_batch * 64000                     # the padded size of a call of max_batch 4 s clips
+    own = shard_clips(lengths, rank, world)
+    mine = [[own[k] for k in b] for b in plan_batches([lengths[i] for i in own], max_batch, batch_samples,
+                                                       model in RAGGED_MODELS, max_pad)]
+    if stats is not None:
+        pad, use = sum(len(b) * max(lengths[i] for i in b) for b in mine), sum(lengths[i] for i in own)
+        stats.update(files=len(files), files_rank=len(own), calls_rank=len(mine), world=world,
+                     pad_frac=round(pad / max(use, 1) - 1.0, 4), audio_s_rank=round(use / 16000.0, 2))
+    if not mine:
         return 0
-    # the workspace is sized for the calls this rank actually makes, not for max_batch x the longest clip
-    eng_batch = max(len(b) for b in batches)
-    eng_len = max(lengths[i] for b in batches for i in b)
+    # ---- engine: the workspace is sized for the calls this rank actually makes, not for max_batch x the longest clip
+    eng_batch = max(len(b) for b in mine)
+    eng_len = max(lengths[i] for b in mine for i in b)
+    nat_len = max(native[i] for b in mine for i in b)
     net = _build(model, checkpoint, state_dict, device=device, max_batch=eng_batch, max_samples=max(eng_len, 512),
                  p_in=p_in, p_out=p_out)
-    cnt = 0
-    for b in batches:
+    eng = net.engine
+    lib = _lib.load()
+    n_out_max = eng.output_samples(eng_len)
+    NS = 3
+    slots = [_Slot(torch, eng_batch, nat_len, eng_len, n_out_max, device, raw16) for _ in range(NS)]
+    free = queue.Queue()
+    for sl in slots:
+        free.put(sl)
+    staged, finished = queue.Queue(), queue.Queue()
+    side = torch.cuda.Stream(device)
+    main = torch.cuda.current_stream(device)
+    errors = []
+    t_ready = time.perf_counter()
+
+    def _check(rc):
+        if rc:
+            raise RuntimeError(lib.se_last_error(None).decode())
+
+    def load_row(sl, r, i):
+        path = os.path.join(mix, files[i])
+        if raw16:
+            wavio.read_pcm16_into(path, info[i][5], native[i], sl.h_in[r].numpy())
+        else:
+            x, _ = wavio.read_wav(path)
+            sl.h_in[r, :native[i]] = torch.from_numpy(x.astype(np.float32))
+
+    def reader():
+        try:
+            torch.cuda.set_device(device)
+            with ThreadPoolExecutor(max(1, readers)) as pool:
+                for b in mine:
+                    sl = free.get()
+                    list(pool.map(lambda ri: load_row(sl, *ri), enumerate(b)))
+                    nb, nmax = len(b), max(native[i] for i in b)
+                    with torch.cuda.stream(side):
+                        st = C.c_void_p(side.cuda_stream)
+                        sl.d_in[:nb, :nmax].copy_(sl.h_in[:nb, :nmax], non_blocking=True)
+                        if raw16:
+                            _check(lib.se_pcm16_decode(C.c_void_p(sl.d_in.data_ptr()), sl.d_in.stride(0), nb, nmax,
+                                                       C.c_void_p(sl.d_nat.data_ptr()), sl.d_nat.stride(0), st))
+                        for r, i in enumerate(b):
+                            if rates[i] == 16000:
+                                continue
+                            # librosa.resample(feat_wav, orig_fs, 16000, fix=True, scale=False), dccrn_decode_vb.py:26
+                            _check(lib.se_resample(C.c_void_p(sl.d_nat[r].data_ptr()), native[i], 1, native[i], rates[i], 16000,
+                                                   C.c_void_p(sl.wav[r].data_ptr()), lengths[i], st))
+                        same = [r for r, i in enumerate(b) if rates[i] == 16000]
+                        if len(same) == nb:
+                            sl.wav[:nb, :nmax].copy_(sl.d_nat[:nb, :nmax], non_blocking=True)
+                        else:
+                            for r in same:
+                                sl.wav[r, :native[b[r]]].copy_(sl.d_nat[r, :native[b[r]]], non_blocking=True)
+                        sl.ready.record(side)
+                    staged.put((b, sl))
+        except Exception as ex:                    # surface reader failures in the caller's thread
+            errors.append(ex)
+        finally:
+            staged.put(None)
+
+    cnt = [0]
+
+    def writer():
+        try:
+            while True:
+                item = finished.get()
+                if item is None:
+                    return
+                b, sl = item
+                sl.done.synchronize()
+                q = sl.h_q.numpy()
+                for r, i in enumerate(b):
+                    n = eng.output_samples(lengths[i])
+                    with open(os.path.join(out_dir, files[i]), 'wb') as f:
+                        f.write(wavio.wav_header_pcm16(2 * n, args.fs))
+                        f.write(memoryview(q[r, :n]).cast('B'))
+                    cnt[0] += 1
+                    if verbose:
+                        print(' The %d utterance has been decoded!' % cnt[0])
+                free.put(sl)
+        except Exception as ex:
+            errors.append(ex)
+            while True:                            # keep the ring moving so the other stages can finish
+                item = finished.get()
+                if item is None:
+                    return
+                free.put(item[1])
+
+    tr, tw = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
+    tr.start()
+    tw.start()
+    t_gpu0 = None
+    while True:
+        item = staged.get()
+        if item is None or errors:
+            break
+        b, sl = item
         lens = [lengths[i] for i in b]
-        wav = np.zeros((len(b), max(lens)), np.float32)
-        for r, i in enumerate(b):
-            wav[r, :lens[r]] = clips[i][1]
-        wt = torch.from_numpy(wav).cuda()
-        y = (net.enhance_batch(wt) if min(lens) == max(lens) else net.enhance_ragged(wt, lens)).cpu().numpy()
-        for r, i in enumerate(b):
-            n = net.engine.output_samples(lens[r])
-            wavio.write_wav_pcm16(os.path.join(out_dir, clips[i][0]), y[r, :n], args.fs)
-            cnt += 1
-            print(' The %d utterance has been decoded!' % cnt)
-    return cnt
+        nb, lmax = len(b), max(lens)
+        main.wait_event(sl.ready)
+        if t_gpu0 is None:
+            t_gpu0 = time.perf_counter()
+        wav = sl.wav[:nb, :lmax]
+        n_out = eng.output_samples(lmax)
+        out = sl.out[:nb, :n_out]
+        if min(lens) == lmax:
+            eng.enhance_batch(wav, out)
+        else:
+            eng.enhance_ragged(wav, lens, out)
+        _check(lib.se_pcm16_encode(C.c_void_p(out.data_ptr()), out.stride(0), nb, n_out, C.c_void_p(sl.d_q.data_ptr()),
+                                   sl.d_q.stride(0), C.c_void_p(main.cuda_stream)))
+        sl.h_q[:nb, :n_out].copy_(sl.d_q[:nb, :n_out], non_blocking=True)
+        sl.done.record(main)
+        finished.put((b, sl))
+    finished.put(None)
+    tw.join()
+    tr.join(timeout=5.0)
+    if errors:
+        raise errors[0]
+    if stats is not None:
+        t_end = time.perf_counter()
+        stats.update(decoded=cnt[0], setup_s=round(t_ready - t_begin, 3), pipeline_s=round(t_end - t_ready, 3),
+                     total_s=round(t_end - t_begin, 3), clips_per_s=round(cnt[0] / max(t_end - t_ready, 1e-9), 1),
+                     raw_pcm16=bool(raw16))
+    return cnt[0]
 
 
 def main():
@@ -142,7 +312,9 @@ def main():
     parser.add_argument('--esti_clean_file_path', '--esti_file_path', dest='esti_clean_file_path', type=str, required=True)
     parser.add_argument('--fs', type=int, default=16000)
     parser.add_argument('--model', type=str, default='dccrn', choices=MODELS)
-    parser.add_argument('--checkpoint', type=str, nargs='+', default=None, help='state dict file (two for ctsnet)')
+    parser.add_argument('--checkpoint', '--Model_path', dest='checkpoint', type=str, nargs='+', default=None,
+                        help='state dict file (two for ctsnet); --Model_path is G2Net\'s name for it (G2Net_VB/com_decode.py:103)')
+    parser.add_argument('--max_batch', type=int, default=64, help='most clips per engine call')
     parser.add_argument('--cprs', action='store_true', help='compressed-spectrum variant: exponents 0.5 / 2.0')
     parser.add_argument('--noncprs', action='store_true', help='uncompressed variant: exponents 1.0 / 1.0')
     # WSJ0-SI84 grid drivers (`*_decode.py`): decode <mix>/<noise_type>/<seen>/<snr>/
@@ -154,7 +326,12 @@ def main():
     ck = args.checkpoint
     if ck is not None and not args.model.startswith('ctsnet'):
         ck = ck[0]
-    enhance(args, args.model, ck, p_in, p_out)
+    # one process per GPU: under a launcher (torch.distributed.run) the file list is dealt to the ranks by RANK / WORLD_SIZE;
+    # no process group is needed - there is no collective on this path, every rank writes its own output files
+    import torch
+    if 'LOCAL_RANK' in os.environ:
+        torch.cuda.set_device(int(os.environ['LOCAL_RANK']) % max(torch.cuda.device_count(), 1))
+    enhance(args, args.model, ck, p_in, p_out, max_batch=args.max_batch)
 
 
 if __name__ == '__main__':

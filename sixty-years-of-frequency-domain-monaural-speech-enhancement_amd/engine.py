@@ -25,6 +25,7 @@ class Engine:
         self.device = device
         self.max_batch, self.max_samples = max_batch, max_samples
         self.finalized = False
+        self._stream_batch = 0          # rows of the open frame-online stream (0 = none)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc):
@@ -85,6 +86,30 @@ class Engine:
                                          C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    def uformer_forward(self, inputs, src=None, spectra=True):
+        """`model(inputs, src)` of Uformer/uformer.py:172-287: (output, src_out, output_cplx, src_cplx); the source outputs
+        are None without `src`, the spectra None with spectra=False."""
+        import torch
+        self._check_tensor(inputs, 'uformer_forward inputs', 2)
+        if not inputs.is_contiguous():
+            raise EngineError("uformer_forward inputs: expected dense rows")
+        B, L = inputs.shape
+        n_out, T, F = self.output_samples(L), self.num_frames(L), self.num_bins()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=inputs.device)
+        out = new(B, n_out)
+        out_c = new(B, 2, F, T) if spectra else None
+        src_o = src_c = None
+        if src is not None:
+            self._check_tensor(src, 'uformer_forward src', 2)
+            if tuple(src.shape) != (B, L) or not src.is_contiguous():
+                raise EngineError(f"uformer_forward src: expected a dense {(B, L)} tensor, got {tuple(src.shape)}")
+            src_o = new(B, n_out)
+            src_c = new(B, 2, F, T) if spectra else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(self._lib.se_uformer_forward(self._h, ptr(inputs), ptr(src), B, L, ptr(out), ptr(src_o), ptr(out_c),
+                                                 ptr(src_c), self._stream()))
+        return out, src_o, out_c, src_c
+
     def output_samples(self, n):
         return int(self._lib.se_output_samples(self._h, n))
 
@@ -139,17 +164,27 @@ class Engine:
     # ------------------------------------------------------------------ frame-online decoding
     def stream_begin(self, batch, c=None, max_chunk_frames=16):
         """Start `batch` parallel streams; c: per-stream scale tensor (what rms_scale() returns offline) or None = 1."""
+        batch = int(batch)
+        if not 1 <= batch <= self.max_batch:
+            raise EngineError(f"stream_begin: batch {batch} outside 1..max_batch ({self.max_batch})")
         if c is not None:
             self._check_tensor(c, 'stream_begin c')
-        self._stream_batch = batch
+            if not c.is_contiguous() or c.numel() < batch:        # the engine copies `batch` floats from c
+                raise EngineError(f"stream_begin c: need a contiguous tensor of >= {batch} scales, got shape {tuple(c.shape)}")
+        self._stream_batch = 0
         self._check(self._lib.se_stream_begin(self._h, batch, max_chunk_frames,
                                               C.c_void_p(c.data_ptr()) if c is not None else None, self._stream()))
+        self._stream_batch = batch
 
     def stream_push(self, wav):
         """wav [batch, n_new] -> the output samples that became final, [batch, n_out] (n_out may be 0)."""
         import torch
         self._check_tensor(wav, 'stream_push input', 2)
         B, n = wav.shape
+        if not self._stream_batch:
+            raise EngineError("stream_push without stream_begin")
+        if B != self._stream_batch:      # the engine reads and writes exactly the stream's rows
+            raise EngineError(f"stream_push: {B} rows pushed into a stream of {self._stream_batch}")
         out = torch.empty((B, n + 1024), dtype=torch.float32, device=wav.device)
         n_out = C.c_int32(0)
         pitch = wav.stride(0) if B > 1 else max(n, 1)
@@ -160,10 +195,13 @@ class Engine:
     def stream_flush(self):
         """End of the streams: the remaining output samples, [batch, n_out]."""
         import torch
+        if not self._stream_batch:
+            raise EngineError("stream_flush without stream_begin")
         out = torch.empty((self._stream_batch, self.max_samples), dtype=torch.float32, device=torch.device('cuda', self.device))
         n_out = C.c_int32(0)
         self._check(self._lib.se_stream_flush(self._h, C.c_void_p(out.data_ptr()), out.stride(0), C.byref(n_out),
                                               self._stream()))
+        self._stream_batch = 0
         return out[:, :n_out.value]
 
     # ------------------------------------------------------------------ stage hooks

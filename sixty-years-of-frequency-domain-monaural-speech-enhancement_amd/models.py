@@ -245,9 +245,10 @@ def _g2net(**kw):
 
 
 class Uformer(_EngineModule):
-    """Uformer/uformer.py:30 `Uformer()`.  forward(inputs, src): waveforms [B, L] -> (enhanced waveform
-    [B, 160*floor(L/160)], src, None, None) - the STFT / iSTFT are inside the model (uformer.py:178, 276); the spectra the
-    reference also returns (training-only) are not materialised."""
+    """Uformer/uformer.py:30 `Uformer()`.  forward(inputs, src): waveforms [B, L] -> the reference's 4-tuple
+    (enhanced waveform [B, 160*floor(L/160)], istft(stft(src)), output_cplx [B,2,257,T], src_cplx [B,2,257,T]) - the STFT /
+    iSTFT are inside the model (uformer.py:178, 276).  Without `src` the two source outputs are None (the decode script
+    only reads [0], uformer_decode_vb.py:40)."""
     _model = 'uformer'
     _IGNORED = ('stft.K', 'stft.w', 'istft.K', 'istft.w')
 
@@ -259,13 +260,13 @@ class Uformer(_EngineModule):
     def load_state_dict(self, sd, strict=True):
         return super().load_state_dict({k: v for k, v in sd.items() if k not in self._IGNORED}, strict)
 
-    def forward(self, inputs, src=None):
-        B, L = inputs.shape
-        out = self.engine.forward(inputs.contiguous(), out_shape=(B, self.engine.output_samples(L)))
-        return out, src, None, None
+    def forward(self, inputs, src=None, spectra=True):
+        if self.engine is None:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        return self.engine.uformer_forward(inputs.contiguous(), None if src is None else src.contiguous(), spectra)
 
-    def __call__(self, inputs, src=None):
-        return self.forward(inputs, src)
+    def __call__(self, inputs, src=None, spectra=True):
+        return self.forward(inputs, src, spectra)
 
 
 MODEL_CLASSES = {'fullsubnet': Model, 'uformer': Uformer, 'g2net': _g2net, 'taylorsenet': _taylor, 'gcrn': Net, 'lstm': lstm_net, 'crn': crn_net, 'dpcrn': dpcrn,

@@ -53,6 +53,54 @@ def read_wav(path):
     return x, fs
 
 
+def wav_info(path):
+    """-> (frames, sample_rate, channels, format tag, bits, byte offset of the samples) from the header only: the decode
+    driver plans its engine calls from the clip lengths before it reads any audio."""
+    with open(path, 'rb') as f:
+        head = f.read(12)
+        if head[:4] != b'RIFF' or head[8:12] != b'WAVE':
+            raise ValueError(f'{path}: not a RIFF/WAVE file')
+        fmt = None
+        while True:
+            hdr = f.read(8)
+            if len(hdr) < 8:
+                raise ValueError(f'{path}: missing fmt/data chunk')
+            cid, size = hdr[:4], struct.unpack('<I', hdr[4:])[0]
+            if cid == b'fmt ':
+                body = f.read(size + (size & 1))
+                tag, ch, fs, _, _, bits = struct.unpack('<HHIIHH', body[:16])
+                if tag == 0xFFFE and len(body) >= 26:
+                    tag = struct.unpack('<H', body[24:26])[0]
+                fmt = (tag, ch, fs, bits)
+            elif cid == b'data':
+                if fmt is None:
+                    raise ValueError(f'{path}: data chunk before fmt chunk')
+                tag, ch, fs, bits = fmt
+                return size // (ch * (bits // 8)), fs, ch, tag, bits, f.tell()
+            else:
+                f.seek(size + (size & 1), 1)
+
+
+def read_pcm16_into(path, offset, frames, dst):
+    """Raw little-endian PCM_16 mono samples of `path` straight into dst[:frames] (an int16 view of a pinned staging row):
+    no float conversion on the host - x / 32768 is exact in float32 and is done on the GPU."""
+    with open(path, 'rb') as f:
+        f.seek(offset)
+        n = f.readinto(memoryview(dst[:frames]).cast('B'))
+    if n != 2 * frames:
+        raise ValueError(f'{path}: short read ({n} of {2 * frames} bytes)')
+
+
+def pcm16_bytes(y):
+    """float samples -> PCM_16 little-endian array (clipped, round-to-nearest-even like soundfile / np.rint)."""
+    return np.clip(np.rint(np.asarray(y, dtype=np.float64) * 32768.0), -32768, 32767).astype('<i2')
+
+
+def wav_header_pcm16(n_bytes, fs, ch=1):
+    return b'RIFF' + struct.pack('<I', 36 + n_bytes) + b'WAVE' + b'fmt ' + struct.pack(
+        '<IHHIIHH', 16, 1, ch, fs, fs * ch * 2, ch * 2, 16) + b'data' + struct.pack('<I', n_bytes)
+
+
 def write_wav_pcm16(path, y, fs):
     """soundfile.write(path, y, fs) default for .wav: PCM_16, values clipped to [-1, 1)."""
     y = np.asarray(y, dtype=np.float64)

@@ -149,3 +149,28 @@ def test_streaming_is_refused_where_the_model_is_not_causal():
     m = MODEL_CLASSES['fullsubnet'](max_batch=1, max_samples=4000).load_synthetic(15)
     with pytest.raises(EngineError):
         m.engine.stream_begin(1)
+
+
+def test_stream_argument_checks():
+    """the wrappers must refuse what would be an out-of-bounds device access in se_stream_push / _begin."""
+    import torch
+    from se_amd.models import MODEL_CLASSES
+    from se_amd.engine import EngineError
+    eng = MODEL_CLASSES['crn'](max_batch=4, max_samples=8000).load_synthetic(12).engine
+    x = torch.zeros((4, 4000), device='cuda') + 0.01
+    with pytest.raises(EngineError):
+        eng.stream_flush()                                  # no stream open
+    with pytest.raises(EngineError):
+        eng.stream_push(x)                                  # no stream open
+    with pytest.raises(EngineError):
+        eng.stream_begin(5)                                 # more rows than max_batch
+    with pytest.raises(EngineError):
+        eng.stream_begin(4, c=torch.ones(3, device='cuda'))  # fewer scales than rows
+    eng.stream_begin(4, c=torch.ones(4, device='cuda'))
+    with pytest.raises(EngineError):
+        eng.stream_push(x[:2])                              # fewer rows than the stream has
+    a = eng.stream_push(x)
+    b = eng.stream_flush()
+    assert a.shape[0] == 4 and a.shape[1] + b.shape[1] == 4000
+    with pytest.raises(EngineError):
+        eng.stream_flush()                                  # the stream ended with the first flush

@@ -30,3 +30,27 @@ def test_uformer_decode_matches_reference():
     c = float(np.sqrt(len(G['wav']) / np.sum(G['wav'].astype(np.float64) ** 2)))
     out = m(torch.from_numpy((G['wav'].astype(np.float64) * c).astype(np.float32)[None]).cuda())[0].cpu().numpy()[0]
     assert rms(out / c - G['enh']) < 1e-4
+
+
+def test_uformer_full_return_matches_reference():
+    """`output, src, output_cplx, src_cplx = model(inputs, src)` (uformer.py:287) against the reference's own 4-tuple
+    (tests/golden/uformer.npz: cplx, src_wav, src_cplx) with a source that differs from the input; in a batch of 2."""
+    import torch
+    from se_amd.models import Uformer
+    G = load_golden('uformer')
+    c = float(np.sqrt(len(G['wav']) / np.sum(G['wav'].astype(np.float64) ** 2)))
+    x = (G['wav'].astype(np.float64) * c).astype(np.float32)
+    src = (synth.synth_clip(13, 'speech', 4000).astype(np.float64) * c).astype(np.float32)
+    other = synth.synth_clip(56, 'white', 4000)
+    m = Uformer(max_batch=2, max_samples=4000).load_synthetic(21)
+    out, src_out, out_c, src_c = m(torch.from_numpy(np.stack([other, x])).cuda(), torch.from_numpy(np.stack([x, src])).cuda())
+    assert out_c.shape == (2, 2, 257, 26) and src_c.shape == (2, 2, 257, 26) and src_out.shape == out.shape == (2, 4000)
+    for name, got, ref in (('output', out[1].cpu().numpy() / c, G['enh']), ('src', src_out[1].cpu().numpy(), G['src_wav'][0]),
+                           ('output_cplx', out_c[1].cpu().numpy(), G['cplx'][0]),
+                           ('src_cplx', src_c[1].cpu().numpy(), G['src_cplx'][0])):
+        e = rms(got - ref)
+        print('uformer 4-tuple', name, 'rms err', e, 'rms ref', rms(ref))
+        assert got.shape == ref.shape and e < 1e-4 and e < 5e-4 * max(rms(ref), 1e-3), (name, e, rms(ref))
+    # without a source the source outputs are None; spectra=False skips the RI tensors
+    o2, s2, c2, sc2 = m(torch.from_numpy(x[None]).cuda(), spectra=False)
+    assert s2 is None and c2 is None and sc2 is None and torch.equal(o2[0], m(torch.from_numpy(x[None]).cuda())[0][0])

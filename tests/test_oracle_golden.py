@@ -116,6 +116,19 @@ def test_uformer_matches_reference():
     assert rms(y - G['enh']) < 1e-5 * max(rms(G['enh']), 1e-3)
 
 
+def test_uformer_full_return_matches_reference():
+    """The 4-tuple of Uformer.forward (uformer.py:287) with a source that differs from the input."""
+    G = load_golden('uformer')
+    sd = synth.synth_state_dict(load_schema('uformer'), 21)
+    c = np.sqrt(len(G['wav']) / np.sum(G['wav'].astype(np.float64) ** 2.0))
+    x = (G['wav'].astype(np.float64) * c).astype(np.float32)
+    src = (synth.synth_clip(13, 'speech', 4000).astype(np.float64) * c).astype(np.float32)
+    out, src_out, out_c, src_c = D.uformer_forward4(sd, x, src)
+    assert rms(out / c - G['enh']) < 1e-5 * max(rms(G['enh']), 1e-3)
+    for got, ref in ((src_out, G['src_wav'][0]), (out_c, G['cplx'][0]), (src_c, G['src_cplx'][0])):
+        assert got.shape == ref.shape and rms(got - ref) < 1e-5 * rms(ref), (got.shape, ref.shape)
+
+
 # ---- the `*_new` directories: same networks with CumulativeLayerNorm, decoded with the 0.5 / 2.0 exponents ----------
 def test_cumulative_layernorm_against_definition():
     """cLN statistics at frame t == plain mean / biased variance over everything up to t."""

@@ -57,6 +57,10 @@ enum se_model_id {
  *                               instead of real halves together, imaginary halves together */
 #define SE_CFG_DCCRN_BIAS_PER_PART 2
 #define SE_CFG_DCCRN_PLAIN_CAT 4
+/* FullSubNet only: `sequence_model="GRU"` of Model(...) - both sequence models are torch.nn.GRU stacks instead of nn.LSTM
+ * (FullSubNet/fullsubnet_net_sa/sequence_model.py:36-43; the decode script passes "LSTM", fullsubnet_sa_decode_vb.py:16).
+ * The state dict then carries the GRU's [3H, .] weight_ih / weight_hh / bias_ih / bias_hh entries. */
+#define SE_CFG_FSN_GRU 8
 
 typedef struct se_config {
     int32_t model;        /* enum se_model_id */

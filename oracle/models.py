@@ -234,8 +234,13 @@ def _fsn_unfold(x, nn_):
 
 
 def _fsn_seq(sd, p, x, act):
-    """SequenceModel.forward: x [B,F,T] -> [B,O,T] (LSTM x2 -> Linear -> act)."""
-    o = nn.lstm(np.swapaxes(x, 1, 2), sd, p + 'sequence_model.', 2, batch_first=True)
+    """SequenceModel.forward: x [B,F,T] -> [B,O,T] (LSTM x2 | GRU x2 -> Linear -> act); the cell is read off the state
+    dict (nn.GRU stores [3H, .] matrices, nn.LSTM [4H, .]; sequence_model.py:28-43)."""
+    H = sd[p + 'sequence_model.weight_hh_l0'].shape[1]
+    if sd[p + 'sequence_model.weight_hh_l0'].shape[0] == 3 * H:
+        o = nn.gru(np.swapaxes(x, 1, 2), sd, p + 'sequence_model.', 2, batch_first=True)
+    else:
+        o = nn.lstm(np.swapaxes(x, 1, 2), sd, p + 'sequence_model.', 2, batch_first=True)
     o = nn.linear(o, sd[p + 'fc_output_layer.weight'], sd[p + 'fc_output_layer.bias'])
     if act == 'ReLU':
         o = nn.relu(o)

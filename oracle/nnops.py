@@ -202,6 +202,39 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
     return out
 
 
+def gru_layer(x, w_ih, w_hh, b_ih, b_hh):
+    """One torch.nn.GRU layer (gate order r, z, n), zero initial state.  x [T, B, I] -> h [T, B, H]:
+    r = s(W_ir x + b_ir + W_hr h + b_hr), z = s(W_iz x + b_iz + W_hz h + b_hz),
+    n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) * n + z * h."""
+    T, B, _ = x.shape
+    H = w_hh.shape[1]
+    dt = x.dtype
+    gx = x @ w_ih.T.astype(dt) + b_ih.astype(dt)
+    whhT, bh = w_hh.T.astype(dt), b_hh.astype(dt)
+    h = np.zeros((B, H), dtype=dt)
+    out = np.empty((T, B, H), dtype=dt)
+    for t in range(T):
+        gh = h @ whhT + bh
+        r = sigmoid(gx[t][:, 0:H] + gh[:, 0:H])
+        z = sigmoid(gx[t][:, H:2 * H] + gh[:, H:2 * H])
+        n = np.tanh(gx[t][:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        out[t] = h
+    return out
+
+
+def gru(x, sd, prefix, num_layers=1, batch_first=False):
+    """nn.GRU forward (unidirectional) with parameters read from state-dict `sd` under `prefix`."""
+    if batch_first:
+        x = np.swapaxes(x, 0, 1)
+    for k in range(num_layers):
+        x = gru_layer(x, sd[f'{prefix}weight_ih_l{k}'], sd[f'{prefix}weight_hh_l{k}'], sd[f'{prefix}bias_ih_l{k}'],
+                      sd[f'{prefix}bias_hh_l{k}'])
+    if batch_first:
+        x = np.swapaxes(x, 0, 1)
+    return x
+
+
 def lstm(x, sd, prefix, num_layers=1, bidirectional=False, batch_first=False):
     """nn.LSTM forward with parameters read from state-dict `sd` under
     `prefix` ('' or 'name.'), key names weight_ih_l{k}[_reverse] etc."""

@@ -34,7 +34,7 @@ constexpr int gc_blocks_per_cu(int BM) { return BM <= 32 ? 6 : 3; }
 enum Act : int { ACT_NONE = 0, ACT_PRELU = 1, ACT_ELU = 2, ACT_SOFTPLUS = 3, ACT_SIGMOID = 4, ACT_TANH = 5, ACT_RELU = 6 };
 enum Epi : int {
     EPI_ACT = 0,     // dst = act(acc + bias)
-    EPI_LSTM = 1,    // rows are gate-interleaved (4j+{i,f,g,o}); dst = h_t, c updated in place
+    EPI_LSTM = 1,    // rows are gate-interleaved (4j+{i,f,g,o}); dst = h_t, c updated in place (GCParams::gru: the GRU cell on the same 4-row layout)
     EPI_GLU = 2,     // rows are pair-interleaved (2j, 2j+1): dst[j] = (a+bias) * sigmoid(g+bias)
     EPI_ADD = 3,     // dst = act(acc + bias) + res   (res laid out like dst)
     EPI_MUL = 4,     // dst = act(acc + bias) * aux   (gated TCM branches, CTSNet/Step1_network.py:184)
@@ -69,6 +69,7 @@ struct GCParams {
     int n_ttiles, n_mtiles, Z;
     int dbg;                 // ablation switches for tuning (0 in production): 1 no global loads, 4 no MFMA, 8 no epilogue
     int first_step;          // EPI_LSTM: 1 -> h_{-1} = c_{-1} = 0 (nchunks forced to 0 by the host)
+    int gru;                 // EPI_LSTM with the GRU cell: rows 4u + {r, z, n, 0}; aux rows 4u + {gx_r, gx_z, gx_n, b_hn}; `cell` holds h_{t-1}
     unsigned long long* timing;   // tuning builds (-DGC_TIMING): per-phase s_memtime accumulators, else unused
     const unsigned* desc4;   // descriptors of the patch seen as 16 B groups (same packing as desc, w = first frame)
     int t_base;              // first frame of time tile 0 of this launch (tail launches start at the last tile)

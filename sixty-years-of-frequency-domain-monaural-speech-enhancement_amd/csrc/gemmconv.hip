@@ -594,8 +594,20 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
                     const float go = acc[i][j][4 * g4 + 3] + g[4 * g4 + 3];
                     // fast exp / reciprocal as in the persistent LSTM kernels (5 transcendentals per cell, 16 cells per lane
                     // and tile: libm's tanhf / expf made this the longest phase of a step block)
-                    const float cn = fsig_(gf) * cp[g4] + fsig_(gi) * ftanh_(gg);
-                    const float hn = fsig_(go) * ftanh_(cn);
+                    float cn, hn;
+                    if (p.gru) {
+                        // torch.nn.GRU: r = s(W_ir x + b_ir + W_hr h + b_hr), z likewise, n = tanh(W_in x + b_in + r (W_hn h + b_hn)),
+                        // h' = (1 - z) n + z h.  Rows (r, z, n, -): gi / gf / gg hold the r / z / n sums, the aux row of the unused
+                        // fourth gate carries b_hn (go = 0 + b_hn), `cell` keeps h for the next step
+                        const float r = fsig_(gi), zz = fsig_(gf);
+                        const float hw = acc[i][j][4 * g4 + 2] + go;            // W_hn h + b_hn
+                        const float nn = ftanh_(g[4 * g4 + 2] + r * hw);
+                        hn = (1.f - zz) * nn + zz * cp[g4];
+                        cn = hn;
+                    } else {
+                        cn = fsig_(gf) * cp[g4] + fsig_(gi) * ftanh_(gg);
+                        hn = fsig_(go) * ftanh_(cn);
+                    }
                     if (m + 3 < p.M && t < p.Tout) {
                         const long oi = (long)(m >> 2) * p.d_c + t;
                         cell[oi] = cn;

@@ -14,6 +14,7 @@
 //                     place a recurrent step is a large GEMM (M = 1536, K = 384, N = 257*B), run on f32 MFMA with the
 //                     LSTM cell fused in the epilogue.
 #include "rnn.h"
+#include "../../include/se_engine.h"
 
 namespace se {
 
@@ -141,13 +142,18 @@ class FullSubNet final : public Model {
 
     void finalize(const TrackedSD& sd) override {
         const int S = NBIN * ctx.max_batch;
-        fb[0].build(load_lstm(sd, "fb_model.sequence_model.", 0, "", NBIN, 512), ctx.max_batch);
-        fb[1].build(load_lstm(sd, "fb_model.sequence_model.", 1, "", 512, 512), ctx.max_batch);
+        // sequence_model = "LSTM" (the decode script's choice, fullsubnet_sa_decode_vb.py:16) or "GRU" (sequence_model.py:36-43)
+        const bool gru = (ctx.flags & SE_CFG_FSN_GRU) != 0;
+        auto load = [&](const std::string& p, int layer, int I, int H) {
+            return gru ? load_gru(sd, p, layer, "", I, H) : load_lstm(sd, p, layer, "", I, H);
+        };
+        fb[0].build(load("fb_model.sequence_model.", 0, NBIN, 512), ctx.max_batch, gru);
+        fb[1].build(load("fb_model.sequence_model.", 1, 512, 512), ctx.max_batch, gru);
         fb_fc = make_pointwise_plan(linear_weights(sd.get("fb_model.fc_output_layer.weight", {NBIN, 512}),
                                                    &sd.get("fb_model.fc_output_layer.bias", {NBIN})),
                                     ACT_RELU, {}, ctx.max_batch);
-        sbl[0].build(load_lstm(sd, "sb_model.sequence_model.", 0, "", SBW, 384), S);
-        sbl[1].build(load_lstm(sd, "sb_model.sequence_model.", 1, "", 384, 384), S);
+        sbl[0].build(load("sb_model.sequence_model.", 0, SBW, 384), S, gru);
+        sbl[1].build(load("sb_model.sequence_model.", 1, 384, 384), S, gru);
         sb_fc = make_pointwise_plan(linear_weights(sd.get("sb_model.fc_output_layer.weight", {2, 384}),
                                                    &sd.get("sb_model.fc_output_layer.bias", {2})),
                                     ACT_NONE, {}, S);

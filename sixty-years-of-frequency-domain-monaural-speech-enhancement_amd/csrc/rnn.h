@@ -32,6 +32,41 @@ inline LstmW load_lstm(const TrackedSD& sd, const std::string& prefix, int layer
     return w;
 }
 
+// torch.nn.GRU layer (FullSubNet `sequence_model="GRU"`, sequence_model.py:36-43) on the LSTM step kernel's 4-rows-per-unit
+// layout: unit u owns rows 4u + {r, z, n, -}.  Input projection rows: W_ir / W_iz / W_in with biases b_ir + b_hr, b_iz + b_hz,
+// b_in, and a zero row whose bias is b_hn (the cell epilogue reads it as the constant inside r * (W_hn h + b_hn));
+// recurrent rows: W_hr / W_hz / W_hn and a zero row.  A quarter of the matrix work is padding - the decode scripts never
+// select the GRU (fullsubnet_sa_decode_vb.py:16), it is built for completeness of the north star's "LSTM/GRU time step".
+inline LstmW load_gru(const TrackedSD& sd, const std::string& prefix, int layer, const std::string& suffix, int I, int H) {
+    const std::string l = "_l" + std::to_string(layer) + suffix;
+    const HostTensor& wi = sd.get(prefix + "weight_ih" + l, {3 * H, I});
+    const HostTensor& wh = sd.get(prefix + "weight_hh" + l, {3 * H, H});
+    const HostTensor& bi = sd.get(prefix + "bias_ih" + l, {3 * H});
+    const HostTensor& bh = sd.get(prefix + "bias_hh" + l, {3 * H});
+    auto pad4 = [&](const HostTensor& w, int K) {
+        HostTensor o;
+        o.shape = {4 * H, K};
+        o.data.assign((size_t)4 * H * K, 0.f);
+        for (int u = 0; u < H; ++u)
+            for (int g = 0; g < 3; ++g)
+                std::copy(w.data.begin() + ((size_t)g * H + u) * K, w.data.begin() + ((size_t)g * H + u + 1) * K,
+                          o.data.begin() + ((size_t)4 * u + g) * K);
+        return o;
+    };
+    LstmW w;
+    w.I = I;
+    w.H = H;
+    w.wih = linear_weights(pad4(wi, I), nullptr);
+    w.whh = linear_weights(pad4(wh, H), nullptr);
+    for (int u = 0; u < H; ++u) {
+        w.wih.bias[4 * u + 0] = bi.data[u] + bh.data[u];
+        w.wih.bias[4 * u + 1] = bi.data[H + u] + bh.data[H + u];
+        w.wih.bias[4 * u + 2] = bi.data[2 * H + u];
+        w.wih.bias[4 * u + 3] = bh.data[2 * H + u];
+    }
+    return w;
+}
+
 // per-stream state of the frame-online mode: history columns of every chunk tensor, LSTM (h, c)
 struct StreamState {
     int B = 0;
@@ -105,12 +140,15 @@ struct LstmBig {
     GCPlan gin, step;
     float* whh_dev = nullptr;     // row-major [4H][H] (gate-interleaved rows) for the weight-stationary cooperative kernel
     int I = 0, H = 0;
-    void build(const LstmW& w, int s_hint) {
+    // gru: w comes from load_gru (GRU cell in the step epilogue; one launch per step - the weight-stationary cooperative
+    // kernel only knows the LSTM cell)
+    void build(const LstmW& w, int s_hint, bool gru = false) {
         I = w.I;
         H = w.H;
         gin = make_pointwise_plan(w.wih, ACT_NONE, {}, s_hint);
         step = gc_make_plan(4 * H, H, one_tap(), w.whh.w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, s_hint);
-        if (H == 512 || H == 1024) whh_dev = to_device(w.whh.w);
+        step.p.gru = gru ? 1 : 0;
+        if (!gru && (H == 512 || H == 1024)) whh_dev = to_device(w.whh.w);
     }
     void free() {
         gc_free_plan(gin);

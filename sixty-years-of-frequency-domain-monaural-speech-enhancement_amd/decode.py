@@ -104,17 +104,22 @@ def _rank_world(rank, world):
 
 
 class _Slot:
-    """One stage of the pipeline's ring: pinned host + device staging for a call's input and output."""
+    """One stage of the pipeline's ring: pinned host + device staging for a call's input and output.  The buffers are flat;
+    a call of nb rows x n samples uses the first nb * n elements as a dense [nb, n] matrix, so every host <-> device
+    copy is one contiguous pinned transfer (a strided sub-view makes torch stage the copy through pageable memory and
+    block the issuing thread until the decode in front of it has finished)."""
 
     def __init__(self, torch, rows, n_in, n16, n_out, device, raw16):
         dev = torch.device('cuda', device)
-        self.h_in = torch.empty((rows, n_in), dtype=torch.int16 if raw16 else torch.float32).pin_memory()
-        self.d_in = torch.empty((rows, n_in), dtype=self.h_in.dtype, device=dev)
-        self.d_nat = torch.empty((rows, n_in), dtype=torch.float32, device=dev) if raw16 else self.d_in
-        self.wav = torch.zeros((rows, n16), dtype=torch.float32, device=dev)
-        self.out = torch.empty((rows, n_out), dtype=torch.float32, device=dev)
-        self.d_q = torch.empty((rows, n_out), dtype=torch.int16, device=dev)
-        self.h_q = torch.empty((rows, n_out), dtype=torch.int16).pin_memory()
+        self.h_in = torch.empty(rows * n_in, dtype=torch.int16 if raw16 else torch.float32).pin_memory()
+        self.h_in_np = self.h_in.numpy()
+        self.d_in = torch.empty(rows * n_in, dtype=self.h_in.dtype, device=dev)
+        self.d_nat = torch.empty(rows * n_in, dtype=torch.float32, device=dev) if raw16 else self.d_in
+        self.wav = torch.empty(rows * n16, dtype=torch.float32, device=dev)
+        self.out = torch.empty(rows * n_out, dtype=torch.float32, device=dev)
+        self.d_q = torch.empty(rows * n_out, dtype=torch.int16, device=dev)
+        self.h_q = torch.empty(rows * n_out, dtype=torch.int16).pin_memory()
+        self.h_q_np = self.h_q.numpy()
         self.ready = torch.cuda.Event()     # input resident on the device
         self.done = torch.cuda.Event()      # quantised output resident in h_q
 
@@ -192,48 +197,61 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_bat
     side = torch.cuda.Stream(device)
     main = torch.cuda.current_stream(device)
     errors = []
+    busy = {'read': 0.0, 'stage': 0.0, 'write': 0.0, 'wait_in': 0.0, 'issue': 0.0}      # seconds per stage (stats)
     t_ready = time.perf_counter()
 
     def _check(rc):
         if rc:
             raise RuntimeError(lib.se_last_error(None).decode())
 
-    def load_row(sl, r, i):
+    def load_row(sl, r, i, nmax):
         path = os.path.join(mix, files[i])
+        row = sl.h_in_np[r * nmax:r * nmax + native[i]]
         if raw16:
-            wavio.read_pcm16_into(path, info[i][5], native[i], sl.h_in[r].numpy())
+            fd = os.open(path, os.O_RDONLY)
+            try:
+                got = os.preadv(fd, [memoryview(row).cast('B')], info[i][5])
+            finally:
+                os.close(fd)
+            if got != 2 * native[i]:
+                raise ValueError(f'{path}: short read ({got} of {2 * native[i]} bytes)')
         else:
-            x, _ = wavio.read_wav(path)
-            sl.h_in[r, :native[i]] = torch.from_numpy(x.astype(np.float32))
+            row[:] = wavio.read_wav(path)[0]
 
     def reader():
         try:
             torch.cuda.set_device(device)
+            p = lambda t: C.c_void_p(t.data_ptr())
             with ThreadPoolExecutor(max(1, readers)) as pool:
                 for b in mine:
                     sl = free.get()
-                    list(pool.map(lambda ri: load_row(sl, *ri), enumerate(b)))
-                    nb, nmax = len(b), max(native[i] for i in b)
+                    t0 = time.perf_counter()
+                    nb, nmax, lmax = len(b), max(native[i] for i in b), max(lengths[i] for i in b)
+                    list(pool.map(lambda ri: load_row(sl, ri[0], ri[1], nmax), enumerate(b)))
+                    t1 = time.perf_counter()
+                    busy['read'] += t1 - t0
                     with torch.cuda.stream(side):
                         st = C.c_void_p(side.cuda_stream)
-                        sl.d_in[:nb, :nmax].copy_(sl.h_in[:nb, :nmax], non_blocking=True)
+                        sl.d_in[:nb * nmax].copy_(sl.h_in[:nb * nmax], non_blocking=True)
                         if raw16:
-                            _check(lib.se_pcm16_decode(C.c_void_p(sl.d_in.data_ptr()), sl.d_in.stride(0), nb, nmax,
-                                                       C.c_void_p(sl.d_nat.data_ptr()), sl.d_nat.stride(0), st))
-                        for r, i in enumerate(b):
-                            if rates[i] == 16000:
-                                continue
-                            # librosa.resample(feat_wav, orig_fs, 16000, fix=True, scale=False), dccrn_decode_vb.py:26
-                            _check(lib.se_resample(C.c_void_p(sl.d_nat[r].data_ptr()), native[i], 1, native[i], rates[i], 16000,
-                                                   C.c_void_p(sl.wav[r].data_ptr()), lengths[i], st))
-                        same = [r for r, i in enumerate(b) if rates[i] == 16000]
-                        if len(same) == nb:
-                            sl.wav[:nb, :nmax].copy_(sl.d_nat[:nb, :nmax], non_blocking=True)
+                            _check(lib.se_pcm16_decode(p(sl.d_in), nmax, nb, nmax, p(sl.d_nat), nmax, st))
+                        if all(rates[i] == 16000 for i in b):
+                            wav = sl.d_nat                     # already at 16 kHz: rows of pitch nmax = lmax
                         else:
-                            for r in same:
-                                sl.wav[r, :native[b[r]]].copy_(sl.d_nat[r, :native[b[r]]], non_blocking=True)
+                            wav = sl.wav
+                            esz = 4
+                            for r, i in enumerate(b):
+                                src = C.c_void_p(sl.d_nat.data_ptr() + esz * r * nmax)
+                                dst = C.c_void_p(sl.wav.data_ptr() + esz * r * lmax)
+                                if rates[i] == 16000:     # librosa.resample returns its input when the rates agree
+                                    sl.wav[r * lmax:r * lmax + native[i]].copy_(sl.d_nat[r * nmax:r * nmax + native[i]],
+                                                                                non_blocking=True)
+                                else:
+                                    # librosa.resample(feat_wav, orig_fs, 16000, fix=True, scale=False), dccrn_decode_vb.py:26
+                                    _check(lib.se_resample(src, native[i], 1, native[i], rates[i], 16000, dst, lengths[i], st))
                         sl.ready.record(side)
-                    staged.put((b, sl))
+                    busy['stage'] += time.perf_counter() - t1
+                    staged.put((b, sl, wav))
         except Exception as ex:                    # surface reader failures in the caller's thread
             errors.append(ex)
         finally:
@@ -247,17 +265,17 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_bat
                 item = finished.get()
                 if item is None:
                     return
-                b, sl = item
+                b, sl, n_out = item
                 sl.done.synchronize()
-                q = sl.h_q.numpy()
+                t0 = time.perf_counter()
                 for r, i in enumerate(b):
                     n = eng.output_samples(lengths[i])
-                    with open(os.path.join(out_dir, files[i]), 'wb') as f:
-                        f.write(wavio.wav_header_pcm16(2 * n, args.fs))
-                        f.write(memoryview(q[r, :n]).cast('B'))
+                    with open(os.path.join(out_dir, files[i]), 'wb', buffering=0) as f:
+                        f.write(wavio.wav_header_pcm16(2 * n, args.fs) + sl.h_q_np[r * n_out:r * n_out + n].tobytes())
                     cnt[0] += 1
                     if verbose:
                         print(' The %d utterance has been decoded!' % cnt[0])
+                busy['write'] += time.perf_counter() - t0
                 free.put(sl)
         except Exception as ex:
             errors.append(ex)
@@ -270,29 +288,30 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_bat
     tr, tw = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
     tr.start()
     tw.start()
-    t_gpu0 = None
     while True:
+        t0 = time.perf_counter()
         item = staged.get()
         if item is None or errors:
             break
-        b, sl = item
+        t1 = time.perf_counter()
+        busy['wait_in'] += t1 - t0
+        b, sl, wav_flat = item
         lens = [lengths[i] for i in b]
         nb, lmax = len(b), max(lens)
         main.wait_event(sl.ready)
-        if t_gpu0 is None:
-            t_gpu0 = time.perf_counter()
-        wav = sl.wav[:nb, :lmax]
         n_out = eng.output_samples(lmax)
-        out = sl.out[:nb, :n_out]
+        wav = wav_flat[:nb * lmax].view(nb, lmax)
+        out = sl.out[:nb * n_out].view(nb, n_out)
         if min(lens) == lmax:
             eng.enhance_batch(wav, out)
         else:
             eng.enhance_ragged(wav, lens, out)
-        _check(lib.se_pcm16_encode(C.c_void_p(out.data_ptr()), out.stride(0), nb, n_out, C.c_void_p(sl.d_q.data_ptr()),
-                                   sl.d_q.stride(0), C.c_void_p(main.cuda_stream)))
-        sl.h_q[:nb, :n_out].copy_(sl.d_q[:nb, :n_out], non_blocking=True)
+        _check(lib.se_pcm16_encode(C.c_void_p(out.data_ptr()), n_out, nb, n_out, C.c_void_p(sl.d_q.data_ptr()), n_out,
+                                   C.c_void_p(main.cuda_stream)))
+        sl.h_q[:nb * n_out].copy_(sl.d_q[:nb * n_out], non_blocking=True)
         sl.done.record(main)
-        finished.put((b, sl))
+        busy['issue'] += time.perf_counter() - t1
+        finished.put((b, sl, n_out))
     finished.put(None)
     tw.join()
     tr.join(timeout=5.0)
@@ -302,7 +321,7 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_bat
         t_end = time.perf_counter()
         stats.update(decoded=cnt[0], setup_s=round(t_ready - t_begin, 3), pipeline_s=round(t_end - t_ready, 3),
                      total_s=round(t_end - t_begin, 3), clips_per_s=round(cnt[0] / max(t_end - t_ready, 1e-9), 1),
-                     raw_pcm16=bool(raw16))
+                     raw_pcm16=bool(raw16), stage_busy_s={k: round(v, 3) for k, v in busy.items()})
     return cnt[0]
 
 

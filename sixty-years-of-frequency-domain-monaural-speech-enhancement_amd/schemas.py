@@ -15,14 +15,15 @@ def _bn(d, p, c):
     d[p + 'num_batches_tracked'] = ((), 'i64')
 
 
-def _lstm(d, p, inp, hid, layers=1, bidir=False):
+def _lstm(d, p, inp, hid, layers=1, bidir=False, gates=4):
+    """torch.nn.LSTM (gates=4) / torch.nn.GRU (gates=3) parameter entries."""
     for k in range(layers):
         i = inp if k == 0 else hid * (2 if bidir else 1)
         for suf in (('', '_reverse') if bidir else ('',)):
-            d[f'{p}weight_ih_l{k}{suf}'] = ((4 * hid, i), 'f32')
-            d[f'{p}weight_hh_l{k}{suf}'] = ((4 * hid, hid), 'f32')
-            d[f'{p}bias_ih_l{k}{suf}'] = ((4 * hid,), 'f32')
-            d[f'{p}bias_hh_l{k}{suf}'] = ((4 * hid,), 'f32')
+            d[f'{p}weight_ih_l{k}{suf}'] = ((gates * hid, i), 'f32')
+            d[f'{p}weight_hh_l{k}{suf}'] = ((gates * hid, hid), 'f32')
+            d[f'{p}bias_ih_l{k}{suf}'] = ((gates * hid,), 'f32')
+            d[f'{p}bias_hh_l{k}{suf}'] = ((gates * hid,), 'f32')
 
 
 def _conv(d, p, co, ci, k):
@@ -124,16 +125,21 @@ def dccrn_schema(kernel_num=(32, 64, 128, 256, 256, 256), rnn_units=256, fft_len
     return d
 
 
-def fullsubnet_schema():
-    """FullSubNet/fullsubnet_net_sa/model.py:38-56 with the decode script's sizes (fullsubnet_sa_decode_vb.py:11-24)."""
+def fullsubnet_schema(gates=4):
+    """FullSubNet/fullsubnet_net_sa/model.py:38-56 with the decode script's sizes (fullsubnet_sa_decode_vb.py:11-24);
+    gates=3: `sequence_model="GRU"` (sequence_model.py:36-43)."""
     d = OrderedDict()
-    _lstm(d, 'fb_model.sequence_model.', 257, 512, 2)
+    _lstm(d, 'fb_model.sequence_model.', 257, 512, 2, gates=gates)
     d['fb_model.fc_output_layer.weight'] = ((257, 512), 'f32')
     d['fb_model.fc_output_layer.bias'] = ((257,), 'f32')
-    _lstm(d, 'sb_model.sequence_model.', 32, 384, 2)
+    _lstm(d, 'sb_model.sequence_model.', 32, 384, 2, gates=gates)
     d['sb_model.fc_output_layer.weight'] = ((2, 384), 'f32')
     d['sb_model.fc_output_layer.bias'] = ((2,), 'f32')
     return d
+
+
+def fullsubnet_gru_schema():
+    return fullsubnet_schema(gates=3)
 
 
 def gcrn_schema():
@@ -264,5 +270,5 @@ def cln_variant(schema):
     return out
 
 
-SCHEMAS = {'taylorsenet': taylorsenet_schema, 'uformer': uformer_schema, 'g2net': g2net_schema, 'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
+SCHEMAS = {'fullsubnet_gru': fullsubnet_gru_schema, 'taylorsenet': taylorsenet_schema, 'uformer': uformer_schema, 'g2net': g2net_schema, 'cts_step1': cts_step1_schema, 'cts_step2': cts_step2_schema, 'gcrn': gcrn_schema, 'fullsubnet': fullsubnet_schema, 'lstm': lstm_schema, 'crn': crn_schema, 'dpcrn': dpcrn_schema, 'dccrn': dccrn_schema}
 SCHEMAS.update({n + '_new': (lambda n=n: cln_variant(SCHEMAS[n]())) for n in ('cts_step1', 'cts_step2', 'taylorsenet', 'g2net')})

@@ -45,6 +45,37 @@ def test_enhance_matches_reference_fixture(name):
     assert err < 1e-4 and err < 5e-4 * max(rms(G['enh']), 1e-3), (err, rms(G['enh']))
 
 
+def test_fullsubnet_gru_sequence_model():
+    """The GRU time step (`Model(sequence_model="GRU")`, sequence_model.py:36-43; SE_CFG_FSN_GRU): forward and decode
+    against the reference-generated fixture, a ragged pair against the oracle, and the key schema is the GRU's."""
+    torch = _torch()
+    from se_amd.models import Model
+    from oracle import decode as D
+    G = load_golden('fullsubnet_gru')
+    kw = dict(sb_num_neighbors=15, fb_num_neighbors=0, num_freqs=257, look_ahead=2, sequence_model="GRU",
+              fb_output_activate_function="ReLU", sb_output_activate_function=None, fb_model_hidden_size=512,
+              sb_model_hidden_size=384, weight_init=True, norm_type="offline_laplace_norm", num_groups_in_drop_band=2)
+    m = Model(max_batch=2, max_samples=8000, p_in=0.5, p_out=2.0, **kw)
+    assert m.state_dict_schema()['fb_model.sequence_model.weight_ih_l0'][0] == (3 * 512, 257)
+    m.load_synthetic(25)
+    y = m(torch.from_numpy(G['x']).cuda()).cpu().numpy()
+    err = rms(y - G['y'])
+    print('fullsubnet GRU forward rms err', err, 'rms ref', rms(G['y']))
+    assert y.shape == G['y'].shape and err < 2e-5 * max(rms(G['y']), 1.0)
+    other = synth.synth_clip(61, 'white', 5000)
+    x = np.zeros((2, 6000), np.float32)
+    x[0], x[1, :5000] = G['wav'], other
+    out = m.enhance_ragged(torch.from_numpy(x).cuda(), [6000, 5000]).cpu().numpy()
+    err = rms(out[0] - G['enh_cprs'])
+    print('fullsubnet GRU decode rms err', err, 'rms ref', rms(G['enh_cprs']))
+    assert err < 1e-4 and err < 5e-4 * max(rms(G['enh_cprs']), 1e-3)
+    sd = synth.synth_state_dict(m.state_dict_schema(), 25)
+    ref = D.ENHANCE['fullsubnet'](sd, other, 0.5, 2.0)
+    assert rms(out[1, :5000] - ref) < 1e-4
+    with pytest.raises(RuntimeError):                       # an LSTM state dict is not a GRU state dict (strict load)
+        Model(max_batch=1, max_samples=8000, **kw).load_state_dict(synth.synth_state_dict(Model().state_dict_schema(), 15))
+
+
 def test_dpcrn_real_checkpoint_forward_and_decode():
     """Real weights: vb_dpcrn_noncprs (1.0/1.0) and vb_dpcrn_cprs (0.5/2.0) on a full 4 s clip."""
     torch = _torch()

@@ -63,6 +63,18 @@ def test_enhance_matches_reference(name, seed):
     assert rms(y - G['enh']) < 1e-6 * max(rms(G['enh']), 1e-3), (rms(y - G['enh']), rms(G['enh']))
 
 
+def test_fullsubnet_gru_matches_reference():
+    """`Model(sequence_model="GRU")` (FullSubNet/fullsubnet_net_sa/sequence_model.py:36-43): the GRU time step of the north
+    star, pinned like the rest - forward and decode of the imported reference with seeded weights."""
+    G = load_golden('fullsubnet_gru')
+    sd = _sd('fullsubnet_gru', 25)
+    assert sd['sb_model.sequence_model.weight_hh_l0'].shape == (3 * 384, 384)
+    y = M.fullsubnet_forward(sd, G['x'])
+    assert y.shape == G['y'].shape and rms(y - G['y']) < 2e-6 * max(rms(G['y']), 1.0)
+    e = D.ENHANCE['fullsubnet'](sd, G['wav'], 0.5, 2.0)
+    assert e.shape == G['enh_cprs'].shape and rms(e - G['enh_cprs']) < 1e-6 * max(rms(G['enh_cprs']), 1e-3)
+
+
 def test_dccrn_compressed_variant():
     G = load_golden('dccrn')
     y = D.enhance_dccrn(_sd('dccrn', 14), G['wav'], 0.5, 2.0)

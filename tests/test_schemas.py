@@ -5,7 +5,7 @@ from se_amd import schemas
 from conftest import load_schema
 
 
-@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'dccrn', 'fullsubnet', 'gcrn', 'cts_step1', 'cts_step2', 'taylorsenet', 'g2net', 'uformer',
+@pytest.mark.parametrize('name', ['lstm', 'crn', 'dpcrn', 'dccrn', 'fullsubnet', 'fullsubnet_gru', 'gcrn', 'cts_step1', 'cts_step2', 'taylorsenet', 'g2net', 'uformer',
                                   'cts_step1_new', 'cts_step2_new', 'taylorsenet_new', 'g2net_new'])
 def test_schema_matches_reference(name):
     ref = load_schema(name)

@@ -53,6 +53,8 @@ def main():
     ap.add_argument('--readers', type=int, default=4)
     ap.add_argument('--dir', default='/dev/shm/se_corpus')
     ap.add_argument('--keep', action='store_true')
+    ap.add_argument('--repeat', type=int, default=2, help='decode the directory this many times; the LAST pass is reported '
+                    '(the first also pays one-time costs: code-object load, resampler tables, first touch of pinned pages)')
     args = ap.parse_args()
     import torch
     import se_amd  # noqa: F401
@@ -78,9 +80,12 @@ def main():
     else:
         sd = synth.synth_state_dict(schemas.SCHEMAS[name](), 1)
     ns = types.SimpleNamespace(mix_file_path=mix, esti_clean_file_path=out, fs=16000)
-    stats = {}
-    n = decode.enhance(ns, name, state_dict=sd, max_batch=args.max_batch, p_in=0.5, p_out=2.0, verbose=False, stats=stats,
-                       readers=args.readers, rank=rank, world=world)
+    first = None
+    for k in range(max(1, args.repeat)):
+        stats = {}
+        n = decode.enhance(ns, name, state_dict=sd, max_batch=args.max_batch, p_in=0.5, p_out=2.0, verbose=False, stats=stats,
+                           readers=args.readers, rank=rank, world=world)
+        first = first or dict(stats)
     torch.cuda.synchronize()
     # ---- the same calls from device-resident tensors (no file I/O, no upload, no resampling, no PCM conversion)
     lens16 = [wavio.wav_info(os.path.join(mix, f))[0] * 16000 // args.fs for f in sorted(os.listdir(mix))]
@@ -107,6 +112,7 @@ def main():
            'x_realtime': round(stats['audio_s_rank'] / stats['pipeline_s'], 0),
            'resident_clips_per_s': round(len(own) / dt, 1),
            'file_vs_resident': round(stats['clips_per_s'] / (len(own) / dt), 3),
+           'first_pass': {k: first[k] for k in ('setup_s', 'pipeline_s', 'clips_per_s')},
            'corpus_write_s': round(t_corpus, 2), 'host_cpus': os.cpu_count()}
     assert n == len(own) and len(os.listdir(out)) >= n
     print(json.dumps(row), flush=True)

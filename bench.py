@@ -61,36 +61,9 @@ def pmc_traffic():
     return d
 
 
-def _cpu_worker(args):
-    """One CPU worker = one copy of the reference's batch-1 decode loop pinned to a single BLAS thread."""
-    seed, p_in, p_out, clips = args
-    import se_amd  # noqa: F401
-    from se_amd import synth, schemas
-    from oracle import decode as D
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except Exception:       # threadpoolctl missing: OMP/BLAS env limits set by the parent still apply
-        import contextlib
-        ctx = contextlib.nullcontext()
-    sd = synth.synth_state_dict(schemas.dccrn_schema(), seed)
-    with ctx:
-        D.enhance_dccrn(sd, synth.synth_clip(0, 'speech', CLIP_SAMPLES), p_in, p_out)      # warm-up (imports, page-in)
-        t0 = time.time()
-        for n in range(clips):
-            D.enhance_dccrn(sd, synth.synth_clip(n, 'speech', CLIP_SAMPLES), p_in, p_out)
-        return time.time() - t0
-
-
-def cpu_baseline(seed, p_in, p_out):
-    """The numpy oracle (a port of the reference decode loop) on the host cores, bounded sample of the same workload:
-    whole-path decode of 4 s clips, one at a time like the reference's batch-1 loop.  The port's BLAS calls do not scale
-    with threads (a 256-thread run is slower than one thread), so the all-core figure is utterance-parallel: P
-    single-thread worker processes (`bench.py --cpu-worker`), each a copy of the reference loop - how the reference
-    would be spread over a host."""
-    import subprocess
+def _host_cpu():
+    """(model string, physical core count, logical CPU count) of this host."""
     ncpu = os.cpu_count() or 1
-    clips = 2
     cpu_model, cores = 'unknown', set()
     try:
         with open('/proc/cpuinfo') as f:
@@ -104,33 +77,106 @@ def cpu_baseline(seed, p_in, p_out):
                     cores.add((phys, ln.split(':', 1)[1].strip()))
     except OSError:
         pass
-    # one single-thread copy of the reference loop per PHYSICAL core: measured on the 2 x 64-core / 256-thread host of the
-    # GPU box, 64 workers decode 12.0 utt/s, 256 (one per SMT thread) only 5.3 - the port is memory-bound
-    P = len(cores) if cores else max(1, ncpu // 2)
-    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1',
-               HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', str(clips), '--cpu-worker-args',
-           f'{seed},{p_in},{p_out}']
+    return cpu_model, (len(cores) if cores else max(1, ncpu // 2)), ncpu
+
+
+def _cpu_worker(spec):
+    """`bench.py --cpu-worker seed,p_in,p_out,P`: times oracle/dccrn_cpu.cpp (the C++ / OpenMP restatement of the DCCRN
+    decode, pinned by tests/test_dccrn_cpu.py to the reference-generated fixtures) on this host and prints one JSON object.
+    Runs in its own process so that OMP_PROC_BIND / OMP_PLACES take effect before the OpenMP runtime starts."""
+    seed, p_in, p_out, P = spec.split(',')
+    seed, p_in, p_out, P = int(seed), float(p_in), float(p_out), int(P)
+    import se_amd  # noqa: F401
+    from se_amd import synth, schemas
+    from oracle.dccrn_cpu import DccrnCpu
+    net = DccrnCpu(synth.synth_state_dict(schemas.dccrn_schema(), seed))
+    clips = np.stack([synth.synth_clip(n, 'speech', CLIP_SAMPLES) for n in range(8)])
+    net.enhance(clips[:1], p_in, p_out, threads=1, mode=0)                      # warm-up (page-in, first touch)
+    out = {}
+    t0 = time.perf_counter()
+    net.enhance(clips[:3], p_in, p_out, threads=1, mode=0)
+    out['one_thread_utt_s'] = 3 / (time.perf_counter() - t0)
+    # the reference's shape: one clip after the other (`for file_id in file_list`), all cores inside each layer
+    net.enhance(clips[:1], p_in, p_out, threads=P, mode=0)
+    t0 = time.perf_counter()
+    net.enhance(clips[:8], p_in, p_out, threads=P, mode=0)
+    out['batch1_loop_all_cores_utt_s'] = 8 / (time.perf_counter() - t0)
+    # how a host would be filled: P clips in flight, one core each
+    big = np.tile(clips, ((2 * P + 7) // 8, 1))[:2 * P]
+    net.enhance(big[:P], p_in, p_out, threads=P, mode=1)
+    t0 = time.perf_counter()
+    net.enhance(big, p_in, p_out, threads=P, mode=1)
+    out['utterance_parallel_utt_s'] = 2 * P / (time.perf_counter() - t0)
+    out['clips_utterance_parallel'] = 2 * P
+    return out
+
+
+def cpu_baseline(seed, p_in, p_out):
+    """The CPU path next to the GPU number: a compiled C++ / OpenMP restatement of the same DCCRN decode loop
+    (oracle/dccrn_cpu.cpp; kind "port" - the Python reference cannot travel to the GPU box), pinned by the same
+    reference-generated fixtures as the numpy oracle, timed on this host at 1 thread and at all physical cores
+    (SURVEY 8(d)): a bounded sample of the same workload, 4 s clips decoded whole-path."""
+    import subprocess
+    cpu_model, P, ncpu = _host_cpu()
+    env = dict(os.environ, OMP_PROC_BIND='spread', OMP_PLACES='cores', OMP_NUM_THREADS=str(P), HIP_VISIBLE_DEVICES='',
+               ROCR_VISIBLE_DEVICES='')
     t0 = time.time()
-    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(P)]
-    spans = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=max(5.0, 240.0 - (time.time() - t0)))
-            spans.append(float(out.strip().splitlines()[-1]))
-        except Exception:           # a worker that is late or died is dropped from the sample (and reaped)
-            p.kill()
-            p.communicate()
-    if not spans:
-        return {"value": None, "unit": "utt/s", "cores": 0, "kind": "port", "sample": "no CPU worker finished within 240 s",
-                "cpu_model": cpu_model}
-    wall = max(spans)
-    return {"value": round(len(spans) * clips / wall, 3), "unit": "utt/s", "cores": len(spans), "kind": "port",
-            "sample": f"{len(spans)} single-thread worker processes x {clips} x 4 s clips, batch-1 loop each, numpy oracle "
-                      f"(oracle/decode.py:enhance_dccrn), slowest worker {wall:.1f} s, {time.time() - t0:.1f} s with start-up; "
-                      f"host has {ncpu} logical CPUs ({cpu_model})",
-            "cpu_model": cpu_model, "logical_cpus": ncpu, "physical_cores": P,
-            "value_per_worker_best": round(clips / min(spans), 4)}
+    base = {"unit": "utt/s", "kind": "port", "language": "c++ (g++ -O3, OpenMP, AVX-512 / AVX2 clones of the conv micro-kernel)",
+            "source": "oracle/dccrn_cpu.cpp (pinned by tests/test_dccrn_cpu.py to tests/golden/dccrn.npz)",
+            "cpu_model": cpu_model, "logical_cpus": ncpu, "physical_cores": P}
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', f'{seed},{p_in},{p_out},{P}'], env=env,
+                           capture_output=True, text=True, timeout=240)
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as ex:
+        return dict(base, value=None, cores=0, sample=f"CPU worker failed: {type(ex).__name__}")
+    return dict(base, value=round(r['utterance_parallel_utt_s'], 2), cores=P,
+                sample=f"{r['clips_utterance_parallel']} x 4 s clips, {P} in flight (one physical core each, OMP_PLACES=cores); "
+                       f"also 3 clips on 1 thread and 8 clips one after the other with {P} threads inside each layer; "
+                       f"{time.time() - t0:.1f} s with start-up",
+                one_thread_utt_s=round(r['one_thread_utt_s'], 3),
+                one_thread_gflops=round(r['one_thread_utt_s'] * DCCRN_GFLOP_PER_UTT, 1),
+                batch1_loop_all_cores_utt_s=round(r['batch1_loop_all_cores_utt_s'], 2),
+                all_cores_gflops=round(r['utterance_parallel_utt_s'] * DCCRN_GFLOP_PER_UTT, 1))
+
+
+# BASELINE.json's other configurations on the same clock (a few unprofiled steps each, after the headline's timed region):
+# (config, host class key, batch per GPU, SURVEY 8(d) GFLOP per 4 s utterance, constructor exponents)
+OTHER_CONFIGS = [
+    ("configs[0]: LSTM magnitude-mask, one 4 s clip (the reference's CPU plumbing case, here on the GPU)", 'lstm', 1, 17.5, {}),
+    ("configs[1]: CRN real-spectrum mask, batch 64 x 4 s clips", 'crn', 64, 17.3, {}),
+    ("configs[3]: FullSubNet full-band + sub-band LSTM, per-GPU utterance shard of 128 clips", 'fullsubnet', 128, 238.5, {}),
+    ("configs[4]: Uformer dual-path complex conformer, per-GPU utterance shard of 256 clips", 'uformer', 256, 27.5, {}),
+]
+
+
+def run_other_configs(torch, local_rank, steps):
+    from se_amd import synth
+    from se_amd.models import MODEL_CLASSES
+    rows = []
+    base = synth.synth_batch(16, 'speech', CLIP_SAMPLES, seed0=300)
+    for cfg, name, B, gflop, kw in OTHER_CONFIGS:
+        m = MODEL_CLASSES[name](device=local_rank, max_batch=B, max_samples=CLIP_SAMPLES, **kw).load_synthetic(1)
+        eng = m.engine
+        wav = torch.from_numpy(np.tile(base, ((B + 15) // 16, 1))[:B].copy()).cuda()
+        out = torch.empty((B, eng.output_samples(CLIP_SAMPLES)), dtype=torch.float32, device=wav.device)
+        for _ in range(2):
+            eng.enhance_batch(wav, out)
+        torch.cuda.synchronize()
+        k = max(steps, 20) if B == 1 else steps
+        t0 = time.perf_counter()
+        for _ in range(k):
+            eng.enhance_batch(wav, out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        assert bool(torch.isfinite(out).all()), name
+        ups = B / dt
+        rows.append({"config": cfg, "model": name, "batch": B, "steps": k, "utt_s": round(ups, 1), "ms_per_step": round(dt * 1e3, 3),
+                     "x_realtime": round(ups * CLIP_SECONDS, 0), "gflop_per_utt": gflop,
+                     "achieved": round(ups * gflop / 1e3, 2), "frac": round(ups * gflop / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)})
+        del m, eng, wav, out
+        torch.cuda.empty_cache()
+    return rows
 
 
 def self_launch(n):
@@ -159,12 +205,11 @@ def main():
                     help='initialise the process group and run the gather collective even with one rank (RCCL smoke on a 1-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--cpu-worker', type=int, default=0, help='internal: decode N clips with the numpy oracle, print seconds')
-    ap.add_argument('--cpu-worker-args', type=str, default='14,0.5,2.0')
+    ap.add_argument('--no-configs', action='store_true', help="skip BASELINE's other configurations (roofline.configs)")
+    ap.add_argument('--cpu-worker', type=str, default='', help='internal: "seed,p_in,p_out,P" - time the C++ CPU restatement, print JSON')
     args = ap.parse_args()
     if args.cpu_worker:
-        seed, p_in, p_out = args.cpu_worker_args.split(',')
-        print(_cpu_worker((int(seed), float(p_in), float(p_out), args.cpu_worker)), flush=True)
+        print(json.dumps(_cpu_worker(args.cpu_worker)), flush=True)
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -273,6 +318,10 @@ def main():
                 "algorithmic_GB_per_launch": round((rd_b + wr_b) / 1e9 / max(prof['gemm_launches'], 1), 3),
                 "launches_per_step": prof['gemm_launches'],
                 "algorithmic_gflop_per_step": round(prof['gemm_flops'] / 1e9, 1),
+                "algorithmic_gflop_note": "counted on the clips' own frame count (T = 501), not on the 504 frames the engine "
+                                          "runs to keep rows whole 16 B groups",
+                "profiler_events_in_timed_region": True,
+                "traffic_source_commit": pmc.get('commit') if pmc else None,
                 "kernel_ms_per_step": round(prof['gemm_ms'], 3),
                 "avg_launch_us": round(1e3 * prof['gemm_ms'] / max(prof['gemm_launches'], 1), 2),
                 "share_of_step": round(prof['gemm_ms'] / (1e3 * dt / args.steps), 4),
@@ -295,6 +344,19 @@ def main():
                  "frac": round(v['bytes'] / 1e9 / max(v['ms'] * 1e-3, 1e-12) / HBM_PEAK_GBS, 4),
                  "share_of_step": round(v['ms'] / (1e3 * dt / args.steps), 5)}
                 for k, v in stages.items() if v['launches'] > 0]
+        if world == 1 and not args.no_configs and "roofline" in res:
+            # the headline engine's 24 GB go back first (FullSubNet's shard needs most of the HBM)
+            del model, eng, pipe, out, wav
+            torch.cuda.empty_cache()
+            head = {"config": "configs[2]: DCCRN complex-mask, compressed input, batch %d (the headline above)" % B,
+                    "model": "dccrn", "batch": B, "steps": args.steps, "utt_s": round(value, 1),
+                    "ms_per_step": round(1e3 * dt / args.steps, 3), "x_realtime": round(value * CLIP_SECONDS, 0),
+                    "gflop_per_utt": DCCRN_GFLOP_PER_UTT, "achieved": res["roofline_whole_path"]["achieved"],
+                    "frac": res["roofline_whole_path"]["frac"]}
+            rows = run_other_configs(torch, local_rank, max(3, min(args.steps, 10)))
+            res["roofline"]["configs"] = rows[:2] + [head] + rows[2:]
+            res["roofline"]["configs_note"] = ("whole decode path per config: utt/s x SURVEY 8(d) GFLOP per utterance against the "
+                                              "f32 MFMA peak; unprofiled steps timed by the host clock around a device sync")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(seed, p_in, p_out)
         print(json.dumps(res), flush=True)

@@ -98,6 +98,8 @@ struct Profiler {
     std::vector<hipEvent_t> ev;
     size_t used = 0;
     double flops = 0.0;
+    double fscale = 1.0;    // algorithmic / executed frames: PadFrames runs a batch with the frame count rounded up to whole 16 B
+                            // groups; the FLOPs reported are those of the clip's own frame count, not of the padding
     long launches = 0;
     void begin(hipStream_t st);
     void end(hipStream_t st, double fl);

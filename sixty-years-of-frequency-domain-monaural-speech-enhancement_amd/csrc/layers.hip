@@ -335,7 +335,7 @@ void Profiler::end(hipStream_t st, double fl) {
     if (!on) return;
     SE_HIP(hipEventRecord(ev[used + 1], st));
     used += 2;
-    flops += fl;
+    flops += fl * fscale;
     launches += 1;
 }
 double Profiler::total_ms() {

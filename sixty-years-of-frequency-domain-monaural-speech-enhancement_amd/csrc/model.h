@@ -90,9 +90,19 @@ struct PadFrames {
         rg = Ragged{ctx.eq_rows, ctx.eq_rows + MB, ctx.eq_rows + 2 * MB, ctx.eq_rows + 3 * MB};
         set_ragged_ctx(&rg);
         on = true;
+        pctx = &ctx;
+        set_fscale((double)T_true / T);        // every launch of these networks is linear in the frame count
     }
     ~PadFrames() {
-        if (on) set_ragged_ctx(nullptr);
+        if (on) {
+            set_ragged_ctx(nullptr);
+            set_fscale(1.0);
+        }
+    }
+    EngineCtx* pctx = nullptr;
+    void set_fscale(double v) {
+        pctx->prof.fscale = v;
+        for (auto& p : pctx->aux_prof) p.fscale = v;
     }
     PadFrames(const PadFrames&) = delete;
     PadFrames& operator=(const PadFrames&) = delete;

@@ -28,6 +28,7 @@ def load(path):
 def main():
     src, out = sys.argv[1], sys.argv[2]
     steps = int(sys.argv[sys.argv.index('--steps') + 1]) if '--steps' in sys.argv else 1
+    commit = sys.argv[sys.argv.index('--commit') + 1] if '--commit' in sys.argv else None      # HEAD of the profiled tree
     fe = load(os.path.join(src, 'FETCH_SIZE', 'p_counter_collection.csv'))
     wr = load(os.path.join(src, 'WRITE_SIZE', 'p_counter_collection.csv'))
     sq = load(os.path.join(src, 'SQ_VALU_MFMA_BUSY_CYCLES', 'p_counter_collection.csv'))
@@ -55,6 +56,7 @@ def main():
            'read_GB_per_step': round(sum(r['read_GB_per_step'] for r in gc), 3),
            'write_GB_per_step': round(sum(r['write_GB_per_step'] for r in gc), 3)}
     fam['traffic_GB_per_launch'] = round((fam['read_GB_per_step'] + fam['write_GB_per_step']) / fam['launches_per_step'], 4)
+    fam['commit'] = commit
     res = {'steps': steps, 'gc_family': fam, 'kernels': rows}
     json.dump(res, open(out + '.json', 'w'), indent=1)
     with open(out + '.md', 'w') as f:

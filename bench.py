@@ -334,9 +334,9 @@ def main():
             # the HBM-bound front / back-end kernels of the same (last timed) step: algorithmic bytes over
             # their HIP-event time, against the HBM peak
             names = {'rms': 'se::rms_partial_kernel + rms_finish_kernel (c = sqrt(L / sum x^2))',
-                     'stft': 'se::stft_kernel<512> (frame, reflect pad, Hann, LDS Stockham FFT, x*c, |X|^p)',
+                     'stft': 'se::stft2_kernel<512> (frame, reflect pad, Hann, register-resident radix-8 FFT, x*c, |X|^p, 128 B runs)',
                      'mask': 'se::dccrn_mask_kernel (E mask + decompress)',
-                     'istft': 'se::istft_ola_kernel<512> (inverse FFT + overlap-add + /c, frames stay in LDS)'}
+                     'istft': 'se::istft2_kernel<512> (register-resident inverse FFT + overlap-add + /c, frames stay in LDS)'}
             res["roofline_stages"] = [
                 {"stage": k, "kernel": names[k], "bound": "hbm", "ms_per_step": round(v['ms'], 4),
                  "algorithmic_GB_per_step": round(v['bytes'] / 1e9, 4),

@@ -114,10 +114,12 @@ void run_layer(const Layer& L, const Tensor& in, Tensor& out, int Fout, int thre
     const int T = in.T;
     out.shape(L.Cout, Fout, T);
     const int ncb = L.CoP / CB, ntt = (T + TB - 1) / TB;
-    const long tasks = (long)Fout * ncb;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) if (threads > 1)
+    const long tasks = (long)Fout * ntt;
+    // one task = one output row x one 32-frame tile, all output channels: the input patch of the tile (<= 5 rows x Cin x 32
+    // frames) stays in the core's L2 while the layer's weights stream through it from the shared L3
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads) if (threads > 1)
     for (long task = 0; task < tasks; ++task) {
-        const int fo = (int)(task / ncb), cb = (int)(task % ncb);
+        const int fo = (int)(task / ntt), tt = (int)(task % ntt);
         RowTap rt[10];
         int n = 0;
         for (int kf = 0; kf < 5; ++kf) {
@@ -138,13 +140,14 @@ void run_layer(const Layer& L, const Tensor& in, Tensor& out, int Fout, int thre
                 ++n;
             }
         }
-        float* orow[CB];
-        const int co0 = cb * CB, ncv = std::min(CB, L.Cout - co0);
-        for (int c = 0; c < ncv; ++c) orow[c] = out.row(co0 + c, fo);
-        for (int tt = 0; tt < ntt; ++tt)
+        for (int cb = 0; cb < ncb; ++cb) {
+            float* orow[CB];
+            const int co0 = cb * CB, ncv = std::min(CB, L.Cout - co0);
+            for (int c = 0; c < ncv; ++c) orow[c] = out.row(co0 + c, fo);
             conv_tile(rt, n, L.Cin, L.CoP, co0, tt * TB, orow, L.scale.data(), L.shift.data(), L.slope, ncv);
-        for (int c = 0; c < ncv; ++c)                    // frames past T must read as zeros for the next layer's look-ahead
-            std::fill(orow[c] + T, orow[c] + (out.P - LEAD), 0.f);
+            if (tt == ntt - 1)                               // frames past T must read as zeros for the next layer's look-ahead
+                for (int c = 0; c < ncv; ++c) std::fill(orow[c] + T, orow[c] + (out.P - LEAD), 0.f);
+        }
     }
 }
 
@@ -307,8 +310,10 @@ struct Model {
     }
 };
 
-struct Work {                       // per-thread activations
-    Tensor x0, e[6], d, cat, r, i, a, b, c2, d2, gx, ro, io, r2, i2, pr, pi;
+struct Work {                       // per-thread buffers, reused from clip to clip (no allocation after the first clip)
+    Tensor x0, e[6], d, tmp, cat, r, i, a, b, c2, d2, gx, ro, io, r2, i2, pr, pi;
+    std::vector<float> x, feat, est;
+    std::vector<double> y, env, frames;
 };
 
 // NavieComplexLSTM.forward([r, i]): real = real_lstm(r) - imag_lstm(i); imag = real_lstm(i) + imag_lstm(r)
@@ -361,7 +366,7 @@ void forward(const Model& m, const float* in, int T, float* out, Work& w, int th
         }
     // :196-199 decoder: complex_cat([out, skip]) = [out_r, skip_r, out_i, skip_i]
     Tensor* dcur = &w.d;
-    Tensor tmp;
+    Tensor& tmp = w.tmp;
     F = 4;
     for (int k = 0; k < 6; ++k) {
         const Tensor& sk = w.e[5 - k];
@@ -443,10 +448,13 @@ void enhance_one(const Model& m, const float* wav, long n, float p_in, float p_o
     for (long k = 0; k < n; ++k) ss += (double)wav[k] * wav[k];
     const double c = std::sqrt((double)n / ss);                                        // :27
     const long L = padded_len(n);
-    std::vector<float> x(L, 0.f);
+    std::vector<float>& x = w.x;
+    x.assign(L, 0.f);
     for (long k = 0; k < n; ++k) x[k] = (float)((double)wav[k] * c);                  // :28, FloatTensor :36
     const int T = 1 + (int)(L / HOP), pad = NFFT / 2;
-    std::vector<float> feat((size_t)2 * NBIN * T), est((size_t)2 * NBIN * T);
+    std::vector<float>&feat = w.feat, &est = w.est;
+    feat.resize((size_t)2 * NBIN * T);
+    est.resize((size_t)2 * NBIN * T);
     const Fft& F = fft();
 #pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
     for (int t = 0; t < T; ++t) {                                                      // torch.stft, centre = True, reflect pad
@@ -469,8 +477,10 @@ void enhance_one(const Model& m, const float* wav, long n, float p_in, float p_o
     }
     forward(m, feat.data(), T, est.data(), w, threads);                                // :44
     const long full = NFFT + (long)HOP * (T - 1);
-    std::vector<double> y(full, 0.0), env(full, 0.0);
-    std::vector<double> frames((size_t)T * NFFT);
+    std::vector<double>&y = w.y, &env = w.env, &frames = w.frames;
+    y.assign(full, 0.0);
+    env.assign(full, 0.0);
+    frames.resize((size_t)T * NFFT);
 #pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
     for (int t = 0; t < T; ++t) {                                                      // :45-58 + irfft per frame
         std::complex<double> a[NFFT];

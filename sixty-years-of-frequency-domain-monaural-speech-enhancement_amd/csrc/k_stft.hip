@@ -427,6 +427,10 @@ void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, 
     StageScope prof(STAGE_STFT, s, 4.0 * L * B + (spec_ri ? 8.0 : 0.0) * g.F() * T * B + (mag ? 4.0 : 0.0) * g.F() * T * B);
     StftArgs a{wav, pitch, B, L, Lpad, c_scale, p_in, spec_ri, mag, T, Tp, g.hop, g.win,
                rg ? rg->len : nullptr, rg ? rg->lpad : nullptr, rg ? rg->tlen : nullptr, t_first, col0};
+    if (stft2_enabled() && (g.n_fft == 512 || g.n_fft == 320)) {       // register-resident FFT, 128 B runs (k_stft2.hip)
+        launch_stft2(g, wav, pitch, B, L, Lpad, c_scale, p_in, spec_ri, mag, T, Tp, s, t_first, col0);
+        return;
+    }
     dim3 grid((T - t_first + FPB - 1) / FPB, B);
     if (g.n_fft == 512) {
         static bool seen[64] = {};
@@ -446,6 +450,11 @@ void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp,
                   const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo) {
     const Ragged* rg = ragged_ctx();
     StageScope prof(STAGE_ISTFT, s, 8.0 * g.F() * T * B + 4.0 * Lout * B);
+    SE_CHECK(Lout > o_lo, "launch_istft: empty output range");
+    if (stft2_enabled() && (g.n_fft == 512 || g.n_fft == 320)) {
+        launch_istft2(g, spec_ri, B, T, Tp, c_scale, wav_out, out_pitch, Lout, s, t_off, t_lo, o_lo);
+        return;
+    }
     int halo = (g.n_fft + g.hop - 1) / g.hop - 1;
     halo += halo & 1;                                       // frames are transformed in pairs
     SE_CHECK(halo < FPB, "hop too small for the fused overlap-add window");

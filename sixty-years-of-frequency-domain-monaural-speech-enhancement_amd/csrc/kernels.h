@@ -79,6 +79,14 @@ void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp,
                   const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s, int t_off = 0, int t_lo = 0,
                   int o_lo = 0);
 
+// round-3 kernels behind the two launchers above (k_stft2.hip): FFT points in registers, two LDS exchanges, 32-frame tiles
+// moved through LDS so that the [F][T]-major spectrogram is touched in 128 B runs; SE_STFT_V1=1 selects the old kernels
+bool stft2_enabled();
+void launch_stft2(const StftGeom& g, const float* wav, long pitch, int B, int L, int Lpad, const float* c_scale, float p_in,
+                  float* spec_ri, float* mag, int T, int Tp, hipStream_t s, int t_first, int col0);
+void launch_istft2(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, const float* c_scale, float* wav_out,
+                   long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo);
+
 // Frame-online context of the models that are built from shared blocks (blocks.h / unet.h: the cLN `_new` variants).
 // While a chunk is decoded the model publishes it thread-locally; every activation of the chunk is a window of H history
 // columns + n new frames (row pitch H + n), and the shared launch helpers then

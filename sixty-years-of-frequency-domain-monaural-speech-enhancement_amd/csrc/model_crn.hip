@@ -189,10 +189,18 @@ class Crn final : public Model {
             x = act4(b.E[i], EC[i], EF[i], T);
         }
         // CRN.py:27-31  [B,256,T,4] -> [B,T,1024] -> LSTM x2 -> back;  engine: [B][1024][T] <-> [T][1024][B]
-        launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, 1024L * B, B, st);
-        lstm[0].run(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
-        lstm[1].run(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
-        launch_transpose_akt(b.Hs[1], b.D[0], T, 1024, B, 1024L * B, B, 1024L * T, T, st);
+        if (lstm[0].fm_ok(B) && lstm[1].fm_ok(B)) {
+            // feature-major [1024][T][B] (rnn.h run_fm): the two 4096 x 1024 input projections are full-width GEMMs
+            launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, B, (long)T * B, st);
+            lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
+            lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+            launch_transpose_akt(b.Hs[1], b.D[0], T, 1024, B, B, (long)T * B, 1024L * T, T, st);
+        } else {
+            launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, 1024L * B, B, st);
+            lstm[0].run(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
+            lstm[1].run(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+            launch_transpose_akt(b.Hs[1], b.D[0], T, 1024, B, 1024L * B, B, 1024L * T, T, st);
+        }
         const int DCo[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
         int cin = 256, fin = 4;
         for (int i = 0; i < 5; ++i) {
@@ -212,6 +220,7 @@ class LstmNet final : public Model {
     ~LstmNet() override {
         for (auto& l : lstm) l.free();
         gc_free_plan(fc);
+        gc_free_plan(fc_fm);
     }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
 
@@ -225,6 +234,7 @@ class LstmNet final : public Model {
         lstm[2].build(load_lstm(sd, "lstm2.", 1, "", 1024, 1024), ctx.max_batch);
         DenseW f = linear_weights(sd.get("fc.0.weight", {NBIN, 1024}), &sd.get("fc.0.bias", {NBIN}));
         fc = make_pointwise_plan(f, ACT_SOFTPLUS, {}, ctx.max_batch);       // :20-22
+        fc_fm = make_pointwise_plan(f, ACT_SOFTPLUS, {}, 4096);             // the same layer over feature-major rows
     }
 
     void plan_buffers(int B, int T) override {
@@ -236,6 +246,13 @@ class LstmNet final : public Model {
         SE_CHECK(ndim == 3 && shape[2] == NBIN, "LSTM forward expects [B,T,161]");
         const int B = (int)shape[0], T = (int)shape[1];
         Bufs& b = bufs(B, T);
+        if (fm(B)) {
+            // [B][T][161] -> [161][T][B] and back
+            launch_transpose_akt(in, b.X, B, T, NBIN, (long)T * NBIN, NBIN, (long)T * B, B, st);
+            network_fm(b, st);
+            launch_transpose_akt(b.Y, out, NBIN, T, B, (long)T * B, B, (long)T * NBIN, NBIN, st);
+            return;
+        }
         // [B][T*161] -> [T*161][B]
         launch_transpose_akt(in, b.X, B, 1, T * NBIN, (long)T * NBIN, 0, B, 0, st);
         network(b, st);
@@ -247,9 +264,15 @@ class LstmNet final : public Model {
         Bufs& b = bufs(B, T);
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // lstm_decode_vb.py:35-36
         launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, b.mag, T, T, st);        // :37-38
-        launch_transpose_akt(b.mag, b.X, B, NBIN, T, (long)NBIN * T, T, (long)NBIN * B, B, st);    // [B][161][T] -> [T][161][B]
-        network(b, st);                                                                            // :44
-        launch_transpose_akt(b.Y, b.mag, T, NBIN, B, (long)NBIN * B, B, (long)NBIN * T, T, st);
+        if (fm(B)) {
+            launch_transpose_akt(b.mag, b.X, B, NBIN, T, (long)NBIN * T, T, B, (long)T * B, st);       // [B][161][T] -> [161][T][B]
+            network_fm(b, st);                                                                         // :44
+            launch_transpose_akt(b.Y, b.mag, T, NBIN, B, B, (long)T * B, (long)NBIN * T, T, st);
+        } else {
+            launch_transpose_akt(b.mag, b.X, B, NBIN, T, (long)NBIN * T, T, (long)NBIN * B, B, st);    // [B][161][T] -> [T][161][B]
+            network(b, st);                                                                            // :44
+            launch_transpose_akt(b.Y, b.mag, T, NBIN, B, (long)NBIN * B, B, (long)NBIN * T, T, st);
+        }
         launch_mag_phase(b.mag, b.spec, b.est, B, NBIN, T, ctx.p_out, st);                         // :47-49
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :50-52
     }
@@ -300,7 +323,7 @@ class LstmNet final : public Model {
         float *c, *spec, *mag, *est, *frames, *X, *Y, *G, *Hs[2], *cell;
     } cur;
     LstmBig lstm[3];
-    GCPlan fc;
+    GCPlan fc, fc_fm;
     StreamState ss;
 
     Bufs& bufs(int B, int T) {
@@ -326,6 +349,17 @@ class LstmNet final : public Model {
         return cur;
     }
 
+    bool fm(int B) const { return lstm[0].fm_ok(B) && lstm[1].fm_ok(B) && lstm[2].fm_ok(B); }
+    // feature-major twin of network(): b.X [161][T][B] -> b.Y [161][T][B] (rnn.h run_fm)
+    void network_fm(Bufs& b, hipStream_t st) {
+        const int B = b.B, T = b.T;
+        const long N = (long)T * B;
+        Profiler* pf = &ctx.prof;
+        lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
+        lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+        lstm[2].run_fm(b.Hs[1], b.G, b.cell, b.Hs[0], T, B, st, pf);
+        run_pointwise(fc_fm, b.Hs[0], 0, N, b.Y, 0, N, 1, (int)N, st, pf);
+    }
     // b.X [T][161][B] -> b.Y [T][161][B]
     void network(Bufs& b, hipStream_t st) {
         const int B = b.B, T = b.T;

@@ -138,6 +138,7 @@ inline void run_pointwise_cols(const GCPlan& pl, const float* src, long s_o, lon
 // as one GEMM over all steps, then one fused GEMM + LSTM-cell launch per step (weights stream from L2 / Infinity Cache).
 struct LstmBig {
     GCPlan gin, step;
+    GCPlan gin_fm;                // the input projection planned for feature-major activations (rows of T * S frames)
     float* whh_dev = nullptr;     // row-major [4H][H] (gate-interleaved rows) for the weight-stationary cooperative kernel
     int I = 0, H = 0;
     // gru: w comes from load_gru (GRU cell in the step epilogue; one launch per step - the weight-stationary cooperative
@@ -148,11 +149,38 @@ struct LstmBig {
         gin = make_pointwise_plan(w.wih, ACT_NONE, {}, s_hint);
         step = gc_make_plan(4 * H, H, one_tap(), w.whh.w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, s_hint);
         step.p.gru = gru ? 1 : 0;
-        if (!gru && (H == 512 || H == 1024)) whh_dev = to_device(w.whh.w);
+        if (!gru && (H == 512 || H == 1024)) {
+            whh_dev = to_device(w.whh.w);
+            gin_fm = make_pointwise_plan(w.wih, ACT_NONE, {}, 4096);
+            has_fm = true;
+        }
+    }
+    bool has_fm = false;
+    // Feature-major form: x [I][T][S] -> out [H][T][S] (G scratch [4H][T][S]).  In the time-major layout a row of the input
+    // projection is the S sequences of ONE step, so its GEMM tiles are at most S columns wide: 128 x 64 tiles at batch 64
+    // (97 TFLOP/s on CRN's 4096 x 1024 projections), one useful column of 64 at batch 1 (LSTM model: 0.9 ms per layer for
+    // 3.4 GFLOP).  With the features outermost the T * S (frame, sequence) pairs of a feature are ONE contiguous row and
+    // the projection is a full-width GEMM whatever the batch; the cooperative recurrence reads / writes through strides.
+    bool fm_ok(int S) const { return has_fm && coop_enabled() && lstm_coop_supported(H, S, 1); }
+    void run_fm(const float* x, float* G, float* cell, float* out, int T, int S, hipStream_t st, Profiler* prof) const {
+        const long N = (long)T * S;
+        run_pointwise(gin_fm, x, 0, N, G, 0, N, 1, (int)N, st, prof);
+        LstmCoopArgs a{};
+        a.gx = G; a.whh = whh_dev; a.out = out; a.cell = cell;
+        a.gx_z = 0; a.gx_t = S; a.gx_row = N;
+        a.whh_z = 0;
+        a.out_z = 0; a.out_t = S; a.out_row = N;
+        a.H = H; a.T = T; a.S = S; a.Z = 1; a.reverse = 0;
+        const bool timed = prof && prof->on;
+        if (timed) prof->begin(st);
+        launch_lstm_coop(a, st);
+        if (timed) prof->end(st, 2.0 * 4 * H * (double)H * S * (T - 1));
     }
     void free() {
         gc_free_plan(gin);
         gc_free_plan(step);
+        if (has_fm) gc_free_plan(gin_fm);
+        has_fm = false;
         if (whh_dev) (void)hipFree(whh_dev);
         whh_dev = nullptr;
     }

@@ -375,11 +375,24 @@ __global__ __launch_bounds__(Shape<true>::NT) void istft2_kernel(const Istft2Arg
     float* tile = smem;
     float* wls = smem + NFB * N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
+    // Neighbouring blocks of a row read overlapping frame windows (halo) out of the same 128 B lines, but consecutive
+    // workgroup ids go to different XCDs (id mod 8), each with its own L2: remap so that an XCD walks a contiguous range of
+    // (row, window) pairs and the shared lines are L2 hits (PMC: 0.598 -> 0.266 GB read per launch at batch 256, 2.3x -> 1.0x
+    // the algorithmic bytes)
+    int bx = blockIdx.x, b = blockIdx.y;
+    {
+        const unsigned nx = gridDim.x, total = nx * gridDim.y, lin = blockIdx.x + nx * blockIdx.y;
+        const unsigned per = total >> 3, body = per << 3;
+        if (per > 0 && lin < body) {
+            const unsigned m = (lin & 7) * per + (lin >> 3);
+            bx = m % nx;
+            b = m / nx;
+        }
+    }
     const int Tb = a.tlen ? a.tlen[b] : a.T;
     const int Lo = a.olen ? a.olen[b] : a.Lout;
     const int span = a.own * a.hop;
-    const int pos0 = a.pos_base + blockIdx.x * span;
+    const int pos0 = a.pos_base + bx * span;
     const int tb = pos0 / a.hop - a.halo;
     float* outp = a.out + (long)b * a.out_pitch - a.o_lo;
     if (pos0 - N / 2 >= Lo || tb >= Tb) {       // nothing of this row left: zeros up to Lout (block-uniform)

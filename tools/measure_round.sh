@@ -10,11 +10,11 @@ mkdir -p $OUT $OUT/pmc
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o s -- \
-    python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/kt.log 2>&1
+    python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-configs > $OUT/kt.log 2>&1
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"; do
     D=$OUT/pmc/$(echo $C | cut -d' ' -f1)
     timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o p -- \
-        python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $D.log 2>&1
+        python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-profile > $D.log 2>&1
 done
 ls -la $OUT $OUT/pmc/*/ | head -40
 tail -c 600 $OUT/bench.json

@@ -98,14 +98,22 @@ inline bool first_on_device(bool (&seen)[64]) {
 // into its kernel nodes (cooperative-LSTM exchange / flags, cLN statistics, InstanceNorm partial sums) and the old
 // buffer is large enough for that shape, so replaying it after a larger shape has grown the slot stays valid.  Capacity
 // at least doubles on growth, so the retired buffers of a slot sum to less than its final size.
-inline char* device_scratch(int purpose, size_t need, hipStream_t s) {
+struct ScratchPool {
     struct Slot { char* p = nullptr; size_t cap = 0; std::vector<char*> retired; };
-    static std::map<std::tuple<int, int, hipStream_t>, Slot> slots;
-    static std::mutex mu;
+    std::map<std::tuple<int, int, hipStream_t>, Slot> slots;
+    std::mutex mu;
+    int live[64] = {};            // engines alive per device
+};
+inline ScratchPool& scratch_pool() {
+    static ScratchPool pool;
+    return pool;
+}
+inline char* device_scratch(int purpose, size_t need, hipStream_t s) {
+    ScratchPool& P = scratch_pool();
     int dev = 0;
     SE_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    Slot& sl = slots[std::make_tuple(purpose, dev, s)];
+    std::lock_guard<std::mutex> lk(P.mu);
+    ScratchPool::Slot& sl = P.slots[std::make_tuple(purpose, dev, s)];
     if (need > sl.cap) {
         if (sl.p) sl.retired.push_back(sl.p);
         const size_t cap = need > 2 * sl.cap ? need : 2 * sl.cap;
@@ -113,6 +121,29 @@ inline char* device_scratch(int purpose, size_t need, hipStream_t s) {
         sl.cap = cap;
     }
     return sl.p;
+}
+// Engine lifetime bookkeeping (se_engine_create / se_engine_destroy): when the LAST engine of a device goes away, the
+// device's scratch slots (and the buffers they retired) are freed - a long-lived process that creates and destroys engines
+// does not accumulate them, and a recycled stream handle cannot inherit another engine's slot.
+inline void scratch_engine_created(int dev) {
+    ScratchPool& P = scratch_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (dev >= 0 && dev < 64) ++P.live[dev];
+}
+inline void scratch_engine_destroyed(int dev) {
+    ScratchPool& P = scratch_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (dev < 0 || dev >= 64 || --P.live[dev] > 0) return;
+    P.live[dev] = 0;
+    for (auto it = P.slots.begin(); it != P.slots.end();) {
+        if (std::get<1>(it->first) == dev) {
+            if (it->second.p) (void)hipFree(it->second.p);
+            for (char* r : it->second.retired) (void)hipFree(r);
+            it = P.slots.erase(it);
+        } else {
+            ++it;
+        }
+    }
 }
 
 // A host copy of one state-dict entry (fp32; int64 buffers are accepted and dropped).

@@ -151,6 +151,7 @@ int se_engine_create(const se_config* cfg, se_engine** out) {
             e->ctx.geom = StftGeom{cfg->n_fft, cfg->hop > 0 ? cfg->hop : e->ctx.geom.hop, cfg->win > 0 ? cfg->win : cfg->n_fft};
         }
         *out = e;
+        scratch_engine_created(cfg->device);
     });
     if (rc && e) {
         delete e;
@@ -181,7 +182,9 @@ int se_engine_destroy(se_engine* e) {
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     if (e->ctx.arena.base()) gc_unregister_overread_range(e->ctx.arena.base());
+    const int dev = e->cfg.device;
     delete e;
+    scratch_engine_destroyed(dev);      // the device's last engine takes the engine-lifetime scratch slots with it
     if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     return 0;
 }

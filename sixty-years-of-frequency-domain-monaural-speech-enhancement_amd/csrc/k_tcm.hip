@@ -19,6 +19,11 @@
 
 namespace se {
 
+static int tcm_dbg_env() {
+    static const int v = getenv("SE_TCM_DBG") ? atoi(getenv("SE_TCM_DBG")) : 0;
+    return v;
+}
+
 typedef float tcm_x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -429,7 +434,7 @@ void launch_tcm_fused(const TcmFusedW& f, const TcmFusedHeads& hd, const float* 
     const Ragged* rg = ragged_ctx();
     TcmFusedArgs a{x, y, B, T, Tp, f.w1, f.w2L, f.w2R, f.w3,
                    {hd.sL, hd.gL, hd.bL, hd.firL}, {hd.sR, hd.gR, hd.bR, hd.firR}, {hd.sO, hd.gO, hd.bO, nullptr},
-                   dil, K, rg ? rg->tlen : nullptr, 0, getenv("SE_TCM_DBG") ? atoi(getenv("SE_TCM_DBG")) : 0};
+                   dil, K, rg ? rg->tlen : nullptr, 0, tcm_dbg_env()};
     size_t lds = ((size_t)TCM_C * Tp + TCM_NW * TCM_C + 5 * TCM_C + 2 * 16 * 128) * sizeof(float);
     static const bool strip_env = !(getenv("SE_TCM_STRIP") && atoi(getenv("SE_TCM_STRIP")) == 0);
     const size_t strip_bytes = (size_t)TCM_NW * 32 * 36 * sizeof(float);

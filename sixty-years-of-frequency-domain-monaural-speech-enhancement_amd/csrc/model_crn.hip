@@ -86,10 +86,10 @@ class Crn final : public Model {
         ss.release();
         ss.B = B;
         ss.first = true;
-        for (long rows : stream_rows()) ss.hist.push_back(zeros((size_t)B * rows * STREAM_HC, st));
+        for (long rows : stream_rows()) ss.hist.push_back(ss.zeros((size_t)B * rows * STREAM_HC, st));
         for (int l = 0; l < 2; ++l) {
-            ss.h[l] = zeros((size_t)1024 * B, st);
-            ss.c[l] = zeros((size_t)1024 * B, st);
+            ss.h[l] = ss.zeros((size_t)1024 * B, st);
+            ss.c[l] = ss.zeros((size_t)1024 * B, st);
         }
         (void)max_chunk;
     }
@@ -283,11 +283,11 @@ class LstmNet final : public Model {
         ss.release();
         ss.B = B;
         ss.first = true;
-        ss.hist.push_back(zeros((size_t)B * 2 * NBIN * STREAM_HC, st));      // spec
-        ss.hist.push_back(zeros((size_t)B * NBIN * STREAM_HC, st));          // est magnitudes
+        ss.hist.push_back(ss.zeros((size_t)B * 2 * NBIN * STREAM_HC, st));      // spec
+        ss.hist.push_back(ss.zeros((size_t)B * NBIN * STREAM_HC, st));          // est magnitudes
         for (int l = 0; l < 3; ++l) {
-            ss.h[l] = zeros((size_t)1024 * B, st);
-            ss.c[l] = zeros((size_t)1024 * B, st);
+            ss.h[l] = ss.zeros((size_t)1024 * B, st);
+            ss.c[l] = ss.zeros((size_t)1024 * B, st);
         }
         (void)max_chunk;
     }

@@ -204,10 +204,10 @@ class Dccrn final : public Model {
         ss.release();
         ss.B = B;
         ss.first = true;
-        for (long rows : stream_rows()) ss.hist.push_back(zeros((size_t)B * rows * DHC, st));
+        for (long rows : stream_rows()) ss.hist.push_back(ss.zeros((size_t)B * rows * DHC, st));
         for (int l = 0; l < 2; ++l) {           // [2 real LSTMs][128][2B]
-            ss.h[l] = zeros((size_t)2 * 128 * 2 * B, st);
-            ss.c[l] = zeros((size_t)2 * 128 * 2 * B, st);
+            ss.h[l] = ss.zeros((size_t)2 * 128 * 2 * B, st);
+            ss.c[l] = ss.zeros((size_t)2 * 128 * 2 * B, st);
         }
         (void)max_chunk;
     }

@@ -118,10 +118,10 @@ class Dpcrn final : public Model {
         ss.release();
         ss.B = B;
         ss.first = true;
-        for (long rows : stream_rows()) ss.hist.push_back(zeros((size_t)B * rows * STREAM_HC, st));
+        for (long rows : stream_rows()) ss.hist.push_back(ss.zeros((size_t)B * rows * STREAM_HC, st));
         for (int l = 0; l < 4; ++l) {
-            ss.h[l] = zeros((size_t)CH * NF * B, st);
-            ss.c[l] = zeros((size_t)CH * NF * B, st);
+            ss.h[l] = ss.zeros((size_t)CH * NF * B, st);
+            ss.c[l] = ss.zeros((size_t)CH * NF * B, st);
         }
         (void)max_chunk;
     }

@@ -117,10 +117,10 @@ class Gcrn final : public Model {
         ss.release();
         ss.B = B;
         ss.first = true;
-        ss.hist.push_back(zeros((size_t)B * 2 * NBIN * STREAM_HC, st));      // est
+        ss.hist.push_back(ss.zeros((size_t)B * 2 * NBIN * STREAM_HC, st));      // est
         for (int l = 0; l < 4; ++l) {
-            ss.h[l] = zeros((size_t)512 * B, st);
-            ss.c[l] = zeros((size_t)1024 * B, st);          // layer 1 writes its units to every other row (stride 2 S)
+            ss.h[l] = ss.zeros((size_t)512 * B, st);
+            ss.c[l] = ss.zeros((size_t)1024 * B, st);          // layer 1 writes its units to every other row (stride 2 S)
         }
         (void)max_chunk;
     }

@@ -5,6 +5,7 @@
 #pragma once
 #include "model.h"
 #include <algorithm>
+#include <map>
 #include <vector>
 
 namespace se {
@@ -67,31 +68,49 @@ inline LstmW load_gru(const TrackedSD& sd, const std::string& prefix, int layer,
     return w;
 }
 
-// per-stream state of the frame-online mode: history columns of every chunk tensor, LSTM (h, c)
+// per-stream state of the frame-online mode: history columns of every chunk tensor, LSTM (h, c).  A new stream on the same
+// engine re-uses the buffers of the last one (release() parks them by size, zeros() takes a parked buffer of the wanted size
+// and clears it on the stream): starting a stream costs memsets, not a device-synchronising hipFree + hipMalloc per buffer
+// (ADVICE r2 - per-utterance streams would serialise with every other stream on the device).
 struct StreamState {
     int B = 0;
     bool first = true;
     std::vector<float*> hist;
     float *h[4] = {}, *c[4] = {};
+    std::multimap<size_t, float*> parked;
+    std::map<float*, size_t> size_of;
     void release() {
-        for (float* p : hist)
-            if (p) (void)hipFree(p);
+        auto park = [&](float*& p) {
+            if (p) parked.emplace(size_of[p], p);
+            p = nullptr;
+        };
+        for (float*& p : hist) park(p);
         hist.clear();
         for (int l = 0; l < 4; ++l) {
-            if (h[l]) (void)hipFree(h[l]);
-            if (c[l]) (void)hipFree(c[l]);
-            h[l] = c[l] = nullptr;
+            park(h[l]);
+            park(c[l]);
         }
         B = 0;
     }
-    ~StreamState() { release(); }
+    float* zeros(size_t n, hipStream_t st) {
+        n = std::max<size_t>(n, 1);
+        float* p = nullptr;
+        auto it = parked.find(n);
+        if (it != parked.end()) {
+            p = it->second;
+            parked.erase(it);
+        } else {
+            SE_HIP(hipMalloc(&p, n * sizeof(float)));
+            size_of[p] = n;
+        }
+        SE_HIP(hipMemsetAsync(p, 0, n * sizeof(float), st));
+        return p;
+    }
+    ~StreamState() {
+        release();
+        for (auto& kv : parked) (void)hipFree(kv.second);
+    }
 };
-inline float* zeros(size_t n, hipStream_t st) {
-    float* p = nullptr;
-    SE_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
-    SE_HIP(hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(float), st));
-    return p;
-}
 
 inline TapSpec one_tap() {
     TapSpec t;

@@ -160,3 +160,28 @@ def test_recurrent_exchange_never_serves_a_previous_launch(name):
     # and the first 16 sequences alone (one tile, another slicing of the chip) give the same waveforms
     y16 = MODEL_CLASSES[name](max_batch=16, max_samples=L).load_synthetic(5).enhance_batch(xa[:16])
     assert rms((y16 - ya[:16]).cpu().numpy()) < 1e-6
+
+
+def test_engine_lifetime_scratch_is_released_with_the_last_engine():
+    """engine-lifetime scratch (cooperative-LSTM exchange tensor, norm partial sums, RMS slices) lives in
+    per-(purpose, device, stream) slots; the device's LAST engine frees them, so a process that creates and destroys
+    engines does not accumulate device memory."""
+    torch = _torch()
+    import gc
+    from se_amd.models import crn_net
+
+    def cycle(batch):
+        m = crn_net(max_batch=batch, max_samples=8000).load_synthetic(12)
+        y = m.enhance_batch(torch.from_numpy(synth.synth_batch(batch, 'speech', 8000, seed0=7)).cuda())
+        assert bool(torch.isfinite(y).all())
+        del m, y
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    cycle(4)                                            # first use pays one-time allocations (tables, code objects)
+    free0 = torch.cuda.mem_get_info()[0]
+    for b in (8, 16, 32, 48):                           # growing shapes: every cycle would retire and re-grow the slots
+        cycle(b)
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)     # nothing of the 4 engines' arenas / scratch is left behind

@@ -72,6 +72,7 @@ inline void tcm_head(const NormAct& n, const float* fir, int K, const float* x, 
 struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:126-158)
     GCPlan in_conv, convL, convR, out_conv;
     TcmFusedW fused;       // the same block as one kernel per utterance (k_tcm.hip), built when every norm is an InstanceNorm
+    TcmStreamW sfused;     // frame-online chunks of the cLN variants as one kernel per block (k_tcm_stream.hip)
     NormAct nL, nR, nO;
     float *firL = nullptr, *firR = nullptr;
     int K = 0, d = 1;
@@ -98,8 +99,10 @@ struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:
         if (gated) convR = make_conv_plan(w_r, 1, 0, (ks - 1) * d, 1, d, ACT_SIGMOID, {}, EPI_ACT, 401);
         convL = make_conv_plan(w_l, 1, 0, (ks - 1) * d, 1, d, ACT_NONE, {}, gated ? EPI_MUL : EPI_ACT, 401);
         out_conv = make_pointwise_plan(w_out, ACT_NONE, {}, 401, EPI_ADD);
-        if ((ks == 3 || ks == 5) && !sd.has(p + left + ".1.gain"))       // cLN variants keep the multi-launch path
+        if ((ks == 3 || ks == 5) && !sd.has(p + left + ".1.gain"))       // cLN variants keep the multi-launch path offline
             fused = tcm_fused_build(w_in.w, w_l.w, gated ? &w_r.w : nullptr, w_out.w, ks);
+        if (sd.has(p + left + ".1.gain"))                                 // ... and stream through one kernel per block
+            sfused = tcm_stream_build(w_in.w, w_l.w, gated ? &w_r.w : nullptr, w_out.w, ks);
         nL.load(sd, p + left + ".1.", p + left + ".0.");
         if (gated) nR.load(sd, p + right + ".1.", p + right + ".0.");
         nO.load(sd, p + "out_conv.1.", p + "out_conv.0.");
@@ -111,6 +114,7 @@ struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:
     void free() {
         for (GCPlan* g : {&in_conv, &convL, &convR, &out_conv}) gc_free_plan(*g);
         tcm_fused_free(fused);
+        tcm_stream_free(sfused);
         nL.free();
         nR.free();
         nO.free();
@@ -130,6 +134,11 @@ inline int tcm_fused_min_batch() {
     return v;
 }
 inline void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratch& s, int B, int T, hipStream_t st, Profiler* pf) {
+    if (stream_ctx() && k.sfused.w_in && k.nL.cum && k.nO.cum && tcm_stream_enabled()) {
+        const TcmFusedHeads hd{k.nL.s, k.nL.g, k.nL.b, k.firL, k.nR.s, k.nR.g, k.nR.b, k.firR, k.nO.s, k.nO.g, k.nO.b};
+        launch_tcm_stream(k.sfused, hd, x, y, k.d, k.K, st);
+        return;
+    }
     if (k.fused.w1 && tcm_fused_min_batch() > 0 && B >= tcm_fused_min_batch() && tcm_fused_supported(T)) {
         const TcmFusedHeads hd{k.nL.s, k.nL.g, k.nL.b, k.firL, k.nR.s, k.nR.g, k.nR.b, k.firR, k.nO.s, k.nO.g, k.nO.b};
         const bool timed = pf && pf->on;

@@ -193,6 +193,18 @@ bool tcm_fused_supported(int T);
 void launch_tcm_fused(const TcmFusedW& f, const TcmFusedHeads& hd, const float* x, float* y, int B, int T, int dil, int K,
                       hipStream_t s);
 
+// The same block in the frame-online mode of the cumulative-LayerNorm variants: one launch per block and chunk, one workgroup
+// per stream, state (cLN sums, FIR / dilated-conv history) in one slot of the stream context (k_tcm_stream.hip).
+struct TcmStreamW {         // device weights, transposed (output row contiguous), owned by the block
+    float *w_in = nullptr, *w_l = nullptr, *w_r = nullptr, *w_out = nullptr;     // w_r == nullptr: single branch (no gate)
+    int ks = 0;
+};
+TcmStreamW tcm_stream_build(const std::vector<float>& w_in, const std::vector<float>& w_left, const std::vector<float>* w_right,
+                            const std::vector<float>& w_out, int ks);
+void tcm_stream_free(TcmStreamW& f);
+bool tcm_stream_enabled();      // SE_TCM_STREAM=0: the multi-launch path of round 2
+void launch_tcm_stream(const TcmStreamW& f, const TcmFusedHeads& hd, const float* x, float* y, int dil, int K, hipStream_t s);
+
 // CumulativeLayerNorm2d / 1d of the `_new` variants (CTSNet_new/Step1_network.py:213-286): frame t is normalised by the
 // statistics of all C*F values of frames 0..t;  x [B][C][F][T] (F = 1 for 1-D), gain / bias [C].
 //   y = FIR_K( cLN( PReLU_pre(x) ) )   (TCM branch head, K > 0, not in place)   or   y = PReLU_post( cLN(x) )

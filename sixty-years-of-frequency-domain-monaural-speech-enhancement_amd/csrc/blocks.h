@@ -99,7 +99,7 @@ struct TcmBlock {      // Glu / glu (Step1_network.py:158-188, Step2_network.py:
         if (gated) convR = make_conv_plan(w_r, 1, 0, (ks - 1) * d, 1, d, ACT_SIGMOID, {}, EPI_ACT, 401);
         convL = make_conv_plan(w_l, 1, 0, (ks - 1) * d, 1, d, ACT_NONE, {}, gated ? EPI_MUL : EPI_ACT, 401);
         out_conv = make_pointwise_plan(w_out, ACT_NONE, {}, 401, EPI_ADD);
-        if ((ks == 3 || ks == 5) && !sd.has(p + left + ".1.gain"))       // cLN variants keep the multi-launch path offline
+        if (ks == 3 || ks == 5)        // InstanceNorm and (round 3) cumulative-LayerNorm heads
             fused = tcm_fused_build(w_in.w, w_l.w, gated ? &w_r.w : nullptr, w_out.w, ks);
         if (sd.has(p + left + ".1.gain"))                                 // ... and stream through one kernel per block
             sfused = tcm_stream_build(w_in.w, w_l.w, gated ? &w_r.w : nullptr, w_out.w, ks);
@@ -139,11 +139,13 @@ inline void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratc
         launch_tcm_stream(k.sfused, hd, x, y, k.d, k.K, st);
         return;
     }
-    if (k.fused.w1 && tcm_fused_min_batch() > 0 && B >= tcm_fused_min_batch() && tcm_fused_supported(T)) {
+    static const bool cum_fused = !(getenv("SE_TCM_FUSED_CLN") && atoi(getenv("SE_TCM_FUSED_CLN")) == 0);
+    if (k.fused.w1 && !stream_ctx() && (!k.nL.cum || cum_fused) && tcm_fused_min_batch() > 0 && B >= tcm_fused_min_batch() &&
+        tcm_fused_supported(T)) {
         const TcmFusedHeads hd{k.nL.s, k.nL.g, k.nL.b, k.firL, k.nR.s, k.nR.g, k.nR.b, k.firR, k.nO.s, k.nO.g, k.nO.b};
         const bool timed = pf && pf->on;
         if (timed) pf->begin(st);
-        launch_tcm_fused(k.fused, hd, x, y, B, T, k.d, k.K, st);
+        launch_tcm_fused(k.fused, hd, x, y, B, T, k.d, k.K, st, k.nL.cum);
         if (timed) pf->end(st, 2.0 * B * T * (64.0 * 256 * 2 + 64.0 * 64 * k.fused.ks * (k.gated ? 2 : 1)));
         return;
     }

@@ -57,7 +57,11 @@ struct TcmFusedArgs {
     int dbg;       // tuning ablations (SE_TCM_DBG): 1 no GEMM 1, 2 no head statistics, 4 no dilated conv, 8 no GEMM 3, 16 no FIR
 };
 
-template <int KS, bool GATED>
+// CUM: the heads normalise with CumulativeLayerNorm1d (the `_new` directories, CTSNet_new/Step1_network.py:213-251: frame t by
+// the mean / biased variance of all 64 * (t + 1) values of frames 0..t) instead of InstanceNorm1d (per channel over the
+// utterance): the statistics are per COLUMN - a lane sums its 32 rows of its two columns, the partner lane (lane ^ 32) has the
+// other 32 - and a float64 prefix scan over the <= 512 columns by one wave turns them into running sums.
+template <int KS, bool GATED, bool CUM>
 __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Tp = a.Tp, T = a.T;
@@ -148,6 +152,78 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
         if (tid < TCM_C) prm[tid] = hp.slope[tid];
         if (K > 0 && tid >= TCM_C && tid < TCM_C + K) prm[4 * TCM_C + tid - TCM_C] = hp.fir[tid - TCM_C];     // K <= 64
         __syncthreads();
+        if constexpr (CUM) {
+            // Ws is free between the GEMMs: [Tp] float64 column sums, [Tp] sums of squares, [Tp] mean, [Tp] rstd
+            double* cs = reinterpret_cast<double*>(Ws);
+            double* cq = cs + Tp;
+            float* cmu = reinterpret_cast<float*>(cq + Tp);
+            float* crs = cmu + Tp;
+            if (tid < TCM_C) {
+                prm[TCM_C + tid] = hp.gamma[tid];
+                prm[2 * TCM_C + tid] = hp.beta[tid];
+            }
+            float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sl = prm[32 * mt + acc_row(r, hi)];
+                    float v0 = src[mt][0][r], vv1 = src[mt][1][r];
+                    v0 = v0 >= 0.f ? v0 : sl * v0;
+                    vv1 = vv1 >= 0.f ? vv1 : sl * vv1;
+                    s0 += v0; q0 += v0 * v0;
+                    s1 += vv1; q1 += vv1 * vv1;
+                }
+            s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+            s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+            if (hi == 0) {
+                if (tj0 < Tp) { cs[tj0] = s0; cq[tj0] = q0; }
+                if (v1 && tj1 < Tp) { cs[tj1] = s1; cq[tj1] = q1; }
+            }
+            __syncthreads();
+            if (wave == 0) {            // 64 lanes x 8 consecutive columns cover Tp <= 512
+                double ls[8], lq[8], as = 0.0, aq = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = lane * 8 + i;
+                    if (t < Tp) { as += cs[t]; aq += cq[t]; }
+                    ls[i] = as; lq[i] = aq;
+                }
+                double ps = as, pq = aq;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double ts = __shfl_up(ps, o, 64), tq = __shfl_up(pq, o, 64);
+                    if (lane >= o) { ps += ts; pq += tq; }
+                }
+                const double bs = ps - as, bq = pq - aq;        // sums of all columns in front of this lane's eight
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int t = lane * 8 + i;
+                    if (t < Tp) {
+                        const double S = bs + ls[i], Q = bq + lq[i], cnt = 64.0 * (double)(t + 1), mm = S / cnt;
+                        const double var = (Q - 2.0 * mm * S) / cnt + mm * mm;
+                        cmu[t] = (float)mm;
+                        crs[t] = (float)(1.0 / sqrt(var + 1e-5));
+                    }
+                }
+            }
+            __syncthreads();
+            const int c0i = min(tj0, Tp - 1), c1i = min(tj1, Tp - 1);
+            const float mu0 = cmu[c0i], rs0 = crs[c0i], mu1 = cmu[c1i], rs1 = crs[c1i];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * mt + acc_row(r, hi);
+                    const float sl = prm[row], ga = prm[TCM_C + row], be = prm[2 * TCM_C + row];
+                    float v0 = src[mt][0][r], vv1 = src[mt][1][r];
+                    v0 = v0 >= 0.f ? v0 : sl * v0;
+                    vv1 = vv1 >= 0.f ? vv1 : sl * vv1;
+                    if (tj0 < Tp) A[row * Tp + tj0] = (v0 - mu0) * rs0 * ga + be;
+                    if (v1 && tj1 < Tp) A[row * Tp + tj1] = (vv1 - mu1) * rs1 * ga + be;
+                }
+            __syncthreads();
+        } else {
         // pass 1: mean of PReLU(src) per channel
         const bool in0 = tj0 < Tv, in1 = v1 && tj1 < Tv;
         if (!(a.dbg & 2)) {
@@ -209,6 +285,7 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
                 if (v1 && tj1 < Tp) A[row * Tp + tj1] = vv1 * sc + sh;
             }
         __syncthreads();
+        }
         if (K > 0 && !(a.dbg & 16)) {
             // ShareSepConv (Step1_network.py:190-204): y[t] = sum_k fir[k] * n[t - (K-1) + k], one wave per row, in place -
             // every output of the row is formed in registers before the first one is written back
@@ -428,7 +505,7 @@ void tcm_fused_free(TcmFusedW& f) {
 bool tcm_fused_supported(int T) { return T >= 32 && T <= 512; }
 
 void launch_tcm_fused(const TcmFusedW& f, const TcmFusedHeads& hd, const float* x, float* y, int B, int T, int dil, int K,
-                      hipStream_t s) {
+                      hipStream_t s, bool cum) {
     SE_CHECK(tcm_fused_supported(T) && f.w1, "fused TCM block: unsupported shape");
     const int Tp = (T + 31) / 32 * 32;
     const Ragged* rg = ragged_ctx();
@@ -443,17 +520,31 @@ void launch_tcm_fused(const TcmFusedW& f, const TcmFusedHeads& hd, const float* 
         lds += strip_bytes;
     }
     const bool gated = f.w2R != nullptr;
-    auto go = [&](auto kern) {
+    {
         static bool seen[64] = {};
-        if (first_on_device(seen))
-            SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds, s, a);
-    };
-    if (f.ks == 5 && gated) go(tcm_fused_kernel<5, true>);
-    else if (f.ks == 5) go(tcm_fused_kernel<5, false>);
-    else if (f.ks == 3 && gated) go(tcm_fused_kernel<3, true>);
-    else if (f.ks == 3) go(tcm_fused_kernel<3, false>);
-    else SE_CHECK(false, "fused TCM block: kernel size must be 3 or 5");
+        if (first_on_device(seen)) {        // (all variants share one function-pointer type: raise every limit once per device)
+            auto up = [](auto kern) {
+                SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            };
+            up(tcm_fused_kernel<5, true, false>); up(tcm_fused_kernel<5, false, false>); up(tcm_fused_kernel<3, true, false>);
+            up(tcm_fused_kernel<3, false, false>); up(tcm_fused_kernel<5, true, true>); up(tcm_fused_kernel<5, false, true>);
+            up(tcm_fused_kernel<3, true, true>); up(tcm_fused_kernel<3, false, true>);
+        }
+    }
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(B), dim3(512), lds, s, a); };
+    if (cum) {
+        if (f.ks == 5 && gated) go(tcm_fused_kernel<5, true, true>);
+        else if (f.ks == 5) go(tcm_fused_kernel<5, false, true>);
+        else if (f.ks == 3 && gated) go(tcm_fused_kernel<3, true, true>);
+        else if (f.ks == 3) go(tcm_fused_kernel<3, false, true>);
+        else SE_CHECK(false, "fused TCM block: kernel size must be 3 or 5");
+    } else {
+        if (f.ks == 5 && gated) go(tcm_fused_kernel<5, true, false>);
+        else if (f.ks == 5) go(tcm_fused_kernel<5, false, false>);
+        else if (f.ks == 3 && gated) go(tcm_fused_kernel<3, true, false>);
+        else if (f.ks == 3) go(tcm_fused_kernel<3, false, false>);
+        else SE_CHECK(false, "fused TCM block: kernel size must be 3 or 5");
+    }
     SE_HIP(hipGetLastError());
 }
 

@@ -191,7 +191,7 @@ TcmFusedW tcm_fused_build(const std::vector<float>& w_in, const std::vector<floa
 void tcm_fused_free(TcmFusedW& f);
 bool tcm_fused_supported(int T);
 void launch_tcm_fused(const TcmFusedW& f, const TcmFusedHeads& hd, const float* x, float* y, int B, int T, int dil, int K,
-                      hipStream_t s);
+                      hipStream_t s, bool cum = false);     // cum: CumulativeLayerNorm heads (the `_new` variants)
 
 // The same block in the frame-online mode of the cumulative-LayerNorm variants: one launch per block and chunk, one workgroup
 // per stream, state (cLN sums, FIR / dilated-conv history) in one slot of the stream context (k_tcm_stream.hip).

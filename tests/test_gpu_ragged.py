@@ -121,10 +121,10 @@ def test_ragged_argument_checks():
         m.enhance_ragged(x, [4000])                 # one length per row
 
 
-@pytest.mark.parametrize('name', ['ctsnet', 'g2net', 'taylorsenet'])
+@pytest.mark.parametrize('name', ['ctsnet', 'g2net', 'taylorsenet', 'ctsnet_new', 'g2net_new', 'taylorsenet_new'])
 def test_fused_tcm_block_matches_multi_launch_path(name):
-    """From batch 96 a TCM / GLU block runs as ONE kernel per utterance (k_tcm.hip); below, as 3-4 GEMM + 2-3 norm
-    launches.  A batch of 100 (fused) must reproduce, clip for clip, what the fixture-pinned small-batch path gives - for
+    """From batch 96 a TCM / GLU block runs as ONE kernel per utterance (k_tcm.hip; round 3: also with the cumulative-LayerNorm
+    heads of the `_new` variants); below, as 3-4 GEMM + 2-3 norm launches.  A batch of 100 (fused) must reproduce, clip for clip, what the fixture-pinned small-batch path gives - for
     equal lengths and for a ragged batch (statistics over each row's own frames inside the fused kernel)."""
     import torch
     L, B = 6000, 100

@@ -287,27 +287,54 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
         __syncthreads();
         }
         if (K > 0 && !(a.dbg & 16)) {
-            // ShareSepConv (Step1_network.py:190-204): y[t] = sum_k fir[k] * n[t - (K-1) + k], one wave per row, in place -
-            // every output of the row is formed in registers before the first one is written back
-            constexpr int NI = 8;                          // T <= 512
+            // ShareSepConv (Step1_network.py:190-204): y[t] = sum_k fir[k] * n[t - (K-1) + k], in place, one wave per row.
+            // A lane owns EIGHT CONSECUTIVE frames and first pulls the 72 values [8 lane - 64, 8 lane + 8) of the row into
+            // registers (18 x ds_read_b128), then runs all taps out of them: 18 LDS reads per lane and row instead of 8 per tap
+            // (round 2: 504 for K = 63 - 129 of CTSNet's 434 us per block).  The taps sit right-aligned in a 63-entry table
+            // (zeros in front), so one fully unrolled loop serves every K <= 63.
+            typedef float fv4 __attribute__((ext_vector_type(4)));
+            float* tp63 = prm + 4 * TCM_C;                 // [64]: prm[4*64 + k] holds tap k of K; re-pack right-aligned
+            __syncthreads();
+            float mytap = 0.f;
+            if (tid < 64) mytap = (tid >= 63 - K && tid < 63) ? tp63[tid - (63 - K)] : 0.f;
+            __syncthreads();
+            if (tid < 64) tp63[tid] = mytap;
+            __syncthreads();
+#pragma unroll 1
             for (int row = wave; row < TCM_C; row += TCM_NW) {
                 float* Ar = A + row * Tp;
-                float o[NI];
+                const int t0 = 8 * lane;
+                float o[8];
 #pragma unroll
-                for (int i = 0; i < NI; ++i) o[i] = 0.f;
-                for (int k = 0; k < K; ++k) {
-                    const float w = prm[4 * TCM_C + k];      // taps from LDS: a global (scalar) load per tap cost 131 us per block
+                for (int i = 0; i < 8; ++i) o[i] = 0.f;
+                // four passes of 16 (15) taps, each out of a 28-value register window (one 72-value window next to the block's
+                // 128 accumulator registers spilled 150-190 VGPRs): output t0 + i reads n[t0 + i - 62 + k'] for the
+                // right-aligned tap k' - index 2 + i + (k' - k0) of the window that starts at t0 - 64 + k0
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 16 * q;
+                    float xw[28];
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        const int ti = lane + 64 * i - (K - 1) + k;
-                        if (ti >= 0 && ti < Tp) o[i] = fmaf(w, Ar[ti], o[i]);
+                    for (int g = 0; g < 7; ++g) {
+                        const int ti = t0 - 64 + k0 + 4 * g;
+                        fv4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (ti >= 0 && ti + 3 < Tp) v = *reinterpret_cast<const fv4*>(Ar + ti);
+                        xw[4 * g] = v[0]; xw[4 * g + 1] = v[1]; xw[4 * g + 2] = v[2]; xw[4 * g + 3] = v[3];
                     }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        {
+                            const float w = tp63[k0 + k];          // entry 63 is zero
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) o[i] = fmaf(w, xw[2 + i + k], o[i]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int t = lane + 64 * i;
-                    if (t < Tp) Ar[t] = o[i];
+                if (t0 + 7 < Tp) {
+                    *reinterpret_cast<fv4*>(Ar + t0) = fv4{o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<fv4*>(Ar + t0 + 4) = fv4{o[4], o[5], o[6], o[7]};
                 }
             }
             __syncthreads();

@@ -407,7 +407,7 @@ static void stream_process(se_engine* e, int t_end, bool last, float* out_dev, i
         float *spec = nullptr, *mag = nullptr, *est = nullptr;
         e->model->stream_bufs(B, n, &spec, &mag, &est);
         launch_stft(g, S.wav, e->ctx.max_samples, B, S.n_total, Lpad, S.c, e->ctx.p_in, spec, mag, t0 + n, Tw, st, t0, HC);
-        e->model->stream_chunk(B, t0, n, st);
+        e->model->stream_chunk(B, t0, n, st, last && t0 + n == t_end);
         S.t_done = t0 + n;
         const bool end = last && S.t_done == t_end;
         // estimate frames below t_fin are final (a model that looks ahead finalises LAG frames late); samples whose every

@@ -40,6 +40,9 @@ enum Epi : int {
     EPI_MUL = 4,     // dst = act(acc + bias) * aux   (gated TCM branches, CTSNet/Step1_network.py:184)
 };
 
+// launches that produce at most this many frames per row go to the thin kernel (frame-online chunks)
+constexpr int GC_THIN_NT = 8;
+
 struct GCParams {
     const float* A;          // packed weights [nchunks][KCp][Mp]
     const float* Ws;         // direct small-M path (M <= 4): plain weights [z][ci][tap][MM]; nullptr -> MFMA path
@@ -73,6 +76,8 @@ struct GCParams {
     unsigned long long* timing;   // tuning builds (-DGC_TIMING): per-phase s_memtime accumulators, else unused
     const unsigned* desc4;   // descriptors of the patch seen as 16 B groups (same packing as desc, w = first frame)
     int t_base;              // first frame of time tile 0 of this launch (tail launches start at the last tile)
+    int tb_soft;             // 1: the frames just below t_base may be produced again (their inputs are there): the MFMA path
+                             // then starts at the multiple of 4 below t_base
     int pw4;                 // per launch: 1 -> stage the patch in 16 B groups
     int causal;              // no tap looks ahead in time (dt <= 0 for every tap)
     const int* tlen;         // per launch (optional, device [B]): output frames >= tlen[b] are stored as zeros (MFMA path)

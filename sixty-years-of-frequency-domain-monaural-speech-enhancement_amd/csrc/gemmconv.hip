@@ -861,13 +861,12 @@ __global__ __launch_bounds__(256) void gc_small_lds_kernel(const GCParams p, con
 // them - with up to 8 frame accumulators, the 16 partial sums per output are folded through LDS, and the epilogues of the
 // MFMA kernel follow.
 // ------------------------------------------------------------------------------------------------
-constexpr int GC_THIN_NT = 8;
 // NT = frames per row (1, 2, 4, 8: no masked loads for the frames a short chunk does not have).  A thread's whole K walk is
 // issued in batches of 8 independent (weight, activation) loads - a block lives for 2-3 memory round trips - and the tap
 // table travels in the kernel arguments (GCParams::tdf / tdt), so that no address waits for a table fetch.
 template <int EPI, int NT>
 __global__ __launch_bounds__(256) void gc_thin_kernel(const GCParams p) {
-    constexpr int RB = 8, KG = 32, UN = 8;          // rows per workgroup, K groups, loads in flight per thread
+    constexpr int RB = 8, KG = 32, UN = 8;          // rows per workgroup, K groups, K rows in flight per thread
     __shared__ float part[KG][RB][NT + 1];
     __shared__ int s_df[GC_MAX_TAPS], s_dt[GC_MAX_TAPS];
     const int tid = threadIdx.x, mi = tid & (RB - 1), kg = tid / RB;
@@ -878,7 +877,7 @@ __global__ __launch_bounds__(256) void gc_thin_kernel(const GCParams p) {
             s_dt[j] = p.tdt[j];
         }
     __syncthreads();
-    const int nm = p.Mp / RB;
+    const int nm = (p.M + RB - 1) / RB;          // (rows M .. Mp of the packed matrix are padding)
     const int mt = blockIdx.x % nm;
     const int rest = blockIdx.x / nm;
     const int q = rest % p.Q, b = rest / p.Q;
@@ -923,7 +922,7 @@ __global__ __launch_bounds__(256) void gc_thin_kernel(const GCParams p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) part[kg][mi][t] = acc[t];
     __syncthreads();
-    const bool fold = tid < RB * NT;
+    const bool fold = tid < RB * NT;          // (NT <= 16: at most 128 threads)
     const int r = tid & (RB - 1), t = (tid / RB) & (NT - 1);
     float tot = 0.f;
     if (fold) {
@@ -965,12 +964,25 @@ static void gc_thin_launch_n(const GCParams& p, dim3 grid, int n, hipStream_t st
 static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
     static const int thin_env = getenv("SE_GC_THIN") ? atoi(getenv("SE_GC_THIN")) : 1;
     const int n = p.Tout - p.t_base;
-    if (!thin_env || p.Ws || n > GC_THIN_NT || p.Z > 1 || p.epi == EPI_LSTM || p.stats) return false;
-    const long nblk = (long)(p.Mp >> 3) * p.Q * p.B;
+    // (layers with <= 4 output channels have the packed matrix too: a one-frame launch of the direct kernel walks its whole K
+    // in one thread per output - 20-40 us; the fused parity pair of a transposed conv only exists there)
+    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.epi == EPI_LSTM || p.stats) return false;
+    const long nblk = (long)((p.M + 7) >> 3) * p.Q * p.B;
     // (a few frames per row is not yet a small launch: the LSTM input projections of a batch-1 decode are 1 "frame" wide
     // and 401 rows high with K = 1024 - matrix work)
     static const long thin_max = getenv("SE_GC_THIN_MAX") ? atol(getenv("SE_GC_THIN_MAX")) : 8192;
     if (nblk > thin_max) return false;
+    // Both paths are latency-bound at these sizes: a thin block walks K / 32 rows with 1 + NT loads each (~0.08 us per row
+    // and load, ~2 048 blocks in flight) and re-reads its 8 weight rows from L2 (32 B x K per block: 16 streams x one frame of
+    // DCCRN's 256-channel layers = 4 096 blocks x 80 KB - 110 us against 80 us of the MFMA tiles); an MFMA workgroup makes K / 16
+    // staged steps of ~0.5 us (~512 in flight).  Measured on the frame-online chunks of CRN / GCRN / DPCRN / DCCRN with 1 and 16
+    // streams x 1 and 8 frames: up to 64 columns in all go to the thin kernel unless its weight traffic or its waves say no.
+    if (!p.Ws) {
+        const int nt = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
+        const double waves_thin = std::ceil((double)nblk / 2048.0);
+        const double waves_mfma = std::ceil((double)std::max(p.Z, 1) * p.B * p.Q * std::max(p.n_mtiles, 1) / 512.0);
+        if ((long)p.B * n > 64 || nblk > 2800 * waves_mfma || waves_thin * (1 + nt) > 12 * waves_mfma) return false;
+    }
     dim3 grid((unsigned)nblk);
     switch (p.epi) {
         case EPI_ACT: gc_thin_launch_n<EPI_ACT>(p, grid, n, stream); break;
@@ -1400,6 +1412,8 @@ bool gc_stats_supported(const GCPlan& pl) {
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     // p.t_base (default 0): first output frame of the launch - frame-online chunks only produce the frames behind their
     // history columns.  A multiple of 4, so that the 16 B staging groups keep their alignment to frame 0.
+    if (p.t_base > 0 && gc_thin_launch(p, stream)) return;       // (any first frame)
+    if (p.tb_soft) p.t_base &= ~3;
     const int tb = p.t_base, Tspan = p.Tout - tb;
     SE_CHECK(tb >= 0 && (tb & 3) == 0 && Tspan > 0, "gc_launch: first output frame must be a multiple of 4 below Tout");
     SE_CHECK(tb == 0 || !p.stats, "gc_launch: the statistics epilogue needs whole rows");

@@ -790,6 +790,29 @@ void launch_hist_save(const float* buf, float* state, int B, long rows, int Tw, 
     SE_HIP(hipGetLastError());
 }
 
+// every history tensor of a model in one launch (blockIdx.y = tensor)
+__global__ __launch_bounds__(256) void hist_batch_kernel(const HistBatch hb, int B, int Tw, int hc, int save) {
+    const int e = blockIdx.y;
+    const long nrows = (long)B * hb.rows[e];
+    float* __restrict__ buf = hb.buf[e];
+    float* __restrict__ state = hb.state[e];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nrows * hc; i += (long)gridDim.x * 256) {
+        const long r = i / hc;
+        const int k = (int)(i - r * hc);
+        if (save) state[i] = buf[r * Tw + (Tw - hc) + k];
+        else buf[r * Tw + k] = state[i];
+    }
+}
+void launch_hist_batch(const HistBatch& hb, int B, int Tw, int hc, bool save, hipStream_t s) {
+    if (hb.n <= 0) return;
+    SE_CHECK(hb.n <= HistBatch::MAX, "launch_hist_batch: too many tensors");
+    long most = 0;
+    for (int e = 0; e < hb.n; ++e) most = std::max(most, (long)B * hb.rows[e] * hc);
+    const unsigned gx = (unsigned)std::min<long>((most + 255) / 256, 256);
+    hipLaunchKernelGGL(hist_batch_kernel, dim3(gx, (unsigned)hb.n), dim3(256), 0, s, hb, B, Tw, hc, save ? 1 : 0);
+    SE_HIP(hipGetLastError());
+}
+
 // ---- frame-online context of the block-built models (kernels.h: StreamCtx) -------------------------------------------
 static thread_local StreamCtx* g_stream_ctx = nullptr;
 StreamCtx* stream_ctx() { return g_stream_ctx; }

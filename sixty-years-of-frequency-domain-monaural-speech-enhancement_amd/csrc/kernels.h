@@ -143,6 +143,22 @@ struct StreamScope {
 void launch_hist_restore(float* buf, const float* state, int B, long rows, int Tw, int hc, hipStream_t s);
 void launch_hist_save(const float* buf, float* state, int B, long rows, int Tw, int hc, hipStream_t s);
 
+// the same for up to 16 tensors of one chunk in one launch (a one-frame push is bound by its launch count)
+struct HistBatch {
+    static constexpr int MAX = 16;
+    float* buf[MAX];
+    float* state[MAX];
+    long rows[MAX];
+    int n = 0;
+    void add(float* b, float* s, long r) {
+        buf[n] = b;
+        state[n] = s;
+        rows[n] = r;
+        ++n;
+    }
+};
+void launch_hist_batch(const HistBatch& hb, int B, int Tw, int hc, bool save, hipStream_t s);
+
 // DCCRN 'E' mask (DCCRN_cprs.py:201-225) + the decode script's mag/phase/decompress (dccrn_decode_vb.py:45-58):
 //   mask [B][2][F-1][Tp] (bins 1..F-1), spec [B][2][F][Tp] -> est [B][2][F][Tp], DC bin = 0.
 void launch_dccrn_mask(const float* mask, const float* spec, float* est, int B, int F, int T, int Tp, float p_out,

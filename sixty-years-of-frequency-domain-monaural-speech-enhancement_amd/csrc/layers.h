@@ -86,9 +86,12 @@ inline Act4 act4(const float* p, int C, int F, int Tp) { return Act4{p, C, F, (l
 struct Profiler;
 // stats (optional): [B][dstC][Fout][ceil(T / 32)][2] partial sums of the stored output (GCParams::stats)
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr);
+              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0);
+// frame-online chunks: only output frames [t_base, t_out) of the T-frame window are produced (t_out < 0: up to T); tb_soft:
+// GCParams::tb_soft
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
-                int Tp, hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr);
+                int Tp, hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, int t_out = -1,
+                bool tb_soft = false);
 bool conv_stats_supported(const GCPlan& pl);
 bool deconv_stats_supported(const DeconvPlan& pl);
 

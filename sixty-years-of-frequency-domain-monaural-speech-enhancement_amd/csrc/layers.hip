@@ -419,8 +419,9 @@ bool deconv_stats_supported(const DeconvPlan& pl) {
 }
 
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof, float* stats) {
+              hipStream_t st, Profiler* prof, float* stats, int t_base) {
     GCParams p = pl.p;
+    p.t_base = t_base;
     if (stats) set_stats(p, stats, dstC, Fout, T);
     fill_src(p, s0, s1);
     p.Fin = s0.F;
@@ -437,8 +438,13 @@ void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int 
 }
 
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
-                int Tp, hipStream_t st, Profiler* prof, float* stats) {
-    if (pl.has_pair && !stats && !pl.par[0].p.post_scale) {      // (a BatchNorm attached to the class plans later is not in the pair)
+                int Tp, hipStream_t st, Profiler* prof, float* stats, int t_base, int t_out, bool tb_soft) {
+    if (t_out < 0) t_out = T;
+    // (a BatchNorm attached to the class plans later is not in the pair; the few frames of a frame-online chunk go through
+    // the thin kernel, one launch per class)
+    const StreamCtx* cx = stream_ctx();
+    const bool few = (cx ? cx->n : t_out - t_base) <= GC_THIN_NT;
+    if (pl.has_pair && !stats && !pl.par[0].p.post_scale && !few) {
         GCParams p = pl.pair.p;
         fill_src(p, s0, s1);
         p.Fin = s0.F;
@@ -446,7 +452,9 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
         p.B = B;
         p.Q = (Fout + p.so - 1) / p.so;
         p.fo_lim = Fout;
-        p.Tout = T;
+        p.Tout = t_out;
+        p.t_base = t_base;
+        p.tb_soft = tb_soft;
         p.dst = dst;
         p.d_b = (long)dstC * Fout * Tp;
         p.d_c = (long)Fout * Tp;
@@ -462,7 +470,9 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
         p.Tin = T;
         p.B = B;
         p.Q = (Fout - p.po + p.so - 1) / p.so;
-        p.Tout = T;
+        p.Tout = t_out;
+        p.t_base = t_base;
+        p.tb_soft = tb_soft;
         p.dst = dst;
         p.d_b = (long)dstC * Fout * Tp;
         p.d_c = (long)Fout * Tp;

@@ -137,7 +137,8 @@ class Model {
     // LSTM (h, c), the iSTFT's overlap) across calls instead of seeing the whole utterance.  stream_chunk() handles frames
     // [t0, t0 + n) of B parallel streams: the engine has written their STFT into columns [STREAM_HC, STREAM_HC + n) of
     // stream_spec() / stream_mag() (row pitch STREAM_HC + n) and reads the estimate from stream_est() in the same layout.
-    static constexpr int STREAM_HC = 2;     // history columns in front of every chunk tensor (convs look back 1 frame, the iSTFT 1)
+    static constexpr int STREAM_HC = 4;     // history columns in front of every chunk tensor (convs look back 1 frame, the iSTFT 1;
+                                            // a multiple of 4: the convs start at frame STREAM_HC, gemmconv.hip gc_launch)
     // models whose front end overlaps more frames, or whose network looks a bounded number of frames AHEAD (DCCRN's decoder:
     // one frame per transposed conv), keep more history and finalise their estimate `stream_lag()` frames late: the chunk
     // tensors then start stream_hc() frames before the new ones and the last stream_lag() estimate frames of a chunk are
@@ -147,7 +148,8 @@ class Model {
     virtual bool stream_supported() const { return false; }
     virtual void stream_begin(int B, int max_chunk, hipStream_t st) { SE_CHECK(false, "this model has no streaming mode"); }
     virtual void stream_bufs(int B, int n, float** spec, float** mag, float** est) { SE_CHECK(false, "no streaming mode"); }
-    virtual void stream_chunk(int B, int t0, int n, hipStream_t st) { SE_CHECK(false, "no streaming mode"); }
+    // (`last`: no frame follows this chunk - a model that looks ahead finalises its provisional frames)
+    virtual void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) { SE_CHECK(false, "no streaming mode"); }
     // false: enhance() forks onto auxiliary streams and is not replayed from a captured hipGraph (SE_CFG_GRAPHS)
     virtual bool graph_capturable() const { return true; }
 

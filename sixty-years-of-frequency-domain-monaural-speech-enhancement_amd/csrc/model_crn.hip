@@ -99,40 +99,39 @@ class Crn final : public Model {
         *mag = b.mag;
         *est = b.est;
     }
-    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+    void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) override {
+        (void)last;
         SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
         const int HC = STREAM_HC, Tw = HC + n;
         Bufs& b = bufs(B, Tw);
         Profiler* pf = &ctx.prof;
         const std::vector<long> rows = stream_rows();
         float* tens[13] = {b.spec, b.mag, b.E[0], b.E[1], b.E[2], b.E[3], b.E[4], b.D[0], b.D[1], b.D[2], b.D[3], b.D[4], b.D[5]};
-        auto restore = [&](int k) { launch_hist_restore(tens[k], ss.hist[k], B, rows[k], Tw, HC, st); };
-        restore(0);
-        restore(1);
+        // every layer only produces the new frames; the history columns its successor looks back on come from the state
+        HistBatch hb;
+        for (int k = 0; k < 13; ++k) hb.add(tens[k], ss.hist[k], rows[k]);
+        launch_hist_batch(hb, B, Tw, HC, false, st);
         const int EC[5] = {16, 32, 64, 128, 256}, EF[5] = {80, 39, 19, 9, 4};
         Act4 x = act4(b.mag, 1, NBIN, Tw);
         for (int i = 0; i < 5; ++i) {
-            run_conv(enc[i], x, nullptr, b.E[i], EC[i], EF[i], B, Tw, Tw, st, pf);
-            restore(2 + i);                     // column 0 was recomputed without its own history
+            run_conv(enc[i], x, nullptr, b.E[i], EC[i], EF[i], B, Tw, Tw, st, pf, nullptr, HC);
             x = act4(b.E[i], EC[i], EF[i], Tw);
         }
         launch_transpose_akt(b.E[4] + HC, b.X, B, 1024, n, 1024L * Tw, Tw, 1024L * B, B, st);
         lstm[0].run_stream(b.X, b.G, ss.c[0], ss.h[0], b.Hs[0], n, B, ss.first, st, pf);
         lstm[1].run_stream(b.Hs[0], b.G, ss.c[1], ss.h[1], b.Hs[1], n, B, ss.first, st, pf);
         launch_transpose_akt(b.Hs[1], b.D[0] + HC, n, 1024, B, 1024L * B, B, 1024L * Tw, Tw, st);
-        restore(7);
         const int DCo[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
         int cin = 256, fin = 4;
         for (int i = 0; i < 5; ++i) {
             Act4 a0 = act4(b.D[i], cin, fin, Tw);
             Act4 a1 = act4(b.E[4 - i], cin, fin, Tw);
-            run_deconv(dec[i], a0, &a1, b.D[i + 1], DCo[i], DF[i], B, Tw, Tw, st, pf);
-            restore(8 + i);
+            run_deconv(dec[i], a0, &a1, b.D[i + 1], DCo[i], DF[i], B, Tw, Tw, st, pf, nullptr, HC);
             cin = DCo[i];
             fin = DF[i];
         }
         launch_mag_phase(b.D[5], b.spec, b.est, B, NBIN, Tw, ctx.p_out, st);     // history columns come out as last time
-        for (int k = 0; k < 13; ++k) launch_hist_save(tens[k], ss.hist[k], B, rows[k], Tw, HC, st);
+        launch_hist_batch(hb, B, Tw, HC, true, st);
         ss.first = false;
         (void)t0;
     }
@@ -297,7 +296,8 @@ class LstmNet final : public Model {
         *mag = b.mag;
         *est = b.est;
     }
-    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+    void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) override {
+        (void)last;
         SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
         const int HC = STREAM_HC, Tw = HC + n;
         Bufs& b = bufs(B, Tw);

@@ -175,7 +175,8 @@ class CtsNet final : public Model {
         *mag = b.mag;
         *est = b.est;
     }
-    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+    void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) override {
+        (void)last;
         Bufs& b = bufs(B, SH + n);
         const int T = b.T;
         StreamScope sc(slots, SH, n, t0, B);

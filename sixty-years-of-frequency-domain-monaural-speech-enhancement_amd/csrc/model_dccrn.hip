@@ -191,12 +191,14 @@ class Dccrn final : public Model {
     }
 
     // ---- frame-online mode (model.h).  The encoder convs look back one frame (causal time pad, :66-72) and the complex LSTM
-    // carries (h, c); the DECODER looks one frame AHEAD per transposed conv (`out[..., 1:]`, :199), six frames in all.  A
-    // chunk therefore keeps the last DHC = 10 final frames of the decoder's inputs (encoder outputs, LSTM output, spectrum)
-    // in front of the n new ones and runs the decoder over the whole window: its last six output frames saw zeros where
-    // their future will be and are provisional - the next chunk recomputes them (the engine finalises the estimate six frames
-    // late) - except at the end of the stream, where zeros past the last frame are what the offline decode sees too.
-    static constexpr int DHC = 10;          // 6 look-ahead + 3 frames of iSTFT overlap (512 / 128), rounded up to even
+    // carries (h, c); the DECODER looks one frame AHEAD per transposed conv (`out[..., 1:]`, :199), six frames in all.  Every
+    // chunk tensor is a window of DHC = 12 history columns + the n new frames (column c = frame t0 - DHC + c).  The encoder
+    // and the LSTM produce the n new columns; decoder layer k (1..6) runs k frames behind them - columns [DHC - k, DHC - k + n),
+    // whose look-ahead column DHC - k + n its input already has - and the estimate six frames behind (the engine finalises
+    // it six frames late, stream_lag).  The chunk that ends the stream fills the remaining columns with zeros where their
+    // future would be - what the offline decode sees past its last frame.  The history columns of all fourteen tensors come
+    // back from / go to the state in one launch each.
+    static constexpr int DHC = 12;          // 6 look-ahead + 3 frames of iSTFT overlap (512 / 128), rounded up to a multiple of 4
     int stream_hc() const override { return DHC; }
     int stream_lag() const override { return NL; }
     bool stream_supported() const override { return true; }
@@ -217,20 +219,20 @@ class Dccrn final : public Model {
         *mag = nullptr;
         *est = b.est;
     }
-    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+    void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) override {
         SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
         const int Tw = DHC + n;
         Bufs& b = bufs(B, Tw);
         Profiler* pf = &ctx.prof;
         const std::vector<long> rows = stream_rows();
-        float* tens[8] = {b.spec, b.E[0], b.E[1], b.E[2], b.E[3], b.E[4], b.E[5], b.D[0]};
-        auto restore = [&](int k) { launch_hist_restore(tens[k], ss.hist[k], B, rows[k], Tw, DHC, st); };
-        restore(0);
+        float* tens[14] = {b.spec, b.E[0], b.E[1], b.E[2], b.E[3], b.E[4], b.E[5], b.D[0], b.D[1], b.D[2], b.D[3], b.D[4], b.D[5], b.est};
+        HistBatch hb;
+        for (int k = 0; k < 14; ++k) hb.add(tens[k], ss.hist[k], rows[k]);
+        launch_hist_batch(hb, B, Tw, DHC, false, st);
         Act4 x{b.spec + Tw, 2, 256, 2L * NBIN * Tw, (long)NBIN * Tw, (long)Tw};
         int F = 256;
-        for (int k = 0; k < NL; ++k) {
-            run_conv(enc[k], x, nullptr, b.E[k], KN[k + 1], F / 2, B, Tw, Tw, st, pf);
-            restore(1 + k);                      // column 0 was recomputed without its own history
+        for (int k = 0; k < NL; ++k) {        // only the new frames: the history columns came back from the state
+            run_conv(enc[k], x, nullptr, b.E[k], KN[k + 1], F / 2, B, Tw, Tw, st, pf, nullptr, DHC);
             F /= 2;
             x = act4(b.E[k], KN[k + 1], F, Tw);
         }
@@ -267,26 +269,28 @@ class Dccrn final : public Model {
         for (int part = 0; part < 2; ++part)
             launch_transpose_akt(b.P + (size_t)part * 512 * B, b.D[0] + (size_t)part * 512 * Tw + DHC, n, 512, B, 1024L * B, B,
                                  1024L * Tw, Tw, st);
-        restore(7);
-        // decoder over the whole window (no look-back: every column is exact given its own and the next input column)
         F = 4;
         for (int k = 0; k < NL; ++k) {
-            const int cin = KN[NL - k];
+            const int cin = KN[NL - k], c0 = DHC - (k + 1);
             Act4 a0 = act4(b.D[k], cin, F, Tw);
             Act4 a1 = act4(b.E[NL - 1 - k], cin, F, Tw);
-            run_deconv(dec[k], a0, &a1, b.D[k + 1], KN[NL - k - 1], 2 * F, B, Tw, Tw, st, pf);
+            run_deconv(dec[k], a0, &a1, b.D[k + 1], KN[NL - k - 1], 2 * F, B, Tw, Tw, st, pf, nullptr, c0, last ? Tw : c0 + n, true);
             F *= 2;
         }
-        launch_dccrn_mask(b.D[NL], b.spec, b.est, B, NBIN, Tw, Tw, ctx.p_out, st);
-        for (int k = 0; k < 8; ++k) launch_hist_save(tens[k], ss.hist[k], B, rows[k], Tw, DHC, st);
+        {
+            const int c0 = DHC - NL;
+            launch_dccrn_mask(b.D[NL] + c0, b.spec + c0, b.est + c0, B, NBIN, last ? Tw - c0 : n, Tw, ctx.p_out, st);
+        }
+        launch_hist_batch(hb, B, Tw, DHC, true, st);
         ss.first = false;
         (void)t0;
     }
 
   private:
     StreamState ss;
-    static std::vector<long> stream_rows() {      // rows (C * F) of spec, E[0..5], D[0]
-        return {2L * NBIN, 32L * 128, 64L * 64, 128L * 32, 256L * 16, 256L * 8, 256L * 4, 1024L};
+    static std::vector<long> stream_rows() {      // rows (C * F) of spec, E[0..5], D[0..5], est
+        return {2L * NBIN, 32L * 128, 64L * 64, 128L * 32, 256L * 16, 256L * 8, 256L * 4, 1024L, 256L * 8, 256L * 16, 128L * 32,
+                64L * 64, 32L * 128, 2L * NBIN};
     }
     GCPlan enc[NL], g1, g2, proj;
     float *whh1 = nullptr, *whh2 = nullptr;

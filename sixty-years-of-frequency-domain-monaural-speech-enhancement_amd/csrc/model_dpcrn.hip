@@ -131,7 +131,8 @@ class Dpcrn final : public Model {
         *mag = nullptr;
         *est = b.est;
     }
-    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+    void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) override {
+        (void)last;
         SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
         const int HC = STREAM_HC, Tw = HC + n;
         Bufs& b = bufs(B, Tw);
@@ -139,12 +140,17 @@ class Dpcrn final : public Model {
         const std::vector<long> rows = stream_rows();
         float* tens[13] = {b.spec, b.E[0], b.E[1], b.E[2], b.E[3], b.E[4], b.P1, b.D[0], b.D[1], b.D[2], b.D[3], b.D[4], b.D[5]};
         auto restore = [&](int k) { launch_hist_restore(tens[k], ss.hist[k], B, rows[k], Tw, HC, st); };
-        restore(0);
+        // the (de)convs only produce the new frames: the history columns of their outputs come from the state in one launch
+        HistBatch hb, hb_all;
+        for (int k = 0; k < 13; ++k) {
+            hb_all.add(tens[k], ss.hist[k], rows[k]);
+            if (k != 6 && k != 7) hb.add(tens[k], ss.hist[k], rows[k]);
+        }
+        launch_hist_batch(hb, B, Tw, HC, false, st);
         const int EC[5] = {32, 32, 32, 64, 128}, EF[5] = {80, 39, 19, 9, 4};
         Act4 x = act4(b.spec, 2, NBIN, Tw);
         for (int i = 0; i < 5; ++i) {
-            run_conv(enc[i], x, nullptr, b.E[i], EC[i], EF[i], B, Tw, Tw, st, pf);
-            restore(1 + i);
+            run_conv(enc[i], x, nullptr, b.E[i], EC[i], EF[i], B, Tw, Tw, st, pf, nullptr, HC);
             x = act4(b.E[i], EC[i], EF[i], Tw);
         }
         dprnn(b, b.E[4], b.P1, st, n, 0);
@@ -156,13 +162,12 @@ class Dpcrn final : public Model {
         for (int i = 0; i < 5; ++i) {
             Act4 a0 = act4(b.D[i], cin, fin, Tw);
             Act4 a1 = act4(b.E[4 - i], cin, fin, Tw);
-            run_deconv(dec[i], a0, &a1, b.D[i + 1], DCo[i], DF[i], B, Tw, Tw, st, pf);
-            restore(8 + i);
+            run_deconv(dec[i], a0, &a1, b.D[i + 1], DCo[i], DF[i], B, Tw, Tw, st, pf, nullptr, HC);
             cin = DCo[i];
             fin = DF[i];
         }
         launch_cmask_apply(b.D[5], b.spec, b.est, B, NBIN, Tw, ctx.p_out, st);
-        for (int k = 0; k < 13; ++k) launch_hist_save(tens[k], ss.hist[k], B, rows[k], Tw, HC, st);
+        launch_hist_batch(hb_all, B, Tw, HC, true, st);
         ss.first = false;
         (void)t0;
     }

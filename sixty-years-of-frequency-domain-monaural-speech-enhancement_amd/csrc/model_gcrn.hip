@@ -130,7 +130,8 @@ class Gcrn final : public Model {
         *mag = nullptr;
         *est = b.est;
     }
-    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+    void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) override {
+        (void)last;
         SE_CHECK(ss.B == B && !ss.hist.empty(), "stream_chunk without stream_begin");
         const int HC = STREAM_HC, Tw = HC + n;
         Bufs& b = bufs(B, Tw);
@@ -211,9 +212,11 @@ class Gcrn final : public Model {
     void network(Bufs& b, hipStream_t st, int n_stream = 0) {
         const int B = b.B, T = b.T;
         Profiler* pf = &ctx.prof;
+        // (frame-online chunk: nothing here has an extent in time, so only the n new columns are produced)
+        const int tb = n_stream > 0 ? T - n_stream : 0;
         Act4 x = act4(b.spec, 2, NBIN, T);
         for (int k = 0; k < 5; ++k) {
-            run_conv(enc[k], x, nullptr, b.E[k], EC[k + 1], EF[k], B, T, T, st, pf);
+            run_conv(enc[k], x, nullptr, b.E[k], EC[k + 1], EF[k], B, T, T, st, pf, nullptr, tb);
             x = act4(b.E[k], EC[k + 1], EF[k], T);
         }
         for (int k = 0; k < 4; ++k) launch_elu(b.E[k], b.EE[k], (long)B * EC[k + 1] * EF[k] * T, st);
@@ -249,14 +252,14 @@ class Gcrn final : public Model {
             Act4 a0 = act4(b.L0, 256, 4, T);
             Act4 a1 = act4(b.E[4], 256, 4, T);          // cat((out, e5)) without ELU :147
             for (int i = 0; i < 5; ++i) {
-                run_deconv(dec[br][i], a0, &a1, b.D[br][i], DCO[i], DF[i], B, T, T, st, pf);
+                run_deconv(dec[br][i], a0, &a1, b.D[br][i], DCO[i], DF[i], B, T, T, st, pf, nullptr, tb);
                 a0 = act4(b.D[br][i], DCO[i], DF[i], T);
                 if (i < 4) a1 = act4(b.EE[3 - i], EC[4 - i], EF[3 - i], T);
             }
             // Linear(161,161) over F (:161-162): the [B][1][161][T] map is a 161-channel pointwise layer
             GCParams p = fc[br].p;
             p.src0 = b.D[br][4]; p.s0_b = (long)NBIN * T; p.s0_c = T; p.s0_f = 0; p.src1 = nullptr;
-            p.Fin = 1; p.Tin = T; p.B = B; p.Q = 1; p.Tout = T;
+            p.Fin = 1; p.Tin = T; p.B = B; p.Q = 1; p.Tout = T; p.t_base = tb;
             p.dst = b.est + (long)br * NBIN * T; p.d_b = 2L * NBIN * T; p.d_c = T; p.d_f = 0;
             gc_launch_prof(fc[br], p, st, pf);
         }

@@ -149,7 +149,8 @@ class TaylorSENet final : public Model {
         *mag = nullptr;
         *est = b.est;
     }
-    void stream_chunk(int B, int t0, int n, hipStream_t st) override {
+    void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) override {
+        (void)last;
         Bufs& b = bufs(B, SH + n);
         StreamScope sc(slots, SH, n, t0, B);
         network(b, st);

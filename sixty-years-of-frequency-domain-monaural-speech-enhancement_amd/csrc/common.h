@@ -49,7 +49,17 @@ class Arena {
         base_ = nullptr;
         cap_ = off_ = 0;
     }
-    void reset() { off_ = 0; }
+    void reset() {
+        off_ = 0;
+        // SE_ARENA_POISON=1 (tests): every re-carve fills the slab with NaN patterns, so that a kernel that reads a column
+        // nobody wrote shows up deterministically instead of depending on what the previous carve left there
+        static const bool poison = getenv("SE_ARENA_POISON") && atoi(getenv("SE_ARENA_POISON")) != 0;
+        if (poison && base_ && !measuring_) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(base_, 0xFF, cap_);
+            (void)hipDeviceSynchronize();
+        }
+    }
     // measuring mode: no memory behind the pointers, only the high-water mark is tracked
     void measure_begin() {
         release();

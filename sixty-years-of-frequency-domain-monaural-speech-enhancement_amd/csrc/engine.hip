@@ -38,6 +38,7 @@ struct se_engine {
     struct Stream {
         bool active = false;
         int batch = 0, max_chunk = 0, n_total = 0, t_done = 0, o_done = 0;
+        int carve_B = -1, carve_n = -1;      // (batch, chunk frames) the arena was last carved and zero-filled for
         float* wav = nullptr;
         float* c = nullptr;
     } strm;
@@ -244,6 +245,7 @@ int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
+        e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         SE_CHECK(in_dev && out_dev && in_shape, "null argument");
         e->ctx.prof_reset();
         e->model->forward(in_dev, in_shape, in_ndim, out_dev, static_cast<hipStream_t>(stream));
@@ -255,6 +257,7 @@ int se_uformer_forward(se_engine* e, const float* inputs_dev, const float* src_d
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
+        e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         SE_CHECK(inputs_dev && output_dev, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples, "n_samples outside [n_fft, max_samples]");
@@ -269,6 +272,7 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
+        e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         SE_CHECK(wav_in_dev && wav_out_dev, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples,
@@ -348,6 +352,7 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
+        e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         SE_CHECK(wav_in_dev && wav_out_dev && lengths, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(e->model->ragged_supported(),
@@ -406,6 +411,15 @@ static void stream_process(se_engine* e, int t_end, bool last, float* out_dev, i
         const int t0 = S.t_done, n = std::min(S.max_chunk, t_end - t0), Tw = HC + n;
         float *spec = nullptr, *mag = nullptr, *est = nullptr;
         e->model->stream_bufs(B, n, &spec, &mag, &est);
+        // A chunk size that differs from the last one re-carves the arena: the history columns of the new windows would hold
+        // whatever the old carve left there.  Layers only look at the columns their taps reach (restored from the state),
+        // but zero-weight padding of the matrix operands may touch a neighbouring column - finite values are harmless there,
+        // stale bit patterns need not be finite.
+        if (S.carve_B != B || S.carve_n != n) {
+            SE_HIP(hipMemsetAsync(const_cast<void*>(e->ctx.arena.base()), 0, e->ctx.arena.used(), st));
+            S.carve_B = B;
+            S.carve_n = n;
+        }
         launch_stft(g, S.wav, e->ctx.max_samples, B, S.n_total, Lpad, S.c, e->ctx.p_in, spec, mag, t0 + n, Tw, st, t0, HC);
         e->model->stream_chunk(B, t0, n, st, last && t0 + n == t_end);
         S.t_done = t0 + n;
@@ -427,6 +441,7 @@ int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
+        e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         SE_CHECK(e->model->stream_supported(), "this model has no frame-online mode (CRN, LSTM, GCRN, DPCRN, DCCRN and the cLN `_new` weights of CTSNet / TaylorSENet / G2Net have)");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         const StftGeom& g = e->ctx.geom;
@@ -443,6 +458,7 @@ int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const
         else launch_fill(S.c, batch, 1.f, st);
         S.batch = batch;
         S.n_total = S.t_done = S.o_done = 0;
+        S.carve_B = S.carve_n = -1;
         e->model->stream_begin(batch, S.max_chunk, st);
         S.active = true;
     });

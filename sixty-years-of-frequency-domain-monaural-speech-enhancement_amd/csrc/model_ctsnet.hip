@@ -162,7 +162,10 @@ class CtsNet final : public Model {
     // runs the same launch sequence as enhance() on windows of SH history columns + n new frames; the shared helpers keep
     // the per-layer history and the cLN sums (kernels.h: StreamCtx).  SH = the deepest look-back: (5 - 1) * 32 frames of
     // the last dilated conv of a TCM group (its ShareSepConv reaches 62 back).
-    static constexpr int SH = 128;
+    // (with one kernel per TCM block, k_tcm_stream.hip, the dilated convs and FIRs keep their own ring state and the windows
+    // only serve the U-Net's one-frame look-back and the iSTFT overlap: 4 columns - rows of 5 floats instead of 129, and a
+    // one-frame access touches a fraction of the cache lines)
+    const int SH = tcm_stream_enabled() ? 4 : 128;
     bool stream_supported() const override { return has1 && has2 && cum; }
     int stream_hc() const override { return SH; }
     void stream_begin(int B, int max_chunk, hipStream_t st) override {

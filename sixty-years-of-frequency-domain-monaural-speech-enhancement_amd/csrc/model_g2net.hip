@@ -130,7 +130,10 @@ class G2Net final : public Model {
     // ---- frame-online mode (G2Net_new: cumulative LayerNorms only).  Windows of SH history columns + n new frames through
     // the same launch sequence; history / cLN sums are kept by the shared helpers (kernels.h: StreamCtx).  SH covers the
     // deepest look-back, (3 - 1) * 9 frames of the widest dilated conv.
-    static constexpr int SH = 20;
+    // (with one kernel per TCM block, k_tcm_stream.hip, the dilated convs and FIRs keep their own ring state and the windows
+    // only serve the U-Net's one-frame look-back and the iSTFT overlap: 4 columns - rows of 5 floats instead of 21, and a
+    // one-frame access touches a fraction of the cache lines)
+    const int SH = tcm_stream_enabled() ? 4 : 20;
     bool stream_supported() const override { return cum; }
     int stream_hc() const override { return SH; }
     void stream_begin(int B, int max_chunk, hipStream_t st) override {

@@ -174,5 +174,37 @@ inline void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratc
     }
 }
 
+// blocks blk[0..n) feed each other through the ping-pong buffers X[0] / X[1]; returns the buffer that holds the result.
+// Frame-online chunks of the cLN variants run up to 8 of them per launch (k_tcm_stream.hip: tcm_chain_kernel).
+inline const float* run_tcm_chain(const TcmBlock* blk, int n, const float* x, float* const X[2], const TcmScratch& s, int B, int T,
+                                  hipStream_t st, Profiler* pf) {
+    int i = 0;
+    while (i < n) {
+        int m = 1;
+        auto chainable = [&](const TcmBlock& k) { return k.sfused.w_in && k.nL.cum && k.nO.cum; };
+        if (stream_ctx() && tcm_chain_enabled() && chainable(blk[i])) {
+            while (m < 8 && i + m < n && chainable(blk[i + m]) && blk[i + m].sfused.ks == blk[i].sfused.ks) ++m;
+            const TcmStreamW* f[8];
+            TcmFusedHeads hd[8];
+            int dil[8], K[8];
+            for (int j = 0; j < m; ++j) {
+                const TcmBlock& k = blk[i + j];
+                f[j] = &k.sfused;
+                hd[j] = TcmFusedHeads{k.nL.s, k.nL.g, k.nL.b, k.firL, k.nR.s, k.nR.g, k.nR.b, k.firR, k.nO.s, k.nO.g, k.nO.b};
+                dil[j] = k.d;
+                K[j] = k.K;
+            }
+            float* y = X[(i + m - 1) & 1];
+            launch_tcm_chain(f, hd, dil, K, m, x, y, st);
+            x = y;
+        } else {
+            float* y = X[i & 1];
+            run_tcm(blk[i], x, y, s, B, T, st, pf);
+            x = y;
+        }
+        i += m;
+    }
+    return x;
+}
 
 }  // namespace se

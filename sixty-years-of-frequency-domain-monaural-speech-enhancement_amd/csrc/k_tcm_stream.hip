@@ -301,6 +301,243 @@ __global__ __launch_bounds__(256) void tcm_stream_kernel(const TcmStreamArgs a) 
     if (tid < 6) g_carry[tid] = carry[tid];
 }
 
+// ---- a CHAIN of blocks in one launch ------------------------------------------------------------------------------------
+// A kernel of this size costs ~4.7 us before its first instruction does anything useful (dispatch, cache maintenance at the
+// kernel boundaries) and another ~1.5 us until its head parameters have arrived - a third to a half of a block's time at one
+// frame per push.  The blocks of a TCM stack feed each other (6 per group in CTSNet, 8 per stack in G2Net / TaylorSENet), so
+// ONE launch walks the whole chain frame by frame: every block is causal and advances its own state (rings, cLN sums) by
+// one frame, the 256-channel column between two blocks never leaves LDS, all blocks' head parameters, FIR taps and cLN
+// sums arrive in one batch at kernel entry, and the next block's in-conv weights are requested before the current block's
+// output is written.
+constexpr int TCM_CHAIN_MAX = 8;
+struct TcmStreamBlk {
+    const float *w_in, *w_l, *w_r, *w_out;
+    TcmFusedHeads hd;
+    int K, dil;
+    char* state; long state_stride;
+};
+struct TcmChainArgs {
+    const float* x; float* y;       // windows [B][256][Tw] of the chain's input / output, new frames in columns [H, H + n)
+    int Tw, H, n; long t0;
+    int nblk, fp_max;               // fp_max: widest FIR window of the chain (K - 1 + NS)
+    TcmStreamBlk blk[TCM_CHAIN_MAX];
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void tcm_chain_kernel(const TcmChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NB = a.nblk;
+    float* xs = sm;                        // [256] the column that enters the current block (its residual)
+    float* hb = xs + 256;                  // [64]  in-conv output
+    float* part = hb + 64;                 // [4][64] partial sums of the four k-parts (waves)
+    float* ab = part + 4 * 64;             // [64]  branch value
+    float* rg = ab + 64;                   // [64]  gate
+    float* mu = rg + 64;                   // mean, rstd
+    double* ds = reinterpret_cast<double*>(mu + 2);            // [2] column sums
+    double* carry_all = ds + 2;                                // [NB][8] running cLN sums (6 used)
+    float* hp_all = reinterpret_cast<float*>(carry_all + 8 * TCM_CHAIN_MAX);      // [NB][9][64]
+    float* ft_all = hp_all + TCM_CHAIN_MAX * 9 * 64;           // [NB][2][64] FIR taps
+    float* ct = ft_all + TCM_CHAIN_MAX * 2 * 64;               // [2][64][KS] tap columns of the dilated conv
+    float* wf = ct + 2 * 64 * KS;                              // [2][64][fp_max] FIR windows
+    const float* xb = a.x + (long)b * 256 * a.Tw + a.H;
+    float* yb = a.y + (long)b * 256 * a.Tw + a.H;
+    const int r = tid & 63, p = tid >> 6;
+
+    float wreg[64 > 16 * KS ? 64 : 16 * KS];
+    {
+        const float* w = a.blk[0].w_in + (long)(64 * p) * 64 + r;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) wreg[k] = w[k * 64];
+    }
+    for (int bi = 0; bi < NB; ++bi) {
+        const TcmStreamBlk& B = a.blk[bi];
+        float* hp = hp_all + bi * 9 * 64;
+        float* ft = ft_all + bi * 2 * 64;
+        const bool gated = B.w_r != nullptr;
+        if (tid < 64) {
+            hp[tid] = B.hd.sL[tid]; hp[64 + tid] = B.hd.gL[tid]; hp[128 + tid] = B.hd.bL[tid];
+            hp[384 + tid] = B.hd.sO[tid]; hp[448 + tid] = B.hd.gO[tid]; hp[512 + tid] = B.hd.bO[tid];
+            if (gated) { hp[192 + tid] = B.hd.sR[tid]; hp[256 + tid] = B.hd.gR[tid]; hp[320 + tid] = B.hd.bR[tid]; }
+            if (tid < B.K) {
+                ft[tid] = B.hd.firL[tid];
+                if (gated) ft[64 + tid] = B.hd.firR[tid];
+            }
+        }
+        if (tid < 6) carry_all[bi * 8 + tid] = reinterpret_cast<const double*>(B.state + (long)b * B.state_stride)[tid];
+    }
+
+    for (int c0 = 0; c0 < a.n; ++c0) {
+        const long tbase = a.t0 + c0;                  // stream index of this frame
+        xs[tid] = xb[(long)tid * a.Tw + c0];
+        for (int bi = 0; bi < NB; ++bi) {
+            const TcmStreamBlk& B = a.blk[bi];
+            const int KH = B.K > 0 ? B.K - 1 : 0, CH = (KS - 1) * B.dil;
+            const int RF = ring_of(KH), RC = ring_of(CH), FP = a.fp_max;
+            const bool gated = B.w_r != nullptr;
+            const int nb = gated ? 2 : 1;
+            float* hp = hp_all + bi * 9 * 64;
+            const float* ft = ft_all + bi * 2 * 64;
+            double* carry = carry_all + bi * 8;
+            char* stb = B.state + (long)b * B.state_stride;
+            float* g_fir = reinterpret_cast<float*>(stb + 64);
+            float* g_cv = g_fir + (KH > 0 ? nb * 64 * RF : 0);
+            // ---- one batch of global reads: FIR history, history taps of the dilated convs
+            {
+                const int n = nb * 64 * KH;
+                for (int i0 = tid; i0 < n; i0 += 16 * 256) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int i = i0 + u * 256;
+                        if (i < n) {
+                            const int row = i / KH, col = i - row * KH;
+                            v[u] = ld_agent(g_fir + (long)row * RF + ((int)(tbase - KH + col) & (RF - 1)));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int i = i0 + u * 256;
+                        if (i < n) wf[(i / KH) * FP + (i % KH)] = v[u];
+                    }
+                }
+                const int m = nb * 64 * KS;
+                for (int i = tid; i < m; i += 256) {
+                    const int tap = i % KS, row = i / KS;
+                    const int back = (KS - 1 - tap) * B.dil;
+                    if (back > 0) ct[row * KS + tap] = ld_agent(g_cv + (long)row * RC + ((int)(tbase - back) & (RC - 1)));
+                }
+            }
+            __syncthreads();           // xs of this block is complete
+            {
+                float acc = 0.f;
+                const float* xv = xs + 64 * p;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    if ((k & 7) == 0) SE_TS_FENCE();
+                    acc += wreg[k] * xv[k];
+                }
+                part[p * 64 + r] = acc;
+            }
+            __syncthreads();
+            if (tid < 64) hb[tid] = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];
+            __syncthreads();
+            // PReLU -> cumulative LayerNorm of ab [64] in place (one frame: wave 0 reduces, see tcm_stream_kernel)
+            auto cln = [&](const float* prm, int which) __attribute__((always_inline)) {
+                if (wave == 0) {
+                    float t = ab[lane];
+                    t = t >= 0.f ? t : prm[lane] * t;
+                    ab[lane] = t;
+                    double s1 = t, s2 = (double)t * t;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        s1 += __shfl_xor(s1, o, 64);
+                        s2 += __shfl_xor(s2, o, 64);
+                    }
+                    if (lane == 0) {
+                        const double s = carry[2 * which] + s1, q = carry[2 * which + 1] + s2;
+                        const double cnt = 64.0 * (double)(tbase + 1), m = s / cnt;
+                        const double var = (q - 2.0 * m * s) / cnt + m * m;
+                        mu[0] = (float)m;
+                        mu[1] = (float)(1.0 / sqrt(var + 1e-5));
+                        carry[2 * which] = s;
+                        carry[2 * which + 1] = q;
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) ab[tid] = (ab[tid] - mu[0]) * mu[1] * prm[64 + tid] + prm[128 + tid];
+                __syncthreads();
+            };
+            for (int br = gated ? 1 : 0; br >= 0; --br) {
+                const float* wcv = br ? B.w_r : B.w_l;
+#pragma unroll
+                for (int q = 0; q < 16 * KS; ++q) wreg[q] = wcv[(long)((16 * p) * KS + q) * 64 + r];
+                if (tid < 64) ab[tid] = hb[tid];
+                __syncthreads();
+                cln(hp + br * 192, br ? 1 : 0);
+                if (B.K > 0) {          // ShareSepConv: one causal FIR shared by all channels
+                    float* w = wf + br * 64 * FP;
+                    float* ring = g_fir + (long)br * 64 * RF;
+                    if (tid < 64) {
+                        const float t = ab[tid];
+                        w[tid * FP + KH] = t;
+                        if (KH > 0) st_agent(ring + (long)tid * RF + ((int)tbase & (RF - 1)), t);
+                    }
+                    __syncthreads();
+                    {
+                        // 4 threads per channel walk a quarter of the taps each (K <= 64), folded through part
+                        const int c = tid >> 2, qd = tid & 3;
+                        float o = 0.f;
+                        for (int k = qd; k < B.K; k += 4) o += ft[br * 64 + k] * w[c * FP + k];
+                        o += __shfl_xor(o, 1, 64);
+                        o += __shfl_xor(o, 2, 64);
+                        if (qd == 0) ab[c] = o;
+                    }
+                    __syncthreads();
+                }
+                float* tp = ct + br * 64 * KS;
+                {
+                    float* ring = g_cv + (long)br * 64 * RC;
+                    if (tid < 64) {
+                        const float t = ab[tid];
+                        st_agent(ring + (long)tid * RC + ((int)tbase & (RC - 1)), t);
+                        tp[tid * KS + KS - 1] = t;          // the newest tap reads this frame
+                    }
+                }
+                __syncthreads();
+                {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16 * KS; ++q) {
+                        if ((q & 7) == 0) SE_TS_FENCE();
+                        acc += wreg[q] * tp[16 * p * KS + q];
+                    }
+                    part[p * 64 + r] = acc;
+                }
+                __syncthreads();
+                if (br == 0) {          // the out-conv's weights fly under the gate product and the last cLN
+                    const float* wo = B.w_out + tid;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) wreg[k] = wo[k * 256];
+                }
+                if (tid < 64) {
+                    const float t = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];
+                    if (br) rg[tid] = sigm_(t);
+                    else ab[tid] = gated ? t * rg[tid] : t;
+                }
+                __syncthreads();
+            }
+            // ---- out head: PReLU -> cLN -> W_out + residual
+            cln(hp + 384, 2);
+            {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    if ((k & 7) == 0) SE_TS_FENCE();
+                    acc += wreg[k] * ab[k];
+                }
+                acc += xs[tid];
+                // the in-conv weights of the next block (or of the first block for the next frame) start their trip now
+                const bool more = bi + 1 < NB || c0 + 1 < a.n;
+                if (more) {
+                    const float* w = a.blk[bi + 1 < NB ? bi + 1 : 0].w_in + (long)(64 * p) * 64 + r;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) wreg[k] = w[k * 64];
+                }
+                __syncthreads();                    // every wave has read its part of xs (residual)
+                if (bi + 1 < NB) xs[tid] = acc;     // the next block's input never leaves LDS
+                else yb[(long)tid * a.Tw + c0] = acc;
+            }
+        }
+        // the next frame gathers ring columns written above (agent-scope stores, read back by agent-scope loads: waiting for
+        // the stores' acknowledgement is enough)
+        if (c0 + 1 < a.n) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        __syncthreads();
+    }
+    for (int bi = 0; bi < NB; ++bi)
+        if (tid < 6) reinterpret_cast<double*>(a.blk[bi].state + (long)b * a.blk[bi].state_stride)[tid] = carry_all[bi * 8 + tid];
+}
+
 int ring_host(int need) {
     int r = 16;
     while (r < need + NS) r <<= 1;
@@ -367,6 +604,46 @@ void launch_tcm_stream(const TcmStreamW& f, const TcmFusedHeads& hd, const float
     }
     if (f.ks == 3) hipLaunchKernelGGL(tcm_stream_kernel<3>, dim3(cx->B), dim3(256), lds, s, a);
     else if (f.ks == 5) hipLaunchKernelGGL(tcm_stream_kernel<5>, dim3(cx->B), dim3(256), lds, s, a);
+    else SE_CHECK(false, "tcm_stream: dilated conv with 3 or 5 taps expected");
+    SE_HIP(hipGetLastError());
+}
+
+bool tcm_chain_enabled() {
+    static const bool on = !(getenv("SE_TCM_CHAIN") && atoi(getenv("SE_TCM_CHAIN")) == 0);
+    return on && tcm_stream_enabled();
+}
+
+void launch_tcm_chain(const TcmStreamW* const* f, const TcmFusedHeads* hd, const int* dil, const int* K, int nblk, const float* x,
+                      float* y, hipStream_t s) {
+    StreamCtx* cx = stream_ctx();
+    SE_CHECK(cx && nblk >= 1 && nblk <= TCM_CHAIN_MAX, "launch_tcm_chain: 1..8 blocks inside a frame-online chunk");
+    TcmChainArgs a{};
+    a.x = x; a.y = y; a.Tw = cx->H + cx->n; a.H = cx->H; a.n = cx->n; a.t0 = cx->t0; a.nblk = nblk;
+    const int ks = f[0]->ks;
+    int fp = 1;
+    for (int i = 0; i < nblk; ++i) {
+        SE_CHECK(f[i]->w_in && f[i]->ks == ks, "launch_tcm_chain: blocks of one chain share the dilated conv's tap count");
+        SE_CHECK(K[i] <= 64, "tcm_stream: FIR longer than 64 taps");
+        const bool gated = f[i]->w_r != nullptr;
+        const int KH = K[i] > 0 ? K[i] - 1 : 0, CH = (ks - 1) * dil[i], nb = gated ? 2 : 1;
+        const int RF = ring_host(KH), RC = ring_host(CH);
+        const long stride = 64 + (long)nb * 64 * ((KH > 0 ? RF : 0) + RC) * sizeof(float);
+        char* state = static_cast<char*>(cx->slot((size_t)cx->B * stride, s));       // same slot layout as launch_tcm_stream
+        a.blk[i] = TcmStreamBlk{f[i]->w_in, f[i]->w_l, f[i]->w_r, f[i]->w_out, hd[i], K[i], dil[i], state, stride};
+        fp = std::max(fp, KH + NS);
+    }
+    cx->memo_src = nullptr;
+    a.fp_max = fp;
+    const size_t lds = (size_t)(256 + 64 * 8 + 2) * sizeof(float) + (2 + 8 * TCM_CHAIN_MAX) * sizeof(double) +
+                       (size_t)TCM_CHAIN_MAX * 11 * 64 * sizeof(float) + (size_t)2 * 64 * (ks + fp) * sizeof(float) + 64;
+    SE_CHECK(lds <= 150 * 1024, "tcm_chain: windows too large for LDS");
+    static bool seen[64] = {};
+    if (first_on_device(seen)) {
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tcm_chain_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tcm_chain_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    }
+    if (ks == 3) hipLaunchKernelGGL(tcm_chain_kernel<3>, dim3(cx->B), dim3(256), lds, s, a);
+    else if (ks == 5) hipLaunchKernelGGL(tcm_chain_kernel<5>, dim3(cx->B), dim3(256), lds, s, a);
     else SE_CHECK(false, "tcm_stream: dilated conv with 3 or 5 taps expected");
     SE_HIP(hipGetLastError());
 }

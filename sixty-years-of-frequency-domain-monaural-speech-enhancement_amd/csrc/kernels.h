@@ -220,6 +220,10 @@ TcmStreamW tcm_stream_build(const std::vector<float>& w_in, const std::vector<fl
 void tcm_stream_free(TcmStreamW& f);
 bool tcm_stream_enabled();      // SE_TCM_STREAM=0: the multi-launch path of round 2
 void launch_tcm_stream(const TcmStreamW& f, const TcmFusedHeads& hd, const float* x, float* y, int dil, int K, hipStream_t s);
+// up to 8 blocks that feed each other as one launch (SE_TCM_CHAIN=0: one launch per block)
+bool tcm_chain_enabled();
+void launch_tcm_chain(const TcmStreamW* const* f, const TcmFusedHeads* hd, const int* dil, const int* K, int nblk, const float* x,
+                      float* y, hipStream_t s);
 
 // CumulativeLayerNorm2d / 1d of the `_new` variants (CTSNet_new/Step1_network.py:213-286): frame t is normalised by the
 // statistics of all C*F values of frames 0..t;  x [B][C][F][T] (F = 1 for 1-D), gain / bias [C].

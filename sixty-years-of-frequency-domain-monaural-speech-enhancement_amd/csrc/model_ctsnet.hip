@@ -238,11 +238,7 @@ class CtsNet final : public Model {
         const long n = (long)B * 256 * T;
         const float* x = b.E[4];
         for (int g = 0; g < 3; ++g) {
-            for (int i = 0; i < 6; ++i) {
-                float* y = b.X[(g * 6 + i) & 1];
-                run_tcm(blocks[g * 6 + i], x, y, b.ts, B, T, st, &ctx.prof);
-                x = y;
-            }
+            x = run_tcm_chain(blocks + g * 6, 6, x, b.X, b.ts, B, T, st, &ctx.prof);
             if (g == 0) SE_HIP(hipMemcpyAsync(b.acc, x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
             else launch_add(b.acc, x, b.acc, n, st);
         }

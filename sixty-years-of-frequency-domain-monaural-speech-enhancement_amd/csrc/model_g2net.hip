@@ -50,11 +50,7 @@ struct G2TcmSeq {      // nn.Sequential(Tcm_list, Tcm_list, Conv1d(256, 161, 1)[
     // x [B][256][T] -> dst ([B] planes of 161 x T at stride dst_b)
     void run(const float* x, float* const X[2], const TcmScratch& ts, float* dst, long dst_b, int B, int T, hipStream_t st,
              Profiler* pf) const {
-        for (int n = 0; n < 2 * NDIL; ++n) {
-            float* y = X[n & 1];
-            run_tcm(blk[n], x, y, ts, B, T, st, pf);
-            x = y;
-        }
+        x = run_tcm_chain(blk, 2 * NDIL, x, X, ts, B, T, st, pf);
         run_pointwise(out, x, 256L * T, T, dst, dst_b, T, B, T, st, pf);
     }
 };

@@ -54,12 +54,7 @@ struct TcmStack {       // p x TCM_list(dilations) of SqueezedTCM (:617-685)
     }
     // x [B][256][T] -> result pointer (one of the ping-pong buffers)
     const float* run(const float* x, float* const X[2], const TcmScratch& ts, int B, int T, hipStream_t st, Profiler* pf) const {
-        for (int n = 0; n < 2 * NDIL; ++n) {
-            float* y = X[n & 1];
-            run_tcm(blk[n], x, y, ts, B, T, st, pf);
-            x = y;
-        }
-        return x;
+        return run_tcm_chain(blk, 2 * NDIL, x, X, ts, B, T, st, pf);
     }
 };
 

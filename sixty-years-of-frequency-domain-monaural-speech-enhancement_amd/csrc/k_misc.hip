@@ -689,6 +689,86 @@ __global__ __launch_bounds__(256) void cln_window_kernel(const float* __restrict
     }
 }
 
+// One or two new frames (the latency-critical push): a thread keeps its share of the C * F * W values in registers - one
+// batch of loads, column sums folded by wave shuffles and one LDS step in float64 (fixed order), the stream's running sums
+// continued by one thread, normalise + PReLU straight from the registers.  cln_window_kernel walks the rows twice with a
+// load per loop iteration (9 us on a 64 x 161 layer; this form: the kernel floor + one round trip).
+template <int W, int VPT>
+__global__ __launch_bounds__(256) void cln_window_reg_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ gain, const float* __restrict__ bias,
+                                                             const float* __restrict__ post_slope, int R, int F, int T, int c0,
+                                                             long tg0, double* __restrict__ carry) {
+    __shared__ double sh[4][2 * W];
+    __shared__ float s_mu[W], s_rs[W];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = R * W;
+    const float* xb = x + (long)b * R * T + c0;
+    float* yb = y + (long)b * R * T + c0;
+    float v[VPT];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int e = tid + 256 * u;
+        const int ec = e < N ? e : 0;
+        v[u] = xb[(long)(ec / W) * T + (ec % W)];
+    }
+    double s[W], q[W];
+#pragma unroll
+    for (int t = 0; t < W; ++t) s[t] = q[t] = 0.0;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int e = tid + 256 * u;
+        if (e < N) {
+            // (W divides 256: a thread's elements all belong to column tid % W)
+#pragma unroll
+            for (int t = 0; t < W; ++t)
+                if (W == 1 || (tid % W) == t) {
+                    s[t] += v[u];
+                    q[t] += (double)v[u] * v[u];
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < W; ++t)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s[t] += __shfl_xor(s[t], o, 64);
+            q[t] += __shfl_xor(q[t], o, 64);
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < W; ++t) {
+            sh[wave][2 * t] = s[t];
+            sh[wave][2 * t + 1] = q[t];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = carry[2 * b], qq = carry[2 * b + 1];
+#pragma unroll
+        for (int t = 0; t < W; ++t) {
+            a += (sh[0][2 * t] + sh[1][2 * t]) + (sh[2][2 * t] + sh[3][2 * t]);
+            qq += (sh[0][2 * t + 1] + sh[1][2 * t + 1]) + (sh[2][2 * t + 1] + sh[3][2 * t + 1]);
+            const double cnt = (double)R * (double)(tg0 + c0 + t + 1), m = a / cnt;
+            const double var = (qq - 2.0 * m * a) / cnt + m * m;
+            s_mu[t] = (float)m;
+            s_rs[t] = (float)(1.0 / sqrt(var + 1e-5));
+        }
+        carry[2 * b] = a;
+        carry[2 * b + 1] = qq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int e = tid + 256 * u;
+        if (e < N) {
+            const int r = e / W, t = e % W, c = r / F;
+            float o = (v[u] - s_mu[t]) * s_rs[t] * gain[c] + bias[c];
+            if (post_slope) o = o >= 0.f ? o : post_slope[c] * o;
+            yb[(long)r * T + t] = o;
+        }
+    }
+}
+
 void launch_cln(const float* x, float* y, const float* gain, const float* bias, const float* pre_slope,
                 const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s) {
     // per-(b, t) statistics live in a small engine-lifetime buffer (grown on first use, never on the steady-state path)
@@ -711,6 +791,18 @@ void launch_cln(const float* x, float* y, const float* gain, const float* bias, 
         cx->memo_src = nullptr;
         double* carry = static_cast<double*>(cx->slot((size_t)B * 2 * sizeof(double), s));
         const long tg0 = cx->t0 - cx->H;
+        static const bool reg_on = !(getenv("SE_CLN_REG") && atoi(getenv("SE_CLN_REG")) == 0);
+        if (reg_on && K <= 0 && !pre_slope && cx->n <= 2 && (long)R * cx->n <= 256L * 41 * cx->n && R <= 256 * 41) {
+            // (every frame of the chunk is live: tg0 + c0 = the stream index of the first new frame >= 0)
+            if (cx->n == 1)
+                hipLaunchKernelGGL((cln_window_reg_kernel<1, 41>), dim3(B), dim3(256), 0, s, x, y, gain, bias, post_slope, R, F, T,
+                                   c0, tg0, carry);
+            else
+                hipLaunchKernelGGL((cln_window_reg_kernel<2, 82>), dim3(B), dim3(256), 0, s, x, y, gain, bias, post_slope, R, F, T,
+                                   c0, tg0, carry);
+            SE_HIP(hipGetLastError());
+            return;
+        }
         if ((long)R * (T - c0) <= 32768 && (K <= 0 || (size_t)R * (T - c0) * 4 + (size_t)T * 24 <= 60000)) {   // small windows: one launch
             const size_t lds = (size_t)T * 24 + (K > 0 ? (size_t)R * (T - c0) * 4 : 0);
             hipLaunchKernelGGL(cln_window_kernel, dim3(B), dim3(256), lds, s, x, y, gain, bias, pre_slope, post_slope,

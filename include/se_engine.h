@@ -137,8 +137,8 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
  * normal for short pushes: the algorithmic latency is n_fft / 2 + 1 samples plus up to one hop).  se_stream_flush() ends
  * the stream: the remaining frames (reflected right edge, as the offline STFT) and samples; the concatenated outputs equal
  * se_enhance_batch() of the whole signal sample for sample (up to fp32 rounding of the differently tiled recurrence).
- *   c_dev: the utterance scale c (se_rms_scale) cannot be known before the utterance ends; the caller provides one value
- *          per stream (e.g. from a calibration run or a running estimate), NULL = 1.0.  With the offline c the two paths
+*   c_dev: the utterance scale c (se_rms_scale) cannot be known before the utterance ends; the caller provides one value
+ *          per stream (e.g. from a calibration run), NULL = 1.0; se_stream_begin_running() below estimates it on the fly.  With the offline c the two paths
  *          agree exactly - that is what the tests check.
  *   max_chunk_frames: frames advanced per internal step (latency / efficiency trade-off, default 16).
  * Supported: SE_MODEL_CRN, SE_MODEL_LSTM, SE_MODEL_GCRN, SE_MODEL_DPCRN, SE_MODEL_DCCRN (whose decoder looks six frames ahead:
@@ -148,6 +148,14 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
  * then carries up to 128 history frames per dilated conv and the running cLN sums).  Streams are limited to max_samples
  * of se_config. */
 int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, void* stream);
+/* The same, for a caller that has no scale to give: the stream runs on a RUNNING unit-RMS scale.  After every push
+ * c = sqrt(samples so far / their sum of squares) - the decode scripts' `c = np.sqrt(len(x) / np.sum(x ** 2.0))`
+ * (e.g. CRN/crn_decode_vb.py:34) over what has been heard; the frames that push releases are transformed under that c and
+ * taken back by it in the iSTFT (the overlap-add mixes frames of different c, each divided by its own).  A single push of a
+ * whole utterance followed by se_stream_flush() therefore equals se_enhance_batch(); piecewise, the first frames see the
+ * scale of a short prefix - the price of not knowing the future - and the output tracks the offline decode as the
+ * estimate settles (tests/test_gpu_streaming.py).  Scaling the input by k scales the output by k exactly as offline. */
+int se_stream_begin_running(se_engine* e, int32_t batch, int32_t max_chunk_frames, void* stream);
 int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_new, float* out_dev, int64_t out_pitch,
                    int32_t* n_out, void* stream);
 int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_out, void* stream);

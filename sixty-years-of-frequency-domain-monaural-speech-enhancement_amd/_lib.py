@@ -18,7 +18,7 @@ SYMBOLS = [
     'se_abi_version', 'se_last_error', 'se_engine_create', 'se_engine_destroy', 'se_engine_set_tensor',
     'se_engine_finalize', 'se_forward', 'se_enhance_batch', 'se_output_samples', 'se_rms_scale', 'se_stft',
     'se_istft', 'se_num_frames', 'se_num_bins', 'se_set_profiling', 'se_get_profile', 'se_resample',
-    'se_resample_samples', 'se_enhance_ragged', 'se_get_stage_profile', 'se_stream_begin', 'se_stream_push', 'se_stream_flush',
+    'se_resample_samples', 'se_enhance_ragged', 'se_get_stage_profile', 'se_stream_begin', 'se_stream_begin_running', 'se_stream_push', 'se_stream_flush',
     'se_uformer_forward', 'se_pcm16_decode', 'se_pcm16_encode',
 ]
 
@@ -75,6 +75,7 @@ def load():
     lib.se_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.se_get_stage_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.se_stream_begin.argtypes = [vp, i32, i32, vp, vp]
+    lib.se_stream_begin_running.argtypes = [vp, i32, i32, vp]
     lib.se_stream_push.argtypes = [vp, vp, i64, i32, vp, i64, C.POINTER(i32), vp]
     lib.se_stream_flush.argtypes = [vp, vp, i64, C.POINTER(i32), vp]
     lib.se_resample_samples.restype = i64

@@ -39,6 +39,11 @@ struct se_engine {
         bool active = false;
         int batch = 0, max_chunk = 0, n_total = 0, t_done = 0, o_done = 0;
         int carve_B = -1, carve_n = -1;      // (batch, chunk frames) the arena was last carved and zero-filled for
+        // running unit-RMS scale (se_stream_begin_running): sum of squares so far per stream, 1 / c per frame in a ring
+        bool running = false;
+        double* sumsq = nullptr;
+        float* frame_inv = nullptr;
+        int ring = 0;
         float* wav = nullptr;
         float* c = nullptr;
     } strm;
@@ -107,7 +112,7 @@ int se_pcm16_encode(const float* in_dev, int64_t in_pitch, int32_t batch, int32_
     });
 }
 
-int32_t se_abi_version(void) { return 3; }
+int32_t se_abi_version(void) { return 4; }
 
 const char* se_last_error(const se_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 
@@ -176,6 +181,8 @@ int se_engine_destroy(se_engine* e) {
     }
     if (e->strm.wav) (void)hipFree(e->strm.wav);
     if (e->strm.c) (void)hipFree(e->strm.c);
+    if (e->strm.sumsq) (void)hipFree(e->strm.sumsq);
+    if (e->strm.frame_inv) (void)hipFree(e->strm.frame_inv);
     if (e->rag_host) (void)hipHostFree(e->rag_host);
     if (e->rag_dev) (void)hipFree(e->rag_dev);
     for (auto& ev : e->rag_ev)
@@ -429,15 +436,15 @@ static void stream_process(se_engine* e, int t_end, bool last, float* out_dev, i
         const int t_fin = end ? S.t_done : S.t_done - LAG;
         const int o_hi = end ? n_final : std::min(S.n_total, t_fin * g.hop - g.n_fft / 2);
         if (o_hi > S.o_done) {
-            launch_istft(g, est, B, t_fin, Tw, nullptr, S.c, out_dev + *written, out_pitch, o_hi, st, t0 - HC,
-                         std::max(0, t0 - HC), S.o_done);
+            launch_istft(g, est, B, t_fin, Tw, nullptr, S.running ? nullptr : S.c, out_dev + *written, out_pitch, o_hi, st, t0 - HC,
+                         std::max(0, t0 - HC), S.o_done, S.running ? S.frame_inv : nullptr, S.ring);
             *written += o_hi - S.o_done;
             S.o_done = o_hi;
         }
     }
 }
 
-int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, void* stream) {
+static int stream_begin_impl(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, bool running, void* stream) {
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
@@ -456,12 +463,30 @@ int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const
         }
         if (c_dev) SE_HIP(hipMemcpyAsync(S.c, c_dev, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice, st));
         else launch_fill(S.c, batch, 1.f, st);
+        S.running = running;
+        if (running) {
+            if (!S.sumsq) {
+                S.ring = 64;
+                while (S.ring < e->plan_frames + 64) S.ring <<= 1;
+                SE_HIP(hipMalloc(&S.sumsq, (size_t)e->ctx.max_batch * sizeof(double)));
+                SE_HIP(hipMalloc(&S.frame_inv, (size_t)e->ctx.max_batch * S.ring * sizeof(float)));
+            }
+            SE_HIP(hipMemsetAsync(S.sumsq, 0, (size_t)batch * sizeof(double), st));
+            launch_fill(S.frame_inv, (long)batch * S.ring, 1.f, st);
+        }
         S.batch = batch;
         S.n_total = S.t_done = S.o_done = 0;
         S.carve_B = S.carve_n = -1;
         e->model->stream_begin(batch, S.max_chunk, st);
         S.active = true;
     });
+}
+
+int se_stream_begin(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, void* stream) {
+    return stream_begin_impl(e, batch, max_chunk_frames, c_dev, false, stream);
+}
+int se_stream_begin_running(se_engine* e, int32_t batch, int32_t max_chunk_frames, void* stream) {
+    return stream_begin_impl(e, batch, max_chunk_frames, nullptr, true, stream);
 }
 
 int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_new, float* out_dev, int64_t out_pitch,
@@ -483,6 +508,9 @@ int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_
         // frame t is final once sample t * hop + n_fft / 2 has arrived (its right half is real signal, and frame 0's reflected
         // left half needs sample n_fft / 2 as well)
         const int t_avail = S.n_total > g.n_fft / 2 ? (S.n_total - g.n_fft / 2 - 1) / g.hop + 1 : 0;
+        if (S.running)      // c of the frames this push releases: sqrt(samples so far / their sum of squares)
+            launch_stream_rms(S.wav, e->ctx.max_samples, S.batch, S.n_total, n_new, S.sumsq, S.c, S.frame_inv, S.ring, S.t_done,
+                              std::max(t_avail, S.t_done), st);
         int written = 0;
         const int will = std::max(0, std::min(S.n_total, (t_avail - e->model->stream_lag()) * g.hop - g.n_fft / 2) - S.o_done);
         SE_CHECK(out_pitch >= will, "output row pitch too small for the samples this push completes");
@@ -502,6 +530,9 @@ int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_
         SE_CHECK(out_pitch >= e->model->output_samples(S.n_total) - S.o_done, "output row pitch too small for the rest of the stream");
         int written = 0;
         e->ctx.prof_reset();
+        if (S.running)
+            launch_stream_rms(S.wav, e->ctx.max_samples, S.batch, S.n_total, 0, S.sumsq, S.c, S.frame_inv, S.ring, S.t_done,
+                              e->model->num_frames(S.n_total), static_cast<hipStream_t>(stream));
         stream_process(e, e->model->num_frames(S.n_total), true, out_dev, out_pitch, &written, static_cast<hipStream_t>(stream));
         *n_out = written;
         S.active = false;

@@ -859,6 +859,42 @@ void launch_zero_tail(float* x, int B, long rows, int T, hipStream_t s) {
     SE_HIP(hipGetLastError());
 }
 
+// ---- running unit-RMS scale of a frame-online stream (se_stream_begin_running) ---------------------------------------
+// The decode scripts scale an utterance by c = sqrt(len / sum x^2) (every *_decode_vb.py) - known only when the utterance has
+// ended.  A stream that cannot wait uses what it has heard: after a push, c = sqrt(n_total / sum of squares so far) (float64
+// sum, one workgroup per stream), every frame this push releases ([t0, t1)) is transformed under that c and taken back by
+// it in the iSTFT (ring of 1 / c per frame).  A push that delivers the whole utterance at once therefore IS the offline decode.
+__global__ __launch_bounds__(256) void stream_rms_kernel(const float* __restrict__ wav, long pitch, int n_total, int n_new,
+                                                         double* __restrict__ sumsq, float* __restrict__ c,
+                                                         float* __restrict__ frame_inv, int ring, int t0, int t1) {
+    __shared__ double sh[256];
+    __shared__ float s_inv;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* x = wav + (long)b * pitch + (n_total - n_new);
+    double s = 0.0;
+    for (int i = tid; i < n_new; i += 256) s += (double)x[i] * x[i];
+    sh[tid] = s;
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {
+        if (tid < h) sh[tid] += sh[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double tot = sumsq[b] + sh[0];
+        sumsq[b] = tot;
+        const float cc = tot > 1e-20 ? (float)sqrt((double)n_total / tot) : 1.f;      // (digital silence so far: no scaling)
+        c[b] = cc;
+        s_inv = 1.f / cc;
+    }
+    __syncthreads();
+    for (int t = t0 + tid; t < t1; t += 256) frame_inv[(long)b * ring + (t & (ring - 1))] = s_inv;
+}
+void launch_stream_rms(const float* wav, long pitch, int B, int n_total, int n_new, double* sumsq, float* c, float* frame_inv,
+                       int ring, int t0, int t1, hipStream_t s) {
+    hipLaunchKernelGGL(stream_rms_kernel, dim3(B), dim3(256), 0, s, wav, pitch, n_total, n_new, sumsq, c, frame_inv, ring, t0, t1);
+    SE_HIP(hipGetLastError());
+}
+
 // ---- streaming history columns -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hist_kernel(float* __restrict__ buf, float* __restrict__ state, long nrows, int Tw,
                                                    int hc, int save) {

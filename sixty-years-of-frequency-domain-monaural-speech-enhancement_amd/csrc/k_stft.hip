@@ -447,14 +447,16 @@ void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, 
 }
 
 void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* /*frames: unused since the fused kernel*/,
-                  const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo) {
+                  const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo,
+                  const float* frame_inv, int ring) {
     const Ragged* rg = ragged_ctx();
     StageScope prof(STAGE_ISTFT, s, 8.0 * g.F() * T * B + 4.0 * Lout * B);
     SE_CHECK(Lout > o_lo, "launch_istft: empty output range");
     if (stft2_enabled() && (g.n_fft == 512 || g.n_fft == 320)) {
-        launch_istft2(g, spec_ri, B, T, Tp, c_scale, wav_out, out_pitch, Lout, s, t_off, t_lo, o_lo);
+        launch_istft2(g, spec_ri, B, T, Tp, c_scale, wav_out, out_pitch, Lout, s, t_off, t_lo, o_lo, frame_inv, ring);
         return;
     }
+    SE_CHECK(!frame_inv, "per-frame scales (running-RMS streams) need the round-3 iSTFT kernel (SE_STFT_V1 unset, n_fft 320 / 512)");
     int halo = (g.n_fft + g.hop - 1) / g.hop - 1;
     halo += halo & 1;                                       // frames are transformed in pairs
     SE_CHECK(halo < FPB, "hop too small for the fused overlap-add window");

@@ -362,6 +362,7 @@ struct Istft2Args {
     const int *tlen, *olen;
     int t_off, t_lo, o_lo, pos_base;
     const float* tab;
+    const float* frame_inv; int ring_mask;      // optional [B][ring]: frame t is multiplied by frame_inv[b][t & ring_mask]
 };
 
 template <int N>
@@ -470,12 +471,19 @@ __global__ __launch_bounds__(Shape<true>::NT) void istft2_kernel(const Istft2Arg
         fft_regs<N, true>(z[q], ws, K, lane);
         // z[q][d] = time sample n = k1 + R1 * (c + 8 d): real part -> frame 2P, imaginary part -> frame 2P + 1, windowed
         if (K.act) {
+            // frame-online streams with a running scale: every frame was transformed under its own c and is taken back by it
+            float s0 = invN, s1 = invN;
+            if (a.frame_inv) {
+                const float* fr = a.frame_inv + (long)b * (a.ring_mask + 1);
+                s0 *= fr[(tb + 2 * P) & a.ring_mask];
+                s1 *= fr[(tb + 2 * P + 1) & a.ring_mask];
+            }
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
                 const int n = K.k1 + R1 * (K.b + 8 * d);
-                const float w = wls[n] * invN;
-                frames[(size_t)(2 * P) * N + n] = z[q][d].x * w;
-                frames[(size_t)(2 * P + 1) * N + n] = z[q][d].y * w;
+                const float w = wls[n];
+                frames[(size_t)(2 * P) * N + n] = z[q][d].x * (w * s0);
+                frames[(size_t)(2 * P + 1) * N + n] = z[q][d].y * (w * s1);
             }
         }
     }
@@ -544,14 +552,15 @@ void launch_stft2(const StftGeom& g, const float* wav, long pitch, int B, int L,
 }
 
 void launch_istft2(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, const float* c_scale, float* wav_out,
-                   long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo) {
+                   long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo, const float* frame_inv, int ring) {
     const Ragged* rg = ragged_ctx();
     int halo = (g.n_fft + g.hop - 1) / g.hop - 1;
     halo += halo & 1;                                       // frames are transformed in pairs
     SE_CHECK(halo < NFB, "hop too small for the fused overlap-add window");
+    SE_CHECK(!frame_inv || (ring > 0 && (ring & (ring - 1)) == 0), "launch_istft2: per-frame scales live in a power-of-two ring");
     const int own = NFB - halo;
     Istft2Args a{spec_ri, B, T, Tp, g.hop, c_scale, wav_out, out_pitch, Lout, own, halo,
-                 rg ? rg->tlen : nullptr, rg ? rg->olen : nullptr, t_off, t_lo, o_lo, 0, fft_table(g.n_fft, g.win)};
+                 rg ? rg->tlen : nullptr, rg ? rg->olen : nullptr, t_off, t_lo, o_lo, 0, fft_table(g.n_fft, g.win), frame_inv, frame_inv ? ring - 1 : 0};
     const int span = own * g.hop;
     a.pos_base = (o_lo + g.n_fft / 2) / g.hop * g.hop;
     dim3 grid((g.n_fft / 2 + Lout - a.pos_base + span - 1) / span, B);

@@ -77,7 +77,15 @@ void launch_stft(const StftGeom& g, const float* wav, long pitch, int B, int L, 
 // to wav_out[o - o_lo] (every frame covering them must be in the window).
 void launch_istft(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, float* frames_scratch,
                   const float* c_scale, float* wav_out, long out_pitch, int Lout, hipStream_t s, int t_off = 0, int t_lo = 0,
-                  int o_lo = 0);
+                  int o_lo = 0, const float* frame_inv = nullptr, int ring = 0);
+// frame_inv (optional, [B][ring], ring a power of two): frame t is multiplied by frame_inv[b][t % ring] before the
+// overlap-add - streams that run on a RUNNING unit-RMS scale transform every frame under the c known when it was
+// released (se_stream_begin_running); c_scale is then null
+
+// running unit-RMS scale of frame-online streams (k_misc.hip): sumsq[b] += the n_new newest samples squared, c[b] =
+// sqrt(n_total / sumsq[b]), frames [t0, t1) get 1 / c[b] in the ring frame_inv [B][ring]
+void launch_stream_rms(const float* wav, long pitch, int B, int n_total, int n_new, double* sumsq, float* c, float* frame_inv,
+                       int ring, int t0, int t1, hipStream_t s);
 
 // round-3 kernels behind the two launchers above (k_stft2.hip): FFT points in registers, two LDS exchanges, 32-frame tiles
 // moved through LDS so that the [F][T]-major spectrogram is touched in 128 B runs; SE_STFT_V1=1 selects the old kernels
@@ -85,7 +93,8 @@ bool stft2_enabled();
 void launch_stft2(const StftGeom& g, const float* wav, long pitch, int B, int L, int Lpad, const float* c_scale, float p_in,
                   float* spec_ri, float* mag, int T, int Tp, hipStream_t s, int t_first, int col0);
 void launch_istft2(const StftGeom& g, const float* spec_ri, int B, int T, int Tp, const float* c_scale, float* wav_out,
-                   long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo);
+                   long out_pitch, int Lout, hipStream_t s, int t_off, int t_lo, int o_lo, const float* frame_inv = nullptr,
+                   int ring = 0);
 
 // Frame-online context of the models that are built from shared blocks (blocks.h / unet.h: the cLN `_new` variants).
 // While a chunk is decoded the model publishes it thread-locally; every activation of the chunk is a window of H history

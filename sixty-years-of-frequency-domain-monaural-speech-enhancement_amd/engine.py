@@ -162,8 +162,9 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ frame-online decoding
-    def stream_begin(self, batch, c=None, max_chunk_frames=16):
-        """Start `batch` parallel streams; c: per-stream scale tensor (what rms_scale() returns offline) or None = 1."""
+    def stream_begin(self, batch, c=None, max_chunk_frames=16, running_rms=False):
+        """Start `batch` parallel streams; c: per-stream scale tensor (what rms_scale() returns offline) or None = 1.
+        running_rms=True: no scale from the caller - the engine keeps a running unit-RMS estimate (se_stream_begin_running)."""
         batch = int(batch)
         if not 1 <= batch <= self.max_batch:
             raise EngineError(f"stream_begin: batch {batch} outside 1..max_batch ({self.max_batch})")
@@ -172,6 +173,12 @@ class Engine:
             if not c.is_contiguous() or c.numel() < batch:        # the engine copies `batch` floats from c
                 raise EngineError(f"stream_begin c: need a contiguous tensor of >= {batch} scales, got shape {tuple(c.shape)}")
         self._stream_batch = 0
+        if running_rms:
+            if c is not None:
+                raise EngineError("stream_begin: running_rms=True and a caller-provided scale exclude each other")
+            self._check(self._lib.se_stream_begin_running(self._h, batch, max_chunk_frames, self._stream()))
+            self._stream_batch = batch
+            return
         self._check(self._lib.se_stream_begin(self._h, batch, max_chunk_frames,
                                               C.c_void_p(c.data_ptr()) if c is not None else None, self._stream()))
         self._stream_batch = batch

@@ -174,3 +174,44 @@ def test_stream_argument_checks():
     assert a.shape[0] == 4 and a.shape[1] + b.shape[1] == 4000
     with pytest.raises(EngineError):
         eng.stream_flush()                                  # the stream ended with the first flush
+
+
+@pytest.mark.parametrize('name', ['crn', 'dccrn', 'g2net_new'])
+def test_running_rms_stream(name):
+    """se_stream_begin_running: the stream estimates the decode scripts' unit-RMS scale from what it has heard so far
+    (c = sqrt(samples so far / their sum of squares), `c = np.sqrt(len(x) / np.sum(x ** 2.0))` of every *_decode_vb.py over
+    the prefix) and takes every frame back by the c it was transformed under.
+      * one push of the whole utterance + flush = the offline decode (all frames see the final c);
+      * scaling the input scales the output, as offline (the network sees the same unit-RMS signal);
+      * fed in 10 ms pieces, a stationary signal's output settles on the offline decode as the estimate does."""
+    import torch
+    L, B = 32000, 2
+    m = _new_variant(name, B, L) if name.endswith('_new') else None
+    if m is None:
+        from se_amd.models import MODEL_CLASSES
+        m = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(SEEDS[name])
+    x = np.stack([synth.synth_clip(870 + b, 'white', L) for b in range(B)])
+    xt = torch.from_numpy(x).cuda()
+    ref = m.enhance_batch(xt).cpu().numpy()
+    eng = m.engine
+
+    def run(sig, piece):
+        eng.stream_begin(B, running_rms=True, max_chunk_frames=8)
+        outs = [eng.stream_push(sig[:, p:p + piece].contiguous()).cpu().numpy() for p in range(0, L, piece)]
+        outs.append(eng.stream_flush().cpu().numpy())
+        return np.concatenate(outs, axis=1)
+
+    whole = run(xt, L)
+    assert whole.shape == ref.shape and rms(whole - ref) < 1e-6 + 2e-5 * rms(ref), rms(whole - ref)
+    pieces = run(xt, 160)
+    assert pieces.shape == ref.shape and np.isfinite(pieces).all()
+    scaled = run(xt * 0.25, 160)
+    assert rms(scaled - 0.25 * pieces) < 1e-6 + 2e-5 * rms(pieces)
+    # white noise: the prefix RMS is within a few percent of the utterance RMS after 0.25 s; the tail of the output agrees
+    # with the offline decode to the few percent that the network's sensitivity to its input level leaves
+    tail = slice(L // 2, L)
+    e_tail, e_head = rms(pieces[:, tail] - ref[:, tail]), rms(pieces[:, :L // 8] - ref[:, :L // 8])
+    print(name, 'running-RMS stream vs offline: rel err head', e_head / rms(ref), 'tail', e_tail / rms(ref))
+    assert e_tail < 0.1 * rms(ref[:, tail])
+    with pytest.raises(Exception):
+        eng.stream_begin(B, c=eng.rms_scale(xt), running_rms=True)

@@ -215,3 +215,29 @@ def test_running_rms_stream(name):
     assert e_tail < 0.1 * rms(ref[:, tail])
     with pytest.raises(Exception):
         eng.stream_begin(B, c=eng.rms_scale(xt), running_rms=True)
+
+
+@pytest.mark.parametrize('name', ['ctsnet_new', 'g2net_new', 'taylorsenet_new', 'dccrn'])
+def test_long_stream_equals_offline(name):
+    """10 s (T = 1001 > the 401 frames of the 4 s fixtures) in 40 ms pushes: ring positions wrap many times (TCM rings of 16 ... 128
+    columns, the running cLN sums over a thousand frames, DCCRN's delayed decoder) and the result still equals the offline
+    decode - which tests/test_gpu_long_clips.py pins to the reference's own 10 s / 15 s outputs."""
+    import torch
+    L, B = 160000, 1
+    if name.endswith('_new'):
+        m = _new_variant(name, B, L)
+    else:
+        from se_amd.models import MODEL_CLASSES
+        m = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(SEEDS[name])
+    x = synth.synth_clip(880, 'speech', L)[None]
+    xt = torch.from_numpy(x).cuda()
+    ref = m.enhance_batch(xt).cpu().numpy()
+    eng = m.engine
+    eng.stream_begin(B, c=eng.rms_scale(xt), max_chunk_frames=4)
+    outs = [eng.stream_push(xt[:, p:p + 640].contiguous()).cpu().numpy() for p in range(0, L, 640)]
+    outs.append(eng.stream_flush().cpu().numpy())
+    got = np.concatenate(outs, axis=1)
+    assert got.shape == ref.shape
+    e = rms(got - ref)
+    print(name, '10 s stream vs offline rms err', e, 'rms ref', rms(ref))
+    assert e < 1e-6 + 2e-5 * rms(ref)

@@ -155,5 +155,8 @@ void gc_unregister_overread_range(const void* lo);
 // true when launches of this plan can emit the per-tile statistics of GCParams::stats
 bool gc_stats_supported(const GCPlan& pl);
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream);
+// two launches that would both take the thin path (the frequency-parity classes of a transposed conv on a few frames) as one;
+// false: nothing was launched
+bool gc_launch_thin_pair(const GCParams& p0, const GCParams& p1, hipStream_t stream);
 
 }  // namespace se

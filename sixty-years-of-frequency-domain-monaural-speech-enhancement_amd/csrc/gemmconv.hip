@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256) void gc_small_lds_kernel(const GCParams p, con
 // issued in batches of 8 independent (weight, activation) loads - a block lives for 2-3 memory round trips - and the tap
 // table travels in the kernel arguments (GCParams::tdf / tdt), so that no address waits for a table fetch.
 template <int EPI, int NT>
-__global__ __launch_bounds__(256) void gc_thin_kernel(const GCParams p) {
+__device__ __forceinline__ void gc_thin_body(const GCParams& p, const int blk) {
     constexpr int RB = 8, KG = 32, UN = 8;          // rows per workgroup, K groups, K rows in flight per thread
     __shared__ float part[KG][RB][NT + 1];
     __shared__ int s_df[GC_MAX_TAPS], s_dt[GC_MAX_TAPS];
@@ -878,8 +878,8 @@ __global__ __launch_bounds__(256) void gc_thin_kernel(const GCParams p) {
         }
     __syncthreads();
     const int nm = (p.M + RB - 1) / RB;          // (rows M .. Mp of the packed matrix are padding)
-    const int mt = blockIdx.x % nm;
-    const int rest = blockIdx.x / nm;
+    const int mt = blk % nm;
+    const int rest = blk / nm;
     const int q = rest % p.Q, b = rest / p.Q;
     const int m = mt * RB + mi, t0 = p.t_base, n = p.Tout - p.t_base;
     const int ntaps = p.ntaps, Ktot = (p.C0 + p.C1) * ntaps;
@@ -954,6 +954,22 @@ __global__ __launch_bounds__(256) void gc_thin_kernel(const GCParams p) {
         dst[(long)mr * p.d_c] = v;
     }
 }
+template <int EPI, int NT>
+__global__ __launch_bounds__(256) void gc_thin_kernel(const GCParams p) {
+    gc_thin_body<EPI, NT>(p, (int)blockIdx.x);
+}
+// Both frequency-parity classes of a transposed conv in one launch: a class is a block range with its own taps / weights /
+// output rows (a kernel of this size costs ~4.7 us before it does anything: a one-frame push of TaylorSENet_new made 36 such
+// second launches)
+struct GCThinPair {
+    GCParams p[2];
+    int nblk0;
+};
+template <int EPI, int NT>
+__global__ __launch_bounds__(256) void gc_thin_pair_kernel(const GCThinPair a) {
+    const int cls = (int)blockIdx.x >= a.nblk0 ? 1 : 0;
+    gc_thin_body<EPI, NT>(a.p[cls], (int)blockIdx.x - (cls ? a.nblk0 : 0));
+}
 template <int EPI>
 static void gc_thin_launch_n(const GCParams& p, dim3 grid, int n, hipStream_t stream) {
     if (n <= 1) hipLaunchKernelGGL((gc_thin_kernel<EPI, 1>), grid, dim3(256), 0, stream, p);
@@ -961,17 +977,19 @@ static void gc_thin_launch_n(const GCParams& p, dim3 grid, int n, hipStream_t st
     else if (n <= 4) hipLaunchKernelGGL((gc_thin_kernel<EPI, 4>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gc_thin_kernel<EPI, 8>), grid, dim3(256), 0, stream, p);
 }
-static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
+// number of workgroups of the launch on the thin path, 0: not a thin launch
+static long gc_thin_blocks(const GCParams& p) {
     static const int thin_env = getenv("SE_GC_THIN") ? atoi(getenv("SE_GC_THIN")) : 1;
     const int n = p.Tout - p.t_base;
     // (layers with <= 4 output channels have the packed matrix too: a one-frame launch of the direct kernel walks its whole K
     // in one thread per output - 20-40 us; the fused parity pair of a transposed conv only exists there)
-    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.epi == EPI_LSTM || p.stats) return false;
+    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.epi == EPI_LSTM || p.stats) return 0;
+    if (p.epi != EPI_ACT && p.epi != EPI_ADD && p.epi != EPI_MUL && p.epi != EPI_GLU) return 0;
     const long nblk = (long)((p.M + 7) >> 3) * p.Q * p.B;
     // (a few frames per row is not yet a small launch: the LSTM input projections of a batch-1 decode are 1 "frame" wide
     // and 401 rows high with K = 1024 - matrix work)
     static const long thin_max = getenv("SE_GC_THIN_MAX") ? atol(getenv("SE_GC_THIN_MAX")) : 8192;
-    if (nblk > thin_max) return false;
+    if (nblk > thin_max) return 0;
     // Both paths are latency-bound at these sizes: a thin block walks K / 32 rows with 1 + NT loads each (~0.08 us per row
     // and load, ~2 048 blocks in flight) and re-reads its 8 weight rows from L2 (32 B x K per block: 16 streams x one frame of
     // DCCRN's 256-channel layers = 4 096 blocks x 80 KB - 110 us against 80 us of the MFMA tiles); an MFMA workgroup makes K / 16
@@ -981,14 +999,48 @@ static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
         const int nt = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
         const double waves_thin = std::ceil((double)nblk / 2048.0);
         const double waves_mfma = std::ceil((double)std::max(p.Z, 1) * p.B * p.Q * std::max(p.n_mtiles, 1) / 512.0);
-        if ((long)p.B * n > 64 || nblk > 2800 * waves_mfma || waves_thin * (1 + nt) > 12 * waves_mfma) return false;
+        if ((long)p.B * n > 64 || nblk > 2800 * waves_mfma || waves_thin * (1 + nt) > 12 * waves_mfma) return 0;
     }
+    return nblk;
+}
+static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
+    const long nblk = gc_thin_blocks(p);
+    if (nblk <= 0) return false;
+    const int n = p.Tout - p.t_base;
     dim3 grid((unsigned)nblk);
     switch (p.epi) {
         case EPI_ACT: gc_thin_launch_n<EPI_ACT>(p, grid, n, stream); break;
         case EPI_ADD: gc_thin_launch_n<EPI_ADD>(p, grid, n, stream); break;
         case EPI_MUL: gc_thin_launch_n<EPI_MUL>(p, grid, n, stream); break;
         case EPI_GLU: gc_thin_launch_n<EPI_GLU>(p, grid, n, stream); break;
+        default: return false;
+    }
+    SE_HIP(hipGetLastError());
+    return true;
+}
+
+template <int EPI>
+static void gc_thin_pair_launch_n(const GCThinPair& a, dim3 grid, int n, hipStream_t stream) {
+    if (n <= 1) hipLaunchKernelGGL((gc_thin_pair_kernel<EPI, 1>), grid, dim3(256), 0, stream, a);
+    else if (n <= 2) hipLaunchKernelGGL((gc_thin_pair_kernel<EPI, 2>), grid, dim3(256), 0, stream, a);
+    else if (n <= 4) hipLaunchKernelGGL((gc_thin_pair_kernel<EPI, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gc_thin_pair_kernel<EPI, 8>), grid, dim3(256), 0, stream, a);
+}
+bool gc_launch_thin_pair(const GCParams& p0, const GCParams& p1, hipStream_t stream) {
+    static const int pair_env = getenv("SE_GC_THIN_PAIR") ? atoi(getenv("SE_GC_THIN_PAIR")) : 1;
+    const long n0 = gc_thin_blocks(p0), n1 = gc_thin_blocks(p1);
+    if (!pair_env || n0 <= 0 || n1 <= 0 || p0.epi != p1.epi || p0.Tout - p0.t_base != p1.Tout - p1.t_base) return false;
+    GCThinPair a;
+    a.p[0] = p0;
+    a.p[1] = p1;
+    a.nblk0 = (int)n0;
+    const int n = p0.Tout - p0.t_base;
+    dim3 grid((unsigned)(n0 + n1));
+    switch (p0.epi) {
+        case EPI_ACT: gc_thin_pair_launch_n<EPI_ACT>(a, grid, n, stream); break;
+        case EPI_ADD: gc_thin_pair_launch_n<EPI_ADD>(a, grid, n, stream); break;
+        case EPI_MUL: gc_thin_pair_launch_n<EPI_MUL>(a, grid, n, stream); break;
+        case EPI_GLU: gc_thin_pair_launch_n<EPI_GLU>(a, grid, n, stream); break;
         default: return false;
     }
     SE_HIP(hipGetLastError());

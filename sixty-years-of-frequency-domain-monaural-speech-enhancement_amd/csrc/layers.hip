@@ -354,7 +354,8 @@ Profiler::~Profiler() {
 
 // Frame-online chunk (kernels.h: StreamCtx): bring the history columns the taps reach back to into the sources, then
 // produce only the new frames.
-static void gc_launch_stream(StreamCtx& cx, const GCPlan& pl, GCParams p, hipStream_t st) {
+void gc_launch_prof(const GCPlan& pl, const GCParams& p, hipStream_t st, Profiler* prof);
+static void gc_stream_prepare(StreamCtx& cx, const GCPlan& pl, GCParams& p, hipStream_t st) {
     SE_CHECK(pl.p.causal && p.Z <= 1 && p.epi != EPI_LSTM && !p.stats, "frame-online mode: layer is not a causal feed-forward conv");
     SE_CHECK(p.Tin == cx.H + cx.n && p.Tout == p.Tin && p.B == cx.B, "frame-online mode: tensor is not a window of the current chunk");
     const int need = pl.lookback;
@@ -367,7 +368,24 @@ static void gc_launch_stream(StreamCtx& cx, const GCPlan& pl, GCParams p, hipStr
     cx.memo_src = need > 0 ? p.src0 : nullptr;
     cx.memo_need = need;
     p.t_base = cx.H;
+}
+static void gc_launch_stream(StreamCtx& cx, const GCPlan& pl, GCParams p, hipStream_t st) {
+    gc_stream_prepare(cx, pl, p, st);
     gc_launch(pl, p, st);
+}
+// the two frequency-parity classes of a transposed conv: one thin launch when both would take that path
+static void gc_launch_classes(const GCPlan& pa, GCParams a, const GCPlan& pb, GCParams b, hipStream_t st, Profiler* prof) {
+    if (StreamCtx* cx = stream_ctx()) {
+        gc_stream_prepare(*cx, pa, a, st);
+        gc_stream_prepare(*cx, pb, b, st);
+        if (gc_launch_thin_pair(a, b, st)) return;
+        gc_launch(pa, a, st);
+        gc_launch(pb, b, st);
+        return;
+    }
+    if (!(prof && prof->on) && gc_launch_thin_pair(a, b, st)) return;
+    gc_launch_prof(pa, a, st, prof);
+    gc_launch_prof(pb, b, st, prof);
 }
 
 void gc_launch_prof(const GCPlan& pl, const GCParams& p, hipStream_t st, Profiler* prof) {
@@ -462,6 +480,9 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
         gc_launch_prof(pl.pair, p, st, prof);
         return;
     }
+    GCParams ps[2];
+    int np = 0;
+    const GCPlan* gp[2] = {nullptr, nullptr};
     for (const auto& g : pl.par) {
         GCParams p = g.p;
         if (stats) set_stats(p, stats, dstC, Fout, T);
@@ -478,8 +499,16 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
         p.d_c = (long)Fout * Tp;
         p.d_f = Tp;
         if (const Ragged* rg = ragged_ctx()) p.tlen = rg->tlen;
-        if (p.Q > 0) gc_launch_prof(g, p, st, prof);
+        if (p.Q <= 0) continue;
+        if (few && !stats && pl.par.size() == 2 && np < 2) {      // (a few frames: both classes in one thin launch if they qualify)
+            ps[np] = p;
+            gp[np++] = &g;
+            continue;
+        }
+        gc_launch_prof(g, p, st, prof);
     }
+    if (np == 2) gc_launch_classes(*gp[0], ps[0], *gp[1], ps[1], st, prof);
+    else if (np == 1) gc_launch_prof(*gp[0], ps[0], st, prof);
 }
 
 }  // namespace se

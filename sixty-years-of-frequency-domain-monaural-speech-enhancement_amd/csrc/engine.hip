@@ -234,7 +234,9 @@ int se_engine_finalize(se_engine* e) {
         // (a frame-online window is the model's history columns + the chunk: models that keep a long history - CTSNet_new's
         // dilated convs reach 128 frames back - must be able to stream through an engine created for short clips)
         // (models that look ahead run with the frame count rounded up to whole 16 B groups: model.h PadFrames)
-        e->plan_frames = e->model->stream_supported() ? std::max((T + 3) & ~3, e->model->stream_hc() + 16) : (T + 3) & ~3;
+        const int fm = pad_frames_mult(e->model->frame_multiple());
+        const int Tr = (T + fm - 1) / fm * fm;
+        e->plan_frames = e->model->stream_supported() ? std::max(Tr, e->model->stream_hc() + 16) : Tr;
         e->ctx.arena.measure_begin();
         e->model->plan_buffers(e->ctx.max_batch, e->plan_frames);
         const size_t need = e->ctx.arena.measure_end();

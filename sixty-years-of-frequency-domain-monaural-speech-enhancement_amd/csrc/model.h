@@ -75,14 +75,22 @@ struct TrackedSD {
 // with the frame count rounded up to a multiple of 4 and the added frames treated like the tail of a shorter clip in a
 // ragged batch - zeroed in front of every look-ahead operator, masked in attention - by publishing per-row sizes that
 // are all equal (measured against trimming the straddling groups in LDS: DCCRN + 2 %, Uformer + 1.7 % at batch 256).
+// The multiple itself: 4 (whole 16 B groups).  Uformer rounds to 16 - 401 -> 416 frames are rows of 1 664 B = 13 whole 128 B
+// lines: 3.7 % more frames and still + 1.1 % at batch 256 (its many low-channel layers and elementwise passes move whole
+// lines); DCCRN (501 -> 512 against 504) gains nothing over 4.  SE_PAD_FRAMES_TO=n overrides both.
+inline int pad_frames_mult(int model_default = 4) {
+    static const int m = getenv("SE_PAD_FRAMES_TO") ? std::max(4, atoi(getenv("SE_PAD_FRAMES_TO")) & ~3) : 0;
+    return m ? m : model_default;
+}
 struct PadFrames {
     Ragged rg;
     bool on = false;
     int T;                  // frame count (row pitch) to run with
-    PadFrames(EngineCtx& ctx, int B, int L, int Lpad, int T_true, int olen, hipStream_t st) : T(T_true) {
+    PadFrames(EngineCtx& ctx, int B, int L, int Lpad, int T_true, int olen, hipStream_t st, int mult = 4) : T(T_true) {
         static const bool env = !(getenv("SE_PAD_FRAMES") && atoi(getenv("SE_PAD_FRAMES")) == 0);
-        if (!env || (T_true & 3) == 0) return;
-        T = (T_true + 3) & ~3;
+        const int m = pad_frames_mult(mult);
+        if (!env || T_true % m == 0) return;
+        T = (T_true + m - 1) / m * m;
         if (ragged_ctx()) return;          // rows of different lengths already carry their sizes
         const int MB = ctx.max_batch;
         if (!ctx.eq_rows) SE_HIP(hipMalloc(reinterpret_cast<void**>(&ctx.eq_rows), sizeof(int) * 4 * MB));
@@ -125,6 +133,8 @@ class Model {
     virtual void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) = 0;
     // carve the activation workspace for (B clips, T frames) out of ctx.arena (also used to size it)
     virtual void plan_buffers(int B, int T) = 0;
+    // frame counts (row pitches) this model's workspace is planned for: multiples of
+    virtual int frame_multiple() const { return 4; }
     virtual int64_t output_samples(int L) const { return L; }
     // samples the STFT sees (decode scripts that tail-pad to a hop multiple)
     virtual int padded_samples(int L) const { return L; }

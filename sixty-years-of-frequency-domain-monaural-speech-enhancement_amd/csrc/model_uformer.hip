@@ -501,6 +501,7 @@ struct DsBlock {          // DSConv2d / DSConv2d_Real
 class Uformer final : public Model {
   public:
     explicit Uformer(EngineCtx& c) : Model(c) {}
+    int frame_multiple() const override { return 16; }
     ~Uformer() override {
         for (int k = 0; k < NL; ++k) {
             gc_free_plan(encC[k]);
@@ -759,7 +760,7 @@ class Uformer final : public Model {
     void run(const float* wav, long pitch, int B, int L, float* out, long out_pitch, bool normalise, hipStream_t st,
              float* out_cplx = nullptr) {
         const int T_true = 1 + L / HOP;
-        PadFrames pad(ctx, B, L, L, T_true, HOP * (T_true - 1), st);      // symmetric dilated convs: rows of whole 16 B groups
+        PadFrames pad(ctx, B, L, L, T_true, HOP * (T_true - 1), st, 16);      // symmetric dilated convs: rows of whole 16 B groups (and, at 16, whole 128 B lines for T = 401)
         const int T = pad.T;
         Bufs& b = bufs(B, T);
         Profiler* pf = &ctx.prof;

@@ -207,6 +207,119 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
     }
 }
 
+// ---- K-split form for at most 16 sequences (one MFMA tile) ----------------------------------------------------------
+// At batch 1 ... 16 the kernel above uses 64 of the 256 CUs (one sequence slice) and a step is 3.9 us of MFMAs - a whole
+// 16-column tile for one useful column - plus the exchange.  Here EVERY CU takes part: a workgroup owns 4 hidden units (16
+// gate rows) and its four waves split K - a wave keeps rows x K / 4 in H / 16 VGPRs, stages only its quarter of h_{t-1}
+// (wave-private LDS, no workgroup barrier), runs H / 16 MFMAs (1 us at H = 1024) and leaves a partial tile in LDS; wave 0
+// adds the four partials in a fixed order, updates the cell (kept in a register) and publishes h_t.  Every CU then reads
+// all of h - 4 KB per sequence and step, nothing at these batch sizes (at batch 64 it would be 128 MB per step through the
+// fabric: the sequence-sliced form above stays for more than one tile).  Same flag protocol, H / 4 producers.
+template <int H, int NS>
+__global__ __launch_bounds__(256, 1) void lstm_coop_ks_kernel(const LstmCoopArgs a) {
+    constexpr int KW = H / 4;          // k values per wave
+    constexpr int KQ = KW / 4;         // k values per MFMA k-slot (l4)
+    constexpr int LDW = KW + 4;        // LDS row stride
+    constexpr int NWG = H / 4;         // workgroups per LSTM
+    constexpr int FPL = KW / 64;       // floats of a staged row per lane (2 or 4)
+    constexpr int NLD = NS * FPL / 2;  // 8 B loads per lane and step
+    extern __shared__ float hs[];      // [4][16][LDW] wave-private h tiles, then [4][64] floatx4 partial tiles
+    floatx4* red = reinterpret_cast<floatx4*>(hs + 4 * 16 * LDW);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ug = blockIdx.x % NWG, z = blockIdx.x / NWG;
+    const bool rev = (a.reverse >> z) & 1;
+    const int r0 = ug * 16;
+    floatx4 wa[KQ / 4];
+    {
+        const floatx4* __restrict__ W =
+            reinterpret_cast<const floatx4*>(a.whh + (long)z * a.whh_z + (long)(r0 + l15) * H + wave * KW + l4 * KQ);
+        static_for_c<KQ / 4>([&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            wa[j] = W[j];
+        });
+    }
+    const int u = ug * 4 + l4, n = l15;                          // wave 0: hidden unit / sequence of this lane's accumulator
+    const bool live = n < a.S;
+    const int nc = live ? n : a.S - 1;
+    const float* __restrict__ gx = a.gx + (long)z * a.gx_z + (long)(4 * u) * a.gx_row + nc;
+    float* __restrict__ out = a.out + (long)z * a.out_z + (long)u * a.out_row + nc;
+    float* __restrict__ hx = a.hx + (long)z * 2 * a.S * H;
+    unsigned* flags = a.bar + z * 256;
+    float* hsw = hs + wave * (16 * LDW);
+    for (int i = lane; i < 16 * LDW; i += 64) hsw[i] = 0.f;      // rows >= NS stay zero
+    float g[4] = {0.f, 0.f, 0.f, 0.f}, c = 0.f;
+    auto load_g = [&](int step) {
+        const int t = rev ? a.T - 1 - step : step;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = gx[(long)t * a.gx_t + q * a.gx_row];
+    };
+    if (wave == 0) load_g(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the weight loads retire here (see the kernel above)
+    __syncthreads();
+    for (int step = 0; step < a.T; ++step) {
+        const int t = rev ? a.T - 1 - step : step;
+        const float* hprev = hx + (long)(step & 1) * a.S * H + wave * KW;
+        float* hnext = hx + (long)((step + 1) & 1) * a.S * H;
+        unsigned long long v[NLD];
+        static_for_c<NLD>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            constexpr int row = i / (FPL / 2), part = i % (FPL / 2);
+            const int nn = min(row, a.S - 1);
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(hprev + (long)nn * H + lane * FPL) + part;
+            v[i] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        });
+        static_for_c<NLD>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            constexpr int row = i / (FPL / 2), part = i % (FPL / 2);
+            reinterpret_cast<unsigned long long*>(hsw + row * LDW + lane * FPL)[part] = v[i];
+        });
+        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        {
+            const floatx4* hb = reinterpret_cast<const floatx4*>(hsw + l15 * LDW + l4 * KQ);
+            static_for_c<KQ / 4>([&](auto J_) {
+                constexpr int j = decltype(J_)::value;
+                const floatx4 b = hb[j];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][0], b[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][1], b[1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][2], b[2], acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][3], b[3], acc3, 0, 0, 0);
+            });
+        }
+        red[wave * 64 + lane] = (acc0 + acc1) + (acc2 + acc3);
+        __syncthreads();
+        if (wave == 0) {
+            const floatx4 acc = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+            const float cn = sigm(acc[1] + g[1]) * c + sigm(acc[0] + g[0]) * tanhf_fast(acc[2] + g[2]);
+            const float h = sigm(acc[3] + g[3]) * tanhf_fast(cn);
+            c = cn;
+            if (live) {
+                out[(long)t * a.out_t] = h;
+                __hip_atomic_store(hnext + (long)n * H + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (step + 1 < a.T) {
+                if (!(a.dbg & 8)) __builtin_amdgcn_s_waitcnt(0x0F70);      // our h_t has been acknowledged
+                if (lane == 0 && !(a.dbg & 4))
+                    __hip_atomic_store(flags + ug, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                load_g(step + 1);
+                if (!(a.dbg & 4)) {
+                    const unsigned want = (unsigned)(step + 1);
+                    const unsigned long long t0 = wall_clock64();
+                    for (;;) {
+                        unsigned lo = want;
+#pragma unroll
+                        for (int q = 0; q < NWG / 64; ++q)
+                            lo = min(lo, __hip_atomic_load(flags + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (__builtin_amdgcn_ballot_w64(lo < want) == 0) break;
+                        if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 char* coop_scratch(size_t need, hipStream_t s) { return device_scratch(0, need, s); }
 
 template <int H>
@@ -244,6 +357,36 @@ void launch_t(LstmCoopArgs a, int n_cu, hipStream_t s) {
 
 bool lstm_coop_supported(int H, int S, int Z) { return (H == 512 || H == 1024) && (H / 16) * Z <= 256 && S <= 4096; }
 
+template <int H, int NS>
+static void launch_ks(LstmCoopArgs a, hipStream_t s) {
+    constexpr int NWG = H / 4;
+    static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
+    a.dbg = dbg;
+    a.SS = 1;
+    constexpr size_t NFLAG = 256 * 64;
+    const size_t slab = (size_t)a.S * H, hx_bytes = (size_t)a.Z * 2 * slab * sizeof(float);
+    char* sc = coop_scratch(NFLAG * sizeof(unsigned) + hx_bytes, s);
+    a.bar = reinterpret_cast<unsigned*>(sc);
+    a.hx = reinterpret_cast<float*>(sc + NFLAG * sizeof(unsigned));
+    launch_fill(reinterpret_cast<float*>(a.bar), (long)a.Z * 256, 0.f, s);
+    launch_fill(a.hx, (long)a.Z * 2 * slab, 0.f, s);
+    const size_t shmem = (size_t)4 * 16 * (H / 4 + 4) * sizeof(float) + (size_t)4 * 64 * 16;
+    static bool attr_set[64] = {};
+    if (first_on_device(attr_set)) {
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop_ks_kernel<H, NS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    }
+    void* params[] = {&a};
+    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop_ks_kernel<H, NS>), dim3(NWG * a.Z), dim3(256),
+                                      params, (unsigned)shmem, s));
+}
+template <int H>
+static void launch_ks_n(const LstmCoopArgs& a, hipStream_t s) {
+    if (a.S <= 1) launch_ks<H, 1>(a, s);
+    else if (a.S <= 4) launch_ks<H, 4>(a, s);
+    else launch_ks<H, 16>(a, s);
+}
+
 void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s) {
     static int n_cu = 0;
     if (!n_cu) {
@@ -252,6 +395,15 @@ void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s) {
         SE_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     SE_CHECK(a.Z * std::max(1, std::min((a.S + 15) / 16, n_cu / ((a.H / 16) * a.Z))) <= 256, "cooperative LSTM: too many slices");
+    static const bool ks_on = !(getenv("SE_COOP_KS") && atoi(getenv("SE_COOP_KS")) == 0);
+    // one tile: every CU on the K-split form (H = 1024: 7.5 -> 5.1 ... 5.9 us per step for 1 ... 16 sequences; H = 512: 4.4 -> 3.8 at
+    // one sequence, nothing from 8 on or with two LSTMs per launch - tools/coopbench.cpp)
+    if (ks_on && a.S <= (a.H == 1024 ? 16 : 4) && (a.H == 1024 || a.Z == 1) && (a.H / 4) * a.Z <= n_cu && (a.H / 4) * a.Z <= 256) {
+        if (a.H == 1024) launch_ks_n<1024>(a, s);
+        else if (a.H == 512) launch_ks_n<512>(a, s);
+        else SE_CHECK(false, "cooperative LSTM kernel is built for H = 512 / 1024");
+        return;
+    }
     if (a.H == 1024) launch_t<1024>(a, n_cu, s);
     else if (a.H == 512) launch_t<512>(a, n_cu, s);
     else SE_CHECK(false, "cooperative LSTM kernel is built for H = 512 / 1024");

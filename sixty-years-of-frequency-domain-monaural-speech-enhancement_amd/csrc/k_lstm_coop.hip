@@ -18,6 +18,7 @@
 // DESIGN.md 3.2 has the measurements and the protocols that were tried and dropped.
 #include "kernels.h"
 #include "common.h"
+#include <cstring>
 #include <type_traits>
 
 namespace se {
@@ -215,7 +216,13 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a)
 // adds the four partials in a fixed order, updates the cell (kept in a register) and publishes h_t.  Every CU then reads
 // all of h - 4 KB per sequence and step, nothing at these batch sizes (at batch 64 it would be 128 MB per step through the
 // fabric: the sequence-sliced form above stays for more than one tile).  Same flag protocol, H / 4 producers.
-template <int H, int NS>
+// TAG: the exchange carries its own arrival signal - h_t goes out with its lowest mantissa bit replaced by a step tag (h_t lives
+// in slab (t + 1) & 1 and carries bit ((t + 1) >> 1) & 1; what the slab held before, h_{t-2}, carries the other value), and a
+// wave simply re-loads its quarter of h_{t-1} until every element shows the expected bit: no store acknowledgement, flag store
+// and flag poll in front of the load.  The recurrence then runs on h rounded to 23 mantissa bits (<= 1 ulp per step, identical
+// from run to run); the output tensor keeps the exact h.  A producer cannot overwrite a value a slower consumer still needs: it
+// needs that consumer's h_t - published after the consumer has read h_{t-1} - before it can produce h_{t+1}.
+template <int H, int NS, bool TAG>
 __global__ __launch_bounds__(256, 1) void lstm_coop_ks_kernel(const LstmCoopArgs a) {
     constexpr int KW = H / 4;          // k values per wave
     constexpr int KQ = KW / 4;         // k values per MFMA k-slot (l4)
@@ -262,13 +269,30 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_ks_kernel(const LstmCoopArgs
         const float* hprev = hx + (long)(step & 1) * a.S * H + wave * KW;
         float* hnext = hx + (long)((step + 1) & 1) * a.S * H;
         unsigned long long v[NLD];
-        static_for_c<NLD>([&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            constexpr int row = i / (FPL / 2), part = i % (FPL / 2);
-            const int nn = min(row, a.S - 1);
-            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(hprev + (long)nn * H + lane * FPL) + part;
-            v[i] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        });
+        const unsigned tag_prev = (unsigned)(step >> 1) & 1u, tag_next = (unsigned)((step + 1) >> 1) & 1u;
+        auto issue_h = [&]() {
+            static_for_c<NLD>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                constexpr int row = i / (FPL / 2), part = i % (FPL / 2);
+                const int nn = min(row, a.S - 1);
+                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(hprev + (long)nn * H + lane * FPL) + part;
+                v[i] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
+        };
+        issue_h();
+        if (TAG && !(a.dbg & 4)) {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                unsigned bad = 0;
+                static_for_c<NLD>([&](auto I_) {
+                    constexpr int i = decltype(I_)::value;
+                    bad |= ((unsigned)v[i] ^ tag_prev) | ((unsigned)(v[i] >> 32) ^ tag_prev);
+                });
+                if (__builtin_amdgcn_ballot_w64((bad & 1u) != 0) == 0) break;
+                if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
+                issue_h();
+            }
+        }
         static_for_c<NLD>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
             constexpr int row = i / (FPL / 2), part = i % (FPL / 2);
@@ -295,9 +319,12 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_ks_kernel(const LstmCoopArgs
             c = cn;
             if (live) {
                 out[(long)t * a.out_t] = h;
-                __hip_atomic_store(hnext + (long)n * H + u, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float ht = TAG ? __uint_as_float((__float_as_uint(h) & ~1u) | tag_next) : h;
+                __hip_atomic_store(hnext + (long)n * H + u, ht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (step + 1 < a.T) {
+            if (TAG) {
+                if (step + 1 < a.T) load_g(step + 1);
+            } else if (step + 1 < a.T) {
                 if (!(a.dbg & 8)) __builtin_amdgcn_s_waitcnt(0x0F70);      // our h_t has been acknowledged
                 if (lane == 0 && !(a.dbg & 4))
                     __hip_atomic_store(flags + ug, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -357,7 +384,7 @@ void launch_t(LstmCoopArgs a, int n_cu, hipStream_t s) {
 
 bool lstm_coop_supported(int H, int S, int Z) { return (H == 512 || H == 1024) && (H / 16) * Z <= 256 && S <= 4096; }
 
-template <int H, int NS>
+template <int H, int NS, bool TAG>
 static void launch_ks(LstmCoopArgs a, hipStream_t s) {
     constexpr int NWG = H / 4;
     static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
@@ -370,21 +397,35 @@ static void launch_ks(LstmCoopArgs a, hipStream_t s) {
     a.hx = reinterpret_cast<float*>(sc + NFLAG * sizeof(unsigned));
     launch_fill(reinterpret_cast<float*>(a.bar), (long)a.Z * 256, 0.f, s);
     launch_fill(a.hx, (long)a.Z * 2 * slab, 0.f, s);
+    if (TAG) {      // slab 1 must not look like h_0 (tag 0) before h_0 has been written
+        const unsigned one = 1u;
+        float stale;
+        memcpy(&stale, &one, sizeof(float));
+        for (int z = 0; z < a.Z; ++z) launch_fill(a.hx + ((long)z * 2 + 1) * slab, (long)slab, stale, s);
+    }
     const size_t shmem = (size_t)4 * 16 * (H / 4 + 4) * sizeof(float) + (size_t)4 * 64 * 16;
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {
-        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop_ks_kernel<H, NS>),
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop_ks_kernel<H, NS, TAG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     }
     void* params[] = {&a};
-    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop_ks_kernel<H, NS>), dim3(NWG * a.Z), dim3(256),
+    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop_ks_kernel<H, NS, TAG>), dim3(NWG * a.Z), dim3(256),
                                       params, (unsigned)shmem, s));
 }
 template <int H>
 static void launch_ks_n(const LstmCoopArgs& a, hipStream_t s) {
-    if (a.S <= 1) launch_ks<H, 1>(a, s);
-    else if (a.S <= 4) launch_ks<H, 4>(a, s);
-    else launch_ks<H, 16>(a, s);
+    // (the tagged exchange pays while a wave's share of h is one or two loads per lane: 4.9 -> 3.1 us per step at one sequence,
+    // 5.4 -> 4.2 at four, nothing at sixteen; SE_COOP_TAG=0: flags everywhere)
+    static const bool tag = !(getenv("SE_COOP_TAG") && atoi(getenv("SE_COOP_TAG")) == 0);
+    if (tag && a.S <= 4) {
+        if (a.S <= 1) launch_ks<H, 1, true>(a, s);
+        else launch_ks<H, 4, true>(a, s);
+        return;
+    }
+    if (a.S <= 1) launch_ks<H, 1, false>(a, s);
+    else if (a.S <= 4) launch_ks<H, 4, false>(a, s);
+    else launch_ks<H, 16, false>(a, s);
 }
 
 void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s) {
@@ -398,7 +439,8 @@ void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s) {
     static const bool ks_on = !(getenv("SE_COOP_KS") && atoi(getenv("SE_COOP_KS")) == 0);
     // one tile: every CU on the K-split form (H = 1024: 7.5 -> 5.1 ... 5.9 us per step for 1 ... 16 sequences; H = 512: 4.4 -> 3.8 at
     // one sequence, nothing from 8 on or with two LSTMs per launch - tools/coopbench.cpp)
-    if (ks_on && a.S <= (a.H == 1024 ? 16 : 4) && (a.H == 1024 || a.Z == 1) && (a.H / 4) * a.Z <= n_cu && (a.H / 4) * a.Z <= 256) {
+    static const int ks_z = getenv("SE_COOP_KS_Z") ? atoi(getenv("SE_COOP_KS_Z")) : 2;      // (two LSTMs per launch, GCRN: 4.4 -> 2.5 ... 3.0 us)
+    if (ks_on && a.S <= (a.H == 1024 ? 16 : 4) && (a.H == 1024 || a.Z <= ks_z) && (a.H / 4) * a.Z <= n_cu && (a.H / 4) * a.Z <= 256) {
         if (a.H == 1024) launch_ks_n<1024>(a, s);
         else if (a.H == 512) launch_ks_n<512>(a, s);
         else SE_CHECK(false, "cooperative LSTM kernel is built for H = 512 / 1024");

@@ -936,7 +936,31 @@ __device__ __forceinline__ void gc_thin_body(const GCParams& p, const int blk) {
     const int fo = q * p.so + p.po, mr = mt * RB + r;
     const float* __restrict__ bias = (fo < p.pad_lo) ? p.bias_pad : p.bias;
     float* __restrict__ dst = p.dst + (long)b * p.d_b + (long)fo * p.d_f + t0 + t;
-    if (EPI == EPI_GLU) {
+    if (EPI == EPI_LSTM) {
+        // rows 4u + {i, f, g, o} (GCParams::gru: {r, z, n, -}): the thread of a unit's first row updates the cell, as the
+        // MFMA kernel's epilogue does (a frame-online step of a 1024-wide LSTM is a 16.7 MB matrix-vector product: 64 us as
+        // a latency-bound K loop of one MFMA workgroup per 128 rows, ~12 us here)
+        if ((r & 3) || mr + 3 >= p.M) return;
+        const int tc = t0 + t;
+        const float* __restrict__ gx = p.aux + (long)b * p.x_b + (long)fo * p.x_f + (long)mr * p.x_c + tc;
+        float* __restrict__ cell = p.cell + (long)b * p.d_b + (long)fo * p.d_f + (long)(mr >> 2) * p.d_c + tc;
+        const float g0 = gx[0], g1 = gx[p.x_c], g2 = gx[2 * p.x_c], g3 = gx[3 * p.x_c];
+        const float cp = p.first_step ? 0.f : *cell;
+        const float gi = part[0][r][t] + g0, gf = part[0][r + 1][t] + g1, gg = part[0][r + 2][t] + g2, go = part[0][r + 3][t] + g3;
+        float cn, hn;
+        if (p.gru) {
+            const float rr = fsig_(gi), zz = fsig_(gf);
+            const float hw = part[0][r + 2][t] + go;            // W_hn h + b_hn
+            const float nn = ftanh_(g2 + rr * hw);
+            hn = (1.f - zz) * nn + zz * cp;
+            cn = hn;
+        } else {
+            cn = fsig_(gf) * cp + fsig_(gi) * ftanh_(gg);
+            hn = fsig_(go) * ftanh_(cn);
+        }
+        *cell = cn;
+        dst[(long)(mr >> 2) * p.d_c] = hn;
+    } else if (EPI == EPI_GLU) {
         if ((r & 1) || mr + 1 >= p.M) return;
         const int oc = mr >> 1;
         const float a = part[0][r][t] + (bias ? bias[mr] : 0.f), g = part[0][r + 1][t] + (bias ? bias[mr + 1] : 0.f);
@@ -983,8 +1007,9 @@ static long gc_thin_blocks(const GCParams& p) {
     const int n = p.Tout - p.t_base;
     // (layers with <= 4 output channels have the packed matrix too: a one-frame launch of the direct kernel walks its whole K
     // in one thread per output - 20-40 us; the fused parity pair of a transposed conv only exists there)
-    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.epi == EPI_LSTM || p.stats) return 0;
-    if (p.epi != EPI_ACT && p.epi != EPI_ADD && p.epi != EPI_MUL && p.epi != EPI_GLU) return 0;
+    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.stats) return 0;
+    if (p.epi != EPI_ACT && p.epi != EPI_ADD && p.epi != EPI_MUL && p.epi != EPI_GLU && p.epi != EPI_LSTM) return 0;
+    if (p.epi == EPI_LSTM && (p.M & 3)) return 0;
     const long nblk = (long)((p.M + 7) >> 3) * p.Q * p.B;
     // (a few frames per row is not yet a small launch: the LSTM input projections of a batch-1 decode are 1 "frame" wide
     // and 401 rows high with K = 1024 - matrix work)
@@ -1013,6 +1038,7 @@ static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
         case EPI_ADD: gc_thin_launch_n<EPI_ADD>(p, grid, n, stream); break;
         case EPI_MUL: gc_thin_launch_n<EPI_MUL>(p, grid, n, stream); break;
         case EPI_GLU: gc_thin_launch_n<EPI_GLU>(p, grid, n, stream); break;
+        case EPI_LSTM: gc_thin_launch_n<EPI_LSTM>(p, grid, n, stream); break;
         default: return false;
     }
     SE_HIP(hipGetLastError());
@@ -1464,6 +1490,8 @@ bool gc_stats_supported(const GCPlan& pl) {
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     // p.t_base (default 0): first output frame of the launch - frame-online chunks only produce the frames behind their
     // history columns.  A multiple of 4, so that the 16 B staging groups keep their alignment to frame 0.
+    SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
+    if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;       // h_{-1} = 0: no matrix work
     if (p.t_base > 0 && gc_thin_launch(p, stream)) return;       // (any first frame)
     if (p.tb_soft) p.t_base &= ~3;
     const int tb = p.t_base, Tspan = p.Tout - tb;
@@ -1475,8 +1503,6 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     p.qq_off = 0;
     static const int dbg_env = getenv("SE_GC_DBG") ? atoi(getenv("SE_GC_DBG")) : 0;
     p.dbg = dbg_env;
-    SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
-    if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;
     // patch offsets inside one staged chunk are 32-bit (the 64-bit part of an address is the per-block / per-chunk base)
     SE_CHECK((double)p.CI_C * (double)std::max(p.s0_c, p.s1_c) + (double)p.Fin * (double)std::max(p.s0_f, p.s1_f) + p.Tin < 4.0e9,
              "gc_launch: source plane too large for 32-bit patch offsets");

@@ -246,8 +246,9 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_ks_kernel(const LstmCoopArgs
             wa[j] = W[j];
         });
     }
-    const int u = ug * 4 + l4, n = l15;                          // wave 0: hidden unit / sequence of this lane's accumulator
-    const bool live = n < a.S;
+    // wave 0: hidden unit / sequence of this lane's accumulator (NS == 1, the dot-product form: lanes 0, 4, 8, 12 own a unit each)
+    const int u = NS == 1 ? ug * 4 + (l15 >> 2) : ug * 4 + l4, n = NS == 1 ? 0 : l15;
+    const bool live = NS == 1 ? (lane < 16 && (lane & 3) == 0) : n < a.S;
     const int nc = live ? n : a.S - 1;
     const float* __restrict__ gx = a.gx + (long)z * a.gx_z + (long)(4 * u) * a.gx_row + nc;
     float* __restrict__ out = a.out + (long)z * a.out_z + (long)u * a.out_row + nc;
@@ -298,8 +299,32 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_ks_kernel(const LstmCoopArgs
             constexpr int row = i / (FPL / 2), part = i % (FPL / 2);
             reinterpret_cast<unsigned long long*>(hsw + row * LDW + lane * FPL)[part] = v[i];
         });
-        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-        {
+        floatx4 acc;
+        if constexpr (NS == 1) {
+            // ONE sequence: 15 of the tile's 16 columns would be padding (1 us of MFMAs per step) - a dot product per lane
+            // instead: lane (row l15, slot l4) multiplies its H / 16 weights with its slice of h, the four slots fold by
+            // shuffles, the four waves through LDS, and lanes 0 / 4 / 8 / 12 of wave 0 collect the gates of a unit each
+            const floatx4* hb = reinterpret_cast<const floatx4*>(hsw + l4 * KQ);
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            static_for_c<KQ / 4>([&](auto J_) {
+                constexpr int j = decltype(J_)::value;
+                const floatx4 b = hb[j];
+                s0 = fmaf(wa[j][0], b[0], s0);
+                s1 = fmaf(wa[j][1], b[1], s1);
+                s2 = fmaf(wa[j][2], b[2], s2);
+                s3 = fmaf(wa[j][3], b[3], s3);
+            });
+            float pr = (s0 + s1) + (s2 + s3);
+            pr += __shfl_xor(pr, 16, 64);
+            pr += __shfl_xor(pr, 32, 64);
+            float* redf = reinterpret_cast<float*>(red);
+            if (lane < 16) redf[wave * 16 + lane] = pr;
+            __syncthreads();
+            const float tot = (redf[l15] + redf[16 + l15]) + (redf[32 + l15] + redf[48 + l15]);
+            const int b0 = lane & 12;
+            acc = floatx4{__shfl(tot, b0, 64), __shfl(tot, b0 + 1, 64), __shfl(tot, b0 + 2, 64), __shfl(tot, b0 + 3, 64)};
+        } else {
+            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
             const floatx4* hb = reinterpret_cast<const floatx4*>(hsw + l15 * LDW + l4 * KQ);
             static_for_c<KQ / 4>([&](auto J_) {
                 constexpr int j = decltype(J_)::value;
@@ -309,11 +334,11 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_ks_kernel(const LstmCoopArgs
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][2], b[2], acc2, 0, 0, 0);
                 acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][3], b[3], acc3, 0, 0, 0);
             });
+            red[wave * 64 + lane] = (acc0 + acc1) + (acc2 + acc3);
+            __syncthreads();
+            acc = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
         }
-        red[wave * 64 + lane] = (acc0 + acc1) + (acc2 + acc3);
-        __syncthreads();
         if (wave == 0) {
-            const floatx4 acc = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
             const float cn = sigm(acc[1] + g[1]) * c + sigm(acc[0] + g[0]) * tanhf_fast(acc[2] + g[2]);
             const float h = sigm(acc[3] + g[3]) * tanhf_fast(cn);
             c = cn;

@@ -372,6 +372,178 @@ __global__ __launch_bounds__(256, 1) void lstm_coop_ks_kernel(const LstmCoopArgs
     }
 }
 
+// ---- a STACK of LSTM layers on one sequence as one launch -----------------------------------------------------------------
+// With one sequence a step of the K-split kernel is the exchange latency and little else (2.65 us, 0.15 us of it arithmetic),
+// and a stack of L layers pays it L x T times.  Here the layers run as a wavefront: at global step s layer l works on frame
+// t = s - l, so every layer's inputs - its own h_l[t-1] and, for l >= 1, the h_{l-1}[t] it projects itself - were published
+// in global step s - 1, and ONE exchange latency serves all layers: T + L - 1 steps instead of L x T.  A workgroup owns the
+// same 4 hidden units (16 gate rows) of every layer; a wave keeps its K quarter of W_hh of all layers and of W_ih of the
+// layers above the first (the first layer's input projection stays one batched GEMM) - 5 x H / 16 = 320 VGPRs for three
+// 1024-wide layers.  Dot products, the tagged exchange (one slab pair per layer) and the fold through LDS are those of the
+// one-sequence K-split kernel; the cell states live in registers of wave 0.
+template <int H, int L>
+__global__ __launch_bounds__(256, 1) void lstm_stack_kernel(const LstmStackArgs a) {
+    constexpr int KW = H / 4, KQ = KW / 4, NWG = H / 4, FPL = KW / 64, NLD1 = FPL / 2, NV = 2 * L - 1;
+    extern __shared__ float hs[];      // [4 waves][NV vectors][KW] staged h quarters, [L][4][16] row partials, then W_ih
+    float* redf = hs + 4 * NV * KW;
+    // the input matrices of the layers above the first live in LDS ([layer][j][thread] 16 B fragments: every read is one
+    // conflict-free ds_read_b128 per lane) - with them in registers too, three 1024-wide layers need 5 x 64 VGPRs for weights
+    // alone and the kernel spills
+    floatx4* wl = reinterpret_cast<floatx4*>(redf + L * 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ug = blockIdx.x;
+    const int r0 = ug * 16;
+    floatx4 whh[L][KQ / 4];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const floatx4* __restrict__ W = reinterpret_cast<const floatx4*>(a.whh[l] + (long)(r0 + l15) * H + wave * KW + l4 * KQ);
+        static_for_c<KQ / 4>([&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            whh[l][j] = W[j];
+        });
+        if (l > 0) {
+            const floatx4* __restrict__ V = reinterpret_cast<const floatx4*>(a.wih[l] + (long)(r0 + l15) * H + wave * KW + l4 * KQ);
+            static_for_c<KQ / 4>([&](auto J_) {
+                constexpr int j = decltype(J_)::value;
+                wl[((l - 1) * (KQ / 4) + j) * 256 + tid] = V[j];
+            });
+        }
+    }
+    const int u = ug * 4 + (l15 >> 2);                           // wave 0, lanes 0 / 4 / 8 / 12: the unit this lane updates
+    const bool live = wave == 0 && lane < 16 && (lane & 3) == 0;
+    const float* __restrict__ gx = a.gx0 + (long)(4 * u) * a.gx_row;
+    float bias[L > 1 ? L - 1 : 1][4];
+#pragma unroll
+    for (int l = 1; l < L; ++l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias[l - 1][q] = a.bias[l][4 * u + q];
+    float c[L], g0[4];
+#pragma unroll
+    for (int l = 0; l < L; ++l) c[l] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g0[q] = gx[q * a.gx_row];
+    float* hsw = hs + wave * (NV * KW);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the weight loads retire here
+    __syncthreads();
+    const int nsteps = a.T + L - 1;
+    for (int s = 0; s < nsteps; ++s) {
+        // vector 2 l: h_l[t - 1] (layer l's own state), vector 2 l - 1: h_{l-1}[t] (its input), t = s - l
+        unsigned long long v[NV][NLD1];
+        auto issue = [&]() {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int t = s - l;
+                if (t < 0 || t >= a.T) continue;
+                const float* own = a.hx + ((long)l * 2 + (t & 1)) * H + wave * KW + lane * FPL;
+#pragma unroll
+                for (int i = 0; i < NLD1; ++i)
+                    v[2 * l][i] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(own) + i, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+                if (l > 0) {
+                    const float* in = a.hx + ((long)(l - 1) * 2 + ((t + 1) & 1)) * H + wave * KW + lane * FPL;
+#pragma unroll
+                    for (int i = 0; i < NLD1; ++i)
+                        v[2 * l - 1][i] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(in) + i, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        issue();
+        {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                unsigned bad = 0;
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const int t = s - l;
+                    if (t < 0 || t >= a.T) continue;
+                    const unsigned town = (unsigned)(t >> 1) & 1u, tin = (unsigned)((t + 1) >> 1) & 1u;
+#pragma unroll
+                    for (int i = 0; i < NLD1; ++i) {
+                        bad |= ((unsigned)v[2 * l][i] ^ town) | ((unsigned)(v[2 * l][i] >> 32) ^ town);
+                        if (l > 0) bad |= ((unsigned)v[2 * l - 1][i] ^ tin) | ((unsigned)(v[2 * l - 1][i] >> 32) ^ tin);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64((bad & 1u) != 0) == 0) break;
+                if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
+                issue();
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int t = s - l;
+            if (t < 0 || t >= a.T) continue;
+#pragma unroll
+            for (int i = 0; i < NLD1; ++i) {
+                reinterpret_cast<unsigned long long*>(hsw + (2 * l) * KW + lane * FPL)[i] = v[2 * l][i];
+                if (l > 0) reinterpret_cast<unsigned long long*>(hsw + (2 * l - 1) * KW + lane * FPL)[i] = v[2 * l - 1][i];
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int t = s - l;
+            if (t < 0 || t >= a.T) continue;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            {
+                const floatx4* hb = reinterpret_cast<const floatx4*>(hsw + (2 * l) * KW + l4 * KQ);
+                static_for_c<KQ / 4>([&](auto J_) {
+                    constexpr int j = decltype(J_)::value;
+                    const floatx4 b = hb[j];
+                    s0 = fmaf(whh[l][j][0], b[0], s0);
+                    s1 = fmaf(whh[l][j][1], b[1], s1);
+                    s2 = fmaf(whh[l][j][2], b[2], s2);
+                    s3 = fmaf(whh[l][j][3], b[3], s3);
+                });
+            }
+            if (l > 0) {
+                const floatx4* xb = reinterpret_cast<const floatx4*>(hsw + (2 * l - 1) * KW + l4 * KQ);
+                static_for_c<KQ / 4>([&](auto J_) {
+                    constexpr int j = decltype(J_)::value;
+                    const floatx4 b = xb[j];
+                    const floatx4 w = wl[((l > 0 ? l - 1 : 0) * (KQ / 4) + j) * 256 + tid];
+                    s0 = fmaf(w[0], b[0], s0);
+                    s1 = fmaf(w[1], b[1], s1);
+                    s2 = fmaf(w[2], b[2], s2);
+                    s3 = fmaf(w[3], b[3], s3);
+                });
+            }
+            float pr = (s0 + s1) + (s2 + s3);
+            pr += __shfl_xor(pr, 16, 64);
+            pr += __shfl_xor(pr, 32, 64);
+            if (lane < 16) redf[(l * 4 + wave) * 16 + lane] = pr;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int t = s - l;
+                if (t < 0 || t >= a.T) continue;
+                const float* rp = redf + l * 64;
+                const float tot = (rp[l15] + rp[16 + l15]) + (rp[32 + l15] + rp[48 + l15]);
+                const int b0 = lane & 12;
+                float gi = __shfl(tot, b0, 64), gf = __shfl(tot, b0 + 1, 64), gg = __shfl(tot, b0 + 2, 64), go = __shfl(tot, b0 + 3, 64);
+                if (l == 0) { gi += g0[0]; gf += g0[1]; gg += g0[2]; go += g0[3]; }
+                else { gi += bias[l > 0 ? l - 1 : 0][0]; gf += bias[l > 0 ? l - 1 : 0][1]; gg += bias[l > 0 ? l - 1 : 0][2]; go += bias[l > 0 ? l - 1 : 0][3]; }
+                const float cn = sigm(gf) * c[l] + sigm(gi) * tanhf_fast(gg);
+                const float h = sigm(go) * tanhf_fast(cn);
+                c[l] = cn;
+                if (live) {
+                    if (l == L - 1) a.out[(long)t * a.out_t + (long)u * a.out_row] = h;
+                    const unsigned tag = (unsigned)((t + 1) >> 1) & 1u;
+                    __hip_atomic_store(a.hx + ((long)l * 2 + ((t + 1) & 1)) * H + u, __uint_as_float((__float_as_uint(h) & ~1u) | tag),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (s + 1 < a.T) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g0[q] = gx[(long)(s + 1) * a.gx_t + q * a.gx_row];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 char* coop_scratch(size_t need, hipStream_t s) { return device_scratch(0, need, s); }
 
 template <int H>
@@ -451,6 +623,43 @@ static void launch_ks_n(const LstmCoopArgs& a, hipStream_t s) {
     if (a.S <= 1) launch_ks<H, 1, false>(a, s);
     else if (a.S <= 4) launch_ks<H, 4, false>(a, s);
     else launch_ks<H, 16, false>(a, s);
+}
+
+template <int H, int L>
+static void launch_stack_t(LstmStackArgs a, hipStream_t s) {
+    constexpr int NWG = H / 4, NV = 2 * L - 1;
+    const size_t hx_bytes = (size_t)L * 2 * H * sizeof(float);
+    char* sc = coop_scratch(256 * 64 * sizeof(unsigned) + hx_bytes, s);
+    a.hx = reinterpret_cast<float*>(sc + 256 * 64 * sizeof(unsigned));
+    launch_fill(a.hx, (long)L * 2 * H, 0.f, s);
+    const unsigned one = 1u;
+    float stale;
+    memcpy(&stale, &one, sizeof(float));
+    for (int l = 0; l < L; ++l) launch_fill(a.hx + ((long)l * 2 + 1) * H, H, stale, s);     // slab 1 must not look like h_0
+    const size_t shmem = ((size_t)4 * NV * (H / 4) + (size_t)L * 64) * sizeof(float) + (size_t)(L - 1) * 16 * H * sizeof(float);
+    static bool attr_set[64] = {};
+    if (first_on_device(attr_set)) {
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_stack_kernel<H, L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)shmem));
+    }
+    void* params[] = {&a};
+    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_stack_kernel<H, L>), dim3(NWG), dim3(256), params,
+                                      (unsigned)shmem, s));
+}
+bool lstm_stack_supported(int H, int L) {
+    static const bool on = !(getenv("SE_LSTM_STACK") && atoi(getenv("SE_LSTM_STACK")) == 0);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        SE_HIP(hipGetDevice(&dev));
+        SE_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    return on && (H == 1024 || H == 512) && (L == 2 || L == 3) && H / 4 <= n_cu;
+}
+void launch_lstm_stack(const LstmStackArgs& a, hipStream_t s) {
+    SE_CHECK(lstm_stack_supported(a.H, a.L), "launch_lstm_stack: 2 or 3 layers of 512 / 1024 units on one sequence");
+    if (a.H == 1024) a.L == 2 ? launch_stack_t<1024, 2>(a, s) : launch_stack_t<1024, 3>(a, s);
+    else a.L == 2 ? launch_stack_t<512, 2>(a, s) : launch_stack_t<512, 3>(a, s);
 }
 
 void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s) {

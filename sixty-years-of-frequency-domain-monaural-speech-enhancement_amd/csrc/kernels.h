@@ -310,6 +310,19 @@ struct LstmCoopArgs {
     float* hx; unsigned* bar; int SS, dbg;
 };
 bool lstm_coop_supported(int H, int S, int Z);
+// A stack of L LSTM layers (equal width) on ONE sequence as one cooperative launch (k_lstm_coop.hip: lstm_stack_kernel):
+// layer l runs l frames behind layer l - 1, one exchange latency per frame serves all layers.  gx0: the first layer's gate
+// pre-activations (input projection + bias, rows 4u + gate); whh / wih / bias: row-major [4H][H] / [4H][H] / [4H] per layer
+// (wih, bias unused for layer 0); out: h of the LAST layer, unit u of frame t at out[t * out_t + u * out_row].
+struct LstmStackArgs {
+    const float* gx0; long gx_t, gx_row;
+    const float* whh[3]; const float* wih[3]; const float* bias[3];
+    float* out; long out_t, out_row;
+    int H, T, L;
+    float* hx;          // internal
+};
+bool lstm_stack_supported(int H, int L);
+void launch_lstm_stack(const LstmStackArgs& a, hipStream_t s);
 void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s);
 
 }  // namespace se

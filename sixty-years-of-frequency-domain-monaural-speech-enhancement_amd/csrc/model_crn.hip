@@ -191,8 +191,13 @@ class Crn final : public Model {
         if (lstm[0].fm_ok(B) && lstm[1].fm_ok(B)) {
             // feature-major [1024][T][B] (rnn.h run_fm): the two 4096 x 1024 input projections are full-width GEMMs
             launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, B, (long)T * B, st);
-            lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
-            lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+            const LstmBig* ly[2] = {&lstm[0], &lstm[1]};
+            if (B == 1 && lstm_stack_fm(ly, 2, b.X, b.G, b.Hs[1], T, st, pf)) {
+                // (one clip: both layers as one wavefront launch, rnn.h)
+            } else {
+                lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
+                lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+            }
             launch_transpose_akt(b.Hs[1], b.D[0], T, 1024, B, B, (long)T * B, 1024L * T, T, st);
         } else {
             launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, 1024L * B, B, st);
@@ -355,9 +360,14 @@ class LstmNet final : public Model {
         const int B = b.B, T = b.T;
         const long N = (long)T * B;
         Profiler* pf = &ctx.prof;
-        lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
-        lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
-        lstm[2].run_fm(b.Hs[1], b.G, b.cell, b.Hs[0], T, B, st, pf);
+        const LstmBig* ly[3] = {&lstm[0], &lstm[1], &lstm[2]};
+        if (B == 1 && lstm_stack_fm(ly, 3, b.X, b.G, b.Hs[0], T, st, pf)) {
+            // (one clip: the three layers as one wavefront launch, rnn.h)
+        } else {
+            lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
+            lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+            lstm[2].run_fm(b.Hs[1], b.G, b.cell, b.Hs[0], T, B, st, pf);
+        }
         run_pointwise(fc_fm, b.Hs[0], 0, N, b.Y, 0, N, 1, (int)N, st, pf);
     }
     // b.X [T][161][B] -> b.Y [T][161][B]

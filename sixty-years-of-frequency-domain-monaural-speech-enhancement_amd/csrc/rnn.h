@@ -159,6 +159,7 @@ struct LstmBig {
     GCPlan gin, step;
     GCPlan gin_fm;                // the input projection planned for feature-major activations (rows of T * S frames)
     float* whh_dev = nullptr;     // row-major [4H][H] (gate-interleaved rows) for the weight-stationary cooperative kernel
+    float *wih_dev = nullptr, *bih_dev = nullptr;      // row-major [4H][I] and [4H] (b_ih + b_hh) for the one-sequence stack kernel
     int I = 0, H = 0;
     // gru: w comes from load_gru (GRU cell in the step epilogue; one launch per step - the weight-stationary cooperative
     // kernel only knows the LSTM cell)
@@ -170,6 +171,10 @@ struct LstmBig {
         step.p.gru = gru ? 1 : 0;
         if (!gru && (H == 512 || H == 1024)) {
             whh_dev = to_device(w.whh.w);
+            if (I == H) {
+                wih_dev = to_device(w.wih.w);
+                bih_dev = to_device(w.wih.bias);
+            }
             gin_fm = make_pointwise_plan(w.wih, ACT_NONE, {}, 4096);
             has_fm = true;
         }
@@ -201,7 +206,9 @@ struct LstmBig {
         if (has_fm) gc_free_plan(gin_fm);
         has_fm = false;
         if (whh_dev) (void)hipFree(whh_dev);
-        whh_dev = nullptr;
+        if (wih_dev) (void)hipFree(wih_dev);
+        if (bih_dev) (void)hipFree(bih_dev);
+        whh_dev = wih_dev = bih_dev = nullptr;
     }
     static bool coop_enabled() {
         static const int on = [] {
@@ -303,6 +310,32 @@ struct LstmBig {
         }
     }
 };
+
+// A stack of 2 / 3 equal-width layers on ONE sequence, feature-major (x [I][T] -> out [H][T] of the last layer): the first
+// layer's input projection as one GEMM, then every layer's recurrence AND the upper layers' input projections in one
+// cooperative launch, layer l one frame behind layer l - 1 (k_lstm_coop.hip: lstm_stack_kernel).  false: not applicable.
+inline bool lstm_stack_fm(const LstmBig* const* ly, int L, const float* x, float* G, float* out, int T, hipStream_t st,
+                          Profiler* prof) {
+    if (L < 2 || L > 3 || !LstmBig::coop_enabled() || !lstm_stack_supported(ly[0]->H, L)) return false;
+    for (int l = 0; l < L; ++l)
+        if (!ly[l]->has_fm || !ly[l]->whh_dev || ly[l]->H != ly[0]->H || (l > 0 && (!ly[l]->wih_dev || ly[l]->I != ly[0]->H))) return false;
+    const int H = ly[0]->H;
+    run_pointwise(ly[0]->gin_fm, x, 0, T, G, 0, T, 1, T, st, prof);
+    LstmStackArgs a{};
+    a.gx0 = G; a.gx_t = 1; a.gx_row = T;
+    for (int l = 0; l < L; ++l) {
+        a.whh[l] = ly[l]->whh_dev;
+        a.wih[l] = ly[l]->wih_dev;
+        a.bias[l] = ly[l]->bih_dev;
+    }
+    a.out = out; a.out_t = 1; a.out_row = T;
+    a.H = H; a.T = T; a.L = L;
+    const bool timed = prof && prof->on;
+    if (timed) prof->begin(st);
+    launch_lstm_stack(a, st);
+    if (timed) prof->end(st, 2.0 * 4 * H * (double)H * ((double)L * (T - 1) + (double)(L - 1) * T));
+    return true;
+}
 
 // Two independent LSTM layers of equal shape (GCRN's grouped LSTM, GCRN/GCRN_noncprs.py:5-39) as ONE cooperative launch
 // (Z = 2): each alone covers H/16 x SS workgroups of the chip, together they fill it.  whh2 = [2][4H][H] device copy of

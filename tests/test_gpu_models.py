@@ -136,3 +136,24 @@ def test_large_batch_matches_small_batch(name, B):
             for k in range(i + j, B, 6):
                 e = rms(yb[k] - ys[j])
                 assert e < 1e-5 * max(rms(ys[j]), 1e-4), (name, k, e, rms(ys[j]))     # fp32 tile shapes differ with the batch
+
+
+@pytest.mark.parametrize('name', ['lstm', 'crn', 'gcrn', 'fullsubnet'])
+def test_recurrence_forms_agree(name):
+    """The recurrent layers run in different forms by batch size (k_lstm_coop.hip): one clip - dot products and, for LSTM / CRN,
+    the whole stack as one wavefront launch with a tagged exchange; 2 ... 4 clips - K-split tiles, tagged exchange; 5 ... 16 - K-split
+    tiles, flags; more - the sequence-sliced kernel.  A clip must decode to the same waveform in all of them (rounding of the
+    differently ordered sums and of the 1-ulp tag aside), and the fixtures pin the small batches to the reference."""
+    import torch
+    from se_amd.models import MODEL_CLASSES
+    L = 16000
+    x = np.stack([synth.synth_clip(930 + b, 'speech', L) for b in range(20)])
+    outs = {}
+    for B in (1, 3, 8, 20):
+        m = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(7)
+        outs[B] = m.enhance_batch(torch.from_numpy(x[:B]).cuda()).cpu().numpy()[0]
+    ref = outs[20]
+    for B in (1, 3, 8):
+        e = float(np.sqrt(np.mean((outs[B] - ref) ** 2)))
+        print(name, 'batch', B, 'vs batch 20: rms err', e, 'rms', float(np.sqrt(np.mean(ref ** 2))))
+        assert e < 1e-6 + 2e-5 * float(np.sqrt(np.mean(ref ** 2))), (name, B, e)

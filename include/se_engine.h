@@ -208,7 +208,7 @@ int se_pcm16_encode(const float* in_dev, int64_t in_pitch, int32_t batch, int32_
                     void* stream);
 
 /* ABI version of this header. */
-int32_t se_abi_version(void);   /* 2: se_enhance_ragged, se_get_stage_profile, se_stream_*; 3: se_uformer_forward, se_pcm16_* */
+int32_t se_abi_version(void);   /* 2: se_enhance_ragged, se_get_stage_profile, se_stream_*; 3: se_uformer_forward, se_pcm16_*; 4: se_stream_begin_running */
 
 #ifdef __cplusplus
 }

@@ -567,7 +567,10 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
     } else {   // EPI_LSTM
         // a lane's 16 accumulators of one MFMA tile are the i,f,g,o gates of 4 cells: all 16 gate pre-activations and
         // the 4 cell states are fetched by unconditional (clamped) loads in one batch, then the cells update
-        const float* __restrict__ gx = p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f;
+        // (p.aux == nullptr: the input projection is part of this GEMM - a second source in the K loop - and the gate
+        // pre-activations only need the bias, FullSubNet's first sub-band layer)
+        const bool has_gx = p.aux != nullptr;
+        const float* __restrict__ gx = has_gx ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : p.bias;
         float* __restrict__ cell = p.cell + (long)z * p.cell_z + (long)b * p.d_b + (long)fo * p.d_f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -580,9 +583,10 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int m = min(mb + 8 * g4, p.M - 4);
-                    const float* gp = gx + (long)m * p.x_c + tc;
+                    const float* gp = has_gx ? gx + (long)m * p.x_c + tc : gx + m;
+                    const long gs = has_gx ? p.x_c : 1;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) g[4 * g4 + k] = gp[(long)k * p.x_c];
+                    for (int k = 0; k < 4; ++k) g[4 * g4 + k] = gp[(long)k * gs];
                     cp[g4] = p.first_step ? 0.f : cell[(long)(m >> 2) * p.d_c + tc];
                 }
 #pragma unroll
@@ -942,9 +946,11 @@ __device__ __forceinline__ void gc_thin_body(const GCParams& p, const int blk) {
         // a latency-bound K loop of one MFMA workgroup per 128 rows, ~12 us here)
         if ((r & 3) || mr + 3 >= p.M) return;
         const int tc = t0 + t;
-        const float* __restrict__ gx = p.aux + (long)b * p.x_b + (long)fo * p.x_f + (long)mr * p.x_c + tc;
+        const bool has_gx = p.aux != nullptr;
+        const float* __restrict__ gx = has_gx ? p.aux + (long)b * p.x_b + (long)fo * p.x_f + (long)mr * p.x_c + tc : p.bias + mr;
+        const long gs = has_gx ? p.x_c : 1;
         float* __restrict__ cell = p.cell + (long)b * p.d_b + (long)fo * p.d_f + (long)(mr >> 2) * p.d_c + tc;
-        const float g0 = gx[0], g1 = gx[p.x_c], g2 = gx[2 * p.x_c], g3 = gx[3 * p.x_c];
+        const float g0 = gx[0], g1 = gx[gs], g2 = gx[2 * gs], g3 = gx[3 * gs];
         const float cp = p.first_step ? 0.f : *cell;
         const float gi = part[0][r][t] + g0, gf = part[0][r + 1][t] + g1, gg = part[0][r + 2][t] + g2, go = part[0][r + 3][t] + g3;
         float cn, hn;
@@ -1491,7 +1497,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     // p.t_base (default 0): first output frame of the launch - frame-online chunks only produce the frames behind their
     // history columns.  A multiple of 4, so that the 16 B staging groups keep their alignment to frame 0.
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
-    if (p.epi == EPI_LSTM && p.first_step) p.C0 = p.C1 = 0;       // h_{-1} = 0: no matrix work
+    if (p.epi == EPI_LSTM && p.first_step && p.C1 == 0) p.C0 = 0;       // h_{-1} = 0: no matrix work (a step that also projects its input keeps both)
     if (p.t_base > 0 && gc_thin_launch(p, stream)) return;       // (any first frame)
     if (p.tb_soft) p.t_base &= ~3;
     const int tb = p.t_base, Tspan = p.Tout - tb;

@@ -189,7 +189,7 @@ class FullSubNet final : public Model {
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *mag, *est, *frames, *mu, *mu2, *part;
-        float *magT, *xfb, *G, *h[2], *cell, *fbo, *sb, *maskT, *maskBT;
+        float *magT, *xfb, *G, *h[2], *cell, *fbo, *sb, *maskT, *maskBT, *hz;
     } cur;
     LstmBig fb[2], sbl[2];
     GCPlan fb_fc, sb_fc;
@@ -218,6 +218,7 @@ class FullSubNet final : public Model {
         b.h[0] = a.alloc_f(Tp * 384 * S);               // also the full-band hidden [Tp][512][B]
         b.h[1] = a.alloc_f(Tp * 384 * S);
         b.cell = a.alloc_f(384 * S + 512 * (size_t)B);
+        b.hz = a.alloc_f(384 * S);                      // zeros: h_{-1} of the sub-band layer that projects its own input
         b.maskT = a.alloc_f(Tp * 2 * S);
         b.maskBT = a.alloc_f(Tp * 2 * S);
         cur = b;
@@ -258,8 +259,12 @@ class FullSubNet final : public Model {
         static const int parts_env = getenv("SE_FSN_SPLIT") ? atoi(getenv("SE_FSN_SPLIT")) : 2;
         const int parts = std::max(1, std::min({parts_env, 1 + EngineCtx::MAX_AUX, S / 256}));
         const int Sp = ((S + parts - 1) / parts + 127) / 128 * 128;           // columns per part (tile aligned)
+        static const bool fuse_x = !(getenv("SE_FSN_FUSE_X") && atoi(getenv("SE_FSN_FUSE_X")) == 0);
+        const bool l0x = fuse_x && sbl[0].has_x;
+        if (l0x) launch_fill(b.hz, 384L * S, 0.f, st);
         auto part = [&](int c0, int Sn, hipStream_t s, Profiler* p) {
-            sbl[0].run_cols(b.sb, (long)SBW * S, b.G, cell, b.h[0], 384L * S, 1, Tp, S, c0, Sn, s, p);
+            if (l0x) sbl[0].run_cols_x(b.sb, (long)SBW * S, cell, b.hz, b.h[0], 384L * S, 1, Tp, S, c0, Sn, s, p);
+            else sbl[0].run_cols(b.sb, (long)SBW * S, b.G, cell, b.h[0], 384L * S, 1, Tp, S, c0, Sn, s, p);
             sbl[1].run_cols(b.h[0], 384L * S, b.G, cell, b.h[1], 384L * S, 1, Tp, S, c0, Sn, s, p);
             run_pointwise(sb_fc, b.h[1] + c0, 384L * S, S, b.maskT + c0, 2L * S, S, Tp, Sn, s, p);
         };

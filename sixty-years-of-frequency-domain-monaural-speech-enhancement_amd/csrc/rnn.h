@@ -157,6 +157,8 @@ inline void run_pointwise_cols(const GCPlan& pl, const float* src, long s_o, lon
 // as one GEMM over all steps, then one fused GEMM + LSTM-cell launch per step (weights stream from L2 / Infinity Cache).
 struct LstmBig {
     GCPlan gin, step;
+    GCPlan step_x;                // recurrent step + input projection in one GEMM (K = H + I): layers with a narrow input
+    bool has_x = false;
     GCPlan gin_fm;                // the input projection planned for feature-major activations (rows of T * S frames)
     float* whh_dev = nullptr;     // row-major [4H][H] (gate-interleaved rows) for the weight-stationary cooperative kernel
     float *wih_dev = nullptr, *bih_dev = nullptr;      // row-major [4H][I] and [4H] (b_ih + b_hh) for the one-sequence stack kernel
@@ -169,6 +171,18 @@ struct LstmBig {
         gin = make_pointwise_plan(w.wih, ACT_NONE, {}, s_hint);
         step = gc_make_plan(4 * H, H, one_tap(), w.whh.w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, s_hint);
         step.p.gru = gru ? 1 : 0;
+        if (!gru && I <= 64) {
+            // Narrow input (FullSubNet's first sub-band layer: 32 features into 4 x 384 gate rows over 257 * B sequences): the
+            // batched input projection is bound by WRITING its output ([T][4H][S]: 51 GB at 128 clips, read back one step at
+            // a time) - as a second source of the step GEMM's K loop it costs 8 % more matrix work per step and no traffic.
+            std::vector<float> wcat((size_t)4 * H * (H + I));
+            for (int m = 0; m < 4 * H; ++m) {
+                for (int k = 0; k < H; ++k) wcat[(size_t)m * (H + I) + k] = w.whh.w[(size_t)m * H + k];
+                for (int k = 0; k < I; ++k) wcat[(size_t)m * (H + I) + H + k] = w.wih.w[(size_t)m * I + k];
+            }
+            step_x = gc_make_plan(4 * H, H + I, one_tap(), wcat, w.wih.bias, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, s_hint, 1, H);
+            has_x = true;
+        }
         if (!gru && (H == 512 || H == 1024)) {
             whh_dev = to_device(w.whh.w);
             if (I == H) {
@@ -203,6 +217,8 @@ struct LstmBig {
     void free() {
         gc_free_plan(gin);
         gc_free_plan(step);
+        if (has_x) gc_free_plan(step_x);
+        has_x = false;
         if (has_fm) gc_free_plan(gin_fm);
         has_fm = false;
         if (whh_dev) (void)hipFree(whh_dev);
@@ -307,6 +323,35 @@ struct LstmBig {
             p.d_f = 0;
             p.cell = cell + c0;
             gc_launch_prof(step, p, st, prof);
+        }
+    }
+    // the same with the input projection inside the step GEMM (step_x): no gate tensor; hz = zeros [H][S] standing in for h_{-1}
+    void run_cols_x(const float* x, long x_t, float* cell, const float* hz, float* out, long out_t, int out_rs, int T, int S, int c0,
+                    int Sn, hipStream_t st, Profiler* prof) const {
+        SE_CHECK(has_x, "run_cols_x: layer was not built with a fused input projection");
+        for (int t = 0; t < T; ++t) {
+            GCParams p = step_x.p;
+            p.first_step = (t == 0);
+            p.src0 = (t > 0 ? out + (size_t)(t - 1) * out_t : hz) + c0;
+            p.s0_b = 0;
+            p.s0_c = t > 0 ? (long)out_rs * S : S;
+            p.s0_f = 0;
+            p.src1 = x + (size_t)t * x_t + c0;
+            p.s1_b = 0;
+            p.s1_c = S;
+            p.s1_f = 0;
+            p.Fin = 1;
+            p.Tin = Sn;
+            p.B = 1;
+            p.Q = 1;
+            p.Tout = Sn;
+            p.aux = nullptr;
+            p.dst = out + (size_t)t * out_t + c0;
+            p.d_b = 0;
+            p.d_c = (long)out_rs * S;
+            p.d_f = 0;
+            p.cell = cell + c0;
+            gc_launch_prof(step_x, p, st, prof);
         }
     }
 };

@@ -214,7 +214,10 @@ class FullSubNet final : public Model {
         b.xfb = a.alloc_f(Tp * S);
         b.fbo = a.alloc_f(Tp * S);
         b.sb = a.alloc_f(Tp * SBW * S);
-        b.G = a.alloc_f(Tp * 1536 * S);                 // also holds the full-band gates [Tp][2048][B]
+        // gate pre-activations: the full-band layers' [Tp][2048][B]; the sub-band layers' [Tp][1536][S] only when they do not
+        // project their inputs inside the step GEMM (51 GB at 128 clips)
+        const bool sb_gates = !(fuse_x_on() && sbl[0].has_x && sbl[1].has_x);
+        b.G = a.alloc_f(sb_gates ? Tp * 1536 * S : Tp * 2048 * (size_t)B);
         b.h[0] = a.alloc_f(Tp * 384 * S);               // also the full-band hidden [Tp][512][B]
         b.h[1] = a.alloc_f(Tp * 384 * S);
         b.cell = a.alloc_f(384 * S + 512 * (size_t)B);
@@ -226,6 +229,11 @@ class FullSubNet final : public Model {
     }
 
     bool graph_capturable() const override { return false; }     // sub-band halves run on two streams
+    // SE_FSN_FUSE_X=0: the sub-band layers' input projections as batched GEMMs into a [T][4H][S] gate tensor (rnn.h step_x)
+    static bool fuse_x_on() {
+        static const bool on = !(getenv("SE_FSN_FUSE_X") && atoi(getenv("SE_FSN_FUSE_X")) == 0);
+        return on;
+    }
 
     // mag [B][257][T] -> maskBT [n*B+b][2][T+2]
     void network(Bufs& b, const float* mag, hipStream_t st) {
@@ -259,13 +267,14 @@ class FullSubNet final : public Model {
         static const int parts_env = getenv("SE_FSN_SPLIT") ? atoi(getenv("SE_FSN_SPLIT")) : 2;
         const int parts = std::max(1, std::min({parts_env, 1 + EngineCtx::MAX_AUX, S / 256}));
         const int Sp = ((S + parts - 1) / parts + 127) / 128 * 128;           // columns per part (tile aligned)
-        static const bool fuse_x = !(getenv("SE_FSN_FUSE_X") && atoi(getenv("SE_FSN_FUSE_X")) == 0);
+        const bool fuse_x = fuse_x_on();
         const bool l0x = fuse_x && sbl[0].has_x;
         if (l0x) launch_fill(b.hz, 384L * S, 0.f, st);
         auto part = [&](int c0, int Sn, hipStream_t s, Profiler* p) {
             if (l0x) sbl[0].run_cols_x(b.sb, (long)SBW * S, cell, b.hz, b.h[0], 384L * S, 1, Tp, S, c0, Sn, s, p);
             else sbl[0].run_cols(b.sb, (long)SBW * S, b.G, cell, b.h[0], 384L * S, 1, Tp, S, c0, Sn, s, p);
-            sbl[1].run_cols(b.h[0], 384L * S, b.G, cell, b.h[1], 384L * S, 1, Tp, S, c0, Sn, s, p);
+            if (fuse_x && sbl[1].has_x) sbl[1].run_cols_x(b.h[0], 384L * S, cell, b.hz, b.h[1], 384L * S, 1, Tp, S, c0, Sn, s, p);
+            else sbl[1].run_cols(b.h[0], 384L * S, b.G, cell, b.h[1], 384L * S, 1, Tp, S, c0, Sn, s, p);
             run_pointwise(sb_fc, b.h[1] + c0, 384L * S, S, b.maskT + c0, 2L * S, S, Tp, Sn, s, p);
         };
         if (parts > 1) {

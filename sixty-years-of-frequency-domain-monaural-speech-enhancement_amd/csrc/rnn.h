@@ -171,10 +171,13 @@ struct LstmBig {
         gin = make_pointwise_plan(w.wih, ACT_NONE, {}, s_hint);
         step = gc_make_plan(4 * H, H, one_tap(), w.whh.w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, s_hint);
         step.p.gru = gru ? 1 : 0;
-        if (!gru && I <= 64) {
-            // Narrow input (FullSubNet's first sub-band layer: 32 features into 4 x 384 gate rows over 257 * B sequences): the
-            // batched input projection is bound by WRITING its output ([T][4H][S]: 51 GB at 128 clips, read back one step at
-            // a time) - as a second source of the step GEMM's K loop it costs 8 % more matrix work per step and no traffic.
+        static const int fuse_i = getenv("SE_LSTM_FUSE_I") ? atoi(getenv("SE_LSTM_FUSE_I")) : 384;
+        if (!gru && I <= fuse_i) {
+            // Layers that run one GEMM launch per step over many sequences (FullSubNet's sub-band LSTMs: 4 x 384 gate rows over
+            // 257 * B sequences): the batched input projection writes [T][4H][S] gate pre-activations - 51 GB at 128 clips, read
+            // back one step at a time - and for the 32-feature first layer that write IS its cost.  As a second source of the
+            // step GEMM's K loop the projection costs its matrix work (8 % of a step for the first layer, as much again as
+            // the step for the 384-feature second one) and no traffic: 414 -> 449 (first layer) -> 463 utt/s (both).
             std::vector<float> wcat((size_t)4 * H * (H + I));
             for (int m = 0; m < 4 * H; ++m) {
                 for (int k = 0; k < H; ++k) wcat[(size_t)m * (H + I) + k] = w.whh.w[(size_t)m * H + k];

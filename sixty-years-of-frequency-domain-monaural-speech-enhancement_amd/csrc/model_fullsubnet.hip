@@ -216,7 +216,7 @@ class FullSubNet final : public Model {
         b.sb = a.alloc_f(Tp * SBW * S);
         // gate pre-activations: the full-band layers' [Tp][2048][B]; the sub-band layers' [Tp][1536][S] only when they do not
         // project their inputs inside the step GEMM (51 GB at 128 clips)
-        const bool sb_gates = !(fuse_x_on() && sbl[0].has_x && sbl[1].has_x);
+        const bool sb_gates = !(fuse_x_on(B) && sbl[0].has_x && sbl[1].has_x);
         b.G = a.alloc_f(sb_gates ? Tp * 1536 * S : Tp * 2048 * (size_t)B);
         b.h[0] = a.alloc_f(Tp * 384 * S);               // also the full-band hidden [Tp][512][B]
         b.h[1] = a.alloc_f(Tp * 384 * S);
@@ -230,9 +230,11 @@ class FullSubNet final : public Model {
 
     bool graph_capturable() const override { return false; }     // sub-band halves run on two streams
     // SE_FSN_FUSE_X=0: the sub-band layers' input projections as batched GEMMs into a [T][4H][S] gate tensor (rnn.h step_x)
-    static bool fuse_x_on() {
+    // (from 16 clips on: below, a step launch is a latency-bound K loop of a few workgroups and a K of 768 instead of 384 costs
+    // more than the batched projection it replaces - one clip: 38 vs 30 utt/s)
+    static bool fuse_x_on(int B) {
         static const bool on = !(getenv("SE_FSN_FUSE_X") && atoi(getenv("SE_FSN_FUSE_X")) == 0);
-        return on;
+        return on && B >= 16;
     }
 
     // mag [B][257][T] -> maskBT [n*B+b][2][T+2]
@@ -267,7 +269,7 @@ class FullSubNet final : public Model {
         static const int parts_env = getenv("SE_FSN_SPLIT") ? atoi(getenv("SE_FSN_SPLIT")) : 2;
         const int parts = std::max(1, std::min({parts_env, 1 + EngineCtx::MAX_AUX, S / 256}));
         const int Sp = ((S + parts - 1) / parts + 127) / 128 * 128;           // columns per part (tile aligned)
-        const bool fuse_x = fuse_x_on();
+        const bool fuse_x = fuse_x_on(B);
         const bool l0x = fuse_x && sbl[0].has_x;
         if (l0x) launch_fill(b.hz, 384L * S, 0.f, st);
         auto part = [&](int c0, int Sn, hipStream_t s, Profiler* p) {

@@ -152,13 +152,37 @@ OTHER_CONFIGS = [
 ]
 
 
-def run_other_configs(torch, local_rank, steps):
+# The rest of the zoo (the north star's ten model families + the three `*_new` directories) on the same clock, batch
+# 256 x 4 s clips: `roofline.zoo` (VERDICT r3 #4 - every network's figure driver-timed, not only the five BASELINE configs).  The
+# `_new` variants do the arithmetic of their bases (cumulative LayerNorm in place of InstanceNorm): same GFLOP per utterance.
+ZOO_CONFIGS = [
+    ("GCRN (GCRN/GCRN_noncprs.py), batch 256", 'gcrn', 256, 13.2, {}),
+    ("DPCRN (DPCRN/DPCRN.py), batch 256", 'dpcrn', 256, 4.8, {}),
+    ("CTSNet (CTSNet/Step1_network.py + Step2_network.py), batch 256", 'ctsnet', 256, 25.6, {}),
+    ("G2Net (G2Net_VB/gaf_net_320.py), batch 256", 'g2net', 256, 10.7, {}),
+    ("TaylorSENet (TaylorSENet/TaylorSENet.py), batch 256", 'taylorsenet', 256, 31.3, {}),
+    ("CTSNet_new (cLN), batch 256", 'ctsnet_new', 256, 25.6, {}),
+    ("G2Net_new (cLN), batch 256", 'g2net_new', 256, 10.7, {}),
+    ("TaylorSENet_new (cLN), batch 256", 'taylorsenet_new', 256, 31.3, {}),
+]
+
+
+def _build_model(name, local_rank, B, kw):
+    from se_amd import models, models_new
+    args = dict(device=local_rank, max_batch=B, max_samples=CLIP_SAMPLES, **kw)
+    if name == 'ctsnet':
+        return models.CTSNet(**args).load_synthetic(17, 18)
+    if name == 'ctsnet_new':
+        return models_new.CTSNet(**args).load_synthetic(17, 18)
+    return models.MODEL_CLASSES[name](**args).load_synthetic(1)
+
+
+def run_other_configs(torch, local_rank, steps, configs=None):
     from se_amd import synth
-    from se_amd.models import MODEL_CLASSES
     rows = []
     base = synth.synth_batch(16, 'speech', CLIP_SAMPLES, seed0=300)
-    for cfg, name, B, gflop, kw in OTHER_CONFIGS:
-        m = MODEL_CLASSES[name](device=local_rank, max_batch=B, max_samples=CLIP_SAMPLES, **kw).load_synthetic(1)
+    for cfg, name, B, gflop, kw in (configs if configs is not None else OTHER_CONFIGS):
+        m = _build_model(name, local_rank, B, kw)
         eng = m.engine
         wav = torch.from_numpy(np.tile(base, ((B + 15) // 16, 1))[:B].copy()).cuda()
         out = torch.empty((B, eng.output_samples(CLIP_SAMPLES)), dtype=torch.float32, device=wav.device)
@@ -208,6 +232,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help="skip BASELINE's other configurations (roofline.configs)")
+    ap.add_argument('--no-zoo', action='store_true', help='skip the other eight networks of the zoo (roofline.zoo)')
     ap.add_argument('--cpu-worker', type=str, default='', help='internal: "seed,p_in,p_out,P" - time the C++ CPU restatement, print JSON')
     args = ap.parse_args()
     if args.cpu_worker:
@@ -357,6 +382,8 @@ def main():
                     "frac": res["roofline_whole_path"]["frac"]}
             rows = run_other_configs(torch, local_rank, max(3, min(args.steps, 10)))
             res["roofline"]["configs"] = rows[:2] + [head] + rows[2:]
+            if not args.no_zoo:
+                res["roofline"]["zoo"] = run_other_configs(torch, local_rank, 3, ZOO_CONFIGS)
             res["roofline"]["configs_note"] = ("whole decode path per config: utt/s x SURVEY 8(d) GFLOP per utterance against the "
                                               "f32 MFMA peak; unprofiled steps timed by the host clock around a device sync")
         if world == 1 and not args.no_cpu_baseline:

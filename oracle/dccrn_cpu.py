@@ -1,4 +1,4 @@
-"""ctypes binding of oracle/_ref/libdccrn_cpu.so - the C++ / OpenMP restatement of the DCCRN decode (oracle/dccrn_cpu.cpp).
+"""ctypes binding of oracle/_port/libdccrn_cpu.so - the C++ / OpenMP restatement of the DCCRN decode (oracle/dccrn_cpu.cpp).
 
 TEST INFRASTRUCTURE / CPU BASELINE.  Imported only by tests/ and bench.py's `cpu_baseline` leg.
 """
@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, '_ref', 'libdccrn_cpu.so')
+LIB = os.path.join(HERE, '_port', 'libdccrn_cpu.so')
 _lib = None
 
 

@@ -46,6 +46,11 @@ struct se_engine {
         int ring = 0;
         float* wav = nullptr;
         float* c = nullptr;
+        // the hipStream the last push / flush / begin of this handle ran on: a new stream that starts on ANOTHER hipStream
+        // re-uses (and clears) the parked state buffers, so it must be ordered behind the work still in flight there
+        bool has_last = false;
+        hipStream_t last_st = nullptr;
+        hipEvent_t ev_order = nullptr;
     } strm;
 };
 
@@ -183,6 +188,7 @@ int se_engine_destroy(se_engine* e) {
     if (e->strm.c) (void)hipFree(e->strm.c);
     if (e->strm.sumsq) (void)hipFree(e->strm.sumsq);
     if (e->strm.frame_inv) (void)hipFree(e->strm.frame_inv);
+    if (e->strm.ev_order) (void)hipEventDestroy(e->strm.ev_order);
     if (e->rag_host) (void)hipHostFree(e->rag_host);
     if (e->rag_dev) (void)hipFree(e->rag_dev);
     for (auto& ev : e->rag_ev)
@@ -237,9 +243,14 @@ int se_engine_finalize(se_engine* e) {
         const int fm = pad_frames_mult(e->model->frame_multiple());
         const int Tr = (T + fm - 1) / fm * fm;
         e->plan_frames = e->model->stream_supported() ? std::max(Tr, e->model->stream_hc() + 16) : Tr;
-        e->ctx.arena.measure_begin();
-        e->model->plan_buffers(e->ctx.max_batch, e->plan_frames);
-        const size_t need = e->ctx.arena.measure_end();
+        // a model's layout may depend on the batch (FullSubNet keeps a [T][4H][S] gate tensor below 16 clips and none from 16
+        // on, so 15 clips need more than 16...42): the arena covers every batch a call may bring, not only the largest
+        size_t need = 0;
+        for (int bq : {e->ctx.max_batch, std::min(e->ctx.max_batch, 15)}) {
+            e->ctx.arena.measure_begin();
+            e->model->plan_buffers(bq, e->plan_frames);
+            need = std::max(need, e->ctx.arena.measure_end());
+        }
         e->ctx.arena.reserve(need + (1 << 20));
         gc_register_overread_range(e->ctx.arena.base(), e->ctx.arena.capacity());
         e->model->plan_buffers(e->ctx.max_batch, T);
@@ -458,6 +469,17 @@ static int stream_begin_impl(se_engine* e, int32_t batch, int32_t max_chunk_fram
                  "front end overlap + look-ahead exceed the history the model keeps");
         hipStream_t st = static_cast<hipStream_t>(stream);
         se_engine::Stream& S = e->strm;
+        if (S.has_last && S.last_st != st) {
+            if (!S.ev_order) SE_HIP(hipEventCreateWithFlags(&S.ev_order, hipEventDisableTiming));
+            if (hipEventRecord(S.ev_order, S.last_st) == hipSuccess) {
+                SE_HIP(hipStreamWaitEvent(st, S.ev_order, 0));
+            } else {      // the caller has destroyed that hipStream in the meantime (its work was drained by the destroy)
+                (void)hipGetLastError();
+                SE_HIP(hipDeviceSynchronize());
+            }
+        }
+        S.has_last = true;
+        S.last_st = st;
         S.max_chunk = std::max(1, std::min(max_chunk_frames > 0 ? max_chunk_frames : 16, e->plan_frames - e->model->stream_hc()));
         if (!S.wav) {
             SE_HIP(hipMalloc(&S.wav, (size_t)e->ctx.max_batch * e->ctx.max_samples * sizeof(float)));
@@ -501,6 +523,7 @@ int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_
         SE_CHECK(S.batch == 1 || pitch >= n_new, "se_stream_push: input row pitch smaller than n_new");
         SE_CHECK(S.n_total + n_new <= e->ctx.max_samples, "stream longer than max_samples given at create");
         hipStream_t st = static_cast<hipStream_t>(stream);
+        S.last_st = st;
         const StftGeom& g = e->ctx.geom;
         if (n_new > 0)
             SE_HIP(hipMemcpy2DAsync(S.wav + S.n_total, (size_t)e->ctx.max_samples * sizeof(float), wav_dev,
@@ -531,6 +554,7 @@ int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_
         SE_CHECK(S.n_total >= e->ctx.geom.n_fft, "stream shorter than one FFT frame");
         SE_CHECK(out_pitch >= e->model->output_samples(S.n_total) - S.o_done, "output row pitch too small for the rest of the stream");
         int written = 0;
+        S.last_st = static_cast<hipStream_t>(stream);
         e->ctx.prof_reset();
         if (S.running)
             launch_stream_rms(S.wav, e->ctx.max_samples, S.batch, S.n_total, 0, S.sumsq, S.c, S.frame_inv, S.ring, S.t_done,

@@ -112,10 +112,13 @@ Tables& tables() {
 
 }  // namespace
 
-// ---- PCM_16 <-> float at the two ends of the decode driver (soundfile.read: int16 / 32768 -> float; soundfile.write default
-// subtype of .wav: PCM_16, round to nearest even, clipped - e.g. DCCRN/dccrn_decode_vb.py:25,64).  x / 32768 is exact in
-// fp32 and y * 32768 is exact unless it overflows, so doing both on the device changes no bit against the host path while
-// the host only moves raw 2-byte samples (half the PCIe bytes, no numpy pass per clip).
+// ---- PCM_16 <-> float at the two ends of the decode driver (e.g. DCCRN/dccrn_decode_vb.py:25,64).  soundfile.read:
+// int16 / 32768 -> float (libsndfile s2f, 1 / 0x8000).  soundfile.write, default subtype of .wav = PCM_16: libsndfile's
+// float -> short conversion with normalisation scales by 0x7FFF (NOT 0x8000) and rounds to nearest even (lrint); it does not
+// clip unless SFC_SET_CLIPPING is on - a sample beyond +-1 wraps there.  The engine takes the 0x7FFF scale and CLIPS instead of
+// wrapping (deliberate: a wrapped sample is a full-scale click).  soundfile is absent from this image: restated from
+// libsndfile's pcm.c as published, unpinned.  x / 32768 is exact in fp32; y * 32767 is formed in fp64 so that the
+// device and the host path (wavio.pcm16_bytes) agree bit for bit, while the host only moves raw 2-byte samples.
 namespace {
 __global__ __launch_bounds__(256) void pcm16_decode_kernel(const short* __restrict__ in, long in_pitch, float* __restrict__ out,
                                                            long out_pitch, int n) {
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(256) void pcm16_encode_kernel(const float* __restri
                                                            long out_pitch, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float v = rintf(in[(long)blockIdx.y * in_pitch + i] * 32768.f);          // round half to even, like np.rint
-    out[(long)blockIdx.y * out_pitch + i] = (short)fminf(fmaxf(v, -32768.f), 32767.f);
+    const double v = rint((double)in[(long)blockIdx.y * in_pitch + i] * 32767.0);   // round half to even, like lrint / np.rint
+    out[(long)blockIdx.y * out_pitch + i] = (short)fmin(fmax(v, -32768.0), 32767.0);
 }
 }  // namespace
 void launch_pcm16_decode(const short* in, long in_pitch, int batch, int n, float* out, long out_pitch, hipStream_t s) {

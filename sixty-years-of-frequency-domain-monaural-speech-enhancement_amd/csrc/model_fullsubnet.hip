@@ -152,8 +152,8 @@ class FullSubNet final : public Model {
         fb_fc = make_pointwise_plan(linear_weights(sd.get("fb_model.fc_output_layer.weight", {NBIN, 512}),
                                                    &sd.get("fb_model.fc_output_layer.bias", {NBIN})),
                                     ACT_RELU, {}, ctx.max_batch);
-        sbl[0].build(load("sb_model.sequence_model.", 0, SBW, 384), S, gru);
-        sbl[1].build(load("sb_model.sequence_model.", 1, 384, 384), S, gru);
+        sbl[0].build(load("sb_model.sequence_model.", 0, SBW, 384), S, gru, true);
+        sbl[1].build(load("sb_model.sequence_model.", 1, 384, 384), S, gru, true);
         sb_fc = make_pointwise_plan(linear_weights(sd.get("sb_model.fc_output_layer.weight", {2, 384}),
                                                    &sd.get("sb_model.fc_output_layer.bias", {2})),
                                     ACT_NONE, {}, S);

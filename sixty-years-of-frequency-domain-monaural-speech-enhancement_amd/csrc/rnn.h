@@ -165,14 +165,16 @@ struct LstmBig {
     int I = 0, H = 0;
     // gru: w comes from load_gru (GRU cell in the step epilogue; one launch per step - the weight-stationary cooperative
     // kernel only knows the LSTM cell)
-    void build(const LstmW& w, int s_hint, bool gru = false) {
+    // fuse_x: also pack the [W_hh | W_ih] plan of a step that projects its own input (run_cols_x) - opt-in, only FullSubNet's
+    // sub-band layers run it (for LSTM / CRN's 1024-wide layers it would be 19-33 MB of dead device memory per layer)
+    void build(const LstmW& w, int s_hint, bool gru = false, bool fuse_x = false) {
         I = w.I;
         H = w.H;
         gin = make_pointwise_plan(w.wih, ACT_NONE, {}, s_hint);
         step = gc_make_plan(4 * H, H, one_tap(), w.whh.w, {}, {}, ACT_NONE, EPI_LSTM, 1, 1, 0, s_hint);
         step.p.gru = gru ? 1 : 0;
         static const int fuse_i = getenv("SE_LSTM_FUSE_I") ? atoi(getenv("SE_LSTM_FUSE_I")) : 384;
-        if (!gru && I <= fuse_i) {
+        if (fuse_x && !gru && I <= fuse_i) {
             // Layers that run one GEMM launch per step over many sequences (FullSubNet's sub-band LSTMs: 4 x 384 gate rows over
             // 257 * B sequences): the batched input projection writes [T][4H][S] gate pre-activations - 51 GB at 128 clips, read
             // back one step at a time - and for the 32-feature first layer that write IS its cost.  As a second source of the

@@ -225,6 +225,8 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_bat
             with ThreadPoolExecutor(max(1, readers)) as pool:
                 for b in mine:
                     sl = free.get()
+                    if errors:
+                        break
                     t0 = time.perf_counter()
                     nb, nmax, lmax = len(b), max(native[i] for i in b), max(lengths[i] for i in b)
                     list(pool.map(lambda ri: load_row(sl, ri[0], ri[1], nmax), enumerate(b)))
@@ -288,34 +290,48 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_bat
     tr, tw = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
     tr.start()
     tw.start()
-    while True:
-        t0 = time.perf_counter()
-        item = staged.get()
-        if item is None or errors:
-            break
-        t1 = time.perf_counter()
-        busy['wait_in'] += t1 - t0
-        b, sl, wav_flat = item
-        lens = [lengths[i] for i in b]
-        nb, lmax = len(b), max(lens)
-        main.wait_event(sl.ready)
-        n_out = eng.output_samples(lmax)
-        wav = wav_flat[:nb * lmax].view(nb, lmax)
-        out = sl.out[:nb * n_out].view(nb, n_out)
-        if min(lens) == lmax:
-            eng.enhance_batch(wav, out)
-        else:
-            eng.enhance_ragged(wav, lens, out)
-        _check(lib.se_pcm16_encode(C.c_void_p(out.data_ptr()), n_out, nb, n_out, C.c_void_p(sl.d_q.data_ptr()), n_out,
-                                   C.c_void_p(main.cuda_stream)))
-        sl.h_q[:nb * n_out].copy_(sl.d_q[:nb * n_out], non_blocking=True)
-        sl.done.record(main)
-        busy['issue'] += time.perf_counter() - t1
-        finished.put((b, sl, n_out))
-    finished.put(None)
-    tw.join()
-    tr.join(timeout=5.0)
-    if errors:
+    # the decode loop may raise (an EngineError, a refused shape): the sentinels below must go out whatever happens, or the
+    # writer would block on `finished` and the reader on `free` for ever with pinned / device slots in their hands
+    aborted = False
+    try:
+        while True:
+            t0 = time.perf_counter()
+            item = staged.get()
+            if item is None or errors:
+                break
+            t1 = time.perf_counter()
+            busy['wait_in'] += t1 - t0
+            b, sl, wav_flat = item
+            lens = [lengths[i] for i in b]
+            nb, lmax = len(b), max(lens)
+            main.wait_event(sl.ready)
+            n_out = eng.output_samples(lmax)
+            wav = wav_flat[:nb * lmax].view(nb, lmax)
+            out = sl.out[:nb * n_out].view(nb, n_out)
+            if min(lens) == lmax:
+                eng.enhance_batch(wav, out)
+            else:
+                eng.enhance_ragged(wav, lens, out)
+            _check(lib.se_pcm16_encode(C.c_void_p(out.data_ptr()), n_out, nb, n_out, C.c_void_p(sl.d_q.data_ptr()), n_out,
+                                       C.c_void_p(main.cuda_stream)))
+            sl.h_q[:nb * n_out].copy_(sl.d_q[:nb * n_out], non_blocking=True)
+            sl.done.record(main)
+            busy['issue'] += time.perf_counter() - t1
+            finished.put((b, sl, n_out))
+    except BaseException:
+        aborted = True
+        raise
+    finally:
+        finished.put(None)
+        if aborted or errors:
+            # un-block a reader waiting for a slot and drop what it staged: it stops at its next `free.get()` / end of list
+            if aborted and not errors:
+                errors.append(RuntimeError('decode aborted'))       # tells the reader to stop
+            for sl in slots:
+                free.put(sl)
+        tw.join(timeout=30.0)
+        tr.join(timeout=30.0 if not (aborted or errors) else 5.0)
+    if errors and not aborted:
         raise errors[0]
     if stats is not None:
         t_end = time.perf_counter()

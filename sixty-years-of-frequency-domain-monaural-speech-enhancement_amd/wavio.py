@@ -2,8 +2,9 @@
 
 The reference reads with `soundfile.read` (float64 in [-1, 1)) and writes with `soundfile.write(path, y, fs)`, whose
 default subtype for .wav is PCM_16 (e.g. DCCRN/dccrn_decode_vb.py:25,64).  soundfile is not available here, so the
-decode driver carries its own I/O: PCM 16/24/32-bit and IEEE float 32/64 in, PCM_16 (clipped, round-to-nearest) out.
+decode driver carries its own I/O: PCM 16/24/32-bit and IEEE float 32/64 in, PCM_16 out (libsndfile's 0x7FFF scale, round-to-nearest-even, clipped).
 """
+import os
 import struct
 
 import numpy as np
@@ -76,7 +77,11 @@ def wav_info(path):
                 if fmt is None:
                     raise ValueError(f'{path}: data chunk before fmt chunk')
                 tag, ch, fs, bits = fmt
-                return size // (ch * (bits // 8)), fs, ch, tag, bits, f.tell()
+                # a streamed / truncated file may announce more than it holds (0xFFFFFFFF, or a size written before the
+                # recording ended): the plan is made from what is really there
+                off = f.tell()
+                size = max(0, min(size, os.fstat(f.fileno()).st_size - off))
+                return size // (ch * (bits // 8)), fs, ch, tag, bits, off
             else:
                 f.seek(size + (size & 1), 1)
 
@@ -92,8 +97,10 @@ def read_pcm16_into(path, offset, frames, dst):
 
 
 def pcm16_bytes(y):
-    """float samples -> PCM_16 little-endian array (clipped, round-to-nearest-even like soundfile / np.rint)."""
-    return np.clip(np.rint(np.asarray(y, dtype=np.float64) * 32768.0), -32768, 32767).astype('<i2')
+    """float samples -> PCM_16 little-endian array as soundfile.write's default subtype makes them: libsndfile scales a
+    normalised float by 0x7FFF and rounds to nearest even (pcm.c f2s_array; restated from the published source - soundfile is
+    not in this image, unpinned).  Out-of-range samples are clipped here, where libsndfile without SFC_SET_CLIPPING wraps."""
+    return np.clip(np.rint(np.asarray(y, dtype=np.float64) * 32767.0), -32768, 32767).astype('<i2')
 
 
 def wav_header_pcm16(n_bytes, fs, ch=1):
@@ -102,9 +109,8 @@ def wav_header_pcm16(n_bytes, fs, ch=1):
 
 
 def write_wav_pcm16(path, y, fs):
-    """soundfile.write(path, y, fs) default for .wav: PCM_16, values clipped to [-1, 1)."""
-    y = np.asarray(y, dtype=np.float64)
-    q = np.clip(np.rint(y * 32768.0), -32768, 32767).astype('<i2')
+    """soundfile.write(path, y, fs) default for .wav: PCM_16 (see pcm16_bytes for the scale and the clipping)."""
+    q = pcm16_bytes(y)
     ch = 1 if q.ndim == 1 else q.shape[1]
     raw = q.tobytes()
     hdr = b'RIFF' + struct.pack('<I', 36 + len(raw)) + b'WAVE' + b'fmt ' + struct.pack(

@@ -25,7 +25,7 @@ def _write_clips(d, lengths, seed0):
 
 
 def _pcm16(y):
-    return np.clip(np.round(np.asarray(y, dtype=np.float64) * 32768.0), -32768, 32767).astype(np.int64)
+    return np.clip(np.rint(np.asarray(y, dtype=np.float64) * 32767.0), -32768, 32767).astype(np.int64)       # wavio.pcm16_bytes
 
 
 def test_vb_driver_matches_oracle_and_pcm16(tmp_path):

@@ -68,6 +68,25 @@ def test_workspace_bounds_are_enforced():
     assert bool(torch.isfinite(y).all())
 
 
+def test_fullsubnet_smaller_batch_fits_the_planned_arena():
+    """FullSubNet's layout is not monotone in the batch (a [T][1536][257 B] gate tensor below 16 clips, none from
+    16 on), so an engine planned for 32 clips must still take 12 full-length clips (the tail call of a sorted corpus) - and
+    give the rows a 12-clip engine gives."""
+    torch = _torch()
+    from se_amd.models import MODEL_CLASSES
+    L = 16000
+    big = MODEL_CLASSES['fullsubnet'](max_batch=32, max_samples=L).load_synthetic(15)
+    x = np.stack([synth.synth_clip(200 + b, 'speech', L) for b in range(12)])
+    y = big.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.isfinite(y).all()
+    y32 = big.enhance_batch(torch.from_numpy(np.tile(x, (3, 1))[:32]).cuda()).cpu().numpy()      # and the planned batch after it
+    del big
+    small = MODEL_CLASSES['fullsubnet'](max_batch=12, max_samples=L).load_synthetic(15)
+    ys = small.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert rms(y - ys) < 2e-6 * max(rms(ys), 1e-3) + 1e-7, rms(y - ys)
+    assert rms(y32[:12] - ys) < 1e-4
+
+
 @pytest.mark.parametrize('name', ['crn', 'dccrn', 'g2net', 'fullsubnet'])
 def test_graph_replay_matches_eager(name):
     """SE_CFG_GRAPHS: the third call of a shape replays a captured hipGraph (first eager, second captures) and must

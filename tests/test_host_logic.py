@@ -37,7 +37,9 @@ def test_wav_roundtrip(tmp_path):
     wavio.write_wav_pcm16(p, y, 16000)
     x, fs = wavio.read_wav(p)
     assert fs == 16000 and x.shape == y.shape
-    assert np.max(np.abs(x - y)) <= 0.5 / 32768 + 1e-12
+    # written with libsndfile's 0x7FFF scale, read back with 1 / 0x8000: |y| / 32768 of level change + half an LSB of rounding
+    assert np.max(np.abs(x - y)) <= (0.5 + np.abs(y).max()) / 32768 + 1e-12
+    assert np.array_equal(wavio.pcm16_bytes(y), np.rint(y * 32767.0).astype('<i2'))
     wavio.write_wav_pcm16(p, np.array([2.0, -2.0, 0.0]), 16000)           # clipping like PCM_16
     x, _ = wavio.read_wav(p)
     assert x[0] == 32767 / 32768 and x[1] == -1.0 and x[2] == 0.0

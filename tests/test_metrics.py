@@ -139,5 +139,5 @@ def test_pesq_of_engine_and_reference_path_outputs():
     print('wb-PESQ noisy %.3f  engine %.3f  reference path %.3f' % (p_noisy, p_eng, p_ref))
     assert abs(p_eng - p_ref) <= 0.01 and round(p_eng, 2) == round(p_ref, 2)
     # the file-level path: PCM_16 quantisation of both does not move the score either
-    q = lambda v: np.clip(np.round(v * 32768.0), -32768, 32767) / 32768.0
+    q = lambda v: np.clip(np.rint(v * 32767.0), -32768, 32767) / 32768.0       # sf.write -> sf.read
     assert abs(P.pesq(clean, q(y)) - P.pesq(clean, q(ref))) <= 0.01

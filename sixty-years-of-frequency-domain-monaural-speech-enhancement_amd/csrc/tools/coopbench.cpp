@@ -4,6 +4,8 @@
 #include "../common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 #include <random>
 #include <vector>
 using namespace se;
@@ -42,6 +44,35 @@ int main(int argc, char** argv) {
     std::vector<float> o(64);
     SE_HIP(hipMemcpy(o.data(), dout + (size_t)(T - 1) * H * S, 64 * 4, hipMemcpyDeviceToHost));
     double cs = 0; for (float v : o) cs += v;
+    // float64 recurrence of a few sequences on the host (sequences are independent): the kernel under test against the definition
+    {
+        const int Tc = std::min(T, getenv("COOPBENCH_TC") ? atoi(getenv("COOPBENCH_TC")) : 24);
+        std::vector<float> og((size_t)Tc * H * S);
+        SE_HIP(hipMemcpy(og.data(), dout, og.size() * 4, hipMemcpyDeviceToHost));      // z = 0
+        std::vector<int> seqs = {0, 1, 3, S / 2, S - 2 < 0 ? 0 : S - 2, S - 1};
+        double md = 0;
+        for (int n : seqs) {
+            if (n < 0 || n >= S) continue;
+            std::vector<double> h(H, 0.0), c(H, 0.0), hn(H);
+            for (int t = 0; t < Tc; ++t) {
+                for (int u = 0; u < H; ++u) {
+                    double gt[4];
+                    for (int q = 0; q < 4; ++q) {
+                        const float* wr = &w[(size_t)(4 * u + q) * H];
+                        double acc = g[((size_t)t * 4 * H + 4 * u + q) * S + n];
+                        for (int k = 0; k < H; ++k) acc += (double)wr[k] * h[k];
+                        gt[q] = acc;
+                    }
+                    auto sg = [](double x) { return 1.0 / (1.0 + exp(-x)); };
+                    c[u] = sg(gt[1]) * c[u] + sg(gt[0]) * tanh(gt[2]);
+                    hn[u] = sg(gt[3]) * tanh(c[u]);
+                }
+                h = hn;
+                for (int u = 0; u < H; ++u) md = std::max(md, std::fabs(h[u] - (double)og[((size_t)t * H + u) * S + n]));
+            }
+        }
+        printf("  max |gpu - float64 host| over %zu sequences x %d steps: %.3e\n", seqs.size(), Tc, md);
+    }
     printf("coop LSTM H=%d S=%d T=%d Z=%d: %.3f ms  %.2f us/step  %.2f us/tile-step  %.1f TFLOP/s  (checksum %.6f)\n", H, S, T, Z, ms,
            ms * 1e3 / T, ms * 1e3 / T / (((S + 15) / 16 + (256 / (H / 16) / Z) - 1) / (256 / (H / 16) / Z)), 2.0 * Z * 4 * H * H * S * T / ms / 1e9, cs);
     return 0;

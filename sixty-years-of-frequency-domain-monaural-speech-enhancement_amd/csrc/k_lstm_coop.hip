@@ -544,26 +544,34 @@ __global__ __launch_bounds__(256, 1) void lstm_stack_kernel(const LstmStackArgs 
     }
 }
 
-// ---- sub-tile pipelined form (round 4): 4-sequence sub-tiles on v_mfma_f32_4x4x1_16b_f32, waves independent ------------------
+// ---- sub-tile pipelined form (round 4): 4-sequence sub-tiles on v_mfma_f32_4x4x1_16b_f32, eight independent waves ---------------
 // lstm_coop_kernel above gives a workgroup ONE 16-sequence tile per step at batch 64 (H = 1024): 3.4 us of matrix work, then the
-// serial chain store -> acknowledge -> flag -> poll -> 64 KB of h -> LDS -> barrier with nothing to overlap it - 8.3 us per step
-// (CRN at batch 64: 46 % of the decode).  Here the unit of work is a SUB-TILE of 4 sequences:
-//   * v_mfma_f32_4x4x1_16b_f32 = 16 independent 4 x 4 x 1 blocks.  Block <-> K slice s16 (lane >> 2), block row <-> gate,
-//     block column <-> sequence: lane (s16, g) holds W[4 u + g][(16 i + s16) 4 + kk] of the wave's four units u (the same H / 4
-//     VGPRs as before), lane (s16, n) feeds h[n][(16 i + s16) 4 + kk] - ONE 16 B LDS read per 16 matrix instructions, and the
-//     row layout in LDS is plain [sequence][H + 16] (bank = 16 n + 4 s16 + kk: conflict free);
-//   * a wave owns its 4 units for ALL of K, so there is no cross-wave reduction: the 16 K slices fold inside the wave with
-//     v_permlane32_swap / v_permlane16_swap (reduce-scatter: row r of the wave ends up with unit r) and two row_ror adds;
-//   * a workgroup walks its sub-tiles round robin (4 per step at batch 64, 16 at batch 256): while sub-tile j's h_t travels,
-//     sub-tiles j + 1 ... run their matrix work.  The exchange carries its own arrival signal (mantissa-LSB step tag, as in
-//     lstm_coop_ks_kernel): a wave fetches ONE sequence row of the sub-tile with 16 B agent-scope (sc1) buffer loads LEAD
-//     slots ahead, checks every word's tag when the slot comes up and only then re-loads (rare path, bounded spin); h_t goes
-//     out as one 16 B sc1 store per sequence and wave (scalar sc1 stores are one fabric write each).  No flags, no store
-//     acknowledgement, one workgroup barrier per sub-tile (LDS publish).
+// serial chain store -> acknowledge -> flag -> poll -> 64 KB of h -> LDS -> barrier with nothing to overlap it - 8.2 us per step
+// (CRN at batch 64: 46 % of the decode); with more tiles per workgroup it still pays 6.2 - 7 us per tile.
+// Here the unit of work is a SUB-TILE of 4 sequences, and a workgroup walks its sub-tiles round robin (4 per step at batch 64,
+// 16 at batch 256): while sub-tile j's h_t travels, sub-tiles j + 1 ... run their matrix work.
+//   * v_mfma_f32_4x4x1_16b_f32 = 16 independent 4 x 4 x 1 blocks.  Block <-> K slice s16 (lane >> 2), block row <-> gate, block
+//     column <-> sequence: lane (s16, g) holds W[4 u + g][(16 i + s16) 4 + kk] of the wave's TWO units u (H / 8 VGPRs), lane
+//     (s16, n) feeds h[n][(16 i + s16) 4 + kk] - one 16 B LDS read per 8 matrix instructions, rows in LDS are plain
+//     [sequence][H + 16] (bank = 16 n + 4 s16 + kk: conflict free).  Four accumulator chains per wave (unit x k parity): a
+//     dependent 4x4x1 issues 16 cycles behind its producer, an independent one 8 (tools/mfma4bench.cpp).
+//   * EIGHT waves per workgroup, two per SIMD (<= 256 registers each): a wave owns its 2 units for ALL of K, so there is no
+//     cross-wave reduction - the 16 K slices fold inside the wave (v_permlane32_swap: unit 0 | unit 1 into the wave halves,
+//     v_permlane16_swap + two row_ror adds inside a half) - and while one wave of a SIMD folds, updates its cells and stores,
+//     the other one keeps the matrix pipe busy (with one wave per SIMD that tail was as long as the matrix work itself).
+//   * The exchange carries its own arrival signal (mantissa-LSB step tag, as in lstm_coop_ks_kernel).  Nothing the compiler
+//     tracks is pending across slots (its wait-count pass parks `s_waitcnt vmcnt(0)` at the loop header otherwise): h rows AND
+//     the slot's gate pre-activations travel global -> LDS by DMA (`global_load_lds_dwordx4 ... sc1`, issued from asm) LEAD slots
+//     ahead into a ring of LEAD + 1 buffers, the cell state lives in LDS for the whole launch, the only compiler-issued vector
+//     memory operations of a slot are its two stores, and the wait in front of a slot's tag check is a counted
+//     `s_waitcnt vmcnt(N)` that names exactly what was issued after that slot's DMA group.  A wave checks the tags of the words
+//     it fetched itself and only then re-fetches (rare path, bounded spin); h_t goes out as one 8 B sc1 store per sequence and wave.
+//     One workgroup barrier per sub-tile (LDS publish); no flags, no store acknowledgement.
 // A producer cannot overwrite a value a slower consumer still needs: it writes h_{t+1}[j] over h_{t-1}[j] only after it has read
 // h_t[j] from everyone, which everyone published after reading h_{t-1}[j].  The recurrence runs on h rounded to 23 mantissa
 // bits (bit-identical from run to run); `out` keeps the exact h.
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float swap_add32(float x, float y) {      // lanes 0-31: x.lo + x.hi, lanes 32-63: y.lo + y.hi
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -573,188 +581,10 @@ __device__ __forceinline__ float swap_add16(float x, float y) {      // 16-lane 
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float row_ror_add(float x, int ctrl8) {   // x + x rotated by 4 / 8 lanes inside its 16-lane row
-    return ctrl8 ? x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, true))
-                 : x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xF, 0xF, true));
+template <int CTRL>
+__device__ __forceinline__ float row_ror_add(float x) {              // x + x rotated by CTRL - 0x120 lanes inside its 16-lane row
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
-
-template <int H, int LEAD>
-__global__ __launch_bounds__(256, 1) void lstm_coop4_kernel(const LstmCoopArgs a) {
-    constexpr int KS = H / 16;         // k values of one K slice (lane group s16)
-    constexpr int NI = KS / 4;         // 16 B operand reads per sub-tile and lane
-    constexpr int NSTR = H + 16;       // LDS row stride (floats): rows 16 banks apart
-    constexpr int US = H / 16;         // unit slices (workgroups) per LSTM
-    constexpr int NL = H / 256;        // 16 B loads per lane and fetch: a wave stages one whole sequence row
-    extern __shared__ __attribute__((aligned(16))) float hs4[];      // [2][4][NSTR]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s16 = lane >> 2, n = lane & 3, row = lane >> 4;
-    const int us = blockIdx.x % US, ss = (blockIdx.x / US) % a.SS, z = blockIdx.x / (US * a.SS);
-    const bool rev = (a.reverse >> z) & 1;
-    const int NS4 = (a.S + 3) >> 2;                          // sub-tiles of the launch
-    const int NSUB = (NS4 - ss + a.SS - 1) / a.SS;           // ... of this sequence slice: ss, ss + SS, ...
-    const int U0 = us * 16 + wave * 4;                       // first hidden unit of this wave
-
-    floatx4 wa[4][NI];
-    static_for_c<4>([&](auto U_) {
-        constexpr int u = decltype(U_)::value;
-        const floatx4* __restrict__ W =
-            reinterpret_cast<const floatx4*>(a.whh + (long)z * a.whh_z + (long)(4 * (U0 + u) + n) * H + s16 * 4);
-        static_for_c<NI>([&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            wa[u][i] = W[i * 16];
-        });
-    });
-
-    float* __restrict__ hx = a.hx + (long)z * 2 * a.S * H;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hx, 0, 2 * a.S * H * 4, 0x00020000);
-    const int Ur = U0 + row;                                 // the unit this lane updates after the fold
-    const float* __restrict__ gx = a.gx + (long)z * a.gx_z + (long)(4 * Ur) * a.gx_row;
-    float* __restrict__ out = a.out + (long)z * a.out_z + (long)Ur * a.out_row;
-    float* __restrict__ cell = a.cell + ((long)z * H + Ur) * a.S;
-    const bool writer = (lane & 12) == 0;                    // one lane per (unit, sequence) of the wave: 16 r + n
-
-    // one slot = one (step, sub-tile); fetch registers + gate pre-activations of the slot LEAD ahead ride in a ring of LEAD sets
-    uintx4 v[LEAD][NL];
-    float gq[LEAD][4];
-    auto issue_h = [&](uintx4 (&vv)[NL], int t, int g) {
-        const int nq = min(4 * g + wave, a.S - 1);           // (clamped inside this sub-tile: 4 g < S)
-        const unsigned base = (unsigned)(((t & 1) * a.S + nq) * (H * 4) + lane * 16);
-        static_for_c<NL>([&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            vv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + i * 1024, 0, 16);      // aux 16 = sc1
-        });
-    };
-    auto issue_g = [&](float (&gg)[4], int t, int g) {
-        const int tt = min(t, a.T - 1), tr = rev ? a.T - 1 - tt : tt;
-        const int nn = min(4 * g + n, a.S - 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gg[k] = gx[(long)tr * a.gx_t + k * a.gx_row + nn];
-    };
-    auto stale = [&](const uintx4 (&vv)[NL], unsigned tag) -> bool {
-        unsigned bad = 0;
-        static_for_c<NL>([&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            bad |= (vv[i][0] ^ tag) | (vv[i][1] ^ tag) | (vv[i][2] ^ tag) | (vv[i][3] ^ tag);
-        });
-        return __builtin_amdgcn_ballot_w64((bad & 1u) != 0) != 0;
-    };
-
-    const int Q = a.T * NSUB;
-    int tf = 0, jf = 0;                                      // the next slot to fetch
-    static_for_c<LEAD>([&](auto P_) {
-        constexpr int p = decltype(P_)::value;
-        issue_h(v[p], tf, ss + jf * a.SS);
-        issue_g(gq[p], tf, ss + jf * a.SS);
-        if (++jf == NSUB) { jf = 0; ++tf; }
-    });
-    int tq = 0, jq = 0, par = 0;
-    // Q is padded to a multiple of LEAD with slots of step T (their h exists: the last step publishes too; nothing is stored)
-    for (int q = 0; q < Q; q += LEAD) {
-        static_for_c<LEAD>([&](auto P_) {
-            constexpr int p = decltype(P_)::value;
-            const int g = ss + jq * a.SS, n0 = 4 * g;
-            const unsigned tag = (unsigned)(tq >> 1) & 1u;
-            // ---- this slot's h rows: fetched LEAD slots ago; re-fetch while any word still shows the older step
-            if (stale(v[p], tag) && !(a.dbg & 4)) {
-                const unsigned long long t0 = wall_clock64();
-                do {
-                    if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
-                    issue_h(v[p], tq, g);
-                } while (stale(v[p], tag));
-            }
-            float* hb = hs4 + par * (4 * NSTR);
-            static_for_c<NL>([&](auto I_) {
-                constexpr int i = decltype(I_)::value;
-                *reinterpret_cast<uintx4*>(hb + wave * NSTR + (i * 64 + lane) * 4) = v[p][i];
-            });
-            float gcur[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) gcur[k] = gq[p][k];
-            // ---- the slot LEAD ahead into the same registers; this slot's cell state (written NSUB slots ago by this lane)
-            issue_h(v[p], tf, ss + jf * a.SS);
-            issue_g(gq[p], tf, ss + jf * a.SS);
-            if (++jf == NSUB) { jf = 0; ++tf; }
-            const int ncol = min(n0 + n, a.S - 1);
-            const float cprev = cell[ncol];
-            __syncthreads();                                 // publishes hb; the other buffer was last read one slot ago
-            floatx4 acc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = floatx4{0.f, 0.f, 0.f, 0.f};
-            {
-                const unsigned haddr = (unsigned)(size_t)(hb + n * NSTR + s16 * 4);
-                floatx4 bq[3];
-#define C4_READ(Qr, J) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Qr) : "v"(haddr), "n"((J) * 256) : "memory")
-#define C4_WAIT(Qr, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Qr))
-                C4_READ(bq[0], 0);
-                C4_READ(bq[1], 1);
-                static_for_c<NI>([&](auto I_) {
-                    constexpr int i = decltype(I_)::value;
-                    if constexpr (i + 2 < NI) {
-                        C4_READ(bq[(i + 2) % 3], i + 2);
-                        C4_WAIT(bq[i % 3], 2);
-                    } else if constexpr (i + 1 < NI) {
-                        C4_WAIT(bq[i % 3], 1);
-                    } else {
-                        C4_WAIT(bq[i % 3], 0);
-                    }
-                    const floatx4 b = bq[i % 3];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[0][i][kk], b[kk], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[1][i][kk], b[kk], acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[2][i][kk], b[kk], acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[3][i][kk], b[kk], acc[3], 0, 0, 0);
-                    }
-                });
-#undef C4_READ
-#undef C4_WAIT
-            }
-            // ---- fold the 16 K slices: halves (units 0 | 2 and 1 | 3), rows (unit r in row r), then the 4 slices of a row
-            float gate[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float p02 = swap_add32(acc[0][k], acc[2][k]);
-                const float p13 = swap_add32(acc[1][k], acc[3][k]);
-                float r = swap_add16(p02, p13);
-                r = row_ror_add(r, 0);
-                r = row_ror_add(r, 1);
-                gate[k] = r + gcur[k];
-            }
-            const float cn = sigm(gate[1]) * cprev + sigm(gate[0]) * tanhf_fast(gate[2]);
-            const float h = sigm(gate[3]) * tanhf_fast(cn);
-            // h of the wave's 4 units in every lane (rows 0..3 -> registers), for one 16 B store per sequence
-            const unsigned hb_ = (__float_as_uint(h) & ~1u) | ((unsigned)((tq + 1) >> 1) & 1u);
-            uintx4 h4;
-            {
-                const auto r1 = __builtin_amdgcn_permlane16_swap(hb_, hb_, false, false);      // [r0, r0, r2, r2] | [r1, r1, r3, r3]
-                const auto e = __builtin_amdgcn_permlane32_swap(r1[0], r1[0], false, false);   // [r0 x 4] | [r2 x 4]
-                const auto o = __builtin_amdgcn_permlane32_swap(r1[1], r1[1], false, false);   // [r1 x 4] | [r3 x 4]
-                h4 = uintx4{e[0], o[0], e[1], o[1]};
-            }
-            if (tq < a.T && n0 + n < a.S) {
-                const int tr = rev ? a.T - 1 - tq : tq;
-                if (writer) {
-                    cell[n0 + n] = cn;
-                    out[(long)tr * a.out_t + n0 + n] = h;
-                }
-                if (lane < 4)
-                    __builtin_amdgcn_raw_buffer_store_b128(h4, rs, (unsigned)((((tq + 1) & 1) * a.S + n0 + n) * (H * 4) + U0 * 4), 0, 16);
-            }
-            if (++jq == NSUB) { jq = 0; ++tq; }
-            par ^= 1;
-        });
-    }
-}
-
-// ---- the same with the fetches as LDS-DMA (`global_load_lds_dwordx4 ... sc1`, issued from asm) ------------------------------------
-// The register form above keeps LEAD fetches in flight across the slot loop's back edge; the compiler's wait-count pass then
-// parks an `s_waitcnt vmcnt(0)` at the loop header (it cannot express "all but the youngest LEAD - 1 fetches" for both the entry
-// and the back edge), which drains every fetch once per LEAD slots.  Here nothing the compiler tracks is pending across slots:
-// the h rows AND the slot's gate pre-activations travel global -> LDS by DMA into a ring of LEAD + 1 buffers (no registers), the
-// cell state lives in LDS for the whole launch, the only compiler-issued vector-memory operations of a slot are its two stores,
-// and the wait in front of a slot's tag check is a counted `s_waitcnt vmcnt(N)` that names exactly what was issued after that
-// slot's DMA group: (LEAD - 1) younger groups of NL + 1 instructions and two stores per slot in between.
 __device__ __forceinline__ void c4_dma16(const float* g, unsigned lds_byte) {      // lane l -> LDS[lds_byte + 16 l], agent-coherent
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1" ::"s"(lds_byte), "v"(g) : "memory");
 }
@@ -765,24 +595,29 @@ template <int N>
 __device__ __forceinline__ void c4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int H, int LEAD>
-__global__ __launch_bounds__(256, 1) void lstm_coop4d_kernel(const LstmCoopArgs a) {
-    constexpr int KS = H / 16, NI = KS / 4, NSTR = H + 16, US = H / 16, NL = H / 256, NR = LEAD + 1;
-    constexpr int GRP = NL + 1;                              // DMA instructions of one slot's group (h rows + gate pre-activations)
-    extern __shared__ __attribute__((aligned(16))) float hs4[];      // [NR][4][NSTR] h ring, [NR][4][64] gx ring, [4][NSUB][16] cells
+__global__ __launch_bounds__(512) void lstm_coop8_kernel(const LstmCoopArgs a) {
+    constexpr int KS = H / 16;         // k values of one K slice (lane group s16)
+    constexpr int NI = KS / 4;         // 16 B operand reads per sub-tile and lane
+    constexpr int NSTR = H + 16;       // LDS row stride (floats): rows 16 banks apart
+    constexpr int US = H / 16;         // unit slices (workgroups) per LSTM
+    constexpr int ND = H / 512;        // 16 B DMA instructions per wave and fetch: a wave stages half a sequence row
+    constexpr int NR = LEAD + 1;       // ring buffers
+    constexpr int GRP = ND + 1;        // DMA instructions of one slot's group (h half row + gate pre-activations)
+    extern __shared__ __attribute__((aligned(16))) float hs4[];      // [NR][4][NSTR] h ring, [NR][8][64] gx ring (a 4 B DMA lands 64 lanes; lanes >= 32 repeat the first 32), [8][NSUB][8] cells
     float* gxs = hs4 + NR * 4 * NSTR;
-    float* cs = gxs + NR * 4 * 64;
+    float* cs = gxs + NR * 8 * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s16 = lane >> 2, n = lane & 3, row = lane >> 4;
+    const int s16 = lane >> 2, n = lane & 3, half = lane >> 5;
     const int us = blockIdx.x % US, ss = (blockIdx.x / US) % a.SS, z = blockIdx.x / (US * a.SS);
     const bool rev = (a.reverse >> z) & 1;
-    const int NS4 = (a.S + 3) >> 2;
-    const int NSUB = (NS4 - ss + a.SS - 1) / a.SS;
+    const int NS4 = (a.S + 3) >> 2;                          // sub-tiles of the launch
+    const int NSUB = (NS4 - ss + a.SS - 1) / a.SS;           // ... of this sequence slice: ss, ss + SS, ...
     const int NSUBmax = (NS4 + a.SS - 1) / a.SS;             // (the launch's LDS is sized for it)
-    const int U0 = us * 16 + wave * 4;
+    const int U0 = us * 16 + wave * 2;                       // first hidden unit of this wave
 
-    floatx4 wa[4][NI];
-    static_for_c<4>([&](auto U_) {
+    floatx4 wa[2][NI];
+    static_for_c<2>([&](auto U_) {
         constexpr int u = decltype(U_)::value;
         const floatx4* __restrict__ W =
             reinterpret_cast<const floatx4*>(a.whh + (long)z * a.whh_z + (long)(4 * (U0 + u) + n) * H + s16 * 4);
@@ -791,34 +626,39 @@ __global__ __launch_bounds__(256, 1) void lstm_coop4d_kernel(const LstmCoopArgs 
             wa[u][i] = W[i * 16];
         });
     });
-    float* cw = cs + wave * (NSUBmax * 16);
-    for (int i = lane; i < NSUBmax * 16; i += 64) cw[i] = 0.f;      // c_{-1} = 0
+    float* cw = cs + wave * (NSUBmax * 8);
+    for (int i = lane; i < NSUBmax * 8; i += 64) cw[i] = 0.f;       // c_{-1} = 0
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the weight loads retire here, before the counted waits below
 
     const float* __restrict__ hx = a.hx + (long)z * 2 * a.S * H;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hx), 0, 2 * a.S * H * 4, 0x00020000);
-    const int Ur = U0 + row;
+    const int Ur = U0 + half;                                // the unit this lane updates after the fold
     float* __restrict__ out = a.out + (long)z * a.out_z + (long)Ur * a.out_row;
-    // gate pre-activations of a slot as ONE 4 B DMA per wave: lane (r, k, n) fetches gate k of unit U0 + r for sequence n
-    const float* __restrict__ gxl = a.gx + (long)z * a.gx_z + (long)(4 * (U0 + row) + ((lane >> 2) & 3)) * a.gx_row;
-    const bool writer = (lane & 12) == 0;
+    // gate pre-activations of a slot as ONE 4 B DMA per wave: lane (u, k, n), l < 32, fetches gate k of unit U0 + u for sequence n
+    const int gl = lane & 31;
+    const float* __restrict__ gxl = a.gx + (long)z * a.gx_z + (long)(4 * (U0 + (gl >> 4)) + ((gl >> 2) & 3)) * a.gx_row;
+    const bool writer = (lane & 28) == 0;                    // lanes 0-3 and 32-35: one lane per (unit, sequence) of the wave
     const unsigned lds0 = (unsigned)(size_t)hs4;             // LDS byte address of the ring (low 32 bits of the flat pointer)
     const unsigned gxs0 = (unsigned)(size_t)gxs;
+    const int frow = wave >> 1, fcol = (wave & 1) * (H / 2); // the half row of a sub-tile this wave fetches
 
-    auto issue = [&](int t, int g, int buf) {                // the DMA group of slot (t, sub-tile g) into ring buffer `buf`
-        const int nq = min(4 * g + wave, a.S - 1);
-        const float* src = hx + ((long)(t & 1) * a.S + nq) * H + lane * 4;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * 4 + wave) * NSTR) * 4u);
-        static_for_c<NL>([&](auto I_) {
+    auto issue_h = [&](int t, int g, int buf) {
+        const int nq = min(4 * g + frow, a.S - 1);           // (clamped inside this sub-tile: 4 g < S)
+        const float* src = hx + ((long)(t & 1) * a.S + nq) * H + fcol + lane * 4;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * 4 + frow) * NSTR + fcol) * 4u);
+        static_for_c<ND>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
             c4_dma16(src + i * 256, dst + i * 1024);
         });
-        const int tt = min(t, a.T - 1), tr = rev ? a.T - 1 - tt : tt;
-        c4_dma4(gxl + (long)tr * a.gx_t + min(4 * g + n, a.S - 1), __builtin_amdgcn_readfirstlane(gxs0 + (unsigned)((buf * 4 + wave) * 64) * 4u));
     };
-    auto stale = [&](const float* rowp, unsigned tag) -> bool {      // this lane's words of the row it fetched
+    auto issue = [&](int t, int g, int buf) {                // the DMA group of slot (t, sub-tile g) into ring buffer `buf`
+        issue_h(t, g, buf);
+        const int tt = min(t, a.T - 1), tr = rev ? a.T - 1 - tt : tt;
+        c4_dma4(gxl + (long)tr * a.gx_t + min(4 * g + n, a.S - 1), __builtin_amdgcn_readfirstlane(gxs0 + (unsigned)((buf * 8 + wave) * 64) * 4u));
+    };
+    auto stale = [&](const float* rowp, unsigned tag) -> bool {      // this lane's words of the half row its wave fetched
         unsigned bad = 0;
-        static_for_c<NL>([&](auto I_) {
+        static_for_c<ND>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
             const uintx4 w = *reinterpret_cast<const uintx4*>(rowp + (i * 64 + lane) * 4);
             bad |= (w[0] ^ tag) | (w[1] ^ tag) | (w[2] ^ tag) | (w[3] ^ tag);
@@ -836,40 +676,34 @@ __global__ __launch_bounds__(256, 1) void lstm_coop4d_kernel(const LstmCoopArgs 
         if (++bf == NR) bf = 0;
     }
     int tq = 0, jq = 0, bq_ = 0;
-    const int Qp = (Q + LEAD - 1) / LEAD * LEAD;             // (uniform trip structure; slots >= Q are sub-tiles of step T: nothing is stored)
+    const int Qp = (Q + LEAD - 1) / LEAD * LEAD;             // (slots >= Q are sub-tiles of step T - their h exists, nothing is stored)
     for (int q = 0; q < Qp; ++q) {
         const int g = ss + jq * a.SS, n0 = 4 * g;
         const unsigned tag = (unsigned)(tq >> 1) & 1u;
-        // younger than this slot's group: LEAD - 1 groups and the two stores of each of the LEAD slots in between (while they stored)
-        // (the first LEAD slots and the padding slots behind step T - 1 take the count without stores: it only waits longer)
+        // younger than this slot's group: LEAD - 1 groups and the two stores of each of the LEAD slots in between (while they stored;
+        // the first LEAD slots and the padding slots behind step T - 1 take the count without stores: it only waits longer)
         if (q >= LEAD && (tq < a.T || (tq == a.T && jq == 0))) c4_wait_vm<(LEAD - 1) * GRP + 2 * LEAD>();
         else c4_wait_vm<(LEAD - 1) * GRP>();
         float* hb = hs4 + bq_ * (4 * NSTR);
-        if (stale(hb + wave * NSTR, tag) && !(a.dbg & 4)) {
+        if (stale(hb + frow * NSTR + fcol, tag) && !(a.dbg & 4)) {
             const unsigned long long t0 = wall_clock64();
             do {
                 if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
-                const int nq = min(4 * g + wave, a.S - 1);
-                const float* src = hx + ((long)(tq & 1) * a.S + nq) * H + lane * 4;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((bq_ * 4 + wave) * NSTR) * 4u);
-                static_for_c<NL>([&](auto I_) {
-                    constexpr int i = decltype(I_)::value;
-                    c4_dma16(src + i * 256, dst + i * 1024);
-                });
+                issue_h(tq, g, bq_);
                 c4_wait_vm<0>();
-            } while (stale(hb + wave * NSTR, tag));
+            } while (stale(hb + frow * NSTR + fcol, tag));
         }
         float gcur[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gcur[k] = gxs[(bq_ * 4 + wave) * 64 + 16 * row + 4 * k + n];
-        const float cprev = cw[jq * 16 + 4 * row + n];
+        for (int k = 0; k < 4; ++k) gcur[k] = gxs[(bq_ * 8 + wave) * 64 + 16 * half + 4 * k + n];
+        const float cprev = cw[jq * 8 + 4 * half + n];
         __syncthreads();                                     // publishes hb; every wave is done with the buffer of slot q - 1
         issue(tf, ss + jf * a.SS, bf);                       // slot q + LEAD -> the buffer slot q - 1 used
         if (++jf == NSUB) { jf = 0; ++tf; }
         if (++bf == NR) bf = 0;
-        floatx4 acc[4];
+        floatx4 acc[2][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 2; ++u) acc[u][0] = acc[u][1] = floatx4{0.f, 0.f, 0.f, 0.f};
         {
             const unsigned haddr = (unsigned)(size_t)(hb + n * NSTR + s16 * 4);
             floatx4 bq[3];
@@ -890,42 +724,36 @@ __global__ __launch_bounds__(256, 1) void lstm_coop4d_kernel(const LstmCoopArgs 
                 const floatx4 b = bq[i % 3];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[0][i][kk], b[kk], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[1][i][kk], b[kk], acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[2][i][kk], b[kk], acc[2], 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[3][i][kk], b[kk], acc[3], 0, 0, 0);
+                    acc[0][kk & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[0][i][kk], b[kk], acc[0][kk & 1], 0, 0, 0);
+                    acc[1][kk & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[1][i][kk], b[kk], acc[1][kk & 1], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             });
 #undef C4_READ
 #undef C4_WAIT
         }
+        // ---- fold the 16 K slices: wave halves (unit 0 | unit 1), the two rows of a half, the 4 slices of a row
         float gate[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float p02 = swap_add32(acc[0][k], acc[2][k]);
-            const float p13 = swap_add32(acc[1][k], acc[3][k]);
-            float r = swap_add16(p02, p13);
-            r = row_ror_add(r, 0);
-            r = row_ror_add(r, 1);
+            const float p = swap_add32(acc[0][0][k] + acc[0][1][k], acc[1][0][k] + acc[1][1][k]);
+            float r = swap_add16(p, p);
+            r = row_ror_add<0x124>(r);
+            r = row_ror_add<0x128>(r);
             gate[k] = r + gcur[k];
         }
         const float cn = sigm(gate[1]) * cprev + sigm(gate[0]) * tanhf_fast(gate[2]);
         const float h = sigm(gate[3]) * tanhf_fast(cn);
+        // h of the wave's 2 units in the lanes of half 0 (one 8 B store per sequence): [h_u0 | h_u1] -> lanes < 32 get both
         const unsigned hb_ = (__float_as_uint(h) & ~1u) | ((unsigned)((tq + 1) >> 1) & 1u);
-        uintx4 h4;
-        {
-            const auto r1 = __builtin_amdgcn_permlane16_swap(hb_, hb_, false, false);
-            const auto e = __builtin_amdgcn_permlane32_swap(r1[0], r1[0], false, false);
-            const auto o = __builtin_amdgcn_permlane32_swap(r1[1], r1[1], false, false);
-            h4 = uintx4{e[0], o[0], e[1], o[1]};
-        }
-        if (writer) cw[jq * 16 + 4 * row + n] = cn;
+        const auto e = __builtin_amdgcn_permlane32_swap(hb_, hb_, false, false);       // [u0 | u0], [u1 | u1]
+        if (writer) cw[jq * 8 + 4 * half + n] = cn;
         if (tq < a.T) {
-            // both stores are issued by every wave of a storing slot (lane 0 always qualifies: 4 g < S), the counted wait above relies on it
+            // both stores are issued by every wave of a storing slot (lane 0 always qualifies: 4 g < S): the counted wait relies on it
             const int tr = rev ? a.T - 1 - tq : tq;
             if (writer && n0 + n < a.S) out[(long)tr * a.out_t + n0 + n] = h;
             if (lane < 4 && n0 + n < a.S)
-                __builtin_amdgcn_raw_buffer_store_b128(h4, rs, (unsigned)((((tq + 1) & 1) * a.S + n0 + n) * (H * 4) + U0 * 4), 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b64(uintx2{e[0], e[1]}, rs, (unsigned)((((tq + 1) & 1) * a.S + n0 + n) * (H * 4) + U0 * 4), 0, 16);
         }
         if (++jq == NSUB) { jq = 0; ++tq; }
         if (++bq_ == NR) bq_ = 0;
@@ -972,7 +800,7 @@ bool lstm_coop_supported(int H, int S, int Z) { return (H == 512 || H == 1024) &
 // sub-tile pipelined form: sequence slices by 4-sequence sub-tiles, LEAD = slots a fetch runs ahead (at most the sub-tiles a
 // workgroup owns: the padding slots at the end of the launch are sub-tiles of step T)
 template <int H, int LEAD>
-static void launch_c4(LstmCoopArgs a, hipStream_t s) {
+static void launch_c8(LstmCoopArgs a, hipStream_t s) {
     constexpr int US = H / 16;
     static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
     a.dbg = dbg;
@@ -986,42 +814,16 @@ static void launch_c4(LstmCoopArgs a, hipStream_t s) {
     float stale;
     memcpy(&stale, &one, sizeof(float));
     for (int z = 0; z < a.Z; ++z) launch_fill(a.hx + ((long)z * 2 + 1) * slab, (long)slab, stale, s);   // ... slab 1 must not look like h_0
-    launch_fill(a.cell, (long)a.Z * H * a.S, 0.f, s);
-    const size_t shmem = (size_t)2 * 4 * (H + 16) * sizeof(float);
-    static bool attr_set[64] = {};
-    if (first_on_device(attr_set)) {
-        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop4_kernel<H, LEAD>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    }
-    void* params[] = {&a};
-    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop4_kernel<H, LEAD>), dim3(US * a.SS * a.Z), dim3(256),
-                                      params, (unsigned)shmem, s));
-}
-template <int H, int LEAD>
-static void launch_c4d(LstmCoopArgs a, hipStream_t s) {
-    constexpr int US = H / 16;
-    static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
-    a.dbg = dbg;
-    constexpr size_t NFLAG = 256 * 64;
-    const size_t slab = (size_t)a.S * H, hx_bytes = (size_t)a.Z * 2 * slab * sizeof(float);
-    char* sc = coop_scratch(NFLAG * sizeof(unsigned) + hx_bytes, s);
-    a.bar = reinterpret_cast<unsigned*>(sc);
-    a.hx = reinterpret_cast<float*>(sc + NFLAG * sizeof(unsigned));
-    launch_fill(a.hx, (long)a.Z * 2 * slab, 0.f, s);
-    const unsigned one = 1u;
-    float stale;
-    memcpy(&stale, &one, sizeof(float));
-    for (int z = 0; z < a.Z; ++z) launch_fill(a.hx + ((long)z * 2 + 1) * slab, (long)slab, stale, s);
     const int nsub_max = ((a.S + 3) / 4 + a.SS - 1) / a.SS;
-    const size_t shmem = ((size_t)(LEAD + 1) * 4 * (H + 16) + (size_t)(LEAD + 1) * 4 * 64 + (size_t)4 * nsub_max * 16) * sizeof(float);
+    const size_t shmem = ((size_t)(LEAD + 1) * 4 * (H + 16) + (size_t)(LEAD + 1) * 8 * 64 + (size_t)8 * nsub_max * 8) * sizeof(float);
     SE_CHECK(shmem <= 160 * 1024, "cooperative LSTM (sub-tile form): too many sequences per workgroup for the LDS-resident cell state");
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {
-        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop4d_kernel<H, LEAD>),
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop8_kernel<H, LEAD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     void* params[] = {&a};
-    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop4d_kernel<H, LEAD>), dim3(US * a.SS * a.Z), dim3(256),
+    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop8_kernel<H, LEAD>), dim3(US * a.SS * a.Z), dim3(512),
                                       params, (unsigned)shmem, s));
 }
 template <int H>
@@ -1033,20 +835,14 @@ static bool launch_c4_n(LstmCoopArgs a, int n_cu, hipStream_t s) {
     if (!on || a.S < min_s || US * a.Z > n_cu || (long)a.S * H * 8 >= (1L << 31)) return false;
     const int NS4 = (a.S + 3) / 4;
     a.SS = std::max(1, std::min(NS4, n_cu / (US * a.Z)));
+    if ((size_t)((NS4 + a.SS - 1) / a.SS) * 256 > 64 * 1024) return false;        // cell state of the slice must fit LDS
     const int nsub_min = NS4 / a.SS;                           // the fewest sub-tiles a workgroup owns (>= 1)
     int lead = std::min(3, nsub_min);
     if (nsub_min >= 3 && nsub_min < 6) lead = 2;             // a fetch issued 3 slots ahead of a 4-slot cycle would read before h_{t-1} is out
     if (lead_env > 0) lead = std::min(lead_env, std::min(3, nsub_min));
-    static const int dma = getenv("SE_COOP4_DMA") ? atoi(getenv("SE_COOP4_DMA")) : 1;      // 0: fetches through registers (compiler-counted waits)
-    if (dma && (size_t)((NS4 + a.SS - 1) / a.SS) * 256 <= 64 * 1024) {
-        if (lead <= 1) launch_c4d<H, 1>(a, s);
-        else if (lead == 2) launch_c4d<H, 2>(a, s);
-        else launch_c4d<H, 3>(a, s);
-        return true;
-    }
-    if (lead <= 1) launch_c4<H, 1>(a, s);
-    else if (lead == 2) launch_c4<H, 2>(a, s);
-    else launch_c4<H, 3>(a, s);
+    if (lead <= 1) launch_c8<H, 1>(a, s);
+    else if (lead == 2) launch_c8<H, 2>(a, s);
+    else launch_c8<H, 3>(a, s);
     return true;
 }
 

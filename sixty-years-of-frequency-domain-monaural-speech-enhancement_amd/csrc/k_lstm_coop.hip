@@ -591,33 +591,58 @@ __device__ __forceinline__ void c4_dma16(const float* g, unsigned lds_byte) {   
 __device__ __forceinline__ void c4_dma4(const float* g, unsigned lds_byte) {       // lane l -> LDS[lds_byte + 4 l]
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_byte), "v"(g) : "memory");
 }
+__device__ __forceinline__ void c4_dma16g(const float* base, unsigned voff, unsigned lds_byte) {     // the same, ordinary cache policy
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte), "v"(voff), "s"(base) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void c4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int H, int LEAD>
-__global__ __launch_bounds__(512) void lstm_coop8_kernel(const LstmCoopArgs a) {
+// one hardware exp2 and one hardware reciprocal per activation (v_exp_f32 / v_rcp_f32, 1 ulp each): `__frcp_rn` is a correctly
+// rounded division - ten instructions - and a slot's tail is what the matrix pipe waits for
+__device__ __forceinline__ float sigm_hw(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896f * x)); }
+__device__ __forceinline__ float tanh_hw(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177793f * x)); }
+// 16 B per lane global -> LDS with a wave-uniform 64-bit base and a 32-bit per-lane byte offset (no 64-bit vector address arithmetic per slot)
+__device__ __forceinline__ void c4_dma16s(const float* base, unsigned voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_byte), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void c4_dma4s(const float* base, unsigned voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_byte), "v"(voff), "s"(base) : "memory");
+}
+
+template <int H, int LEAD, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_coop8_kernel(const LstmCoopArgs a) {
+    constexpr int UW = 16 / NW;        // hidden units per wave (NW = 8 waves: 2, two waves per SIMD; NW = 4: 4, one wave per SIMD)
     constexpr int KS = H / 16;         // k values of one K slice (lane group s16)
     constexpr int NI = KS / 4;         // 16 B operand reads per sub-tile and lane
     constexpr int NSTR = H + 16;       // LDS row stride (floats): rows 16 banks apart
     constexpr int US = H / 16;         // unit slices (workgroups) per LSTM
-    constexpr int ND = H / 512;        // 16 B DMA instructions per wave and fetch: a wave stages half a sequence row
+    constexpr int ND = H / (64 * NW);  // 16 B DMA instructions per wave and fetch: a wave stages 4 / NW of a sequence row
+    constexpr int FW = H * 4 / NW;     // floats of a sub-tile one wave fetches
     constexpr int NR = LEAD + 1;       // ring buffers
-    constexpr int GRP = ND + 1;        // DMA instructions of one slot's group (h half row + gate pre-activations)
-    extern __shared__ __attribute__((aligned(16))) float hs4[];      // [NR][4][NSTR] h ring, [NR][8][64] gx ring (a 4 B DMA lands 64 lanes; lanes >= 32 repeat the first 32), [8][NSUB][8] cells
+    constexpr int GRP = ND + 1;        // DMA instructions of one slot's group (h part + gate pre-activations)
+    // registers: UW x H / 16 x 4 weights per lane = 256 at NW = 4, H = 1024 - with the operand ring and the tail's temporaries more
+    // than the 256 architectural VGPRs, and the compiler then parks one unit's weights in AGPRs and copies them back four at a
+    // time inside the matrix loop (64 extra vector instructions per slot).  That unit's weights live in LDS instead (64 KB per
+    // workgroup) and come in with the operand reads, 16 B per 4 matrix instructions.
+    constexpr int UL = (NW == 4 && H == 1024) ? 1 : 0;       // units of a wave whose weights are LDS-resident
+    constexpr int UG = UW - UL;                              // ... register-resident
+    extern __shared__ __attribute__((aligned(16))) float hs4[];      // [NR][4][NSTR] h ring, [NR][NW][64] gx ring, [NW][NI][64][4] weights, [NW][NSUB][4 UW] cells
     float* gxs = hs4 + NR * 4 * NSTR;
-    float* cs = gxs + NR * 8 * 64;
+    float* wl = gxs + NR * NW * 64;
+    float* cs = wl + UL * NW * NI * 256;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s16 = lane >> 2, n = lane & 3, half = lane >> 5;
+    const int s16 = lane >> 2, n = lane & 3;
+    const int ul = NW == 8 ? lane >> 5 : lane >> 4;          // the unit (of this wave's UW) this lane holds after the fold
     const int us = blockIdx.x % US, ss = (blockIdx.x / US) % a.SS, z = blockIdx.x / (US * a.SS);
     const bool rev = (a.reverse >> z) & 1;
     const int NS4 = (a.S + 3) >> 2;                          // sub-tiles of the launch
     const int NSUB = (NS4 - ss + a.SS - 1) / a.SS;           // ... of this sequence slice: ss, ss + SS, ...
     const int NSUBmax = (NS4 + a.SS - 1) / a.SS;             // (the launch's LDS is sized for it)
-    const int U0 = us * 16 + wave * 2;                       // first hidden unit of this wave
+    const int U0 = us * 16 + wave * UW;                      // first hidden unit of this wave
 
-    floatx4 wa[2][NI];
-    static_for_c<2>([&](auto U_) {
+    floatx4 wa[UG][NI];
+    static_for_c<UG>([&](auto U_) {
         constexpr int u = decltype(U_)::value;
         const floatx4* __restrict__ W =
             reinterpret_cast<const floatx4*>(a.whh + (long)z * a.whh_z + (long)(4 * (U0 + u) + n) * H + s16 * 4);
@@ -626,47 +651,63 @@ __global__ __launch_bounds__(512) void lstm_coop8_kernel(const LstmCoopArgs a) {
             wa[u][i] = W[i * 16];
         });
     });
-    float* cw = cs + wave * (NSUBmax * 8);
-    for (int i = lane; i < NSUBmax * 8; i += 64) cw[i] = 0.f;       // c_{-1} = 0
+    if constexpr (UL > 0) {
+        const floatx4* __restrict__ W =
+            reinterpret_cast<const floatx4*>(a.whh + (long)z * a.whh_z + (long)(4 * (U0 + UG) + n) * H + s16 * 4);
+        for (int i = 0; i < NI; ++i) reinterpret_cast<floatx4*>(wl)[(wave * NI + i) * 64 + lane] = W[i * 16];
+    }
+    float* cw = cs + wave * (NSUBmax * 4 * UW);
+    for (int i = lane; i < NSUBmax * 4 * UW; i += 64) cw[i] = 0.f;  // c_{-1} = 0
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the weight loads retire here, before the counted waits below
 
     const float* __restrict__ hx = a.hx + (long)z * 2 * a.S * H;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hx), 0, 2 * a.S * H * 4, 0x00020000);
-    const int Ur = U0 + half;                                // the unit this lane updates after the fold
-    float* __restrict__ out = a.out + (long)z * a.out_z + (long)Ur * a.out_row;
-    // gate pre-activations of a slot as ONE 4 B DMA per wave: lane (u, k, n), l < 32, fetches gate k of unit U0 + u for sequence n
-    const int gl = lane & 31;
-    const float* __restrict__ gxl = a.gx + (long)z * a.gx_z + (long)(4 * (U0 + (gl >> 4)) + ((gl >> 2) & 3)) * a.gx_row;
-    const bool writer = (lane & 28) == 0;                    // lanes 0-3 and 32-35: one lane per (unit, sequence) of the wave
+    const int Ur = U0 + ul;                                  // the unit this lane updates after the fold
+    // per-lane parts of the addresses as 32-bit offsets, the per-slot parts are wave-uniform (scalar unit): on this chip a vector
+    // instruction does not hide under another wave's f32 matrix instructions (tools/coissuebench.cpp: the times add), so every
+    // vector instruction of a slot's tail is paid in matrix time
+    float* __restrict__ outz = a.out + (long)z * a.out_z;
+    const unsigned ov = (unsigned)((long)Ur * a.out_row + n);        // element offset of (unit, sequence n) inside a frame of `out`
+    // gate pre-activations of a slot as ONE 4 B DMA per wave: lane (u, n, k) fetches gate k of unit U0 + u for sequence n (the
+    // four gates of a (unit, sequence) pair are then one 16 B LDS read); NW = 8: lanes >= 32 repeat the first 32
+    const int gl = lane & (16 * UW - 1);
+    const float* __restrict__ gxz = a.gx + (long)z * a.gx_z;
+    const unsigned gv = (unsigned)(((long)(4 * (U0 + (gl >> 4)) + (gl & 3)) * a.gx_row + ((gl >> 2) & 3)) * 4);   // byte offset
+    const bool writer = NW == 8 ? (lane & 28) == 0 : (lane & 12) == 0;      // one lane per (unit, sequence) of the wave
     const unsigned lds0 = (unsigned)(size_t)hs4;             // LDS byte address of the ring (low 32 bits of the flat pointer)
     const unsigned gxs0 = (unsigned)(size_t)gxs;
-    const int frow = wave >> 1, fcol = (wave & 1) * (H / 2); // the half row of a sub-tile this wave fetches
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int frow_u = wave_u * 4 / NW, fcol_u = (wave_u * 4 % NW) * (H / 4);   // the part of a sub-tile this wave fetches
+    const int fpart = frow_u * NSTR + fcol_u;
 
     auto issue_h = [&](int t, int g, int buf) {
-        const int nq = min(4 * g + frow, a.S - 1);           // (clamped inside this sub-tile: 4 g < S)
-        const float* src = hx + ((long)(t & 1) * a.S + nq) * H + fcol + lane * 4;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * 4 + frow) * NSTR + fcol) * 4u);
+        const int nq = min(4 * g + frow_u, a.S - 1);         // (clamped inside this sub-tile: 4 g < S)
+        const float* src = hx + ((long)(t & 1) * a.S + nq) * H + fcol_u;      // wave-uniform
+        const unsigned dst = lds0 + (unsigned)(buf * 4 * NSTR + fpart) * 4u;
+        if (a.dbg & 32) return;
         static_for_c<ND>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
-            c4_dma16(src + i * 256, dst + i * 1024);
+            c4_dma16s(src, lane * 16 + i * 1024, dst + i * 1024);
         });
     };
     auto issue = [&](int t, int g, int buf) {                // the DMA group of slot (t, sub-tile g) into ring buffer `buf`
         issue_h(t, g, buf);
         const int tt = min(t, a.T - 1), tr = rev ? a.T - 1 - tt : tt;
-        c4_dma4(gxl + (long)tr * a.gx_t + min(4 * g + n, a.S - 1), __builtin_amdgcn_readfirstlane(gxs0 + (unsigned)((buf * 8 + wave) * 64) * 4u));
+        // (the last sub-tile of a launch whose sequence count is no multiple of 4 fetches past its last column: values of the next
+        // row or of the tensor's tail slack, never used - the tail stores nothing for n >= S)
+        c4_dma4s(gxz + (long)tr * a.gx_t + 4 * g, gv, gxs0 + (unsigned)((buf * NW + wave_u) * 64) * 4u);
     };
-    auto stale = [&](const float* rowp, unsigned tag) -> bool {      // this lane's words of the half row its wave fetched
+    auto stale = [&](const float* part, unsigned tag) -> bool {      // this lane's words of the part its wave fetched
         unsigned bad = 0;
         static_for_c<ND>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
-            const uintx4 w = *reinterpret_cast<const uintx4*>(rowp + (i * 64 + lane) * 4);
+            const uintx4 w = *reinterpret_cast<const uintx4*>(part + (i * 64 + lane) * 4);
             bad |= (w[0] ^ tag) | (w[1] ^ tag) | (w[2] ^ tag) | (w[3] ^ tag);
         });
         return __builtin_amdgcn_ballot_w64((bad & 1u) != 0) != 0;
     };
 
-    const int Q = a.T * NSUB;
+    const int Q = a.T * NSUB;                                // slots of this workgroup: (step, sub-tile) pairs
     int tf = 0, jf = 0, bf = 0;                              // the next slot to fetch, its ring buffer
     __syncthreads();                                         // (cell states zeroed)
 #pragma unroll
@@ -675,89 +716,339 @@ __global__ __launch_bounds__(512) void lstm_coop8_kernel(const LstmCoopArgs a) {
         if (++jf == NSUB) { jf = 0; ++tf; }
         if (++bf == NR) bf = 0;
     }
+    // fold the 16 K slices of slot (tt, jj), update the cells, publish h.  (Tried: waves 4 - 7 of the 8-wave form running this one
+    // slot late, in front of their next matrix work, so that the two waves of a SIMD are in opposite phases - no gain, the tail
+    // does not hide under the other wave's matrix instructions either way.)
+    auto tail = [&](const floatx4 (&acc)[UW][2], const float (&gg)[4], int tt, int jj) {
+        const int n0 = 4 * (ss + jj * a.SS);
+        const float cprev = cw[jj * 4 * UW + 4 * ul + n];
+        float gate[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r;
+            if constexpr (NW == 8) {       // wave halves (unit 0 | unit 1), then the two rows of a half
+                const float p = swap_add32(acc[0][0][k] + acc[0][1][k], acc[1][0][k] + acc[1][1][k]);
+                r = swap_add16(p, p);
+            } else {                       // wave halves (units 0 | 2 and 1 | 3), then rows: unit r in row r
+                const float p02 = swap_add32(acc[0][0][k] + acc[0][1][k], acc[2 % UW][0][k] + acc[2 % UW][1][k]);
+                const float p13 = swap_add32(acc[1][0][k] + acc[1][1][k], acc[3 % UW][0][k] + acc[3 % UW][1][k]);
+                r = swap_add16(p02, p13);
+            }
+            r = row_ror_add<0x124>(r);     // ... and the 4 slices of a row
+            r = row_ror_add<0x128>(r);
+            gate[k] = r + gg[k];
+        }
+        const float cn = sigm_hw(gate[1]) * cprev + sigm_hw(gate[0]) * tanh_hw(gate[2]);
+        const float h = sigm_hw(gate[3]) * tanh_hw(cn);
+        const unsigned hb_ = (__float_as_uint(h) & ~1u) | ((unsigned)((tt + 1) >> 1) & 1u);
+        if (writer) cw[jj * 4 * UW + 4 * ul + n] = cn;
+        if (!(a.dbg & 64)) {
+            // both stores are issued by every wave (lane 0 always qualifies: 4 g < S): the counted wait relies on it
+            const int tr = rev ? a.T - 1 - tt : tt;
+            float* __restrict__ of = outz + (long)tr * a.out_t + n0;         // wave-uniform
+            if (writer && n0 + n < a.S) of[ov] = h;
+            const unsigned ho = (unsigned)((((tt + 1) & 1) * a.S + n0 + n) * (H * 4) + U0 * 4);
+            // h of the wave's units gathered into lanes 0 - 3 (sequence n): one 8 B / 16 B store per sequence, not a 4 B fabric write each
+            if constexpr (NW == 8) {
+                const auto e = __builtin_amdgcn_permlane32_swap(hb_, hb_, false, false);       // [u0 | u0], [u1 | u1]
+                if (lane < 4 && n0 + n < a.S) __builtin_amdgcn_raw_buffer_store_b64(uintx2{e[0], e[1]}, rs, ho, 0, 16);
+            } else {
+                const auto r1 = __builtin_amdgcn_permlane16_swap(hb_, hb_, false, false);      // rows [r0, r0, r2, r2], [r1, r1, r3, r3]
+                const auto e = __builtin_amdgcn_permlane32_swap(r1[0], r1[0], false, false);   // [r0 x 4], [r2 x 4]
+                const auto o = __builtin_amdgcn_permlane32_swap(r1[1], r1[1], false, false);   // [r1 x 4], [r3 x 4]
+                if (lane < 4 && n0 + n < a.S) __builtin_amdgcn_raw_buffer_store_b128(uintx4{e[0], o[0], e[1], o[1]}, rs, ho, 0, 16);
+            }
+        }
+    };
     int tq = 0, jq = 0, bq_ = 0;
-    const int Qp = (Q + LEAD - 1) / LEAD * LEAD;             // (slots >= Q are sub-tiles of step T - their h exists, nothing is stored)
-    for (int q = 0; q < Qp; ++q) {
-        const int g = ss + jq * a.SS, n0 = 4 * g;
+    for (int q = 0; q < Q; ++q) {
+        const int g = ss + jq * a.SS;
         const unsigned tag = (unsigned)(tq >> 1) & 1u;
-        // younger than this slot's group: LEAD - 1 groups and the two stores of each of the LEAD slots in between (while they stored;
-        // the first LEAD slots and the padding slots behind step T - 1 take the count without stores: it only waits longer)
-        if (q >= LEAD && (tq < a.T || (tq == a.T && jq == 0))) c4_wait_vm<(LEAD - 1) * GRP + 2 * LEAD>();
+        // younger than this slot's group: LEAD - 1 groups and two stores per slot in between (the first slots take the count
+        // without stores: it only waits longer)
+        if (q >= LEAD) c4_wait_vm<(LEAD - 1) * GRP + 2 * LEAD>();
         else c4_wait_vm<(LEAD - 1) * GRP>();
         float* hb = hs4 + bq_ * (4 * NSTR);
-        if (stale(hb + frow * NSTR + fcol, tag) && !(a.dbg & 4)) {
+        if (!(a.dbg & (4 | 32)) && stale(hb + fpart, tag)) {
             const unsigned long long t0 = wall_clock64();
             do {
                 if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
                 issue_h(tq, g, bq_);
                 c4_wait_vm<0>();
-            } while (stale(hb + frow * NSTR + fcol, tag));
+            } while (stale(hb + fpart, tag));
         }
         float gcur[4];
+        {
+            const floatx4 g4 = *reinterpret_cast<const floatx4*>(gxs + (bq_ * NW + wave) * 64 + 16 * ul + 4 * n);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gcur[k] = gxs[(bq_ * 8 + wave) * 64 + 16 * half + 4 * k + n];
-        const float cprev = cw[jq * 8 + 4 * half + n];
-        __syncthreads();                                     // publishes hb; every wave is done with the buffer of slot q - 1
+            for (int k = 0; k < 4; ++k) gcur[k] = g4[k];
+        }
+        if (!(a.dbg & 128)) __syncthreads();                 // publishes hb; every wave is done with the buffer of slot q - 1
         issue(tf, ss + jf * a.SS, bf);                       // slot q + LEAD -> the buffer slot q - 1 used
         if (++jf == NSUB) { jf = 0; ++tf; }
         if (++bf == NR) bf = 0;
-        floatx4 acc[2][2];
+        floatx4 acc[UW][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u][0] = acc[u][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < UW; ++u) acc[u][0] = acc[u][1] = floatx4{0.f, 0.f, 0.f, 0.f};
         {
             const unsigned haddr = (unsigned)(size_t)(hb + n * NSTR + s16 * 4);
-            floatx4 bq[3];
-#define C4_READ(Qr, J) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Qr) : "v"(haddr), "n"((J) * 256) : "memory")
+            const unsigned waddr = (unsigned)(size_t)(wl + (wave * NI * 64 + lane) * 4);
+            floatx4 bq[3], wq[3];
+            // operand reads run two 16 B groups ahead of the matrix instructions (ring of 3); the reads and their counted waits are
+            // asm: the compiler's own schedule parks an lgkmcnt(0) behind every read (the wait names the register it releases so
+            // that no consumer moves above it)
+#define C4_READ(Qr, AD, J, ST) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Qr) : "v"(AD), "n"((J) * (ST)) : "memory")
 #define C4_WAIT(Qr, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Qr))
-            C4_READ(bq[0], 0);
-            C4_READ(bq[1], 1);
+#define C4_WAIT2(Qr, Wr, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Qr), "+v"(Wr))
+            {
+            C4_READ(bq[0], haddr, 0, 256);
+            if constexpr (UL > 0) C4_READ(wq[0], waddr, 0, 1024);
+            C4_READ(bq[1], haddr, 1, 256);
+            if constexpr (UL > 0) C4_READ(wq[1], waddr, 1, 1024);
             static_for_c<NI>([&](auto I_) {
                 constexpr int i = decltype(I_)::value;
                 if constexpr (i + 2 < NI) {
-                    C4_READ(bq[(i + 2) % 3], i + 2);
-                    C4_WAIT(bq[i % 3], 2);
+                    C4_READ(bq[(i + 2) % 3], haddr, i + 2, 256);
+                    if constexpr (UL > 0) {
+                        C4_READ(wq[(i + 2) % 3], waddr, i + 2, 1024);
+                        C4_WAIT2(bq[i % 3], wq[i % 3], 4);
+                    } else {
+                        C4_WAIT(bq[i % 3], 2);
+                    }
                 } else if constexpr (i + 1 < NI) {
-                    C4_WAIT(bq[i % 3], 1);
+                    if constexpr (UL > 0) C4_WAIT2(bq[i % 3], wq[i % 3], 2);
+                    else C4_WAIT(bq[i % 3], 1);
                 } else {
-                    C4_WAIT(bq[i % 3], 0);
+                    if constexpr (UL > 0) C4_WAIT2(bq[i % 3], wq[i % 3], 0);
+                    else C4_WAIT(bq[i % 3], 0);
                 }
                 const floatx4 b = bq[i % 3];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    acc[0][kk & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[0][i][kk], b[kk], acc[0][kk & 1], 0, 0, 0);
-                    acc[1][kk & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[1][i][kk], b[kk], acc[1][kk & 1], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < UG; ++u)
+                        acc[u][kk & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[u][i][kk], b[kk], acc[u][kk & 1], 0, 0, 0);
+                    if constexpr (UL > 0)
+                        acc[UG][kk & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[i % 3][kk], b[kk], acc[UG][kk & 1], 0, 0, 0);
+                    if (UW == 4) __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (UW != 4) __builtin_amdgcn_sched_barrier(0);
             });
+            }
 #undef C4_READ
 #undef C4_WAIT
+#undef C4_WAIT2
         }
-        // ---- fold the 16 K slices: wave halves (unit 0 | unit 1), the two rows of a half, the 4 slices of a row
-        float gate[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float p = swap_add32(acc[0][0][k] + acc[0][1][k], acc[1][0][k] + acc[1][1][k]);
-            float r = swap_add16(p, p);
-            r = row_ror_add<0x124>(r);
-            r = row_ror_add<0x128>(r);
-            gate[k] = r + gcur[k];
-        }
-        const float cn = sigm(gate[1]) * cprev + sigm(gate[0]) * tanhf_fast(gate[2]);
-        const float h = sigm(gate[3]) * tanhf_fast(cn);
-        // h of the wave's 2 units in the lanes of half 0 (one 8 B store per sequence): [h_u0 | h_u1] -> lanes < 32 get both
-        const unsigned hb_ = (__float_as_uint(h) & ~1u) | ((unsigned)((tq + 1) >> 1) & 1u);
-        const auto e = __builtin_amdgcn_permlane32_swap(hb_, hb_, false, false);       // [u0 | u0], [u1 | u1]
-        if (writer) cw[jq * 8 + 4 * half + n] = cn;
-        if (tq < a.T) {
-            // both stores are issued by every wave of a storing slot (lane 0 always qualifies: 4 g < S): the counted wait relies on it
-            const int tr = rev ? a.T - 1 - tq : tq;
-            if (writer && n0 + n < a.S) out[(long)tr * a.out_t + n0 + n] = h;
-            if (lane < 4 && n0 + n < a.S)
-                __builtin_amdgcn_raw_buffer_store_b64(uintx2{e[0], e[1]}, rs, (unsigned)((((tq + 1) & 1) * a.S + n0 + n) * (H * 4) + U0 * 4), 0, 16);
-        }
+        tail(acc, gcur, tq, jq);
         if (++jq == NSUB) { jq = 0; ++tq; }
         if (++bq_ == NR) bq_ = 0;
     }
+}
+
+// ---- 16-sequence tiles with the sub-tile form's exchange (round 4) ---------------------------------------------------------------
+// What the sub-tile form taught: (1) on this chip a vector instruction never hides under f32 matrix work - v_mfma_f32_* runs at
+// the vector rate on the same pipes, and tools/coissuebench.cpp shows the times of a matrix wave and a vector wave on one SIMD
+// simply add - so a tile's non-matrix instructions are paid in full, and a 4-sequence sub-tile pays the fold / cell / publish
+// tail four times per 16 sequences (1.45 us of work per sub-tile for 1.0 us of matrix instructions); (2) the tagged exchange
+// fetched by LDS-DMA needs no flags, no acknowledgement and - per 64 KB tile - 20 DMA instructions per wave instead of 32 loads +
+// 32 LDS stores per THREAD.  So: the 16 x 16 x 4 tile of lstm_coop_kernel (no K fold: a lane's accumulator holds the four gates
+// of one (unit, sequence) pair) with that exchange.  A wave fetches 4 rows of the next tile (16 x 1 KB DMA + 4 x 256 B of gate
+// pre-activations) right behind the barrier that publishes the current one, checks the tags of its own rows when the tile comes
+// up, re-fetches only then; cell state in LDS; h_t leaves as 16 B sc1 stores (the four units of a wave, gathered by three lane
+// swaps).  Per tile: 256 matrix instructions (8 250 cycles) + ~230 vector instructions.
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_coop16_kernel(const LstmCoopArgs a) {
+    constexpr int KQ = H / 4;          // k values per MFMA k-slot (lane >> 4)
+    constexpr int LDW = H + 4;         // LDS row stride: 16 lanes x 16 B land in 64 distinct banks
+    constexpr int US = H / 16;
+    constexpr int ND = H / 256;        // 1 KB DMA instructions per row
+    constexpr int GRP = 4 * ND + 1;    // DMA instructions of one slot's group: 4 rows + the gate pre-activations
+    extern __shared__ __attribute__((aligned(16))) float hs16[];     // [2][16][LDW] h tiles, [2][4][256] gx, [4][NTL][64] cells
+    float* gxs = hs16 + 2 * 16 * LDW;
+    float* cs = gxs + 2 * 4 * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int us = blockIdx.x % US, ss = (blockIdx.x / US) % a.SS, z = blockIdx.x / (US * a.SS);
+    const bool rev = !a.pz && ((a.reverse >> z) & 1);
+    const int NT = (a.S + 15) >> 4;
+    const int NTL = (NT - ss + a.SS - 1) / a.SS;             // tiles of this workgroup: ss, ss + SS, ...
+    const int NTLmax = (NT + a.SS - 1) / a.SS;
+    const int r0 = us * 64 + wave * 16, U0 = us * 16 + wave * 4;
+    // chunked layer pipeline (a.pz): this LSTM is layer lzz of a stack, on steps tb .. tb + Tn of its recurrence
+    const int lzz = a.pz ? a.lz[z] : z, tb = a.pz ? a.t0[z] : 0, Tn = a.pz ? a.Tz[z] : a.T;
+
+    floatx4 wa[KQ / 4];
+    {
+        const floatx4* __restrict__ W =
+            reinterpret_cast<const floatx4*>((a.pz ? a.whhp[z] : a.whh + (long)z * a.whh_z) + (long)(r0 + l15) * H + l4 * KQ);
+        static_for_c<KQ / 4>([&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            wa[j] = W[j];
+        });
+    }
+    float* cw = cs + wave * (NTLmax * 64);
+    float* __restrict__ cellg = a.cell + ((long)lzz * H + U0 + l4) * a.S + l15;      // this lane's (unit, sequence l15 of tile 0) in `cell`
+    for (int j = 0; j < NTL; ++j) {                          // c_{-1} = 0, or the cells the previous range of steps left
+        const int n = (ss + j * a.SS) * 16 + l15;
+        cw[j * 64 + lane] = (a.pz && tb > 0 && n < a.S) ? cellg[(ss + j * a.SS) * 16] : 0.f;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the weight loads retire here, before the counted waits below
+
+    const float* __restrict__ hx = a.hx + (long)lzz * 2 * a.S * H;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hx), 0, 2 * a.S * H * 4, 0x00020000);
+    float* __restrict__ outz = a.pz ? a.outp[z] : a.out + (long)z * a.out_z;
+    const unsigned ov = (unsigned)((long)(U0 + l4) * a.out_row + l15);       // (unit, sequence) of this lane inside a frame of `out`
+    const float* __restrict__ gxz = a.pz ? a.gxp[z] : a.gx + (long)z * a.gx_z;
+    // the wave's 16 gate rows x 16 sequences of a tile as ONE 16 B DMA: lane (row = lane >> 2, sequences 4 (lane & 3) ..) lands
+    // at gxs[..][lane][4]; the lane that updates (unit l4, sequence l15) then reads gate k at [(4 l4 + k) 4 + l15 / 4][l15 % 4]
+    const unsigned gv = (unsigned)(((long)(4 * U0 + (lane >> 2)) * a.gx_row + 4 * (lane & 3)) * 4);
+    const int gidx = (16 * l4 + (l15 >> 2)) * 4 + (l15 & 3);
+    const unsigned lds0 = (unsigned)(size_t)hs16, gxs0 = (unsigned)(size_t)gxs;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    auto issue_h = [&](int t, int nt, int buf) {             // rows 4 w .. 4 w + 3 of tile nt (h_{t-1}) into buffer buf
+        if (a.dbg & 32) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nq = min(nt * 16 + 4 * wave_u + r, a.S - 1);
+            const float* src = hx + ((long)((tb + t) & 1) * a.S + nq) * H;
+            const unsigned dst = lds0 + (unsigned)((buf * 16 + 4 * wave_u + r) * LDW) * 4u;
+            static_for_c<ND>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                c4_dma16s(src, lane * 16 + i * 1024, dst + i * 1024);
+            });
+        }
+    };
+    auto issue = [&](int t, int nt, int buf) {
+        issue_h(t, nt, buf);
+        const int tt = min(t, Tn - 1), tr = rev ? Tn - 1 - tt : tt;
+        const float* gb = gxz + (long)tr * a.gx_t + nt * 16;         // (a last tile with fewer than 16 sequences fetches past its columns: unused)
+        c4_dma16g(gb, gv, gxs0 + (unsigned)((buf * 4 + wave_u) * 256) * 4u);
+    };
+    // this lane's words of the 4 rows its wave fetched: all low bits = tag?  (tag is wave-uniform: an OR chain for tag 0, an AND
+    // chain for tag 1 - two three-input operations per 16 B instead of four XORs and two ORs)
+    auto stale = [&](const float* tile, unsigned tag) -> bool {
+        unsigned o = 0, n = ~0u;
+        if (tag) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                static_for_c<ND>([&](auto I_) {
+                    constexpr int i = decltype(I_)::value;
+                    const uintx4 w = *reinterpret_cast<const uintx4*>(tile + (4 * wave + r) * LDW + (i * 64 + lane) * 4);
+                    n = (n & w[0] & w[1]) & (w[2] & w[3]);
+                });
+            o = ~n;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                static_for_c<ND>([&](auto I_) {
+                    constexpr int i = decltype(I_)::value;
+                    const uintx4 w = *reinterpret_cast<const uintx4*>(tile + (4 * wave + r) * LDW + (i * 64 + lane) * 4);
+                    o = (o | w[0] | w[1]) | (w[2] | w[3]);
+                });
+        }
+        return __builtin_amdgcn_ballot_w64((o & 1u) != 0) != 0;
+    };
+
+    const int Q = Tn * NTL;                                  // slots: (step, tile) pairs
+    const bool ahead = NTL >= 2;                             // with one tile per step the next slot's h does not exist yet: fetch at the check
+    __syncthreads();                                         // (cell states zeroed)
+    issue(0, ss, 0);
+    int tq = 0, jq = 0, par = 0;
+    for (int q = 0; q < Q; ++q) {
+        const int nt = ss + jq * a.SS;
+        const unsigned tag = (unsigned)((tb + tq) >> 1) & 1u;
+        // younger than this slot's group: the previous slot's two stores (the first slot: nothing)
+        if (q >= 1) c4_wait_vm<2>();
+        else c4_wait_vm<0>();
+        float* hb = hs16 + par * (16 * LDW);
+        // (one tile per step: nothing was fetched ahead, the buffer still holds h_{t-3} - straight to the fetch loop)
+        if (!(a.dbg & (4 | 32)) && ((!ahead && q > 0) || stale(hb, tag))) {
+            const unsigned long long t0 = wall_clock64();
+            do {
+                if (wall_clock64() - t0 > 400000000ull) __builtin_trap();     // 4 s @ 100 MHz: never hang the GPU
+                issue_h(tq, nt, par);
+                c4_wait_vm<0>();
+            } while (stale(hb, tag));
+        }
+        float gcur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gcur[k] = gxs[(par * 4 + wave) * 256 + gidx + 16 * k];
+        const float cprev = cw[jq * 64 + lane];
+        if (!(a.dbg & 128)) __syncthreads();                 // publishes hb; every wave is done with the other buffer
+        // the next slot's group goes out BETWEEN the matrix instructions below (a DMA instruction waits ~60 - 180 cycles for its
+        // turn at the memory pipe; behind a 128-cycle group of matrix instructions that wait is free, in front of the loop it is not)
+        int tn = tq, jn = jq + 1;
+        if (jn == NTL) { jn = 0; ++tn; }
+        const int ntn = ss + jn * a.SS;
+        const float* nsrc[4];
+        unsigned ndst[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nq = min(ntn * 16 + 4 * wave_u + r, a.S - 1);
+            nsrc[r] = hx + ((long)((tb + tn) & 1) * a.S + nq) * H;
+            ndst[r] = lds0 + (unsigned)(((par ^ 1) * 16 + 4 * wave_u + r) * LDW) * 4u;
+        }
+        const bool fetch_h = ahead && !(a.dbg & 32);
+        {
+            const int tt = min(tn, Tn - 1), tr = rev ? Tn - 1 - tt : tt;
+            c4_dma16g(gxz + (long)tr * a.gx_t + ntn * 16, gv, gxs0 + (unsigned)(((par ^ 1) * 4 + wave_u) * 256) * 4u);
+        }
+        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        {
+            const unsigned haddr = (unsigned)(size_t)(hb + l15 * LDW + l4 * KQ);
+            floatx4 bq[3];
+#define CO_READ(Qr, J) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Qr) : "v"(haddr), "n"((J) * 16) : "memory")
+#define CO_WAIT(Qr, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(Qr))
+            CO_READ(bq[0], 0);
+            CO_READ(bq[1], 1);
+            static_for_c<KQ / 4>([&](auto J_) {
+                constexpr int j = decltype(J_)::value;
+                if constexpr (j + 2 < KQ / 4) {
+                    CO_READ(bq[(j + 2) % 3], j + 2);
+                    CO_WAIT(bq[j % 3], 2);
+                } else if constexpr (j + 1 < KQ / 4) {
+                    CO_WAIT(bq[j % 3], 1);
+                } else {
+                    CO_WAIT(bq[j % 3], 0);
+                }
+                const floatx4 b = bq[j % 3];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][0], b[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][1], b[1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][2], b[2], acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][3], b[3], acc3, 0, 0, 0);
+                if constexpr (j < 4 * ND) {
+                    if (fetch_h) c4_dma16s(nsrc[j / ND], lane * 16 + (j % ND) * 1024, ndst[j / ND] + (j % ND) * 1024);
+                }
+            });
+#undef CO_READ
+#undef CO_WAIT
+        }
+        const floatx4 acc = (acc0 + acc1) + (acc2 + acc3);
+        const float cn = sigm_hw(acc[1] + gcur[1]) * cprev + sigm_hw(acc[0] + gcur[0]) * tanh_hw(acc[2] + gcur[2]);
+        const float h = sigm_hw(acc[3] + gcur[3]) * tanh_hw(cn);
+        cw[jq * 64 + lane] = cn;
+        if (!(a.dbg & 64)) {
+            // both stores are issued by every wave (lane 0 always qualifies: 16 nt < S): the counted wait relies on it
+            const int n0 = nt * 16, tr = rev ? Tn - 1 - tq : tq;
+            float* __restrict__ of = outz + (long)tr * a.out_t + n0;         // wave-uniform
+            if (n0 + l15 < a.S) of[ov] = h;
+            // h of the wave's 4 units (lane groups l4 = 0 .. 3 = 16-lane rows) gathered into lanes 0 - 15: one 16 B store per sequence
+            const unsigned hb_ = (__float_as_uint(h) & ~1u) | ((unsigned)((tb + tq + 1) >> 1) & 1u);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(hb_, hb_, false, false);      // rows [r0, r0, r2, r2], [r1, r1, r3, r3]
+            const auto e = __builtin_amdgcn_permlane32_swap(r1[0], r1[0], false, false);   // [r0 x 4], [r2 x 4]
+            const auto o = __builtin_amdgcn_permlane32_swap(r1[1], r1[1], false, false);   // [r1 x 4], [r3 x 4]
+            if (lane < 16 && n0 + l15 < a.S)
+                __builtin_amdgcn_raw_buffer_store_b128(uintx4{e[0], o[0], e[1], o[1]}, rs,
+                                                       (unsigned)((((tb + tq + 1) & 1) * a.S + n0 + l15) * (H * 4) + U0 * 4), 0, 16);
+        }
+        if (++jq == NTL) { jq = 0; ++tq; }
+        par ^= 1;
+    }
+    if (a.pz)                                                // the cells go back for the layer's next range of steps
+        for (int j = 0; j < NTL; ++j)
+            if ((ss + j * a.SS) * 16 + l15 < a.S) cellg[(ss + j * a.SS) * 16] = cw[j * 64 + lane];
 }
 
 char* coop_scratch(size_t need, hipStream_t s) { return device_scratch(0, need, s); }
@@ -799,7 +1090,7 @@ bool lstm_coop_supported(int H, int S, int Z) { return (H == 512 || H == 1024) &
 
 // sub-tile pipelined form: sequence slices by 4-sequence sub-tiles, LEAD = slots a fetch runs ahead (at most the sub-tiles a
 // workgroup owns: the padding slots at the end of the launch are sub-tiles of step T)
-template <int H, int LEAD>
+template <int H, int LEAD, int NW>
 static void launch_c8(LstmCoopArgs a, hipStream_t s) {
     constexpr int US = H / 16;
     static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
@@ -815,16 +1106,108 @@ static void launch_c8(LstmCoopArgs a, hipStream_t s) {
     memcpy(&stale, &one, sizeof(float));
     for (int z = 0; z < a.Z; ++z) launch_fill(a.hx + ((long)z * 2 + 1) * slab, (long)slab, stale, s);   // ... slab 1 must not look like h_0
     const int nsub_max = ((a.S + 3) / 4 + a.SS - 1) / a.SS;
-    const size_t shmem = ((size_t)(LEAD + 1) * 4 * (H + 16) + (size_t)(LEAD + 1) * 8 * 64 + (size_t)8 * nsub_max * 8) * sizeof(float);
+    const size_t wl_floats = (NW == 4 && H == 1024) ? (size_t)NW * (H / 64) * 256 : 0;      // one unit's weights per wave (kernel: UL)
+    const size_t shmem = ((size_t)(LEAD + 1) * 4 * (H + 16) + (size_t)(LEAD + 1) * NW * 64 + wl_floats + (size_t)64 * nsub_max) * sizeof(float);
     SE_CHECK(shmem <= 160 * 1024, "cooperative LSTM (sub-tile form): too many sequences per workgroup for the LDS-resident cell state");
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {
-        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop8_kernel<H, LEAD>),
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop8_kernel<H, LEAD, NW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     void* params[] = {&a};
-    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop8_kernel<H, LEAD>), dim3(US * a.SS * a.Z), dim3(512),
-                                      params, (unsigned)shmem, s));
+    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop8_kernel<H, LEAD, NW>), dim3(US * a.SS * a.Z),
+                                      dim3(64 * NW), params, (unsigned)shmem, s));
+}
+template <int H>
+static bool launch_c16(LstmCoopArgs a, int n_cu, hipStream_t s) {
+    static const int on = getenv("SE_COOP16") ? atoi(getenv("SE_COOP16")) : 1;
+    static const int min_s = getenv("SE_COOP16_MINS") ? atoi(getenv("SE_COOP16_MINS")) : 17;
+    constexpr int US = H / 16;
+    if (!on || a.S < min_s || US * a.Z > n_cu || (long)a.S * H * 8 >= (1L << 31) || (double)a.gx_row * 4 * H * 4 >= 4.0e9 ||
+        (double)a.out_row * H >= 4.0e9)
+        return false;
+    const int NT = (a.S + 15) / 16;
+    a.SS = std::max(1, std::min(NT, n_cu / (US * a.Z)));
+    const int ntl_max = (NT + a.SS - 1) / a.SS;
+    const size_t shmem = ((size_t)2 * 16 * (H + 4) + (size_t)2 * 4 * 256 + (size_t)4 * ntl_max * 64) * sizeof(float);
+    if (shmem > 160 * 1024) return false;
+    static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
+    a.dbg = dbg;
+    constexpr size_t NFLAG = 256 * 64;
+    const size_t slab = (size_t)a.S * H, hx_bytes = (size_t)a.Z * 2 * slab * sizeof(float);
+    char* sc = coop_scratch(NFLAG * sizeof(unsigned) + hx_bytes, s);
+    a.bar = reinterpret_cast<unsigned*>(sc);
+    a.hx = reinterpret_cast<float*>(sc + NFLAG * sizeof(unsigned));
+    launch_fill(a.hx, (long)a.Z * 2 * slab, 0.f, s);          // h_{-1} = 0 (tag 0) ...
+    const unsigned one = 1u;
+    float stale;
+    memcpy(&stale, &one, sizeof(float));
+    for (int z = 0; z < a.Z; ++z) launch_fill(a.hx + ((long)z * 2 + 1) * slab, (long)slab, stale, s);   // ... slab 1 must not look like h_0
+    static bool attr_set[64] = {};
+    if (first_on_device(attr_set)) {
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop16_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+    }
+    void* params[] = {&a};
+    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop16_kernel<H>), dim3(US * a.SS * a.Z), dim3(256), params,
+                                      (unsigned)shmem, s));
+    return true;
+}
+static int coop_n_cu() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        SE_HIP(hipGetDevice(&dev));
+        SE_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    return n_cu;
+}
+bool lstm_coop_chunk_supported(int H, int S, int n_layers) {
+    static const int on = getenv("SE_LSTM_CHUNK") ? atoi(getenv("SE_LSTM_CHUNK")) : 1;
+    if (!on || (H != 512 && H != 1024) || n_layers < 2 || n_layers > 4 || S < 17) return false;
+    const int n_cu = coop_n_cu(), US = H / 16, NT = (S + 15) / 16;
+    // worth it where one layer alone leaves a workgroup a single tile per step (its exchange is then exposed) and the layers
+    // together still fit the chip
+    return US * n_layers <= n_cu && NT <= n_cu / US && (long)S * H * 8 < (1L << 31);
+}
+template <int H>
+static void launch_chunk_t(LstmCoopArgs a, int n_layers, hipStream_t s) {
+    constexpr int US = H / 16;
+    const int n_cu = coop_n_cu(), NT = (a.S + 15) / 16;
+    a.SS = std::max(1, std::min(NT, n_cu / (US * a.Z)));
+    const int ntl_max = (NT + a.SS - 1) / a.SS;
+    const size_t shmem = ((size_t)2 * 16 * (H + 4) + (size_t)2 * 4 * 256 + (size_t)4 * ntl_max * 64) * sizeof(float);
+    SE_CHECK(shmem <= 160 * 1024, "chunked cooperative LSTM: too many tiles per workgroup");
+    static const int dbg = getenv("SE_COOP_DBG") ? atoi(getenv("SE_COOP_DBG")) : 0;
+    a.dbg = dbg;
+    a.pz = 1;
+    constexpr size_t NFLAG = 256 * 64;
+    const size_t slab = (size_t)a.S * H, hx_bytes = (size_t)n_layers * 2 * slab * sizeof(float);
+    char* sc = coop_scratch(NFLAG * sizeof(unsigned) + hx_bytes, s);
+    a.bar = reinterpret_cast<unsigned*>(sc);
+    a.hx = reinterpret_cast<float*>(sc + NFLAG * sizeof(unsigned));
+    const unsigned one = 1u;
+    float stale;
+    memcpy(&stale, &one, sizeof(float));
+    for (int z = 0; z < a.Z; ++z)
+        if (a.t0[z] == 0) {      // a layer's first range: h_{-1} = 0 (tag 0), and slab 1 must not look like h_0
+            launch_fill(a.hx + (long)a.lz[z] * 2 * slab, (long)slab, 0.f, s);
+            launch_fill(a.hx + ((long)a.lz[z] * 2 + 1) * slab, (long)slab, stale, s);
+        }
+    static bool attr_set[64] = {};
+    if (first_on_device(attr_set)) {
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_coop16_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+    }
+    void* params[] = {&a};
+    SE_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&lstm_coop16_kernel<H>), dim3(US * a.SS * a.Z), dim3(256), params,
+                                      (unsigned)shmem, s));
+}
+void launch_lstm_coop_chunk(const LstmCoopArgs& a, int n_layers, hipStream_t s) {
+    SE_CHECK(a.Z >= 1 && a.Z <= 4 && n_layers <= 4 && (a.H == 512 || a.H == 1024), "launch_lstm_coop_chunk: 1 - 4 layers of 512 / 1024 units");
+    SE_CHECK((double)a.gx_row * 4 * a.H * 4 < 4.0e9 && (double)a.out_row * a.H < 4.0e9, "launch_lstm_coop_chunk: tensor too large for 32-bit lane offsets");
+    if (a.H == 1024) launch_chunk_t<1024>(a, n_layers, s);
+    else launch_chunk_t<512>(a, n_layers, s);
 }
 template <int H>
 static bool launch_c4_n(LstmCoopArgs a, int n_cu, hipStream_t s) {
@@ -832,17 +1215,20 @@ static bool launch_c4_n(LstmCoopArgs a, int n_cu, hipStream_t s) {
     static const int min_s = getenv("SE_COOP4_MINS") ? atoi(getenv("SE_COOP4_MINS")) : 17;
     static const int lead_env = getenv("SE_COOP4_LEAD") ? atoi(getenv("SE_COOP4_LEAD")) : 0;
     constexpr int US = H / 16;
-    if (!on || a.S < min_s || US * a.Z > n_cu || (long)a.S * H * 8 >= (1L << 31)) return false;
+    // (the per-lane parts of the gate / output addresses are 32-bit offsets inside one LSTM's tensors)
+    if (!on || a.S < min_s || US * a.Z > n_cu || (long)a.S * H * 8 >= (1L << 31) || (double)a.gx_row * 4 * H * 4 >= 4.0e9 ||
+        (double)a.out_row * H >= 4.0e9)
+        return false;
     const int NS4 = (a.S + 3) / 4;
     a.SS = std::max(1, std::min(NS4, n_cu / (US * a.Z)));
-    if ((size_t)((NS4 + a.SS - 1) / a.SS) * 256 > 64 * 1024) return false;        // cell state of the slice must fit LDS
+    if ((size_t)((NS4 + a.SS - 1) / a.SS) * 256 > 24 * 1024) return false;        // cell state of the slice must fit LDS
     const int nsub_min = NS4 / a.SS;                           // the fewest sub-tiles a workgroup owns (>= 1)
     int lead = std::min(3, nsub_min);
     if (nsub_min >= 3 && nsub_min < 6) lead = 2;             // a fetch issued 3 slots ahead of a 4-slot cycle would read before h_{t-1} is out
     if (lead_env > 0) lead = std::min(lead_env, std::min(3, nsub_min));
-    if (lead <= 1) launch_c8<H, 1>(a, s);
-    else if (lead == 2) launch_c8<H, 2>(a, s);
-    else launch_c8<H, 3>(a, s);
+    if (lead <= 1) launch_c8<H, 1, 4>(a, s);
+    else if (lead == 2) launch_c8<H, 2, 4>(a, s);
+    else launch_c8<H, 3, 4>(a, s);
     return true;
 }
 
@@ -945,6 +1331,16 @@ void launch_lstm_coop(const LstmCoopArgs& a, hipStream_t s) {
         else SE_CHECK(false, "cooperative LSTM kernel is built for H = 512 / 1024");
         return;
     }
+    // 16-sequence tiles (lstm_coop16_kernel) unless a workgroup would own a single tile per step AND fewer than 16 sequences per
+    // unit slice's share of the chip are left to split: there the 4-sequence sub-tiles overlap their own exchange (batch 32,
+    // H = 1024: 5.1 us per step against 7.4; batch 64: 8.1 against 7.8; SE_COOP4_FIRST = 1 / 0 forces / forbids)
+    static const int sub4_env = getenv("SE_COOP4_FIRST") ? atoi(getenv("SE_COOP4_FIRST")) : -1;
+    const int us_z = (a.H / 16) * a.Z, nt16 = (a.S + 15) / 16;
+    const bool sub4 = sub4_env >= 0 ? sub4_env != 0 : (us_z <= n_cu && nt16 <= n_cu / us_z && a.S * us_z < 60 * n_cu / 4 && a.H == 1024);
+    if (sub4 && a.H == 1024 && launch_c4_n<1024>(a, n_cu, s)) return;
+    if (sub4 && a.H == 512 && launch_c4_n<512>(a, n_cu, s)) return;
+    if (a.H == 1024 && launch_c16<1024>(a, n_cu, s)) return;
+    if (a.H == 512 && launch_c16<512>(a, n_cu, s)) return;
     if (a.H == 1024 && launch_c4_n<1024>(a, n_cu, s)) return;
     if (a.H == 512 && launch_c4_n<512>(a, n_cu, s)) return;
     if (a.H == 1024) launch_t<1024>(a, n_cu, s);

@@ -308,8 +308,19 @@ struct LstmCoopArgs {
     long out_z, out_t, out_row;
     int H, T, S, Z, reverse;
     float* hx; unsigned* bar; int SS, dbg;
+    // chunked layer pipeline (launch_lstm_coop_chunk, pz = 1): the Z LSTMs of a launch are LAYERS of one stack, each on its own
+    // range of steps - layer lz[z] runs steps t0[z] .. t0[z] + Tz[z] of its recurrence, continuing from the state the launch of
+    // its previous range left (h in the launcher's exchange slabs, c in `cell`, both indexed by layer); gxp / outp point at the
+    // first step of the range, whhp at the layer's matrix
+    int pz;
+    const float* gxp[4]; const float* whhp[4]; float* outp[4];
+    int lz[4], t0[4], Tz[4];
 };
 bool lstm_coop_supported(int H, int S, int Z);
+// layers of a stack on consecutive chunks of steps in one cooperative launch (k_lstm_coop.hip: lstm_coop16_kernel); false: the
+// shape has no such kernel.  n_layers = layers of the whole stack (sizes the exchange slabs / `cell` = [n_layers][H][S])
+bool lstm_coop_chunk_supported(int H, int S, int n_layers);
+void launch_lstm_coop_chunk(const LstmCoopArgs& a, int n_layers, hipStream_t s);
 // A stack of L LSTM layers (equal width) on ONE sequence as one cooperative launch (k_lstm_coop.hip: lstm_stack_kernel):
 // layer l runs l frames behind layer l - 1, one exchange latency per frame serves all layers.  gx0: the first layer's gate
 // pre-activations (input projection + bias, rows 4u + gate); whh / wih / bias: row-major [4H][H] / [4H][H] / [4H] per layer

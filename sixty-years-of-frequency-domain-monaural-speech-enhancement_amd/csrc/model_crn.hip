@@ -172,7 +172,7 @@ class Crn final : public Model {
         b.G = a.alloc_f(BT * 4096);
         b.Hs[0] = a.alloc_f(BT * 1024);
         b.Hs[1] = a.alloc_f(BT * 1024);
-        b.cell = a.alloc_f((size_t)1024 * B);
+        b.cell = a.alloc_f((size_t)2 * 1024 * B);        // (one per layer: the chunked layer pipeline runs both at once)
         cur = b;
         return cur;
     }
@@ -192,8 +192,11 @@ class Crn final : public Model {
             // feature-major [1024][T][B] (rnn.h run_fm): the two 4096 x 1024 input projections are full-width GEMMs
             launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, B, (long)T * B, st);
             const LstmBig* ly[2] = {&lstm[0], &lstm[1]};
+            float* outs2[2] = {b.Hs[0], b.Hs[1]};
             if (B == 1 && lstm_stack_fm(ly, 2, b.X, b.G, b.Hs[1], T, st, pf)) {
                 // (one clip: both layers as one wavefront launch, rnn.h)
+            } else if (lstm_stack_chunked_fm(ly, 2, b.X, b.G, b.cell, outs2, T, B, st, pf)) {
+                // (up to 64 clips: the two layers as a pipeline over chunks of frames, one cooperative launch per chunk, rnn.h)
             } else {
                 lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
                 lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
@@ -349,7 +352,7 @@ class LstmNet final : public Model {
         b.G = a.alloc_f(BT * 4096);
         b.Hs[0] = a.alloc_f(BT * 1024);
         b.Hs[1] = a.alloc_f(BT * 1024);
-        b.cell = a.alloc_f((size_t)1024 * B);
+        b.cell = a.alloc_f((size_t)3 * 1024 * B);        // (one per layer: the chunked layer pipeline runs all three at once)
         cur = b;
         return cur;
     }
@@ -361,8 +364,11 @@ class LstmNet final : public Model {
         const long N = (long)T * B;
         Profiler* pf = &ctx.prof;
         const LstmBig* ly[3] = {&lstm[0], &lstm[1], &lstm[2]};
+        float* outs3[3] = {b.Hs[0], b.Hs[1], b.Hs[0]};
         if (B == 1 && lstm_stack_fm(ly, 3, b.X, b.G, b.Hs[0], T, st, pf)) {
             // (one clip: the three layers as one wavefront launch, rnn.h)
+        } else if (lstm_stack_chunked_fm(ly, 3, b.X, b.G, b.cell, outs3, T, B, st, pf)) {
+            // (up to 64 clips: the three layers as a pipeline over chunks of frames, rnn.h)
         } else {
             lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
             lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);

@@ -387,6 +387,61 @@ inline bool lstm_stack_fm(const LstmBig* const* ly, int L, const float* x, float
     return true;
 }
 
+// A stack of L equal-width layers over S sequences, feature-major (x [I][T][S], outs[l] [H][T][S], G [4H][T][S], cells
+// [L][H][S]), as a PIPELINE OF LAYERS over chunks of steps: launch s runs layer l on chunk s - l, all in one cooperative launch
+// (k_lstm_coop.hip: lstm_coop16_kernel, a.pz) - where one layer alone leaves a workgroup a single 16-sequence tile per step (batch
+// <= 64 at H = 1024) and nothing to overlap its h exchange with, L layers give it L tiles: CRN's two layers at batch 64 take
+// 10.2 us per step TOGETHER instead of 2 x 8.3.  The input projection of layer l >= 1 on a chunk (a GEMM over out[l - 1]) runs
+// between the launches and writes its gates over the chunk of G the layer below has just consumed - one G serves the stack.
+// outs[l] may alias outs[l - 2] (the projection that read that chunk has run).  false: not applicable (the caller runs the
+// layers one after the other).
+inline bool lstm_stack_chunked_fm(const LstmBig* const* ly, int L, const float* x, float* G, float* cells, float* const* outs, int T, int S,
+                                  hipStream_t st, Profiler* prof) {
+    if (L < 2 || L > 4 || !LstmBig::coop_enabled()) return false;
+    const int H = ly[0]->H;
+    for (int l = 0; l < L; ++l)
+        if (!ly[l]->has_fm || !ly[l]->whh_dev || ly[l]->H != H || (l > 0 && ly[l]->I != H)) return false;
+    if (!lstm_coop_chunk_supported(H, S, L)) return false;
+    static const int chunk_env = getenv("SE_LSTM_CHUNK_T") ? atoi(getenv("SE_LSTM_CHUNK_T")) : 0;
+    // chunk length: the pipeline runs (L - 1) chunks longer than the sequence, every launch costs ~3 steps' worth of launch + fill
+    int Tc = chunk_env > 0 ? chunk_env : 48;                 // (measured at batch 64, T = 401: 24 / 36 / 48 / 64 -> CRN 4 907 / 5 022 / 5 281 / 5 204 utt/s)
+    Tc = std::max(2, std::min(Tc, T)) & ~1;                  // even: a chunk keeps the parity of the exchange slabs
+    if (T < 2 * Tc) return false;
+    const long N = (long)T * S;
+    const int nc = (T + Tc - 1) / Tc;
+    run_pointwise(ly[0]->gin_fm, x, 0, N, G, 0, N, 1, (int)N, st, prof);
+    for (int s = 0; s < nc + L - 1; ++s) {
+        LstmCoopArgs a{};
+        a.cell = cells;
+        a.gx_t = S; a.gx_row = N; a.out_t = S; a.out_row = N;
+        a.H = H; a.S = S; a.reverse = 0;
+        double flops = 0;
+        for (int l = 0; l < L; ++l) {
+            const int c = s - l;
+            if (c < 0 || c >= nc) continue;
+            const int t0 = c * Tc, len = std::min(Tc, T - t0);
+            if (l > 0) {       // gates of layer l on this chunk, over the chunk of G layer l - 1 consumed one launch ago
+                const long off = (long)t0 * S;
+                run_pointwise(ly[l]->gin_fm, outs[l - 1] + off, 0, N, G + off, 0, N, 1, len * S, st, prof);
+            }
+            const int z = a.Z++;
+            a.gxp[z] = G + (long)t0 * S;
+            a.whhp[z] = ly[l]->whh_dev;
+            a.outp[z] = outs[l] + (long)t0 * S;
+            a.lz[z] = l;
+            a.t0[z] = t0;
+            a.Tz[z] = len;
+            a.T = std::max(a.T, len);
+            flops += 2.0 * 4 * H * (double)H * S * (len - (t0 == 0 ? 1 : 0));
+        }
+        const bool timed = prof && prof->on;
+        if (timed) prof->begin(st);
+        launch_lstm_coop_chunk(a, L, st);
+        if (timed) prof->end(st, flops);
+    }
+    return true;
+}
+
 // Two independent LSTM layers of equal shape (GCRN's grouped LSTM, GCRN/GCRN_noncprs.py:5-39) as ONE cooperative launch
 // (Z = 2): each alone covers H/16 x SS workgroups of the chip, together they fill it.  whh2 = [2][4H][H] device copy of
 // both recurrent matrices; G / cell hold both groups back to back.  Falls back to two sequential layers.

@@ -218,10 +218,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persist4_kernel(const LstmPersist
     for (int step = 0; step < a.T; ++step) {
         const int cur = step & 1;
         if (step + 1 < a.T) load_gx(step + 1, gnxt);
-        floatx4 acc[RG];
+        // four accumulator chains per row group (k mod 4): a v_mfma_f32_4x4x1 that depends on the previous one issues 16 cycles
+        // behind it, an independent one 8 (tools/mfma4bench.cpp) - with one chain per row group this loop ran at half rate
+        floatx4 acc4[RG][4];
         static_for_l<RG>([&](auto R_) {
             constexpr int rg = decltype(R_)::value;
-            acc[rg] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc4[rg][q] = floatx4{0.f, 0.f, 0.f, 0.f};
         });
         if (step > 0) {
             const floatx4* hb = reinterpret_cast<const floatx4*>(&hs[cur][j * H]);     // B operand: h_{t-1}[k] of sequence j
@@ -245,17 +248,23 @@ __global__ __launch_bounds__(256, 1) void lstm_persist4_kernel(const LstmPersist
                     P4_WAIT(bq[k4 % 3], 0);
                 }
                 const floatx4 b = bq[k4 % 3];
-                static_for_l<RG>([&](auto R_) {
-                    constexpr int rg = decltype(R_)::value;
-                    acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 0], b[0], acc[rg], 0, 0, 0);
-                    acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 1], b[1], acc[rg], 0, 0, 0);
-                    acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 2], b[2], acc[rg], 0, 0, 0);
-                    acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + 3], b[3], acc[rg], 0, 0, 0);
-                });
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    static_for_l<RG>([&](auto R_) {
+                        constexpr int rg = decltype(R_)::value;
+                        acc4[rg][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[rg][4 * k4 + q], b[q], acc4[rg][q], 0, 0, 0);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
             });
 #undef P4_READ
 #undef P4_WAIT
         }
+        floatx4 acc[RG];
+        static_for_l<RG>([&](auto R_) {
+            constexpr int rg = decltype(R_)::value;
+            acc[rg] = (acc4[rg][0] + acc4[rg][1]) + (acc4[rg][2] + acc4[rg][3]);
+        });
         const int t = rev ? a.T - 1 - step : step;
         float* op = out + (long)t * a.out_t;
         static_for_l<RG>([&](auto R_) {

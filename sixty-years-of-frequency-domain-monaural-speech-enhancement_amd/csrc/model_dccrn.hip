@@ -32,13 +32,95 @@ struct Bufs {
     float *c = nullptr, *spec = nullptr, *est = nullptr, *frames = nullptr;
     float* E[NL] = {};
     float* D[NL + 1] = {};
-    float *X1 = nullptr, *G = nullptr, *H1 = nullptr, *H2 = nullptr, *C1 = nullptr, *C2 = nullptr, *P = nullptr;
+    float *X1 = nullptr, *G = nullptr, *H1 = nullptr, *H2 = nullptr, *C1 = nullptr, *C2 = nullptr, *P = nullptr, *K = nullptr;
+};
+
+// ---- Gauss' three-product complex (de)conv (measure it) -------------------------------------------------
+// The reference computes a complex conv as four real ones (complexnn: r2r - i2i, r2i + i2r); the engine runs them as ONE real
+// conv over the 2 x 2 block matrix.  Gauss: k1 = Wr (xr + xi), k2 = (Wi - Wr) xr, k3 = (Wr + Wi) xi, yr = k1 - k3, yi = k1 + k2 -
+// three real convs of half the rows and half the K: 3/4 of the matrix instructions.  Here as a GROUPED launch of the same
+// gc_kernel (blockIdx.z = product, sources = the planes [xr + xi | xr | xi] of a three-plane tensor, outputs k1..k3 in a scratch
+// tensor) and one elementwise pass that combines them, applies BatchNorm / bias / PReLU and writes the next layer's three planes.
+// tools/gcbench.cpp `gauss` (profiles/r04_gauss_gcbench.log): 128 -> 128 complex channels 0.81x the block GEMM's time, 64 -> 128
+// 0.87x, 32 -> 64 0.97x, 16 -> 32 1.28x (the combine pass is as big as the GEMM there) - so the layers with >= 128 complex output
+// channels take this path: encoder 3 - 5, decoder 0 - 1 (50 % of the step).  Rounding: the products are formed on sums of
+// weights / inputs - 4e-7 ... 1e-6 relative per layer against the four-product form (bar 1e-4 on the waveform).
+// x3 [B][3 C][P] planes (S | R | I): S = R + I
+__global__ __launch_bounds__(256) void gauss_sum_kernel(float* __restrict__ x3, long CP) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4, b = blockIdx.y;
+    if (i >= CP) return;
+    float* xb = x3 + b * 3 * CP;
+    if (i + 3 < CP && (CP & 3) == 0) {
+        const float4 r = *reinterpret_cast<const float4*>(xb + CP + i), m = *reinterpret_cast<const float4*>(xb + 2 * CP + i);
+        *reinterpret_cast<float4*>(xb + i) = make_float4(r.x + m.x, r.y + m.y, r.z + m.z, r.w + m.w);
+    } else {
+        for (long j = i; j < CP && j < i + 4; ++j) xb[j] = xb[CP + j] + xb[2 * CP + j];
+    }
+}
+// k [3][B][Co][F][T] -> y: yr = act((k1 - k3) sc[c] + sh[c]), yi = act((k1 + k2) sc[Co + c] + sh[Co + c]); planes of batch item b at
+// y + b ob + {oS, oR, oI} (oS < 0: no sum plane); frames >= tlen[b] are stored as zeros (ragged rows: the decoder looks ahead)
+__global__ __launch_bounds__(128) void gauss_combine_kernel(const float* __restrict__ k, float* __restrict__ y, int Co, int F, int T,
+                                                            long kz, long ob, long oS, long oR, long oI,
+                                                            const float* __restrict__ sc, const float* __restrict__ sh,
+                                                            const float* __restrict__ slope, const int* __restrict__ tlen) {
+    const int f = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const long row = (((long)b * Co + c) * F + f) * T, orow = (long)b * ob + ((long)c * F + f) * T;
+    const float s_r = sc[c], h_r = sh[c], s_i = sc[Co + c], h_i = sh[Co + c], a_r = slope[c], a_i = slope[Co + c];
+    const int tv = tlen ? tlen[b] : T;
+    const bool v4 = (T & 3) == 0;
+    for (int t = threadIdx.x * 4; t < T; t += 512) {
+        float k1[4], k2[4], k3[4], yr[4], yi[4];
+        if (v4) {
+            *reinterpret_cast<float4*>(k1) = *reinterpret_cast<const float4*>(k + row + t);
+            *reinterpret_cast<float4*>(k2) = *reinterpret_cast<const float4*>(k + kz + row + t);
+            *reinterpret_cast<float4*>(k3) = *reinterpret_cast<const float4*>(k + 2 * kz + row + t);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tt = min(t + j, T - 1);
+                k1[j] = k[row + tt]; k2[j] = k[kz + row + tt]; k3[j] = k[2 * kz + row + tt];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r = (k1[j] - k3[j]) * s_r + h_r, m = (k1[j] + k2[j]) * s_i + h_i;
+            r = r >= 0.f ? r : a_r * r;
+            m = m >= 0.f ? m : a_i * m;
+            const bool live = t + j < tv;
+            yr[j] = live ? r : 0.f;
+            yi[j] = live ? m : 0.f;
+        }
+        if (v4) {
+            *reinterpret_cast<float4*>(y + orow + oR + t) = *reinterpret_cast<const float4*>(yr);
+            *reinterpret_cast<float4*>(y + orow + oI + t) = *reinterpret_cast<const float4*>(yi);
+            if (oS >= 0) *reinterpret_cast<float4*>(y + orow + oS + t) = make_float4(yr[0] + yi[0], yr[1] + yi[1], yr[2] + yi[2], yr[3] + yi[3]);
+        } else {
+            for (int j = 0; j < 4 && t + j < T; ++j) {
+                y[orow + oR + t + j] = yr[j];
+                y[orow + oI + t + j] = yi[j];
+                if (oS >= 0) y[orow + oS + t + j] = yr[j] + yi[j];
+            }
+        }
+    }
+}
+struct GaussLayer {
+    std::vector<GCPlan> pl;      // encoder: one grouped plan (Z = 3); decoder: one per output-parity class
+    float *sc = nullptr, *sh = nullptr, *slope = nullptr;      // [2 co] rows [real; imag]
+    int co = 0;
+    void free() {
+        for (auto& g : pl) gc_free_plan(g);
+        pl.clear();
+        for (float** p : {&sc, &sh, &slope})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+    }
 };
 
 class Dccrn final : public Model {
   public:
     explicit Dccrn(EngineCtx& c) : Model(c) {}
     ~Dccrn() override {
+        for (auto& g : genc) g.free();
+        for (auto& g : gdec) g.free();
         for (auto& p : enc) gc_free_plan(p);
         for (auto& p : dec) free_deconv_plan(p);
         gc_free_plan(g1);
@@ -113,6 +195,80 @@ class Dccrn final : public Model {
                 act = ACT_PRELU;
             }
             dec[k] = make_deconv_plan(w, 2, 2, /*toff: out[..., 1:] :199*/ 1, act, slope, tout, /*C0 = out channels*/ 2 * h);
+        }
+        // ---- the layers with >= 128 complex output channels also as Gauss' three products (see GaussLayer); not with the plain-concat
+        // convention (a decoder input's [real | imag] halves are then not the halves of its two sources)
+        static const int gauss_env = getenv("SE_DCCRN_GAUSS") ? atoi(getenv("SE_DCCRN_GAUSS")) : 1;
+        gauss_on = gauss_env != 0 && !plain_cat;
+        if (gauss_on) {
+            auto three = [](const std::vector<float>& r, const std::vector<float>& i) {
+                std::vector<float> w(3 * r.size());
+                for (size_t k = 0; k < r.size(); ++k) { w[k] = r[k]; w[r.size() + k] = i[k] - r[k]; w[2 * r.size() + k] = r[k] + i[k]; }
+                return w;
+            };
+            auto tail = [&](GaussLayer& g, const std::string& p, const DenseW& wr, const DenseW& wi) {
+                const int co = wr.M;
+                g.co = co;
+                const HostTensor &ga = sd.get(p + "1.weight", {2 * co}), &be = sd.get(p + "1.bias", {2 * co}),
+                                 &mu = sd.get(p + "1.running_mean", {2 * co}), &va = sd.get(p + "1.running_var", {2 * co});
+                std::vector<float> sc(2 * co), sh(2 * co);
+                for (int m = 0; m < 2 * co; ++m) {
+                    const int c = m % co;
+                    const float bias = bias_per_part ? (m < co ? wr.bias[c] : wi.bias[c]) : (m < co ? wr.bias[c] - wi.bias[c] : wr.bias[c] + wi.bias[c]);
+                    const double k = (double)ga.data[m] / std::sqrt((double)va.data[m] + 1e-5);
+                    sc[m] = (float)k;
+                    sh[m] = (float)((double)be.data[m] - (double)mu.data[m] * k + (double)bias * k);
+                }
+                g.sc = to_device(sc);
+                g.sh = to_device(sh);
+                g.slope = to_device(prelu_slopes(sd.get(p + "2.weight"), 2 * co));
+            };
+            for (int k = 3; k < NL; ++k) {
+                const std::string p = "encoder." + std::to_string(k) + ".";
+                const int ci = KN[k] / 2, co = KN[k + 1] / 2;
+                DenseW wr = conv_weights(sd.get(p + "0.real_conv.weight", {co, ci, 5, 2}), &sd.get(p + "0.real_conv.bias", {co}), false);
+                DenseW wi = conv_weights(sd.get(p + "0.imag_conv.weight", {co, ci, 5, 2}), &sd.get(p + "0.imag_conv.bias", {co}), false);
+                TapSpec ts;
+                ts.ntaps = 10;
+                for (int kf = 0; kf < 5; ++kf)
+                    for (int kt = 0; kt < 2; ++kt) { ts.df[kf * 2 + kt] = kf - 2; ts.dt[kf * 2 + kt] = kt - 1; }       // as make_conv_plan(w, 2, 2, 1, 1, 1, ..)
+                GaussLayer& g = genc[k];
+                g.pl.push_back(gc_make_plan(co, ci, ts, three(wr.w, wi.w), {}, {}, ACT_NONE, EPI_ACT, 2, 1, 0, tout, 3));
+                g.pl.back().flop_scale = 4.0 / 3.0;          // the profiler books the reference's four products
+                tail(g, p, wr, wi);
+            }
+            for (int k = 0; k < 2; ++k) {
+                const int idx = NL - k;
+                const std::string p = "decoder." + std::to_string(k) + ".";
+                const int ci = KN[idx], co = KN[idx - 1] / 2;      // complex input channels: [previous (ci / 2) | skip (ci / 2)] (:197)
+                DenseW wr = deconv_weights(sd.get(p + "0.real_conv.weight", {ci, co, 5, 2}), &sd.get(p + "0.real_conv.bias", {co}), false);
+                DenseW wi = deconv_weights(sd.get(p + "0.imag_conv.weight", {ci, co, 5, 2}), &sd.get(p + "0.imag_conv.bias", {co}), false);
+                GaussLayer& g = gdec[k];
+                for (int par = 0; par < 2; ++par) {          // output-parity classes, as make_deconv_plan(w, 2, 2, 1, ..)
+                    TapSpec ts;
+                    std::vector<int> sel;
+                    for (int kf = 0; kf < 5; ++kf) {
+                        const int num = par + 2 - kf;
+                        if (((num % 2) + 2) % 2 != 0) continue;
+                        for (int kt = 0; kt < 2; ++kt) {
+                            ts.df[ts.ntaps] = num / 2;
+                            ts.dt[ts.ntaps] = 1 - kt;
+                            ts.ntaps++;
+                            sel.push_back(kf * 2 + kt);
+                        }
+                    }
+                    std::vector<float> r((size_t)co * ci * ts.ntaps), i(r.size());
+                    for (int m = 0; m < co; ++m)
+                        for (int c = 0; c < ci; ++c)
+                            for (int j = 0; j < ts.ntaps; ++j) {
+                                r[((size_t)m * ci + c) * ts.ntaps + j] = wr.w[((size_t)m * ci + c) * 10 + sel[j]];
+                                i[((size_t)m * ci + c) * ts.ntaps + j] = wi.w[((size_t)m * ci + c) * 10 + sel[j]];
+                            }
+                    g.pl.push_back(gc_make_plan(co, ci, ts, three(r, i), {}, {}, ACT_NONE, EPI_ACT, 1, 2, par, tout, 3, ci / 2));
+                    g.pl.back().flop_scale = 4.0 / 3.0;
+                }
+                tail(g, p, wr, wi);
+            }
         }
         // ---- complex LSTM x2 (:80-94), NavieComplexLSTM(1024|256 -> 256 [-> proj 1024])
         auto lstm_w = [&](const std::string& p, int in, DenseW& wih, DenseW& whh) {
@@ -293,6 +449,8 @@ class Dccrn final : public Model {
                 64L * 64, 32L * 128, 2L * NBIN};
     }
     GCPlan enc[NL], g1, g2, proj;
+    GaussLayer genc[NL], gdec[2];      // encoder 3 - 5 / decoder 0 - 1 as three real products (gauss_on)
+    bool gauss_on = false;
     float *whh1 = nullptr, *whh2 = nullptr;
     DeconvPlan dec[NL];
     Bufs cur;
@@ -309,17 +467,21 @@ class Dccrn final : public Model {
         b.spec = a.alloc_f(BT * 2 * NBIN);
         b.est = a.alloc_f(BT * 2 * NBIN);
         b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
+        // (gauss_on: E[2..5], D[0], D[1] hold THREE planes per complex channel in the offline decode - [xr + xi | xr | xi], the
+        // sources of the three-product layers - and K the three products of one layer; the frame-online mode uses the same
+        // memory as plain [real | imag] tensors)
         int F = 256;
         for (int k = 0; k < NL; ++k) {
             F /= 2;
-            b.E[k] = a.alloc_f(BT * KN[k + 1] * F);
+            b.E[k] = a.alloc_f(BT * KN[k + 1] * F * ((gauss_on && k >= 2) ? 3 : 2) / 2);
         }
         F = 4;
-        b.D[0] = a.alloc_f(BT * 256 * 4);
+        b.D[0] = a.alloc_f(BT * 256 * 4 * (gauss_on ? 3 : 2) / 2);
         for (int k = 0; k < NL; ++k) {
             F *= 2;
-            b.D[k + 1] = a.alloc_f(BT * KN[NL - k - 1] * F);
+            b.D[k + 1] = a.alloc_f(BT * KN[NL - k - 1] * F * ((gauss_on && k == 0) ? 3 : 2) / 2);
         }
+        b.K = gauss_on ? a.alloc_f(BT * 3 * 128 * 16) : nullptr;
         const size_t S = 2 * (size_t)B;
         b.X1 = a.alloc_f((size_t)T * 512 * S);
         b.G = a.alloc_f((size_t)T * 1024 * S);
@@ -347,8 +509,56 @@ class Dccrn final : public Model {
         launch_lstm_persist(a, st);
     }
 
+    // ---- three-product layers: launch helpers.  A three-plane tensor [B][3 C][F][T]: S at +0, R at + C F T, I at + 2 C F T.
+    static Act4 view3(const float* t3, int C, int F, int T) {      // its [R | I] planes as a 2 C-channel tensor
+        return Act4{t3 + (long)C * F * T, 2 * C, F, 3L * C * F * T, (long)F * T, (long)T};
+    }
+    void gauss_sum(float* t3, int B, int C, int F, int T, hipStream_t st) {
+        const long CP = (long)C * F * T;
+        Profiler* pf = &ctx.prof;
+        const bool timed = pf->on;
+        if (timed) pf->begin(st);
+        hipLaunchKernelGGL(gauss_sum_kernel, dim3((unsigned)((CP / 4 + 255) / 256 + 1), B), dim3(256), 0, st, t3, CP);
+        SE_HIP(hipGetLastError());
+        if (timed) pf->end(st, 0.0);
+    }
+    // y = act(BN(complex (de)conv(x))): the grouped three-product launch(es) into b.K, then the combine pass.  src0 / src1:
+    // three-plane tensors of C0 / C1 complex channels (src1 = null: one source); dst3: three-plane output (else [R | I] only)
+    void gauss_layer(const GaussLayer& g, Bufs& b, const float* src0, int C0, const float* src1, int C1, int Fin, int Fout, float* dst,
+                     bool dst3, hipStream_t st) {
+        const int B = b.B, T = b.T, co = g.co;
+        Profiler* pf = &ctx.prof;
+        const long kz = (long)B * co * Fout * T;
+        const Ragged* rg = ragged_ctx();
+        for (const GCPlan& pl : g.pl) {
+            GCParams p = pl.p;
+            p.src0 = src0; p.C0 = C0; p.s0_b = 3L * C0 * Fin * T; p.s0_c = (long)Fin * T; p.s0_f = T; p.src0_z = (long)C0 * Fin * T;
+            if (src1) {
+                p.src1 = src1; p.C1 = C1; p.s1_b = 3L * C1 * Fin * T; p.s1_c = (long)Fin * T; p.s1_f = T; p.src1_z = (long)C1 * Fin * T;
+            } else {
+                p.src1 = nullptr; p.C1 = 0;
+            }
+            p.Fin = Fin; p.Tin = T; p.B = B; p.Tout = T;
+            p.Q = (Fout - p.po + p.so - 1) / p.so;
+            p.dst = b.K; p.d_b = (long)co * Fout * T; p.d_c = (long)Fout * T; p.d_f = T; p.dst_z = kz;
+            if (rg) p.tlen = rg->tlen;
+            gc_launch_prof(pl, p, st, pf);
+        }
+        const long CP = (long)co * Fout * T;
+        const bool timed = pf->on;
+        if (timed) pf->begin(st);
+        hipLaunchKernelGGL(gauss_combine_kernel, dim3(Fout, co, B), dim3(128), 0, st, b.K, dst, co, Fout, T, kz, dst3 ? 3 * CP : 2 * CP,
+                           dst3 ? 0L : -1L, dst3 ? CP : 0L, dst3 ? 2 * CP : CP, g.sc, g.sh, g.slope, rg ? rg->tlen : nullptr);
+        SE_HIP(hipGetLastError());
+        if (timed) pf->end(st, 0.0);
+    }
+
     // spec [B][2][257][T] -> mask in b.D[NL] ([B][2][256][T])
     void network(Bufs& b, const float* spec, hipStream_t st) {
+        if (gauss_on) {
+            network_gauss(b, spec, st);
+            return;
+        }
         const int B = b.B, T = b.T;
         Profiler* pf = &ctx.prof;
         // encoder; first layer reads bins 1..256 (:166)
@@ -402,6 +612,74 @@ class Dccrn final : public Model {
             const int cin = KN[NL - k];
             Act4 a0 = act4(b.D[k], cin, F, T);
             Act4 a1 = act4(b.E[NL - 1 - k], cin, F, T);
+            run_deconv(dec[k], a0, &a1, b.D[k + 1], KN[NL - k - 1], 2 * F, B, T, T, st, pf);
+            if (k + 1 < NL && !conv_zeroes_tail(dec[k])) launch_zero_tail(b.D[k + 1], B, (long)KN[NL - k - 1] * (2 * F), T, st);
+            F *= 2;
+        }
+    }
+
+    // the same network with encoder 3 - 5 and decoder 0 - 1 as three real products; E[2..5], D[0], D[1] are three-plane tensors
+    void network_gauss(Bufs& b, const float* spec, hipStream_t st) {
+        const int B = b.B, T = b.T;
+        Profiler* pf = &ctx.prof;
+        Act4 x{spec + T, 2, 256, 2L * NBIN * T, (long)NBIN * T, (long)T};
+        int F = 256;
+        for (int k = 0; k < 3; ++k) {             // encoder 0 - 2: block form; layer 2 writes the [R | I] planes of E[2]
+            const int c = KN[k + 1] / 2;
+            float* dst = k == 2 ? b.E[k] + (long)c * (F / 2) * T : b.E[k];
+            run_conv(enc[k], x, nullptr, dst, k == 2 ? 3 * c : 2 * c, F / 2, B, T, T, st, pf);
+            if (!conv_zeroes_tail(enc[k])) launch_zero_tail(b.E[k], B, (long)(k == 2 ? 3 * c : 2 * c) * (F / 2), T, st);
+            F /= 2;
+            x = act4(b.E[k], KN[k + 1], F, T);
+        }
+        gauss_sum(b.E[2], B, KN[3] / 2, F, T, st);
+        for (int k = 3; k < NL; ++k) {            // encoder 3 - 5
+            gauss_layer(genc[k], b, b.E[k - 1], KN[k] / 2, nullptr, 0, F, F / 2, b.E[k], true, st);
+            F /= 2;
+        }
+        // ---- complex LSTM (:175-185), time-major, sequences s = part*B + b; E[5] / D[0] are three-plane (512 rows per plane)
+        const int S = 2 * B;
+        for (int part = 0; part < 2; ++part)
+            launch_transpose_akt(b.E[NL - 1] + (size_t)(1 + part) * 512 * T, b.X1 + (size_t)part * B, B, 512, T, 1536L * T, T, 512L * S,
+                                 S, st);
+        {
+            GCParams p = g1.p;
+            p.src0 = b.X1; p.s0_b = 512L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 512; p.C1 = 0;
+            p.Fin = 1; p.Tin = S; p.B = T; p.Q = 1; p.Tout = S;
+            p.dst = b.G; p.d_b = 1024L * S; p.d_c = S; p.d_f = 0;
+            gc_launch_prof(g1, p, st, pf);
+        }
+        lstm_steps(whh1, b.H1, b.G, T, S, st);
+        {
+            GCParams p = g2.p;
+            p.src0 = b.H1; p.src0_z = B; p.s0_b = 256L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 128;
+            p.src1 = b.H1 + 128L * S + B; p.src1_z = -(long)B; p.s1_b = 256L * S; p.s1_c = S; p.s1_f = 0; p.C1 = 128;
+            p.Fin = 1; p.Tin = B; p.B = T; p.Q = 1; p.Tout = B;
+            p.dst = b.G; p.dst_z = B; p.d_b = 1024L * S; p.d_c = S; p.d_f = 0;
+            gc_launch_prof(g2, p, st, pf);
+        }
+        lstm_steps(whh2, b.H2, b.G, T, S, st);
+        {
+            GCParams p = proj.p;
+            p.src0 = b.H2; p.src0_z = B; p.s0_b = 256L * S; p.s0_c = S; p.s0_f = 0; p.C0 = 128;
+            p.src1 = b.H2 + 128L * S + B; p.src1_z = -(long)B; p.s1_b = 256L * S; p.s1_c = S; p.s1_f = 0; p.C1 = 128;
+            p.Fin = 1; p.Tin = B; p.B = T; p.Q = 1; p.Tout = B;
+            p.dst = b.P; p.dst_z = 512L * B; p.d_b = 1024L * B; p.d_c = B; p.d_f = 0;
+            gc_launch_prof(proj, p, st, pf);
+        }
+        for (int part = 0; part < 2; ++part)
+            launch_transpose_akt(b.P + (size_t)part * 512 * B, b.D[0] + (size_t)(1 + part) * 512 * T, T, 512, B, 1024L * B, B, 1536L * T,
+                                 T, st);
+        gauss_sum(b.D[0], B, 128, 4, T, st);
+        launch_zero_tail(b.D[0], B, 1536L, T, st);
+        // ---- decoder: layers 0 - 1 three products (two sources: previous | skip), 2 - 5 block form
+        gauss_layer(gdec[0], b, b.D[0], 128, b.E[5], 128, 4, 8, b.D[1], true, st);
+        gauss_layer(gdec[1], b, b.D[1], 128, b.E[4], 128, 8, 16, b.D[2], false, st);
+        F = 16;
+        for (int k = 2; k < NL; ++k) {
+            const int cin = KN[NL - k];
+            Act4 a0 = act4(b.D[k], cin, F, T);
+            Act4 a1 = (NL - 1 - k) >= 2 ? view3(b.E[NL - 1 - k], cin / 2, F, T) : act4(b.E[NL - 1 - k], cin, F, T);
             run_deconv(dec[k], a0, &a1, b.D[k + 1], KN[NL - k - 1], 2 * F, B, T, T, st, pf);
             if (k + 1 < NL && !conv_zeroes_tail(dec[k])) launch_zero_tail(b.D[k + 1], B, (long)KN[NL - k - 1] * (2 * F), T, st);
             F *= 2;

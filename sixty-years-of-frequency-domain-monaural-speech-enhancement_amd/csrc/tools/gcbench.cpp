@@ -1,8 +1,12 @@
 // Micro-benchmark of the tap-table implicit-GEMM conv on one DCCRN layer shape (tuning tool, not product path).
 //   gcbench <Cin> <Cout> <Fin> <B> [T=501] [deconv=0]
 #include "../layers.h"
+#include "../kernels.h"
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 using namespace se;
@@ -68,8 +72,129 @@ static int bench_step(int H, int S) {
     return 0;
 }
 
+// gcbench gauss <Ci> <Co> <Fin> <B> [T]: a COMPLEX conv layer (Ci -> Co complex channels, DCCRN encoder geometry 5 x 2, stride 2)
+// as the reference's four real products (one real conv over the 2 x 2 block matrix: what the engine runs) against Gauss' three
+// (k1 = Wr (xr + xi), k2 = (Wi - Wr) xr, k3 = (Wr + Wi) xi; yr = k1 - k3, yi = k1 + k2) as a grouped launch of three real convs of
+// half the rows and half the K + the elementwise passes it needs (x_r + x_i in front, the combination + bias + PReLU behind).
+__global__ __launch_bounds__(256) void gauss_combine_kernel(const float* __restrict__ k, float* __restrict__ y, long plane, int Co,
+                                                            long per_c, const float* __restrict__ bias, float slope) {
+    // k [3][B][Co][P] -> y [B][2 Co][P] (+ the sum plane [B][Co][P] the next layer would consume, stored behind y)
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= plane) return;
+    const float k1 = k[i], k2 = k[plane + i], k3 = k[2 * plane + i];
+    const long b = i / ((long)Co * per_c), r = i - b * (long)Co * per_c;
+    const int c = (int)(r / per_c);
+    float yr = k1 - k3 + bias[c], yi = k1 + k2 + bias[Co + c];
+    yr = yr >= 0.f ? yr : slope * yr;
+    yi = yi >= 0.f ? yi : slope * yi;
+    y[b * 2 * Co * per_c + r] = yr;
+    y[b * 2 * Co * per_c + (long)Co * per_c + r] = yi;
+    y[2 * plane + i] = yr + yi;
+}
+static int bench_gauss(int Ci, int Co, int Fin, int B, int T) {
+    const int Fout = Fin / 2;
+    std::mt19937 rng(5);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    DenseW wr, wi;
+    for (DenseW* d : {&wr, &wi}) {
+        d->M = Co; d->Cin = Ci; d->nkf = 5; d->nkt = 2;
+        d->w.resize((size_t)Co * Ci * 10);
+        for (auto& v : d->w) v = U(rng) * 0.05f;
+        d->bias.assign(Co, 0.f);
+    }
+    for (int m = 0; m < Co; ++m) { wr.bias[m] = 0.1f * U(rng); wi.bias[m] = 0.1f * U(rng); }
+    DenseW blk = complex_expand(wr, wi);
+    const float slope = 0.25f;
+    GCPlan pblk = make_conv_plan(blk, 2, 2, 1, 1, 1, ACT_PRELU, std::vector<float>(2 * Co, slope), EPI_ACT, T);
+    // three real convs as one grouped launch (Z = 3): weights Wr, Wi - Wr, Wr + Wi; no bias, no activation
+    TapSpec ts;
+    ts.ntaps = 10;
+    for (int kf = 0; kf < 5; ++kf)
+        for (int kt = 0; kt < 2; ++kt) { ts.df[kf * 2 + kt] = kf - 2; ts.dt[kf * 2 + kt] = kt - 1; }
+    std::vector<float> w3((size_t)3 * Co * Ci * 10);
+    const size_t per = (size_t)Co * Ci * 10;
+    for (size_t i = 0; i < per; ++i) { w3[i] = wr.w[i]; w3[per + i] = wi.w[i] - wr.w[i]; w3[2 * per + i] = wr.w[i] + wi.w[i]; }
+    GCPlan pg = gc_make_plan(Co, Ci, ts, w3, {}, {}, ACT_NONE, EPI_ACT, 2, 1, 0, T, 3);
+    const size_t pin = (size_t)B * Ci * Fin * T, pout = (size_t)B * Co * Fout * T;      // one real plane set
+    std::vector<float> hx(2 * pin);
+    for (auto& v : hx) v = U(rng);
+    float *x3, *xb, *k3, *yb, *yg, *dbias;
+    SE_HIP(hipMalloc(&x3, 3 * pin * 4 + 4096));       // [S; xr; xi] each [B][Ci][F][T]
+    SE_HIP(hipMalloc(&xb, 2 * pin * 4 + 4096));       // block form [B][2 Ci][F][T]
+    SE_HIP(hipMalloc(&k3, 3 * pout * 4));
+    SE_HIP(hipMalloc(&yb, 2 * pout * 4));
+    SE_HIP(hipMalloc(&yg, 3 * pout * 4));
+    {
+        std::vector<float> bb(2 * Co);
+        for (int m = 0; m < Co; ++m) { bb[m] = wr.bias[m] - wi.bias[m]; bb[Co + m] = wr.bias[m] + wi.bias[m]; }
+        SE_HIP(hipMalloc(&dbias, bb.size() * 4));
+        SE_HIP(hipMemcpy(dbias, bb.data(), bb.size() * 4, hipMemcpyHostToDevice));
+    }
+    // xr / xi planes into both layouts
+    const size_t pc = (size_t)Ci * Fin * T;
+    std::vector<float> hb(2 * pin);
+    for (int b = 0; b < B; ++b) {
+        memcpy(&hb[(size_t)b * 2 * pc], &hx[(size_t)b * pc], pc * 4);
+        memcpy(&hb[(size_t)b * 2 * pc + pc], &hx[pin + (size_t)b * pc], pc * 4);
+    }
+    SE_HIP(hipMemcpy(xb, hb.data(), 2 * pin * 4, hipMemcpyHostToDevice));
+    SE_HIP(hipMemcpy(x3 + pin, hx.data(), 2 * pin * 4, hipMemcpyHostToDevice));
+    gc_register_overread_range(x3, 3 * pin * 4 + 4096);
+    gc_register_overread_range(xb, 2 * pin * 4 + 4096);
+    hipEvent_t e[5];
+    for (auto& ev : e) hipEventCreate(&ev);
+    auto run_block = [&]() { run_conv(pblk, act4(xb, 2 * Ci, Fin, T), nullptr, yb, 2 * Co, Fout, B, T, T, 0); };
+    auto run_sum = [&]() { launch_add(x3 + pin, x3 + 2 * pin, x3, (long)pin, 0); };
+    auto run_group = [&]() {
+        GCParams p = pg.p;
+        const Act4 a = act4(x3, Ci, Fin, T);
+        p.src0 = a.p; p.C0 = Ci; p.s0_b = a.sb; p.s0_c = a.sc; p.s0_f = a.sf; p.src1 = nullptr; p.C1 = 0;
+        p.src0_z = (long)pin; p.dst_z = (long)pout;
+        p.Fin = Fin; p.Tin = T; p.B = B; p.Q = Fout; p.Tout = T;
+        p.dst = k3; p.d_b = (long)Co * Fout * T; p.d_c = (long)Fout * T; p.d_f = T;
+        gc_launch(pg, p, 0);
+    };
+    auto run_comb = [&]() {
+        hipLaunchKernelGGL(gauss_combine_kernel, dim3((unsigned)((pout + 255) / 256)), dim3(256), 0, 0, k3, yg, (long)pout, Co,
+                           (long)Fout * T, dbias, slope);
+    };
+    for (int it = 0; it < 2; ++it) { run_block(); run_sum(); run_group(); run_comb(); }
+    SE_HIP(hipDeviceSynchronize());
+    const int reps = 5;
+    float ms[4];
+    auto timeit = [&](auto&& f, float& out) {
+        hipEventRecord(e[0], 0);
+        for (int it = 0; it < reps; ++it) f();
+        hipEventRecord(e[1], 0);
+        SE_HIP(hipEventSynchronize(e[1]));
+        hipEventElapsedTime(&out, e[0], e[1]);
+        out /= reps;
+    };
+    timeit(run_block, ms[0]);
+    timeit(run_sum, ms[1]);
+    timeit(run_group, ms[2]);
+    timeit(run_comb, ms[3]);
+    // the two results against each other
+    std::vector<float> a(2 * pout), g(2 * pout);
+    SE_HIP(hipMemcpy(a.data(), yb, 2 * pout * 4, hipMemcpyDeviceToHost));
+    SE_HIP(hipMemcpy(g.data(), yg, 2 * pout * 4, hipMemcpyDeviceToHost));
+    double se2 = 0, sa2 = 0, mx = 0;
+    for (size_t i = 0; i < 2 * pout; ++i) { const double d = (double)a[i] - g[i]; se2 += d * d; sa2 += (double)a[i] * a[i]; mx = std::max(mx, std::fabs(d)); }
+    const double fl = 2.0 * (2.0 * Co) * (2.0 * Ci) * 10.0 * B * Fout * T;     // the reference's four real products
+    printf("complex conv %d -> %d, F %d -> %d, B %d, T %d\n", Ci, Co, Fin, Fout, B, T);
+    printf("  four products (2x2 block GEMM, BM %d BN %d): %.3f ms  %.1f TFLOP/s\n", pblk.BM, pblk.BN, ms[0], fl / ms[0] / 1e9);
+    printf("  three products: x_r + x_i %.3f ms | grouped GEMM (Z = 3, BM %d BN %d) %.3f ms = %.1f TFLOP/s of its own 3/4 | combine %.3f ms\n",
+           ms[1], pg.BM, pg.BN, ms[2], 0.75 * fl / ms[2] / 1e9, ms[3]);
+    printf("  three products total: %.3f ms = %.2fx the block GEMM (with the sum written by the producer: %.3f ms = %.2fx); algorithmic %.1f TFLOP/s\n",
+           ms[1] + ms[2] + ms[3], (ms[1] + ms[2] + ms[3]) / ms[0], ms[2] + ms[3], (ms[2] + ms[3]) / ms[0], fl / (ms[2] + ms[3]) / 1e9);
+    printf("  difference of the two results: rms %.3e (relative %.3e), max %.3e\n", std::sqrt(se2 / (2 * pout)), std::sqrt(se2 / sa2), mx);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 3 && std::string(argv[1]) == "step") return bench_step(atoi(argv[2]), atoi(argv[3]));
+    if (argc > 5 && std::string(argv[1]) == "gauss")
+        return bench_gauss(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 501);
     int Cin = argc > 1 ? atoi(argv[1]) : 128, Cout = argc > 2 ? atoi(argv[2]) : 256, Fin = argc > 3 ? atoi(argv[3]) : 32;
     int B = argc > 4 ? atoi(argv[4]) : 64, T = argc > 5 ? atoi(argv[5]) : 501;
     int Fout = Fin / 2;

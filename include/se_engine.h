@@ -61,6 +61,10 @@ enum se_model_id {
  * (FullSubNet/fullsubnet_net_sa/sequence_model.py:36-43; the decode script passes "LSTM", fullsubnet_sa_decode_vb.py:16).
  * The state dict then carries the GRU's [3H, .] weight_ih / weight_hh / bias_ih / bias_hh entries. */
 #define SE_CFG_FSN_GRU 8
+/* FullSubNet with norm_type = "cumulative_laplace_norm" (FullSubNet/fullsubnet_net_sa/base_model.py:212-240, selected at
+ * :296-303) instead of the decode script's "offline_laplace_norm": every input is divided by its running mean over the frames
+ * seen so far.  The network is then causal up to its look_ahead = 2 frames, and se_stream_* accepts the engine. */
+#define SE_CFG_FSN_CUMULATIVE 16
 
 typedef struct se_config {
     int32_t model;        /* enum se_model_id */

@@ -79,7 +79,7 @@ ENHANCE = {
 }
 
 
-def enhance_fullsubnet(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+def enhance_fullsubnet(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32, norm_type='offline_laplace_norm'):
     """FullSubNet/fullsubnet_sa_decode_vb.py:37-72 (the computed tail pad :42-45 is never applied)."""
     wav = np.asarray(wav, dtype=np.float64)
     c = S.rms_scale(wav)                                                 # :38
@@ -90,7 +90,7 @@ def enhance_fullsubnet(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
     ph = np.arctan2(im, re)
     fr, fi = mag * np.cos(ph), mag * np.sin(ph)                          # :52
     fmag = np.sqrt(fr ** 2 + fi ** 2)[None, None]                        # :54
-    mask = M.fullsubnet_forward(sd, fmag)                                # :56
+    mask = M.fullsubnet_forward(sd, fmag, norm_type=norm_type)           # :56
     mr, mi = mask[0, 0], mask[0, 1]
     er = mr * fr - mi * fi                                               # :59-60
     ei = mr * fi + mi * fr

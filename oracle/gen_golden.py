@@ -297,7 +297,7 @@ def gen_dccrn():
     save('dccrn', x=x, y=y, wav=wav, enh=enh, enh_cprs=enh_c, enh4_cprs=enh4.astype(np.float32))
 
 
-def _fsn_model(sequence_model="LSTM"):
+def _fsn_model(sequence_model="LSTM", norm_type="offline_laplace_norm"):
     install_stubs()
     scratch = '/tmp/se_golden_scratch'
     os.makedirs(scratch, exist_ok=True)
@@ -311,7 +311,7 @@ def _fsn_model(sequence_model="LSTM"):
         sys.path.pop(0)
     return mod.Model(sb_num_neighbors=15, fb_num_neighbors=0, num_freqs=257, look_ahead=2, sequence_model=sequence_model,
                      fb_output_activate_function="ReLU", sb_output_activate_function=None, fb_model_hidden_size=512,
-                     sb_model_hidden_size=384, weight_init=True, norm_type="offline_laplace_norm",
+                     sb_model_hidden_size=384, weight_init=True, norm_type=norm_type,
                      num_groups_in_drop_band=2)
 
 
@@ -354,6 +354,26 @@ def gen_fullsubnet():
     save('fullsubnet', x=np.concatenate([x, x2]), y=np.concatenate([y, y2]), wav=wav,
          enh=_enhance_fullsubnet(model, wav, 1.0, 1.0), enh_cprs=_enhance_fullsubnet(model, wav, 0.5, 2.0))
     save_full('fullsubnet', 207, lambda w: _enhance_fullsubnet(model, w, 0.5, 2.0))
+
+
+def gen_fullsubnet_cum():
+    """Model(norm_type="cumulative_laplace_norm") - FullSubNet/fullsubnet_net_sa/base_model.py:212-240, :296-303: the causal
+    normalisation (same parameters, same key schema as the decode script's model); forward + decode, and a 2 s clip for the
+    frame-online mode."""
+    if FULL_ONLY:
+        return
+    model = _fsn_model(norm_type="cumulative_laplace_norm")
+    load_synth(model, 15)
+    rng = np.random.default_rng(29)
+    x = np.abs(rng.standard_normal((1, 1, 257, 11))).astype(np.float32)
+    x2 = np.abs(rng.standard_normal((1, 1, 257, 11))).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+        y2 = model(torch.from_numpy(x2)).numpy()
+    wav = synth.synth_clip(9, 'speech', 6000)
+    wav2 = synth.synth_clip(10, 'speech', 32000)
+    save('fullsubnet_cum', x=np.concatenate([x, x2]), y=np.concatenate([y, y2]), wav=wav,
+         enh_cprs=_enhance_fullsubnet(model, wav, 0.5, 2.0), wav2=wav2, enh2_cprs=_enhance_fullsubnet(model, wav2, 0.5, 2.0))
 
 
 def gen_fullsubnet_gru():
@@ -549,7 +569,7 @@ def gen_g2net_new():
     gen_g2net('G2Net_new', '_new')
 
 
-GENS = {'stft': gen_stft, 'fullsubnet_gru': gen_fullsubnet_gru, 'ctsnet_new': gen_ctsnet_new, 'taylorsenet_new': gen_taylorsenet_new, 'g2net_new': gen_g2net_new, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+GENS = {'stft': gen_stft, 'fullsubnet_cum': gen_fullsubnet_cum, 'fullsubnet_gru': gen_fullsubnet_gru, 'ctsnet_new': gen_ctsnet_new, 'taylorsenet_new': gen_taylorsenet_new, 'g2net_new': gen_g2net_new, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

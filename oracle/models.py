@@ -247,13 +247,30 @@ def _fsn_seq(sd, p, x, act):
     return np.swapaxes(o, 1, 2)
 
 
-def fullsubnet_forward(sd, noisy_mag, look_ahead=2, sb_nn=15, fb_nn=0):
-    """noisy_mag [B,1,257,T] -> complex mask [B,2,257,T]; every utterance processed with batch-1 semantics."""
+def _fsn_cumulative_laplace_norm(a):
+    """BaseModel.cumulative_laplace_norm (base_model.py:212-240): a [B,C,F,T] / (mean over (F, frames <= t) per (b, c) + EPSILON);
+    float32 sums in the reference's order (sum over F, then a running sum over t)."""
+    B, C, F, T = a.shape
+    x = a.reshape(B * C, F, T).astype(np.float32)
+    step = x.sum(axis=1, dtype=np.float32)                                               # :223
+    cum = np.cumsum(step, axis=-1, dtype=np.float32)                                     # :224
+    count = np.arange(F, F * T + 1, F, dtype=np.float32)[None, :]                        # :226-233
+    mean = (cum / count)[:, None, :]                                                     # :235-236
+    return (x / (mean + np.finfo(np.float32).eps)).reshape(B, C, F, T)                   # :238 (constant.py:8 EPSILON)
+
+
+def fullsubnet_forward(sd, noisy_mag, look_ahead=2, sb_nn=15, fb_nn=0, norm_type='offline_laplace_norm'):
+    """noisy_mag [B,1,257,T] -> complex mask [B,2,257,T]; every utterance processed with batch-1 semantics.
+    norm_type: 'offline_laplace_norm' (the decode script's, base_model.py:197-209) or 'cumulative_laplace_norm' (:212-240, the
+    causal one: with it the network only looks `look_ahead` frames ahead)."""
     outs = []
     for b in range(noisy_mag.shape[0]):
         x = np.pad(noisy_mag[b:b + 1], ((0, 0), (0, 0), (0, 0), (0, look_ahead)))          # :79
         _, _, F, T = x.shape
-        norm = lambda a: a / (a.mean(axis=(1, 2, 3), keepdims=True) + 1e-5)               # offline_laplace_norm
+        if norm_type == 'cumulative_laplace_norm':
+            norm = _fsn_cumulative_laplace_norm
+        else:
+            norm = lambda a: a / (a.mean(axis=(1, 2, 3), keepdims=True) + 1e-5)           # offline_laplace_norm
         fb_in = norm(x).reshape(1, F, T)                                                  # :84
         fb_out = _fsn_seq(sd, 'fb_model.', fb_in, 'ReLU').reshape(1, 1, F, T)             # :85
         fb_unf = _fsn_unfold(fb_out, fb_nn).reshape(1, F, 2 * fb_nn + 1, T)               # :88-89

@@ -462,7 +462,7 @@ static int stream_begin_impl(se_engine* e, int32_t batch, int32_t max_chunk_fram
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
-        SE_CHECK(e->model->stream_supported(), "this model has no frame-online mode (CRN, LSTM, GCRN, DPCRN, DCCRN and the cLN `_new` weights of CTSNet / TaylorSENet / G2Net have)");
+        SE_CHECK(e->model->stream_supported(), "this model has no frame-online mode (CRN, LSTM, GCRN, DPCRN, DCCRN, FullSubNet with the cumulative norm and the cLN `_new` weights of CTSNet / TaylorSENet / G2Net have)");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         const StftGeom& g = e->ctx.geom;
         SE_CHECK((g.n_fft + g.hop - 1) / g.hop - 1 + e->model->stream_lag() <= e->model->stream_hc(),

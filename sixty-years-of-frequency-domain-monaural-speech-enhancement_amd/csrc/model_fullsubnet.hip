@@ -129,6 +129,76 @@ __global__ __launch_bounds__(256) void fsn_mask_kernel(const float* __restrict__
     out[o + plane] = ei;
 }
 
+// ---- cumulative_laplace_norm (base_model.py:212-240): x / (mean over (features, frames <= t) + EPSILON), float32 sums in the
+// reference's order - the features of a frame first, then a running sum over the frames.  `csum` (optional) carries the running
+// sum across the chunks of a frame-online stream; step 0 of the call is frame t_first of the utterance.
+constexpr float FSN_EPS = 1.1920928955078125e-07f;        // np.finfo(np.float32).eps (constant.py:8)
+// full band: x / y [n][257][B] time-major, one workgroup per utterance
+__global__ __launch_bounds__(256) void fsn_cum_fb_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int B,
+                                                         float* __restrict__ csum, int t_first) {
+    __shared__ float part[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float run = (csum && t_first > 0) ? csum[b] : 0.f;
+    for (int t = 0; t < n; ++t) {
+        const float* xr = x + (long)t * NBIN * B + b;
+        const float v0 = xr[(long)tid * B], v1 = tid + 256 < NBIN ? xr[(long)(tid + 256) * B] : 0.f;
+        float s = v0 + v1;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) part[tid >> 6] = s;
+        __syncthreads();
+        run += (part[0] + part[1]) + (part[2] + part[3]);
+        const float d = run / ((float)NBIN * (float)(t_first + t + 1)) + FSN_EPS;
+        float* yr = y + (long)t * NBIN * B + b;
+        yr[(long)tid * B] = v0 / d;
+        if (tid + 256 < NBIN) yr[(long)(tid + 256) * B] = v1 / d;
+    }
+    if (csum && tid == 0) csum[b] = run;
+}
+// sub bands: sb [n][32][S] in place, one thread per sequence s (sub-band of an utterance)
+__global__ __launch_bounds__(256) void fsn_cum_sb_kernel(float* __restrict__ sb, int n, int S, float* __restrict__ csum, int t_first) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    float run = (csum && t_first > 0) ? csum[s] : 0.f;
+    for (int t = 0; t < n; ++t) {
+        float* xr = sb + (long)t * SBW * S + s;
+        float v[SBW], sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < SBW; ++k) {
+            v[k] = xr[(long)k * S];
+            sum += v[k];
+        }
+        run += sum;
+        const float d = run / ((float)SBW * (float)(t_first + t + 1)) + FSN_EPS;
+#pragma unroll
+        for (int k = 0; k < SBW; ++k) xr[(long)k * S] = v[k] / d;
+    }
+    if (csum) csum[s] = run;
+}
+// frame-online: mask of network step tau (maskT [ns][2][S], s = n B + b) applied to the spectrum of frame tau - LA, which sits in
+// column col0 + tau of the chunk window ([B][2][257][Tw]); frames before the start of the stream (gt0 + tau < LA) do not exist
+__global__ __launch_bounds__(256) void fsn_stream_apply_kernel(const float* __restrict__ maskT, const float* __restrict__ spec,
+                                                               float* __restrict__ est, int B, int Tw, int ns, int col0, int gt0,
+                                                               float p_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x, tau = blockIdx.y;
+    const int S = NBIN * B;
+    if (i >= S || gt0 + tau < LA) return;
+    const int n = i / B, b = i - n * B, col = col0 + tau;
+    const float mr = maskT[((long)tau * 2) * S + i], mi = maskT[((long)tau * 2 + 1) * S + i];
+    const long o = (((long)b * 2) * NBIN + n) * Tw + col, plane = (long)NBIN * Tw;
+    const float xr = spec[o], xi = spec[o + plane];
+    float er = mr * xr - mi * xi, ei = mr * xi + mi * xr;
+    if (p_out != 1.f) {
+        const float mg = sqrtf(er * er + ei * ei);
+        const float sc = mg > 0.f ? ((p_out == 2.f) ? mg : powf(mg, p_out - 1.f)) : 0.f;
+        er *= sc;
+        ei *= sc;
+    }
+    est[o] = er;
+    est[o + plane] = ei;
+    (void)ns;
+}
+
 class FullSubNet final : public Model {
   public:
     explicit FullSubNet(EngineCtx& c) : Model(c) {}
@@ -144,6 +214,8 @@ class FullSubNet final : public Model {
         const int S = NBIN * ctx.max_batch;
         // sequence_model = "LSTM" (the decode script's choice, fullsubnet_sa_decode_vb.py:16) or "GRU" (sequence_model.py:36-43)
         const bool gru = (ctx.flags & SE_CFG_FSN_GRU) != 0;
+        cum = (ctx.flags & SE_CFG_FSN_CUMULATIVE) != 0;      // norm_type = "cumulative_laplace_norm" (base_model.py:212-240)
+        is_gru = gru;
         auto load = [&](const std::string& p, int layer, int I, int H) {
             return gru ? load_gru(sd, p, layer, "", I, H) : load_lstm(sd, p, layer, "", I, H);
         };
@@ -185,7 +257,69 @@ class FullSubNet final : public Model {
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :69-72
     }
 
+    // ---- frame-online mode (model.h), with the cumulative norm only: every operator is then causal and the network looks
+    // look_ahead = 2 frames ahead (model.py:79, :117 - the mask of frame t is the output of step t + 2).  A chunk of n new
+    // frames runs n network steps and finalises the estimate of frames [t0 - 2, t0 + n - 2) (stream_lag); the chunk that ends
+    // the stream runs two more steps on the zero frames the offline forward pads.  State: the two running sums of the norms
+    // (per utterance / per sub-band sequence), (h, c) of the four LSTM layers, the last columns of spectrum and estimate.
+    static constexpr int STREAM_TP_MAX = 64;      // longest window (frames incl. look-ahead) whose sub-band gate tensor is always kept
+    bool stream_supported() const override { return cum && !is_gru; }
+    int stream_lag() const override { return LA; }
+    void stream_begin(int B, int max_chunk, hipStream_t st) override {
+        SE_CHECK(STREAM_HC + max_chunk + LA <= STREAM_TP_MAX, "FullSubNet frame-online mode: chunks of at most 58 frames");
+        ss.release();
+        ss.B = B;
+        ss.first = true;
+        const size_t S = (size_t)NBIN * B;
+        ss.hist.push_back(ss.zeros((size_t)B * 2 * NBIN * STREAM_HC, st));      // spectrum
+        ss.hist.push_back(ss.zeros((size_t)B * 2 * NBIN * STREAM_HC, st));      // estimate
+        ss.hist.push_back(ss.zeros((size_t)B, st));                             // running sum of the full-band norm
+        ss.hist.push_back(ss.zeros(S, st));                                     // ... of the sub-band norm
+        for (int l = 0; l < 2; ++l) {
+            ss.h[l] = ss.zeros((size_t)512 * B, st);
+            ss.c[l] = ss.zeros((size_t)512 * B, st);
+            ss.h[2 + l] = ss.zeros(384 * S, st);
+            ss.c[2 + l] = ss.zeros(384 * S, st);
+        }
+    }
+    void stream_bufs(int B, int n, float** spec, float** mag, float** est) override {
+        Bufs& b = bufs(B, STREAM_HC + n);
+        *spec = b.spec;
+        *mag = b.mag;
+        *est = b.est;
+    }
+    void stream_chunk(int B, int t0, int n, hipStream_t st, bool last) override {
+        SE_CHECK(ss.B == B && ss.hist.size() == 4, "stream_chunk without stream_begin");
+        const int HC = STREAM_HC, Tw = HC + n, S = NBIN * B;
+        const int ns = n + (last ? LA : 0);                 // network steps of this chunk
+        SE_CHECK(Tw + LA <= STREAM_TP_MAX, "FullSubNet frame-online mode: chunk too long");
+        Bufs& b = bufs(B, Tw);
+        Profiler* pf = &ctx.prof;
+        launch_hist_restore(b.spec, ss.hist[0], B, 2L * NBIN, Tw, HC, st);
+        launch_hist_restore(b.est, ss.hist[1], B, 2L * NBIN, Tw, HC, st);
+        // magnitudes of the new frames, time-major [ns][257][B]; at the end of the stream two zero frames (model.py:79)
+        launch_transpose_akt(b.mag + HC, b.magT, B, NBIN, n, (long)NBIN * Tw, Tw, (long)NBIN * B, B, st);
+        if (last) launch_fill(b.magT + (size_t)n * S, (long)LA * S, 0.f, st);
+        hipLaunchKernelGGL(fsn_cum_fb_kernel, dim3(B), dim3(256), 0, st, b.magT, b.xfb, ns, B, ss.hist[2], t0);
+        fb[0].run_stream(b.xfb, b.G, ss.c[0], ss.h[0], b.h[0], ns, B, ss.first, st, pf);
+        fb[1].run_stream(b.h[0], b.G, ss.c[1], ss.h[1], b.h[1], ns, B, ss.first, st, pf);
+        run_pointwise(fb_fc, b.h[1], 512L * B, B, b.fbo, (long)NBIN * B, B, ns, B, st, pf);
+        hipLaunchKernelGGL(fsn_build_sb_kernel, dim3((S + 255) / 256, SBW, ns), dim3(256), 0, st, b.magT, b.fbo, b.sb, B);
+        hipLaunchKernelGGL(fsn_cum_sb_kernel, dim3((S + 255) / 256), dim3(256), 0, st, b.sb, ns, S, ss.hist[3], t0);
+        sbl[0].run_stream(b.sb, b.G, ss.c[2], ss.h[2], b.h[0], ns, S, ss.first, st, pf);
+        sbl[1].run_stream(b.h[0], b.G, ss.c[3], ss.h[3], b.h[1], ns, S, ss.first, st, pf);
+        run_pointwise(sb_fc, b.h[1], 384L * S, S, b.maskT, 2L * S, S, ns, S, st, pf);
+        hipLaunchKernelGGL(fsn_stream_apply_kernel, dim3((S + 255) / 256, ns), dim3(256), 0, st, b.maskT, b.spec, b.est, B, Tw, ns,
+                           HC - LA, t0, ctx.p_out);
+        SE_HIP(hipGetLastError());
+        launch_hist_save(b.spec, ss.hist[0], B, 2L * NBIN, Tw, HC, st);
+        launch_hist_save(b.est, ss.hist[1], B, 2L * NBIN, Tw, HC, st);
+        ss.first = false;
+    }
+
   private:
+    StreamState ss;
+    bool cum = false, is_gru = false;
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *mag, *est, *frames, *mu, *mu2, *part;
@@ -216,7 +350,8 @@ class FullSubNet final : public Model {
         b.sb = a.alloc_f(Tp * SBW * S);
         // gate pre-activations: the full-band layers' [Tp][2048][B]; the sub-band layers' [Tp][1536][S] only when they do not
         // project their inputs inside the step GEMM (51 GB at 128 clips)
-        const bool sb_gates = !(fuse_x_on(B) && sbl[0].has_x && sbl[1].has_x);
+        // (a frame-online window - a few frames - always keeps them: the streamed steps go through LstmBig::run_stream)
+        const bool sb_gates = !(fuse_x_on(B) && sbl[0].has_x && sbl[1].has_x) || (cum && Tp <= STREAM_TP_MAX);
         b.G = a.alloc_f(sb_gates ? Tp * 1536 * S : Tp * 2048 * (size_t)B);
         b.h[0] = a.alloc_f(Tp * 384 * S);               // also the full-band hidden [Tp][512][B]
         b.h[1] = a.alloc_f(Tp * 384 * S);
@@ -244,11 +379,14 @@ class FullSubNet final : public Model {
         // ---- full-band model (model.py:84-85): utterance-mean normalisation, LSTM(257->512)x2, Linear + ReLU
         const Ragged* rg = ragged_ctx();
         const int* tlen = rg ? rg->tlen : nullptr;
-        hipLaunchKernelGGL(fsn_mean_kernel, dim3(B), dim3(256), 0, st, mag, NBIN * T, (float)NBIN * Tp, b.mu, tlen);
+        if (!cum) hipLaunchKernelGGL(fsn_mean_kernel, dim3(B), dim3(256), 0, st, mag, NBIN * T, (float)NBIN * Tp, b.mu, tlen);
         launch_fill(b.magT + (size_t)T * S, (long)LA * S, 0.f, st);                                // look-ahead pad :79 (a kernel, not a memset node: graph-replay safe)
         launch_transpose_akt(mag, b.magT, B, NBIN, T, (long)NBIN * T, T, (long)NBIN * B, B, st);
         const long nfb = (long)Tp * S;
-        hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nfb + 255) / 256)), dim3(256), 0, st, b.magT, b.xfb, nfb, B, b.mu);
+        // (cumulative norm, ragged rows: frames >= tlen[b] are zeros - the STFT wrote them - and everything is causal, so a
+        // row's own frames and its two look-ahead frames see exactly what the clip decoded alone sees)
+        if (cum) hipLaunchKernelGGL(fsn_cum_fb_kernel, dim3(B), dim3(256), 0, st, b.magT, b.xfb, Tp, B, (float*)nullptr, 0);
+        else hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nfb + 255) / 256)), dim3(256), 0, st, b.magT, b.xfb, nfb, B, b.mu);
         fb[0].run(b.xfb, b.G, b.cell, b.h[0], Tp, B, st, pf);
         fb[1].run(b.h[0], b.G, b.cell, b.h[1], Tp, B, st, pf);
         run_pointwise(fb_fc, b.h[1], 512L * B, B, b.fbo, (long)NBIN * B, B, Tp, B, st, pf);
@@ -256,10 +394,14 @@ class FullSubNet final : public Model {
         hipLaunchKernelGGL(fsn_build_sb_kernel, dim3((S + 255) / 256, SBW, Tp), dim3(256), 0, st, b.magT, b.fbo, b.sb, B);
         const long rows = (long)Tp * SBW * NBIN;
         SE_CHECK(B <= 256, "FullSubNet batch per call is limited to 256 utterances");
-        hipLaunchKernelGGL(fsn_colsum_kernel, dim3(FSN_SUM_BLOCKS), dim3(256), 0, st, b.sb, rows, B, b.part, tlen);
-        hipLaunchKernelGGL(fsn_finish_mean_kernel, dim3(1), dim3(256), 0, st, b.part, b.mu2, (float)rows, B, tlen);
-        const long nsb = rows * B;
-        hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, st, b.sb, b.sb, nsb, B, b.mu2);
+        if (cum) {
+            hipLaunchKernelGGL(fsn_cum_sb_kernel, dim3((S + 255) / 256), dim3(256), 0, st, b.sb, Tp, S, (float*)nullptr, 0);
+        } else {
+            hipLaunchKernelGGL(fsn_colsum_kernel, dim3(FSN_SUM_BLOCKS), dim3(256), 0, st, b.sb, rows, B, b.part, tlen);
+            hipLaunchKernelGGL(fsn_finish_mean_kernel, dim3(1), dim3(256), 0, st, b.part, b.mu2, (float)rows, B, tlen);
+            const long nsb = rows * B;
+            hipLaunchKernelGGL(fsn_scale_kernel, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, st, b.sb, b.sb, nsb, B, b.mu2);
+        }
         SE_HIP(hipGetLastError());
         // ---- sub-band model (:106-114): LSTM(32->384)x2 over 257*B sequences, Linear(384->2)
         // The 257 * B sequences are independent: two column halves run on two streams, so that the short per-step

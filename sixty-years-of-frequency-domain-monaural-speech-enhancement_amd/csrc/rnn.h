@@ -100,7 +100,10 @@ struct StreamState {
             p = it->second;
             parked.erase(it);
         } else {
-            SE_HIP(hipMalloc(&p, n * sizeof(float)));
+            // (+ 16 B and registered with gemmconv: a step GEMM stages its h_{t-1} rows in 16 B groups, and the last group of a
+            // row whose sequence count is no multiple of 4 reaches up to 12 B past the tensor)
+            SE_HIP(hipMalloc(&p, (n + 4) * sizeof(float)));
+            gc_register_overread_range(p, (n + 4) * sizeof(float));
             size_of[p] = n;
         }
         SE_HIP(hipMemsetAsync(p, 0, n * sizeof(float), st));
@@ -108,7 +111,10 @@ struct StreamState {
     }
     ~StreamState() {
         release();
-        for (auto& kv : parked) (void)hipFree(kv.second);
+        for (auto& kv : parked) {
+            gc_unregister_overread_range(kv.second);
+            (void)hipFree(kv.second);
+        }
     }
 };
 

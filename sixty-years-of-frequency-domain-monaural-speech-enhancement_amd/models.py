@@ -107,9 +107,11 @@ class dpcrn(_EngineModule):
 class Model(_EngineModule):
     """FullSubNet/fullsubnet_net_sa/model.py:9 `Model(...)` as built at fullsubnet_sa_decode_vb.py:11-24.
     forward: magnitude [B,1,257,T] -> complex mask [B,2,257,T]; each utterance gets batch-1 semantics.
-    sequence_model: "LSTM" (the decode script's) or "GRU" (sequence_model.py:36-43; SE_CFG_FSN_GRU)."""
+    sequence_model: "LSTM" (the decode script's) or "GRU" (sequence_model.py:36-43; SE_CFG_FSN_GRU); norm_type:
+    "offline_laplace_norm" (the decode script's) or "cumulative_laplace_norm" (base_model.py:212-240; SE_CFG_FSN_CUMULATIVE)."""
     _model = 'fullsubnet'
     SE_CFG_FSN_GRU = 8
+    SE_CFG_FSN_CUMULATIVE = 16
 
     def __init__(self, num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
                  fb_output_activate_function="ReLU", sb_output_activate_function=None, fb_model_hidden_size=512,
@@ -117,9 +119,13 @@ class Model(_EngineModule):
                  weight_init=True, **kw):
         cfg = (num_freqs, look_ahead, fb_num_neighbors, sb_num_neighbors, fb_output_activate_function,
                sb_output_activate_function, fb_model_hidden_size, sb_model_hidden_size, norm_type)
-        if cfg != (257, 2, 0, 15, "ReLU", None, 512, 384, "offline_laplace_norm") or sequence_model not in ("LSTM", "GRU"):
+        if (cfg[:-1] != (257, 2, 0, 15, "ReLU", None, 512, 384) or sequence_model not in ("LSTM", "GRU")
+                or norm_type not in ("offline_laplace_norm", "cumulative_laplace_norm")):
             raise NotImplementedError("the engine builds the decode script's FullSubNet configuration (sequence model LSTM "
-                                      "or GRU); got " + repr(cfg + (sequence_model,)))
+                                      "or GRU, norm offline_laplace_norm or cumulative_laplace_norm); got "
+                                      + repr(cfg + (sequence_model,)))
+        if norm_type == "cumulative_laplace_norm":      # base_model.py:212-240: causal - the engine then also streams (se_stream_*)
+            kw['flags'] = kw.get('flags', 0) | self.SE_CFG_FSN_CUMULATIVE
         if sequence_model == "GRU":
             kw['flags'] = kw.get('flags', 0) | self.SE_CFG_FSN_GRU
             self.__class__ = _ModelGRU            # same engine model, the GRU's [3H, .] key schema

@@ -76,6 +76,65 @@ def test_fullsubnet_gru_sequence_model():
         Model(max_batch=1, max_samples=8000, **kw).load_state_dict(synth.synth_state_dict(Model().state_dict_schema(), 15))
 
 
+FSN_KW = dict(sb_num_neighbors=15, fb_num_neighbors=0, num_freqs=257, look_ahead=2, sequence_model="LSTM",
+              fb_output_activate_function="ReLU", sb_output_activate_function=None, fb_model_hidden_size=512,
+              sb_model_hidden_size=384, weight_init=True, num_groups_in_drop_band=2)
+
+
+def test_fullsubnet_cumulative_norm_and_frame_online():
+    """`Model(norm_type="cumulative_laplace_norm")` (base_model.py:212-240, SE_CFG_FSN_CUMULATIVE): forward and decode against
+    the reference-generated fixture, a ragged pair against the oracle, and the frame-online mode (look_ahead = 2 frames: the
+    engine finalises its estimate two frames late) - a 2 s clip pushed in pieces equals the offline decode, which the fixture
+    pins to the reference's own output; the decode script's offline norm stays un-streamable."""
+    torch = _torch()
+    from se_amd.models import Model
+    from oracle import decode as D
+    G = load_golden('fullsubnet_cum')
+    m = Model(max_batch=2, max_samples=32000, p_in=0.5, p_out=2.0, norm_type="cumulative_laplace_norm", **FSN_KW).load_synthetic(15)
+    y = m(torch.from_numpy(G['x']).cuda()).cpu().numpy()
+    err = rms(y - G['y'])
+    print('fullsubnet cumulative forward rms err', err, 'rms ref', rms(G['y']))
+    assert y.shape == G['y'].shape and err < 2e-5 * max(rms(G['y']), 1.0)
+    other = synth.synth_clip(62, 'white', 5000)
+    x = np.zeros((2, 6000), np.float32)
+    x[0], x[1, :5000] = G['wav'], other
+    out = m.enhance_ragged(torch.from_numpy(x).cuda(), [6000, 5000]).cpu().numpy()
+    err = rms(out[0] - G['enh_cprs'])
+    print('fullsubnet cumulative decode rms err', err, 'rms ref', rms(G['enh_cprs']))
+    assert err < 1e-4 and err < 5e-4 * max(rms(G['enh_cprs']), 1e-3)
+    sd = synth.synth_state_dict(m.state_dict_schema(), 15)
+    ref = D.ENHANCE['fullsubnet'](sd, other, 0.5, 2.0, norm_type='cumulative_laplace_norm')
+    assert rms(out[1, :5000] - ref) < 1e-4 and rms(out[1, :5000] - ref) < 5e-4 * max(rms(ref), 1e-3)
+    # ---- frame-online: two streams (the fixture's 2 s clip and another), pieces of 10 ms ... 0.4 s, chunks of up to 5 frames
+    L = 32000
+    xs = np.stack([G['wav2'], synth.synth_clip(63, 'speech', L)])
+    xt = torch.from_numpy(xs).cuda()
+    off = m.enhance_batch(xt).cpu().numpy()
+    e0 = rms(off[0] - G['enh2_cprs'])
+    assert e0 < 1e-4 and e0 < 5e-4 * max(rms(G['enh2_cprs']), 1e-3), e0
+    eng = m.engine
+    for pieces, chunk in (([160, 37, 3000, 7, 6400], 5), ([4000], 16)):
+        eng.stream_begin(2, c=eng.rms_scale(xt), max_chunk_frames=chunk)
+        outs, pos, fed, emitted = [], 0, 0, 0
+        k = 0
+        while pos < L:
+            n = min(pieces[min(k, len(pieces) - 1)], L - pos)
+            outs.append(eng.stream_push(xt[:, pos:pos + n].contiguous()).cpu().numpy())
+            pos += n
+            k += 1
+            fed, emitted = pos, emitted + outs[-1].shape[1]
+            # output arrives within half a window + (look-ahead + 2) hops of the input
+            assert emitted >= fed - 257 - 4 * 256 or fed < 512, (fed, emitted)
+        outs.append(eng.stream_flush().cpu().numpy())
+        got = np.concatenate(outs, axis=1)
+        assert got.shape == off.shape, (got.shape, off.shape)
+        e = rms(got - off)
+        print('fullsubnet cumulative streamed vs offline rms err', e, 'rms ref', rms(off))
+        assert e < 1e-6 + 2e-5 * rms(off), (e, rms(off))
+    with pytest.raises(RuntimeError):                       # the decode script's utterance-mean norm is not causal
+        Model(max_batch=1, max_samples=8000, norm_type="offline_laplace_norm", **FSN_KW).load_synthetic(15).engine.stream_begin(1)
+
+
 def test_dpcrn_real_checkpoint_forward_and_decode():
     """Real weights: vb_dpcrn_noncprs (1.0/1.0) and vb_dpcrn_cprs (0.5/2.0) on a full 4 s clip."""
     torch = _torch()

@@ -75,6 +75,18 @@ def test_fullsubnet_gru_matches_reference():
     assert e.shape == G['enh_cprs'].shape and rms(e - G['enh_cprs']) < 1e-6 * max(rms(G['enh_cprs']), 1e-3)
 
 
+def test_fullsubnet_cumulative_norm_matches_reference():
+    """`Model(norm_type="cumulative_laplace_norm")` (FullSubNet/fullsubnet_net_sa/base_model.py:212-240, :296-303): the causal
+    norm behind the frame-online mode - forward and two decodes of the imported reference (seeded weights of the same schema)."""
+    G = load_golden('fullsubnet_cum')
+    sd = _sd('fullsubnet', 15)
+    y = M.fullsubnet_forward(sd, G['x'], norm_type='cumulative_laplace_norm')
+    assert y.shape == G['y'].shape and rms(y - G['y']) < 2e-6 * max(rms(G['y']), 1.0)
+    assert rms(M.fullsubnet_forward(sd, G['x']) - G['y']) > 1e-3 * rms(G['y'])          # (the offline norm is a different function)
+    e = D.ENHANCE['fullsubnet'](sd, G['wav'], 0.5, 2.0, norm_type='cumulative_laplace_norm')
+    assert e.shape == G['enh_cprs'].shape and rms(e - G['enh_cprs']) < 1e-6 * max(rms(G['enh_cprs']), 1e-3)
+
+
 def test_dccrn_compressed_variant():
     G = load_golden('dccrn')
     y = D.enhance_dccrn(_sd('dccrn', 14), G['wav'], 0.5, 2.0)

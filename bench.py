@@ -38,7 +38,8 @@ def dccrn_conv_bytes(B, T=501):
     launch reads its input activations once and writes its output once (fp32; weights are < 0.1 %).  Encoder: 6 convs;
     decoder: 5 transposed convs = 2 frequency-parity launches each, both reading the (previous, skip) pair, and the last
     one (64 -> 2 channels) as one launch for both classes; LSTM input / output projections: 3 launches.  Channels are real
-    counts (complex = 2 x)."""
+    counts (complex = 2 x).  The layers that run as three real products add x_r + x_i planes and k1..k3 tensors
+    that are written and read back: implementation traffic, part of `traffic` (PMC), not of this figure."""
     ch = [2, 32, 64, 128, 256, 256, 256]
     F = [257, 129, 65, 33, 17, 9, 5]
     act = [ch[i] * F[i] * T for i in range(7)]                 # floats per utterance at each encoder level
@@ -336,7 +337,8 @@ def main():
             pmc = pmc_traffic()
             rd_b, wr_b = dccrn_conv_bytes(B)
             res["roofline"] = {
-                "bound": "mfma", "kernel": "se::gc_kernel<BM,BN,..> (f32-MFMA tap-table implicit-GEMM conv)",
+                "bound": "mfma", "kernel": "se::gc_kernel<BM,BN,..> (f32-MFMA tap-table implicit-GEMM conv; the 128- / 256-channel "
+                                           "complex layers as three real products + sum / combine passes, counted in the family)",
                 "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": pmc['traffic_GB_per_launch'] if pmc and B == 256 else None,
@@ -347,6 +349,11 @@ def main():
                 "algorithmic_gflop_per_step": round(prof['gemm_flops'] / 1e9, 1),
                 "algorithmic_gflop_note": "counted on the clips' own frame count (T = 501), not on the 504 frames the engine "
                                           "runs to keep rows whole 16 B groups",
+                "algorithmic_flops_note": "SURVEY 8(d) counts four real products per complex product; encoder layers 4-6 and "
+                                          "decoder layers 1-2 execute three (Gauss, DESIGN 3.6), so the matrix cores execute "
+                                          "fewer flops than `achieved` prices: executed_mfma_tflop_per_step is the PMC count "
+                                          "(SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, padded tile rows included)",
+                "executed_mfma_tflop_per_step": pmc.get('executed_mfma_tflop_per_step') if pmc and B == 256 else None,
                 "profiler_events_in_timed_region": True,
                 "traffic_source_commit": pmc.get('commit') if pmc else None,
                 "kernel_ms_per_step": round(prof['gemm_ms'], 3),

@@ -65,6 +65,11 @@ enum se_model_id {
  * :296-303) instead of the decode script's "offline_laplace_norm": every input is divided by its running mean over the frames
  * seen so far.  The network is then causal up to its look_ahead = 2 frames, and se_stream_* accepts the engine. */
 #define SE_CFG_FSN_CUMULATIVE 16
+/* DCCRN(masking_mode=...) (DCCRN/DCCRN_cprs.py:205-223): 'E' (default, the decode script's: tanh-bounded magnitude mask and
+ * phase rotation), 'C' (complex ratio mask: est = spec x mask), 'R' (one real mask per part: est_r = spec_r mask_r, est_i =
+ * spec_i mask_i).  At most one of the two bits. */
+#define SE_CFG_DCCRN_MASK_C 32
+#define SE_CFG_DCCRN_MASK_R 64
 
 typedef struct se_config {
     int32_t model;        /* enum se_model_id */

@@ -52,7 +52,7 @@ def enhance_dpcrn(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
     return y / c
 
 
-def enhance_dccrn(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
+def enhance_dccrn(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32, masking_mode='E'):
     """DCCRN/dccrn_decode_vb.py:25-62.  Output length = padded length (:59-60)."""
     wav = np.asarray(wav, dtype=np.float64)
     c = S.rms_scale(wav)                                                 # :27
@@ -62,7 +62,7 @@ def enhance_dccrn(sd, wav, p_in=1.0, p_out=1.0, net_dtype=np.float32):
     mag = np.sqrt(re ** 2 + im ** 2) ** p_in                             # :40
     ph = np.arctan2(im, re)
     feat = np.stack([mag * np.cos(ph), mag * np.sin(ph)], 0)[None]       # :42  [1,2,F,T]
-    est = M.dccrn_forward(sd, feat)                                      # :44
+    est = M.dccrn_forward(sd, feat, masking_mode=masking_mode)           # :44
     emag = np.sqrt(est[:, 0] ** 2 + est[:, 1] ** 2)                      # :45
     eph = np.arctan2(est[:, 1], est[:, 0])                               # :46
     emag = emag ** p_out                                                 # :48

@@ -297,6 +297,25 @@ def gen_dccrn():
     save('dccrn', x=x, y=y, wav=wav, enh=enh, enh_cprs=enh_c, enh4_cprs=enh4.astype(np.float32))
 
 
+def gen_dccrn_mask():
+    """DCCRN(masking_mode='C' | 'R') - DCCRN/DCCRN_cprs.py:220-223: the two masks the class offers besides the decode script's
+    'E' (same parameters, same key schema): forward + compressed-spectrum decode each."""
+    if FULL_ONLY or LONG_ONLY:
+        return
+    mod = import_ref('DCCRN', 'DCCRN_cprs')
+    rng = np.random.default_rng(18)
+    x = rng.standard_normal((2, 2, 257, 7)).astype(np.float32)
+    wav = synth.synth_clip(16, 'speech', 4000)
+    out = {'x': x, 'wav': wav}
+    for mode in ('C', 'R'):
+        model = mod.DCCRN(rnn_units=256, masking_mode=mode, use_clstm=True, kernel_num=[32, 64, 128, 256, 256, 256])
+        load_synth(model, 14)
+        with torch.no_grad():
+            out['y_' + mode] = model(torch.from_numpy(x)).numpy()
+        out['enh_cprs_' + mode] = _enhance_dccrn(model, wav, 0.5, 2.0)[0]
+    save('dccrn_mask', **out)
+
+
 def _fsn_model(sequence_model="LSTM", norm_type="offline_laplace_norm"):
     install_stubs()
     scratch = '/tmp/se_golden_scratch'
@@ -569,7 +588,7 @@ def gen_g2net_new():
     gen_g2net('G2Net_new', '_new')
 
 
-GENS = {'stft': gen_stft, 'fullsubnet_cum': gen_fullsubnet_cum, 'fullsubnet_gru': gen_fullsubnet_gru, 'ctsnet_new': gen_ctsnet_new, 'taylorsenet_new': gen_taylorsenet_new, 'g2net_new': gen_g2net_new, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+GENS = {'stft': gen_stft, 'dccrn_mask': gen_dccrn_mask, 'fullsubnet_cum': gen_fullsubnet_cum, 'fullsubnet_gru': gen_fullsubnet_gru, 'ctsnet_new': gen_ctsnet_new, 'taylorsenet_new': gen_taylorsenet_new, 'g2net_new': gen_g2net_new, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

@@ -206,6 +206,10 @@ def dccrn_forward(sd, inputs, n_layers=6, masking_mode='E', variant=0):
         out = out[..., 1:]
     mr = np.pad(out[:, 0], ((0, 0), (1, 0), (0, 0)))            # :201-204
     mi = np.pad(out[:, 1], ((0, 0), (1, 0), (0, 0)))
+    if masking_mode == 'C':                                     # :220-221 complex ratio mask
+        return np.stack([real * mr - imag * mi, real * mi + imag * mr], axis=1)
+    if masking_mode == 'R':                                     # :222-223 one real mask per part
+        return np.stack([real * mr, imag * mi], axis=1)
     assert masking_mode == 'E'
     mm = (mr ** 2 + mi ** 2) ** 0.5                             # :207
     rp = mr / (mm + 1e-8)

@@ -10,8 +10,10 @@ namespace se {
 //   est_mags = tanh(|M|) * |X|, est_phase = angle(X) + mask_phase, DC row of the mask is zero-padded.
 // DCCRN/dccrn_decode_vb.py:45-58  |est|**p_out * exp(j*angle(est)).
 // cos/sin(angle X + angle M) is evaluated as the product of the two unit phasors (no atan2/sincos round trip).
+// mode (DCCRN(masking_mode=...), DCCRN_cprs.py:205-223): 0 'E' (above), 1 'C' est = spec x mask (complex), 2 'R' est_r = spec_r mask_r,
+// est_i = spec_i mask_i; the decode script's |est|**p_out follows in every mode
 __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict__ mask, const float* __restrict__ spec,
-                                                         float* __restrict__ est, int F, int T, int Tp, float p_out) {
+                                                         float* __restrict__ est, int F, int T, int Tp, float p_out, int mode) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
@@ -22,6 +24,18 @@ __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict
         const long mo = (((long)b * 2) * (F - 1) + (k - 1)) * Tp + t;
         const float mr = mask[mo], mi = mask[mo + (long)(F - 1) * Tp];
         const float xr = spec[so], xi = spec[so + plane];
+        if (mode != 0) {
+            float er = mode == 1 ? xr * mr - xi * mi : xr * mr, ei = mode == 1 ? xr * mi + xi * mr : xi * mi;
+            if (p_out != 1.f) {
+                const float mg = sqrtf(er * er + ei * ei);
+                const float sc = mg > 0.f ? ((p_out == 2.f) ? mg : powf(mg, p_out - 1.f)) : 0.f;
+                er *= sc;
+                ei *= sc;
+            }
+            est[so] = er;
+            est[so + plane] = ei;
+            return;
+        }
         const float mm = sqrtf(mr * mr + mi * mi);
         const float xm = sqrtf(xr * xr + xi * xi);
         float pr = 1.f, pi = 0.f, qr = 1.f, qi = 0.f;
@@ -38,9 +52,9 @@ __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* __restrict
 }
 
 void launch_dccrn_mask(const float* mask, const float* spec, float* est, int B, int F, int T, int Tp, float p_out,
-                       hipStream_t s) {
+                       hipStream_t s, int mode) {
     StageScope prof(STAGE_MASK, s, (8.0 * (F - 1) + 16.0 * F) * T * B);
-    hipLaunchKernelGGL(dccrn_mask_kernel, dim3((T + 255) / 256, F, B), dim3(256), 0, s, mask, spec, est, F, T, Tp, p_out);
+    hipLaunchKernelGGL(dccrn_mask_kernel, dim3((T + 255) / 256, F, B), dim3(256), 0, s, mask, spec, est, F, T, Tp, p_out, mode);
     SE_HIP(hipGetLastError());
 }
 

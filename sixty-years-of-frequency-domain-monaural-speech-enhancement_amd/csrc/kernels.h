@@ -171,7 +171,7 @@ void launch_hist_batch(const HistBatch& hb, int B, int Tw, int hc, bool save, hi
 // DCCRN 'E' mask (DCCRN_cprs.py:201-225) + the decode script's mag/phase/decompress (dccrn_decode_vb.py:45-58):
 //   mask [B][2][F-1][Tp] (bins 1..F-1), spec [B][2][F][Tp] -> est [B][2][F][Tp], DC bin = 0.
 void launch_dccrn_mask(const float* mask, const float* spec, float* est, int B, int F, int T, int Tp, float p_out,
-                       hipStream_t s);
+                       hipStream_t s, int mode = 0);
 
 // Generic tiled transpose of the outer and inner dims:  out[t][k][a] = in[a][k][t]
 //   in element (a,k,t) at a*in_sa + k*in_sk + t ; out element (t,k,a) at t*out_st + k*out_sk + a

@@ -144,6 +144,8 @@ class Dccrn final : public Model {
         // flag + a fixture regeneration.
         const bool bias_per_part = (ctx.flags & SE_CFG_DCCRN_BIAS_PER_PART) != 0;
         const bool plain_cat = (ctx.flags & SE_CFG_DCCRN_PLAIN_CAT) != 0;
+        SE_CHECK(!((ctx.flags & SE_CFG_DCCRN_MASK_C) && (ctx.flags & SE_CFG_DCCRN_MASK_R)), "DCCRN: masking mode 'C' and 'R' are exclusive");
+        mask_mode = (ctx.flags & SE_CFG_DCCRN_MASK_C) ? 1 : ((ctx.flags & SE_CFG_DCCRN_MASK_R) ? 2 : 0);      // DCCRN_cprs.py:205-223
         auto cplx = [&](const DenseW& wr, const DenseW& wi) {
             DenseW w = complex_expand(wr, wi);          // default: real rows get br - bi, imag rows br + bi
             if (bias_per_part) {
@@ -327,7 +329,7 @@ class Dccrn final : public Model {
         const int B = (int)shape[0], T = (int)shape[3];
         Bufs& b = bufs(B, T);
         network(b, in, st);
-        launch_dccrn_mask(b.D[NL], in, out, B, NBIN, T, T, 1.f, st);
+        launch_dccrn_mask(b.D[NL], in, out, B, NBIN, T, T, 1.f, st, mask_mode);
     }
 
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
@@ -338,7 +340,7 @@ class Dccrn final : public Model {
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                           // :27
         launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, nullptr, T, T, st);   // :28-42
         network(b, b.spec, st);                                                                // :44
-        launch_dccrn_mask(b.D[NL], b.spec, b.est, B, NBIN, T, T, ctx.p_out, st);               // model :201-225 + :45-58
+        launch_dccrn_mask(b.D[NL], b.spec, b.est, B, NBIN, T, T, ctx.p_out, st, mask_mode);    // model :201-225 + :45-58
         launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, Lpad, st);       // :59-62
     }
 
@@ -436,7 +438,7 @@ class Dccrn final : public Model {
         }
         {
             const int c0 = DHC - NL;
-            launch_dccrn_mask(b.D[NL] + c0, b.spec + c0, b.est + c0, B, NBIN, last ? Tw - c0 : n, Tw, ctx.p_out, st);
+            launch_dccrn_mask(b.D[NL] + c0, b.spec + c0, b.est + c0, B, NBIN, last ? Tw - c0 : n, Tw, ctx.p_out, st, mask_mode);
         }
         launch_hist_batch(hb, B, Tw, DHC, true, st);
         ss.first = false;
@@ -452,6 +454,7 @@ class Dccrn final : public Model {
     GCPlan enc[NL], g1, g2, proj;
     GaussLayer genc[NL], gdec[3];      // encoder 3 - 5 / decoder 0 - 1 (- 2) as three real products (gauss_on)
     bool gauss_on = false;
+    int mask_mode = 0;                 // 0 'E', 1 'C', 2 'R' (SE_CFG_DCCRN_MASK_*)
     int gauss_dec = 2;                 // decoder layers on the three-product path (SE_DCCRN_GAUSS = 2: 3 of them, = 1: 2)
     float *whh1 = nullptr, *whh2 = nullptr;
     DeconvPlan dec[NL];

@@ -176,7 +176,9 @@ def enhance(args, model='dccrn', checkpoint=None, p_in=None, p_out=None, max_bat
     if stats is not None:
         pad, use = sum(len(b) * max(lengths[i] for i in b) for b in mine), sum(lengths[i] for i in own)
         stats.update(files=len(files), files_rank=len(own), calls_rank=len(mine), world=world,
-                     pad_frac=round(pad / max(use, 1) - 1.0, 4), audio_s_rank=round(use / 16000.0, 2))
+                     pad_frac=round(1.0 - use / max(pad, 1), 4), pad_over_audio=round(pad / max(use, 1) - 1.0, 4),
+                     audio_s_rank=round(use / 16000.0, 2))      # pad_frac: the planner's definition (share of padded rows' samples
+                                                                # that is padding, capped by max_pad); pad_over_audio: extra work / audio
     if not mine:
         return 0
     # ---- engine: the workspace is sized for the calls this rank actually makes, not for max_batch x the longest clip

@@ -51,6 +51,32 @@ def test_forward_matches_reference_fixture():
     assert err < 1e-5 * max(rms(G['y']), 1.0), (err, rms(G['y']))
 
 
+@pytest.mark.parametrize('mode', ['C', 'R'])
+def test_masking_modes_match_reference_fixture(mode):
+    """DCCRN(masking_mode='C' | 'R') (DCCRN/DCCRN_cprs.py:220-223; SE_CFG_DCCRN_MASK_C / _R): forward and compressed-spectrum
+    decode against the imported reference's output, the decode streamed as well (the mask is per frame)."""
+    torch = _torch()
+    from se_amd.models import DCCRN
+    G = load_golden('dccrn_mask')
+    m = DCCRN(**dict(CTOR, masking_mode=mode), p_in=0.5, p_out=2.0, max_batch=2).load_synthetic(14)
+    y = m(torch.from_numpy(G['x']).cuda()).cpu().numpy()
+    err = rms(y - G['y_' + mode])
+    assert y.shape == G['y_' + mode].shape and err < 1e-5 * max(rms(G['y_' + mode]), 1.0), (err, rms(G['y_' + mode]))
+    wav = torch.from_numpy(np.stack([G['wav'], G['wav'][::-1].copy()])).cuda()
+    out = m.enhance_batch(wav).cpu().numpy()
+    ref = G['enh_cprs_' + mode]
+    e = rms(out[0] - ref)
+    print('masking mode', mode, 'decode rms err', e, 'rms ref', rms(ref))
+    assert out.shape[1] == ref.shape[0] and e < 1e-4 and e < 5e-4 * max(rms(ref), 1e-3)
+    assert rms(out[0] - DCCRN(**CTOR, p_in=0.5, p_out=2.0, max_batch=2).load_synthetic(14).enhance_batch(wav).cpu().numpy()[0]) > 1e-2 * rms(ref)
+    eng = m.engine
+    eng.stream_begin(2, c=eng.rms_scale(wav), max_chunk_frames=4)
+    outs = [eng.stream_push(wav[:, :1700].contiguous()).cpu().numpy(), eng.stream_push(wav[:, 1700:].contiguous()).cpu().numpy(),
+            eng.stream_flush().cpu().numpy()]
+    got = np.concatenate(outs, axis=1)
+    assert got.shape == out.shape and rms(got - out) < 1e-6 + 2e-5 * rms(out)
+
+
 @pytest.mark.parametrize('p_in,p_out,key', [(1.0, 1.0, 'enh'), (0.5, 2.0, 'enh_cprs')])
 def test_enhance_matches_reference_fixture(p_in, p_out, key):
     torch = _torch()

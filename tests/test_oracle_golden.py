@@ -87,6 +87,17 @@ def test_fullsubnet_cumulative_norm_matches_reference():
     assert e.shape == G['enh_cprs'].shape and rms(e - G['enh_cprs']) < 1e-6 * max(rms(G['enh_cprs']), 1e-3)
 
 
+@pytest.mark.parametrize('mode', ['C', 'R'])
+def test_dccrn_masking_modes_match_reference(mode):
+    """DCCRN(masking_mode='C' | 'R') (DCCRN/DCCRN_cprs.py:220-223) on top of the same recall of `complexnn` as the 'E' fixtures."""
+    G = load_golden('dccrn_mask')
+    sd = _sd('dccrn', 14)
+    y = M.dccrn_forward(sd, G['x'], masking_mode=mode)
+    assert y.shape == G['y_' + mode].shape and rms(y - G['y_' + mode]) < 2e-6 * max(rms(G['y_' + mode]), 1.0)
+    e = D.enhance_dccrn(sd, G['wav'], 0.5, 2.0, masking_mode=mode)
+    assert rms(e - G['enh_cprs_' + mode]) < 2e-6 * max(rms(G['enh_cprs_' + mode]), 1e-3)
+
+
 def test_dccrn_compressed_variant():
     G = load_golden('dccrn')
     y = D.enhance_dccrn(_sd('dccrn', 14), G['wav'], 0.5, 2.0)

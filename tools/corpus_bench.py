@@ -53,8 +53,10 @@ def main():
     ap.add_argument('--readers', type=int, default=4)
     ap.add_argument('--dir', default='/dev/shm/se_corpus')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--repeat', type=int, default=2, help='decode the directory this many times; the LAST pass is reported '
-                    '(the first also pays one-time costs: code-object load, resampler tables, first touch of pinned pages)')
+    ap.add_argument('--repeat', type=int, default=2, help='at least this many passes over the directory')
+    ap.add_argument('--min_seconds', type=float, default=10.0, help='keep decoding the directory until the passes after the '
+                    'first add up to this much pipeline time; the figure reported is their aggregate (the first pass also '
+                    'pays one-time costs - code-object load, resampler tables, first touch of pinned pages - and is reported apart)')
     args = ap.parse_args()
     import torch
     import se_amd  # noqa: F401
@@ -80,13 +82,23 @@ def main():
     else:
         sd = synth.synth_state_dict(schemas.SCHEMAS[name](), 1)
     ns = types.SimpleNamespace(mix_file_path=mix, esti_clean_file_path=out, fs=16000)
-    first = None
-    for k in range(max(1, args.repeat)):
+    first, passes, t_pipe, n_clips, per_pass = None, 0, 0.0, 0, []
+    while passes < max(2, args.repeat) or (t_pipe < args.min_seconds and passes < 400):
         stats = {}
         n = decode.enhance(ns, name, state_dict=sd, max_batch=args.max_batch, p_in=0.5, p_out=2.0, verbose=False, stats=stats,
                            readers=args.readers, rank=rank, world=world)
-        first = first or dict(stats)
+        passes += 1
+        if first is None:
+            first = dict(stats)
+            continue
+        t_pipe += stats['pipeline_s']
+        n_clips += n
+        per_pass.append(stats['clips_per_s'])
     torch.cuda.synchronize()
+    stats['passes_timed'], stats['pipeline_s'] = passes - 1, round(t_pipe, 3)
+    stats['clips_per_s'] = round(n_clips / t_pipe, 1)
+    stats['clips_per_s_min_max'] = [min(per_pass), max(per_pass)]
+    stats['audio_s_rank'] = round(stats['audio_s_rank'] * (passes - 1), 2)
     # ---- the same calls from device-resident tensors (no file I/O, no upload, no resampling, no PCM conversion)
     lens16 = [wavio.wav_info(os.path.join(mix, f))[0] * 16000 // args.fs for f in sorted(os.listdir(mix))]
     own = decode.shard_clips(lens16, rank, world)
@@ -104,10 +116,12 @@ def main():
             net.enhance_batch(wav) if min(lens) == max(lens) else net.enhance_ragged(wav, lens)
     run()
     torch.cuda.synchronize()
+    reps = max(3, min(200, int(0.3 * args.min_seconds / max(t_pipe / max(passes - 1, 1), 1e-3))))
     t0 = time.perf_counter()
-    run()
+    for _ in range(reps):
+        run()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = (time.perf_counter() - t0) / reps
     row = {'tool': 'corpus_bench', 'model': name, 'fs_in': args.fs, 'max_batch': args.max_batch, 'rank': rank, **stats,
            'x_realtime': round(stats['audio_s_rank'] / stats['pipeline_s'], 0),
            'resident_clips_per_s': round(len(own) / dt, 1),

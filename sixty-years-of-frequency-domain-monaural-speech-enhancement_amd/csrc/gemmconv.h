@@ -92,6 +92,12 @@ struct GCParams {
     // the InstanceNorm that follows does not have to read the plane for its statistics (blocks.h: conv_norm2d_prelu)
     float* stats;
     long st_b, st_c, st_f;   // float strides of the statistics tensor
+    // optional (EPI_ACT / EPI_ADD on the MFMA path; Uformer's interaction of the two branches, fusion.py:13-19, folded into
+    // the magnitude branch's last launch): fz = the complex branch's tensor, real plane at fz, imaginary plane fz_im floats
+    // behind it, laid out like dst with its own strides.  The stored value v and the complex pair (re, im) at the same
+    // (b, channel, row, frame) become  re + sig(v), im + sig(v), v + sig(|re + i im|)  - the pair is rewritten in place
+    float* fz;
+    long fz_b, fz_c, fz_f, fz_im;
 };
 
 // Device tables of one patch geometry (owned by the plan)

@@ -43,6 +43,15 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 __device__ __forceinline__ float fsig_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// GCParams::fz - one frame of the branch interaction (the same expressions as model_uformer.hip: uf_fusion_kernel)
+__device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long im) {
+    const float re = zr[0], ii = zr[im];
+    const float cm = sqrtf(fmaxf(re * re + ii * ii, 1.1920928955078125e-07f));
+    const float s = fsig_(v);
+    zr[0] = re + s;
+    zr[im] = ii + s;
+    return v + fsig_(cm);
+}
 __device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 // 16 B per lane global -> LDS copy without a register round trip (global_load_lds_dwordx4: lane l lands at
@@ -121,8 +130,8 @@ __device__ __forceinline__ float dpp_add8(float x) {
 // per chunk (16 for a 64 x 320 TCM conv, whose matrix work is a few hundred cycles).
 // TRIM: the launch stages 16 B groups under taps that look ahead in time (GC_TRIM_TAIL).  A variant of its own: the mere
 // presence of the LDS stores in the K loop costs the other launches 2-10 % (gcbench, 32- / 64-row tiles most).
-template <int BM, int BN, int WM, int WN, int EPI, bool RES = false, bool TRIM = false>
-__global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {
+template <int BM, int BN, int WM, int WN, int EPI, bool RES = false, bool TRIM = false, bool FZ = false>
+__global__ __launch_bounds__(256, RES ? 1 : FZ ? (BM <= 32 ? 4 : 2) : gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {   // (FZ: room for the prefetched pair)
 #ifdef GC_TIMING
     unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -484,9 +493,30 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
         const int tvalid = p.tlen ? p.tlen[b] : 0x7fffffff;
         const float* __restrict__ res =
             (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fow * p.x_f : nullptr;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        float* __restrict__ fzb = FZ ? p.fz + (long)b * p.fz_b + (long)fow * p.fz_f : nullptr;      // FZ: GCParams::fz (its own instantiations: the
+                                                                                                      // extra live registers of the epilogue spill in the 128-row tile otherwise)
+        // (one column tile per call, its index a compile-time constant: with the interaction operands in the body the unroller
+        // gave up on a `for j` and the accumulators, indexed by a run-time j, went to scratch memory)
+        auto epi_tile = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
             if (j > 0) GC_WAVE_FENCE();                          // the previous column tile has been read back
+            // residual / interaction operands of this column tile: all of a wave's loads issued here, ahead of the transposition
+            // (one load -> wait -> store per 8 rows left an EPI_ADD tile waiting on 8 HBM round trips in a row: the pointwise
+            // layers of Uformer's conformer ran at 0.22 of the matrix peak)
+            constexpr bool PRE = (EPI == EPI_ADD || EPI == EPI_MUL);
+            const int tgp = t0 + wt * (TN * 32) + j * 32 + lc;
+            floatx4 rvp[PRE ? OROWS / 8 : 1], zre[FZ ? OROWS / 8 : 1], zim[FZ ? OROWS / 8 : 1];
+            if ((PRE || FZ) && tgp + 3 < p.Tout && Mo > 0) {
+#pragma unroll
+                for (int it = 0; it < OROWS / 8; ++it) {
+                    const int m = min(mo0 + it * 8 + lr, Mo - 1);      // clamped: rows past M are loaded, not used
+                    if (PRE) rvp[it] = *reinterpret_cast<const floatx4*>(res + (long)m * p.x_c + tgp);
+                    if (FZ) {
+                        zre[it] = *reinterpret_cast<const floatx4*>(fzb + (long)m * p.fz_c + tgp);
+                        zim[it] = *reinterpret_cast<const floatx4*>(fzb + (long)m * p.fz_c + tgp + p.fz_im);
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if (EPI != EPI_GLU) {
@@ -542,13 +572,24 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
                 if (m < Mo) {
                     float* __restrict__ dp = dst + (long)m * p.d_c + tg;
                     if (tg + 3 < p.Tout) {
-                        if (EPI == EPI_ADD || EPI == EPI_MUL) {
-                            const floatx4 rv = *reinterpret_cast<const floatx4*>(res + (long)m * p.x_c + tg);
-                            v = (EPI == EPI_ADD) ? v + rv : v * rv;
-                        }
+                        if (EPI == EPI_ADD || EPI == EPI_MUL) v = (EPI == EPI_ADD) ? v + rvp[it] : v * rvp[it];
                         if (tg + 3 >= tvalid) {      // rows of a ragged batch: frames past the row's own end are stored as zeros
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[k] = (tg + k < tvalid) ? v[k] : 0.f;
+                        }
+                        if (FZ) {
+                            float* __restrict__ zr = fzb + (long)m * p.fz_c + tg;
+                            floatx4 re = zre[it], ii = zim[it];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float cm = sqrtf(fmaxf(re[k] * re[k] + ii[k] * ii[k], 1.1920928955078125e-07f));
+                                const float sg = fsig_(v[k]);
+                                re[k] += sg;
+                                ii[k] += sg;
+                                v[k] += fsig_(cm);
+                            }
+                            *reinterpret_cast<floatx4*>(zr) = re;
+                            *reinterpret_cast<floatx4*>(zr + p.fz_im) = ii;
                         }
                         *reinterpret_cast<floatx4*>(dp) = v;
                     } else {
@@ -558,12 +599,17 @@ __global__ __launch_bounds__(256, RES ? 1 : gc_blocks_per_cu(BM)) void gc_kernel
                                 float o = v[k];
                                 if (EPI == EPI_ADD) o += res[(long)m * p.x_c + tg + k];
                                 if (EPI == EPI_MUL) o *= res[(long)m * p.x_c + tg + k];
-                                dp[k] = (tg + k < tvalid) ? o : 0.f;
+                                o = (tg + k < tvalid) ? o : 0.f;
+                                if (FZ) o = gc_fuse1(o, fzb + (long)m * p.fz_c + tg + k, p.fz_im);
+                                dp[k] = o;
                             }
                     }
                 }
             }
-        }
+        };
+        epi_tile(std::integral_constant<int, 0>{});
+        if constexpr (TN > 1) epi_tile(std::integral_constant<int, 1>{});
+        static_assert(TN <= 2, "epilogue: column tiles per wave");
     } else {   // EPI_LSTM
         // a lane's 16 accumulators of one MFMA tile are the i,f,g,o gates of 4 cells: all 16 gate pre-activations and
         // the 4 cell states are fetched by unconditional (clamped) loads in one batch, then the cells update
@@ -1035,7 +1081,7 @@ static long gc_thin_blocks(const GCParams& p) {
     return nblk;
 }
 static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
-    const long nblk = gc_thin_blocks(p);
+    const long nblk = p.fz ? 0 : gc_thin_blocks(p);          // (GCParams::fz: MFMA kernel only)
     if (nblk <= 0) return false;
     const int n = p.Tout - p.t_base;
     dim3 grid((unsigned)nblk);
@@ -1440,6 +1486,20 @@ static void gc_launch_e(const GCParams& p, hipStream_t stream) {
     }
     const long nblk = (long)p.Z * p.B * p.Qt * p.n_ttiles * p.n_mtiles;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
+    if constexpr ((EPI == EPI_ACT || EPI == EPI_ADD) && !RES) {
+        if (p.fz) {          // branch interaction folded into the store (GCParams::fz)
+            SE_CHECK(!p.trim && !p.stats, "gc_launch: no trimming / statistics variant of the kernel with the folded interaction");
+            static bool attr_fz[64] = {};
+            if (first_on_device(attr_fz)) {
+                SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI, false, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN, EPI, false, false, true>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
+            SE_HIP(hipGetLastError());
+            return;
+        }
+    }
+    SE_CHECK(!p.fz, "gc_launch: this kernel variant cannot fold the branch interaction into its store");
     if constexpr (EPI == EPI_ACT && !RES) {
         if (p.trim) {
             static bool attr_trim[64] = {};
@@ -1474,7 +1534,7 @@ static void gc_launch_t(const GCParams& p, hipStream_t stream) {
 // all chunks of a source resident in LDS at once (gc_kernel RES): launches of at most one workgroup per CU whose staging fits
 static bool gc_resident_fits(GCParams& p, int BM, int BM_div_WM) {
     static const int res_env = getenv("SE_GC_RES") ? atoi(getenv("SE_GC_RES")) : 1;
-    if (!res_env || p.trim || p.epi == EPI_LSTM) return false;
+    if (!res_env || p.trim || p.epi == EPI_LSTM || p.fz) return false;
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     const int nch0 = p.C0 > 0 ? (p.C0 + p.CI_C - 1) / p.CI_C : 0, nch1 = p.C1 > 0 ? (p.C1 + p.CI_C - 1) / p.CI_C : 0;
     int nb = std::max(std::max(nch0, nch1), 1);
@@ -1529,6 +1589,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
              "pointwise layer with a row length that is not a multiple of 4 needs its sources inside the engine arena");
     if (gc_thin_launch(p, stream)) return;
     if (p.Ws) {
+        SE_CHECK(!p.fz, "gc_launch: the direct (<= 4 channel) path cannot fold the branch interaction into its store");
         if (p.M <= 1) gc_small_launch<1>(p, pl.small, stream);
         else if (p.M <= 2) gc_small_launch<2>(p, pl.small, stream);
         else gc_small_launch<4>(p, pl.small, stream);

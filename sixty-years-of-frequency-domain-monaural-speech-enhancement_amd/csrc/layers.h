@@ -85,13 +85,22 @@ inline Act4 act4(const float* p, int C, int F, int Tp) { return Act4{p, C, F, (l
 
 struct Profiler;
 // stats (optional): [B][dstC][Fout][ceil(T / 32)][2] partial sums of the stored output (GCParams::stats)
+// fz (optional, plans for which conv_folds_interaction() holds): the complex branch's tensor [B][2 * dstC][Fout][Tp] whose
+// interaction with this launch's output is folded into the store (GCParams::fz)
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0);
+              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, float* fz = nullptr);
+inline bool conv_folds_interaction(const GCPlan& pl) { return pl.p.Ws == nullptr && (pl.p.epi == EPI_ACT || pl.p.epi == EPI_ADD); }
+inline bool conv_folds_interaction(const DeconvPlan& pl) {
+    if (pl.has_pair || pl.par.empty()) return false;
+    for (const auto& g : pl.par)
+        if (!conv_folds_interaction(g)) return false;
+    return true;
+}
 // frame-online chunks: only output frames [t_base, t_out) of the T-frame window are produced (t_out < 0: up to T); tb_soft:
 // GCParams::tb_soft
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
                 int Tp, hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, int t_out = -1,
-                bool tb_soft = false);
+                bool tb_soft = false, float* fz = nullptr);
 bool conv_stats_supported(const GCPlan& pl);
 bool deconv_stats_supported(const DeconvPlan& pl);
 

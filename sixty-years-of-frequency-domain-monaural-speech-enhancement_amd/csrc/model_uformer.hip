@@ -667,13 +667,21 @@ class Uformer final : public Model {
     }
 
     // pointwise GEMM on a [B][C][P] tensor
-    void pw(const GCPlan& pl, const float* x, int Cin, float* y, int Cout, const float* res, int B, long P, hipStream_t st) {
+    void pw(const GCPlan& pl, const float* x, int Cin, float* y, int Cout, const float* res, int B, long P, hipStream_t st,
+            float* fz = nullptr) {
         GCParams p = pl.p;
+        if (fz) { p.fz = fz; p.fz_im = Cout * P; p.fz_b = 2 * Cout * P; p.fz_c = P; p.fz_f = 0; }
         p.src0 = x; p.s0_b = Cin * P; p.s0_c = P; p.s0_f = 0; p.src1 = nullptr;
         p.Fin = 1; p.Tin = (int)P; p.B = B; p.Q = 1; p.Tout = (int)P;
         p.dst = y; p.d_b = Cout * P; p.d_c = P; p.d_f = 0;
         if (res) { p.aux = res; p.x_b = Cout * P; p.x_c = P; p.x_f = 0; }
         gc_launch_prof(pl, p, st, &ctx.prof);
+    }
+    // SE_UF_FOLD=0: the interaction of the two branches (fusion.py:13-19) as its own launch after every layer pair instead of
+    // inside the store of the magnitude branch's last launch (GCParams::fz)
+    static bool fold_env() {
+        static const bool v = !(getenv("SE_UF_FOLD") && atoi(getenv("SE_UF_FOLD")) == 0);
+        return v;
     }
     void fusion(float* c, float* m, int B, long CP, hipStream_t st) {
         hipLaunchKernelGGL(uf_fusion_kernel, dim3((unsigned)((CP + 255) / 256), B), dim3(256), 0, st, c, m, CP);
@@ -684,11 +692,12 @@ class Uformer final : public Model {
         launch_layernorm_cf(x, res, w.w, w.b, y, Bv, C, 1, (int)P, 1e-5f, st, post, slope);
     }
 
-    void ff(const FFBlock& f, bool cplx, const float* x, float* y, Bufs& b, long P, hipStream_t st) {
+    // fz (magnitude branch only): the complex branch's output of the same step - the interaction goes into the last store
+    void ff(const FFBlock& f, bool cplx, const float* x, float* y, Bufs& b, long P, hipStream_t st, float* fz = nullptr) {
         const int m = cplx ? 2 : 1;
         ln(f.ln, x, b.t1, m * b.B, CC, P, st);
         pw(f.l1, b.t1, m * CC, b.t2, m * 64, nullptr, b.B, P, st);
-        pw(f.l2, b.t2, m * 64, y, m * CC, x, b.B, P, st);
+        pw(f.l2, b.t2, m * 64, y, m * CC, x, b.B, P, st, fz);
     }
     void att(const AttBlock& a, bool cplx, bool along_t, const float* x, float* y, Bufs& b, int F, int T, hipStream_t st) {
         const int m = cplx ? 2 : 1, B = b.B;
@@ -726,7 +735,7 @@ class Uformer final : public Model {
         pw(a.trans, b.t1, m * HD, b.t3, m * CC, nullptr, B, P, st);
         ln(a.ln3, b.t3, y, m * B, CC, P, st, 0, a.slope, x);
     }
-    void ds(const DsBlock& d, bool cplx, const float* x, float* y, Bufs& b, int F, int T, hipStream_t st) {
+    void ds(const DsBlock& d, bool cplx, const float* x, float* y, Bufs& b, int F, int T, hipStream_t st, float* fz = nullptr) {
         const int m = cplx ? 2 : 1, B = b.B;
         const long P = (long)F * T;
         Profiler* pf = &ctx.prof;
@@ -753,6 +762,7 @@ class Uformer final : public Model {
             p.Fin = F; p.Tin = T; p.B = B; p.Q = F; p.Tout = T;
             p.dst = y; p.d_b = (long)m * CC * P; p.d_c = P; p.d_f = T;
             p.aux = x; p.x_b = (long)m * CC * P; p.x_c = P; p.x_f = T;
+            if (fz) { p.fz = fz; p.fz_im = (long)CC * P; p.fz_b = 2L * CC * P; p.fz_c = P; p.fz_f = T; }
             gc_launch_prof(d.sc, p, st, pf);
         }
     }
@@ -775,8 +785,9 @@ class Uformer final : public Model {
         for (int k = 0; k < NL; ++k) {
             F /= 2;
             run_conv(encC[k], xc, nullptr, b.EC[k], 2 * KN[k + 1], F, B, T, T, st, pf);
-            run_conv(encR[k], xm, nullptr, b.ER[k], KN[k + 1], F, B, T, T, st, pf);
-            fusion(b.EC[k], b.ER[k], B, (long)KN[k + 1] * F * T, st);
+            const bool fold = fold_env() && conv_folds_interaction(encR[k]);
+            run_conv(encR[k], xm, nullptr, b.ER[k], KN[k + 1], F, B, T, T, st, pf, nullptr, 0, fold ? b.EC[k] : nullptr);
+            if (!fold) fusion(b.EC[k], b.ER[k], B, (long)KN[k + 1] * F * T, st);
             xc = act4(b.EC[k], 2 * KN[k + 1], F, T);
             xm = act4(b.ER[k], KN[k + 1], F, T);
         }
@@ -784,23 +795,26 @@ class Uformer final : public Model {
         const long P = 4L * T, CP = (long)CC * P;
         const float *c = b.EC[NL - 1], *m = b.ER[NL - 1];
         int pp = 0;
-        auto step = [&](auto&& fc, auto&& fr) {
+        auto step = [&](auto&& fc, auto&& fr, bool fold = false) {
             fc(c, b.XC[pp]);
             fr(m, b.XR[pp]);
-            fusion(b.XC[pp], b.XR[pp], B, CP, st);
+            if (!fold) fusion(b.XC[pp], b.XR[pp], B, CP, st);
             c = b.XC[pp];
             m = b.XR[pp];
             pp ^= 1;
         };
-        step([&](const float* x, float* y) { ff(ffC[0], true, x, y, b, P, st); }, [&](const float* x, float* y) { ff(ffR[0], false, x, y, b, P, st); });
+        const bool fold_pw = fold_env() && conv_folds_interaction(ffR[0].l2) && conv_folds_interaction(dsR[0].sc);
+        step([&](const float* x, float* y) { ff(ffC[0], true, x, y, b, P, st); },
+             [&](const float* x, float* y) { ff(ffR[0], false, x, y, b, P, st, fold_pw ? b.XC[pp] : nullptr); }, fold_pw);
         step([&](const float* x, float* y) { att(attC[0], true, true, x, y, b, 4, T, st); },
              [&](const float* x, float* y) { att(attR[0], false, true, x, y, b, 4, T, st); });
         step([&](const float* x, float* y) { att(attC[1], true, false, x, y, b, 4, T, st); },
              [&](const float* x, float* y) { att(attR[1], false, false, x, y, b, 4, T, st); });
         for (int k = 0; k < NDS; ++k)
             step([&](const float* x, float* y) { ds(dsC[k], true, x, y, b, 4, T, st); },
-                 [&](const float* x, float* y) { ds(dsR[k], false, x, y, b, 4, T, st); });
-        step([&](const float* x, float* y) { ff(ffC[1], true, x, y, b, P, st); }, [&](const float* x, float* y) { ff(ffR[1], false, x, y, b, P, st); });
+                 [&](const float* x, float* y) { ds(dsR[k], false, x, y, b, 4, T, st, fold_pw ? b.XC[pp] : nullptr); }, fold_pw);
+        step([&](const float* x, float* y) { ff(ffC[1], true, x, y, b, P, st); },
+             [&](const float* x, float* y) { ff(ffR[1], false, x, y, b, P, st, fold_pw ? b.XC[pp] : nullptr); }, fold_pw);
         ln(lnC, c, b.XC[pp], 2 * B, CC, P, st);
         ln(lnR, m, b.XR[pp], B, CC, P, st);
         c = b.XC[pp];
@@ -812,9 +826,10 @@ class Uformer final : public Model {
             Act4 s0 = act4(b.EC[NL - 1 - k], 2 * ci, F, T), s1 = act4(c, 2 * ci, F, T);
             run_deconv(decC[k], s0, &s1, b.DC[k], 2 * co, 2 * F, B, T, T, st, pf);
             Act4 r0 = act4(b.ER[NL - 1 - k], ci, F, T), r1 = act4(m, ci, F, T);
-            run_deconv(decR[k], r0, &r1, b.DR[k], co, 2 * F, B, T, T, st, pf);
+            const bool fold = fold_env() && conv_folds_interaction(decR[k]);
+            run_deconv(decR[k], r0, &r1, b.DR[k], co, 2 * F, B, T, T, st, pf, nullptr, 0, -1, false, fold ? b.DC[k] : nullptr);
             F *= 2;
-            fusion(b.DC[k], b.DR[k], B, (long)co * F * T, st);
+            if (!fold) fusion(b.DC[k], b.DR[k], B, (long)co * F * T, st);
             c = b.DC[k];
             m = b.DR[k];
         }

@@ -2,8 +2,6 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-mkdir -p gpurun_out/r4_evid
-timeout 600 python -m pytest tests/test_gpu_dccrn.py -x -q -m gpu 2>&1 | tail -5
-timeout 300 python tools/corpus_bench.py > gpurun_out/r4_evid/corpus.json 2> gpurun_out/r4_evid/corpus.err; tail -c 900 gpurun_out/r4_evid/corpus.json
-bash tools/pmc_models.sh r04 "crn 64" "uformer 256" "g2net 256" "fullsubnet 128"
-bash tools/measure_round.sh r04 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_uformer.py -x -q -m gpu 2>&1 | tail -3
+for f in 0 1; do echo "SE_UF_FOLD=$f"; SE_UF_FOLD=$f timeout 300 python tools/sweep.py --models uformer --batch 256 --steps 5 2>&1 | tail -1 | cut -c1-200; done
+timeout 300 python tools/sweep.py --models dccrn,g2net,crn --batch 256 --steps 5 2>&1 | tail -3 | cut -c1-120

@@ -191,8 +191,73 @@ static int bench_gauss(int Ci, int Co, int Fin, int B, int T) {
     return 0;
 }
 
+// pointwise layer on a [B][C][P] tensor (Uformer's conformer: model_uformer.hip pw()): gcbench pw <Cin> <Cout> <B> <P> [res 0|1]
+static int bench_pw(int Cin, int Cout, int B, int P, int res) {
+    std::mt19937 rng(1);
+    std::uniform_real_distribution<float> U(-1.f, 1.f);
+    DenseW d;
+    d.M = Cout; d.Cin = Cin; d.nkf = 1; d.nkt = 1;
+    d.w.resize((size_t)Cout * Cin);
+    for (auto& v : d.w) v = U(rng) * 0.05f;
+    d.bias.assign(Cout, 0.1f);
+    GCPlan pl = make_pointwise_plan(d, ACT_NONE, {}, P, res ? EPI_ADD : EPI_ACT);
+    size_t nin = (size_t)B * Cin * P, nout = (size_t)B * Cout * P;
+    float *din, *dout, *dres;
+    SE_HIP(hipMalloc(&din, nin * 4 + 4096));
+    SE_HIP(hipMalloc(&dout, nout * 4));
+    SE_HIP(hipMalloc(&dres, nout * 4));
+    SE_HIP(hipMemset(din, 0, nin * 4 + 4096));
+    SE_HIP(hipMemset(dres, 0, nout * 4));
+    gc_register_overread_range(din, nin * 4 + 4096);
+#ifdef GC_TIMING
+    unsigned long long* dt;
+    SE_HIP(hipMalloc(&dt, 128));
+    SE_HIP(hipMemset(dt, 0, 128));
+    pl.p.timing = dt;
+#endif
+    auto run = [&]() {
+        GCParams p = pl.p;
+        p.src0 = din; p.s0_b = (long)Cin * P; p.s0_c = P; p.s0_f = 0; p.src1 = nullptr;
+        p.Fin = 1; p.Tin = P; p.B = B; p.Q = 1; p.Tout = P;
+        p.dst = dout; p.d_b = (long)Cout * P; p.d_c = P; p.d_f = 0;
+        if (res) { p.aux = dres; p.x_b = (long)Cout * P; p.x_c = P; p.x_f = 0; }
+        gc_launch(pl, p, 0);
+    };
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 2; ++it) run();
+    SE_HIP(hipDeviceSynchronize());
+    const int reps = 10;
+    hipEventRecord(e0, 0);
+    for (int it = 0; it < reps; ++it) run();
+    hipEventRecord(e1, 0);
+    SE_HIP(hipEventSynchronize(e1));
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const double fl = 2.0 * Cout * Cin * (double)B * P, by = 4.0 * B * P * (Cin + Cout * (res ? 2 : 1));
+#ifdef GC_TIMING
+    {
+        SE_HIP(hipMemset(dt, 0, 128));
+        run();
+        SE_HIP(hipDeviceSynchronize());
+        unsigned long long h[16];
+        SE_HIP(hipMemcpy(h, dt, 128, hipMemcpyDeviceToHost));
+        const char* nm[6] = {"prologue/desc", "load issue", "mfma", "vmcnt wait", "barrier", "epilogue"};
+        double tot = 0;
+        for (int i = 0; i < 6; ++i) tot += (double)h[i];
+        printf("blocks=%llu  per-block s_memtime ticks (wave 0):", h[6]);
+        for (int i = 0; i < 6; ++i) printf("  %s %.0f (%.1f%%)", nm[i], (double)h[i] / h[6], 100.0 * h[i] / tot);
+        printf("  total %.0f\n", tot / h[6]);
+    }
+#endif
+    printf("pointwise %d -> %d, B %d, P %d%s: BM=%d BN=%d CI_C=%d KCp=%d nchunks=%d: %.3f ms  %.1f TFLOP/s  %.2f TB/s of its own bytes\n", Cin, Cout, B, P,
+           res ? " + residual" : "", pl.BM, pl.BN, pl.p.CI_C, pl.p.KCp, pl.p.nchunks, ms, fl / ms / 1e9, by / ms / 1e9);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 3 && std::string(argv[1]) == "step") return bench_step(atoi(argv[2]), atoi(argv[3]));
+    if (argc > 5 && std::string(argv[1]) == "pw")
+        return bench_pw(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 0);
     if (argc > 5 && std::string(argv[1]) == "gauss")
         return bench_gauss(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 501);
     int Cin = argc > 1 ? atoi(argv[1]) : 128, Cout = argc > 2 ? atoi(argv[2]) : 256, Fin = argc > 3 ? atoi(argv[3]) : 32;

@@ -22,13 +22,16 @@ def build(name, B, L):
     from se_amd.models import MODEL_CLASSES
     if name == 'ctsnet_new':
         return models_new.CTSNet(max_batch=B, max_samples=L).load_synthetic(17, 18)
+    if name == 'fullsubnet_cum':        # the causal norm (base_model.py:143-166) is what makes FullSubNet streamable
+        from se_amd.models import Model
+        return Model(max_batch=B, max_samples=L, norm_type='cumulative_laplace_norm').load_synthetic(15)
     return MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(SEEDS[name])
 
 
 def main():
     import torch
     ap = argparse.ArgumentParser()
-    ap.add_argument('--models', default='crn,lstm,gcrn,dpcrn,dccrn,ctsnet_new,taylorsenet_new,g2net_new')
+    ap.add_argument('--models', default='crn,lstm,gcrn,dpcrn,dccrn,ctsnet_new,taylorsenet_new,g2net_new,fullsubnet_cum')
     ap.add_argument('--batch', default='1,16')
     ap.add_argument('--chunk', default='1,8')
     ap.add_argument('--seconds', type=float, default=2.0)
@@ -38,7 +41,7 @@ def main():
         for B in map(int, a.batch.split(',')):
             m = build(name, B, L)
             eng = m.engine
-            hop = {'dccrn': 128}.get(name, 160)
+            hop = {'dccrn': 128, 'fullsubnet_cum': 256}.get(name, 160)
             x = torch.from_numpy(np.stack([synth.synth_clip(900 + b, 'speech', L) for b in range(B)])).cuda()
             c = eng.rms_scale(x)
             for chunk in map(int, a.chunk.split(',')):

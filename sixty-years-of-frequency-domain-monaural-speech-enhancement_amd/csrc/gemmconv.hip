@@ -131,7 +131,7 @@ __device__ __forceinline__ float dpp_add8(float x) {
 // TRIM: the launch stages 16 B groups under taps that look ahead in time (GC_TRIM_TAIL).  A variant of its own: the mere
 // presence of the LDS stores in the K loop costs the other launches 2-10 % (gcbench, 32- / 64-row tiles most).
 template <int BM, int BN, int WM, int WN, int EPI, bool RES = false, bool TRIM = false, bool FZ = false>
-__global__ __launch_bounds__(256, RES ? 1 : FZ ? (BM <= 32 ? 4 : 2) : gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {   // (FZ: room for the prefetched pair)
+__global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (BM <= 32 ? 4 : 2) : gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {   // (FZ: room for the prefetched pair; 128 x 256: 128 accumulators per lane)
 #ifdef GC_TIMING
     unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, RES ? 1 : FZ ? (BM <= 32 ? 4 : 2) : gc_blocks_
     constexpr int KCP_MAX = gc_kcp_max(BM);
     constexpr int A_IT = (KCP_MAX * BM / 4 + 255) / 256;
     // patch slots staged per thread (flat index e = tid + 256 * i); the 256-column tile is only launched with 16 B groups
-    constexpr int NB = BN >= 256 ? 5 : gc_bld_max(BM);
+    constexpr int NB = BN >= 256 ? (BM >= 128 ? 6 : 5) : gc_bld_max(BM);      // (128 x 256: pointwise layers, 24 rows x 64 groups)
     static_assert(WM * WN == 4, "4 waves");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -439,10 +439,10 @@ __global__ __launch_bounds__(256, RES ? 1 : FZ ? (BM <= 32 ? 4 : 2) : gc_blocks_
                 });
             };
             if (!(p.dbg & 4)) {
-                if (jact == TN) mma_chunk(std::integral_constant<int, TN>{});
-                else if constexpr (TN > 1) {
-                    if (jact == 1) mma_chunk(std::integral_constant<int, 1>{});
-                }
+                // (the 4-tile wave keeps ONE matrix path: with three, the register allocator moved its 128 accumulators between
+                // the paths' own ranges through scratch memory - a partly filled last tile is rare on the layers that use it)
+                if (jact == 1 && TN == 2) mma_chunk(std::integral_constant<int, 1>{});
+                else if (jact >= 1) mma_chunk(std::integral_constant<int, TN>{});
             }
 #undef GC_FETCH
 #undef GC_MMA
@@ -609,7 +609,11 @@ __global__ __launch_bounds__(256, RES ? 1 : FZ ? (BM <= 32 ? 4 : 2) : gc_blocks_
         };
         epi_tile(std::integral_constant<int, 0>{});
         if constexpr (TN > 1) epi_tile(std::integral_constant<int, 1>{});
-        static_assert(TN <= 2, "epilogue: column tiles per wave");
+        if constexpr (TN > 2) {
+            epi_tile(std::integral_constant<int, 2>{});
+            epi_tile(std::integral_constant<int, 3>{});
+        }
+        static_assert(TN == 1 || TN == 2 || TN == 4, "epilogue: column tiles per wave");
     } else {   // EPI_LSTM
         // a lane's 16 accumulators of one MFMA tile are the i,f,g,o gates of 4 cells: all 16 gate pre-activations and
         // the 4 cell states are fetched by unconditional (clamped) loads in one batch, then the cells update
@@ -618,6 +622,20 @@ __global__ __launch_bounds__(256, RES ? 1 : FZ ? (BM <= 32 ? 4 : 2) : gc_blocks_
         const bool has_gx = p.aux != nullptr;
         const float* __restrict__ gx = has_gx ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fo * p.x_f : p.bias;
         float* __restrict__ cell = p.cell + (long)z * p.cell_z + (long)b * p.d_b + (long)fo * p.d_f;
+        // the cell states of ALL the wave's tiles are requested first (one HBM round trip instead of one per tile)
+        float cpa[TM][TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int tc = min(t0 + wn * (TN * 32) + j * 32 + l31, p.Tout - 1);
+                const int mb = m0 + wm * (TM * 32) + i * 32 + 4 * hi;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int m = min(mb + 8 * g4, p.M - 4);
+                    cpa[i][j][g4] = p.first_step ? 0.f : cell[(long)(m >> 2) * p.d_c + tc];
+                }
+            }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -633,7 +651,7 @@ __global__ __launch_bounds__(256, RES ? 1 : FZ ? (BM <= 32 ? 4 : 2) : gc_blocks_
                     const long gs = has_gx ? p.x_c : 1;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g[4 * g4 + k] = gp[(long)k * gs];
-                    cp[g4] = p.first_step ? 0.f : cell[(long)(m >> 2) * p.d_c + tc];
+                    cp[g4] = cpa[i][j][g4];
                 }
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -1341,6 +1359,18 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
             pl.tail[2].Wp = 256 + (dtmax - dtmin);
             pl.tail[2].g = gc_build_geom(taps, rows, dtmin, p.nrows, pl.tail[2].Wp, cic, p.KC, gc_bld_max(pl.BM));
         }
+        // 256-column geometry of the per-step LSTM GEMM (tail[2] as well; FullSubNet's sub-band layers): 2 x 2 waves of 64 x 128 -
+        // a staged K row feeds twice the matrix work of the 128 x 128 tile and a weight chunk is fetched once per 256 columns.
+        // Measured in round 4 on every 128-row pointwise layer: + 1.7 % on FullSubNet (two streams of step launches fill each
+        // other's tails), 1 - 8 % SLOWER on the LSTM input projections, DPCRN's and the conformer's pointwise layers (two
+        // workgroups per CU instead of three, coarser tails; with loads and epilogue ablated both tiles run the same
+        // 132 - 134 TFLOP/s, so the K loop itself gains nothing) - hence only here
+        static const int wide128_env = getenv("SE_GC_WIDE128") ? atoi(getenv("SE_GC_WIDE128")) : 1;
+        if (wide128_env && pl.BN == 128 && pl.BM == 128 && taps.ntaps == 1 && pw_chunks && epi == EPI_LSTM && cic * 256 <= 6 * 1024) {
+            pl.tail[2].BN = 256;
+            pl.tail[2].Wp = 256;
+            pl.tail[2].g = gc_build_geom(taps, rows, dtmin, p.nrows, 256, cic, p.KC, gc_bld_max(pl.BM));
+        }
         if (pl.BN == 128 && (pl.BM == 64 || pl.BM == 128) && epi != EPI_LSTM) {
             pl.tail[1].BN = 64;
             pl.tail[1].Wp = 64 + (dtmax - dtmin);
@@ -1649,6 +1679,25 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
             pa.desc = wd.g.desc;
             pa.desc4 = wd.g.desc4;
             gc_launch_t<64, 256, 1, 4>(pa, stream);
+            return;
+        }
+    }
+    // big launches of the per-step LSTM GEMM: 128 x 256 tiles (two workgroups per CU)
+    {
+        const GCTail& wd = pl.tail[2];
+        static const long wide128_min = getenv("SE_GC_WIDE128_MIN") ? atol(getenv("SE_GC_WIDE128_MIN")) : 1536;
+        static const int wide128_fill = getenv("SE_GC_WIDE128_FILL") ? atoi(getenv("SE_GC_WIDE128_FILL")) : 75;
+        const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
+        const int nt = (Tspan + 255) / 256;
+        if (wd.BN == 256 && pl.BM == 128 && p.epi == EPI_LSTM && p.pw4 && !p.trim && !p.stats && nblk >= wide128_min &&
+            Tspan * 100L >= (long)nt * 256 * wide128_fill) {
+            GCParams pa = p;
+            pa.n_ttiles = nt;
+            pa.Wp = wd.Wp;
+            pa.tab = wd.g.tab;
+            pa.desc = wd.g.desc;
+            pa.desc4 = wd.g.desc4;
+            gc_launch_e<128, 256, 2, 2, EPI_LSTM>(pa, stream);
             return;
         }
     }

@@ -97,6 +97,61 @@ __device__ __forceinline__ void gc_dma16_masked(const float* g, unsigned lds_wav
         : "v"(pred), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)), "v"(g)
         : "memory", "vcc");
 }
+// the same three with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane BYTE offset: no 64-bit vector address per
+// staged group (two VALU instructions and two registers each, live across the matrix loop once the issue is spread over it)
+__device__ __forceinline__ void gc_dma16_s(const float* base, unsigned voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte), "v"(voff), "s"(base) : "memory");
+}
+// (the validity test of a slot - bit `mask` of the lane's `vbits` - inside the asm block: as C++ the scheduler hoisted the
+// thirteen `vbits & mask` of a chunk to the top of the matrix loop and kept them alive)
+__device__ __forceinline__ void gc_dma4_masked_s(const float* base, unsigned voff, unsigned lds_byte, unsigned vbits, unsigned mask) {
+    unsigned long long saved;
+    unsigned tmp;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "v_and_b32_e32 %1, %6, %2\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %1\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %4, %5\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(saved), "=&v"(tmp)
+        : "v"(vbits), "s"(lds_byte), "v"(voff), "s"(base), "s"(mask)
+        : "memory", "vcc");
+}
+__device__ __forceinline__ void gc_dma16_masked_s(const float* base, unsigned voff, unsigned lds_byte, unsigned vbits, unsigned mask) {
+    unsigned long long saved;
+    unsigned tmp;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "v_and_b32_e32 %1, %6, %2\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %1\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(saved), "=&v"(tmp)
+        : "v"(vbits), "s"(lds_byte), "v"(voff), "s"(base), "s"(mask)
+        : "memory", "vcc");
+}
+// unmasked lanes, but the whole instruction only when the wave-uniform `cond` is non-zero (EXEC = 0 otherwise: no branch
+// inside the matrix loop)
+__device__ __forceinline__ void gc_dma16_cond_s(const float* base, unsigned voff, unsigned lds_byte, unsigned cond) {
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_cmp_lg_u32 %1, 0\n\t"
+        "s_cselect_b64 exec, exec, 0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %4\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(saved)
+        : "s"(cond), "s"(lds_byte), "v"(voff), "s"(base)
+        : "memory", "scc");
+}
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
 }
@@ -165,6 +220,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const unsigned wave_u = __builtin_amdgcn_readfirstlane((unsigned)wave);      // in an SGPR for the DMA's LDS bases
     const int l31 = lane & 31;
     const int hi = lane >> 5;
 
@@ -251,7 +307,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         constexpr int i = decltype(I)::value;
         int idx = tid + i * 256;
         if (idx >= nA4) idx = nA4 - 1;
-        aoff[i] = (unsigned)((idx / (BM / 4)) * p.Mp + (idx % (BM / 4)) * 4);
+        aoff[i] = 4u * (unsigned)((idx / (BM / 4)) * p.Mp + (idx % (BM / 4)) * 4);      // bytes
     });
     unsigned boff[NB];
     unsigned vbits = 0;      // bit e set when patch element e lies inside the tensor (else it is a zero of the padding)
@@ -303,7 +359,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             const int fc = f < 0 ? 0 : (f >= p.Fin ? p.Fin - 1 : f);                               \
             const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
-            boff[e] = staged ? (unsigned)cc * sc32 + (unsigned)fc * sf32 + (unsigned)tc : 0u;      \
+            boff[e] = staged ? 4u * ((unsigned)cc * sc32 + (unsigned)fc * sf32 + (unsigned)tc) : 0u;   /* bytes */ \
             /* pw4: the slot is a group of 4 frames; never straddles frame 0, may straddle Tin (see gc_launch)   */ \
             vbits |= (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? (1u << e) : 0u; \
             /* non-causal taps: a 16 B group that straddles the end of its row is trimmed in LDS after it lands (bits 16..) */ \
@@ -330,23 +386,24 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         /* (HBM latency), the weights (L2-resident) behind it                                                        */ \
         const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
         const unsigned bb = __builtin_amdgcn_readfirstlane(lds_addr(Bs + (BUF) * Bs_sz));          \
-        const unsigned bl = bb + 256u * wave, bl4 = bb + 1024u * wave;                             \
+        const unsigned bl = bb + 256u * wave_u, bl4 = bb + 1024u * wave_u;                         \
         if (pw4) {                                                                                 \
             static_for<NB>([&](auto E) {                                                           \
                 constexpr int e = decltype(E)::value;                                              \
-                if (e < bit4) gc_dma16_masked(Bc + boff[e], bl4 + 4096u * e, vbits & (1u << e)); \
+                if (e < bit4) gc_dma16_masked_s(Bc, boff[e], bl4 + 4096u * e, vbits, 1u << e);      \
             });                                                                                    \
         } else {                                                                                   \
             static_for<NB>([&](auto E) {                                                           \
                 constexpr int e = decltype(E)::value;                                              \
-                if (e < bit) gc_dma4_masked(Bc + boff[e], bl + 1024u * e, vbits & (1u << e));      \
+                if (e < bit) gc_dma4_masked_s(Bc, boff[e], bl + 1024u * e, vbits, 1u << e);         \
             });                                                                                    \
         }                                                                                          \
         const float* __restrict__ Ac = Ag + (long)(gchunk + (CH)) * p.KCp * p.Mp;                  \
-        float* Adw = As + (BUF) * As_sz + wave * 256;   /* wave-uniform LDS base of this wave's 1 KB slice */ \
+        /* wave-uniform LDS base of this wave's 1 KB slice */                                      \
+        const unsigned Adw = __builtin_amdgcn_readfirstlane(lds_addr(As + (BUF) * As_sz)) + 1024u * wave_u; \
         static_for<A_IT>([&](auto I) {                                                             \
             constexpr int i = decltype(I)::value;                                                  \
-            if (i < ait) gc_dma16(Ac + aoff[i], Adw + i * 1024);                                   \
+            if (i < ait) gc_dma16_s(Ac, aoff[i], Adw + 4096u * i);                                 \
         });                                                                                        \
     }
 // the DMA writes are invisible to the compiler: drain them by hand before the barrier that publishes the buffer
@@ -394,10 +451,36 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     buf = 0;
                 }
             }
-            if (!RES && c + 1 < nch && !(p.dbg & 1)) {
+            // the next chunk's DMAs: one instruction behind every group of matrix instructions (a slot = one 16 B / 4 B patch
+            // group or one 16 B weight group per lane).  Issued as one batch in front of the MFMAs, the 6 - 13 DMA
+            // instructions of a chunk stalled the wave at issue for half as long as its matrix work took (gcbench_timing:
+            // `load issue` 26 - 29 % of a block's life against 49 - 57 % `mfma`; the vector-memory queue fills and every
+            // further global_load_lds waits for a slot); spread over the matrix stream they find the queue drained
+            // (SE_GC_DBG=16: the batch in front, for the A/B measurement)
+            const bool nxt = !RES && c + 1 < nch && !(p.dbg & 1);
+            // (4 B staging keeps the batch.  So do the 128 x 128 / x 256 and 64 x 256 tiles: with the slots inside their matrix
+            // loop the register allocator parks two accumulator tiles in scratch memory between chunks - 168 registers are not
+            // enough for 64 accumulators + the slots' operands; their chunks also carry 2 - 4 x the matrix work per DMA)
+            constexpr bool ILV_TILE = !RES && !(BM >= 128 && BN >= 128) && BN < 256;
+            const bool ilv = ILV_TILE && nxt && pw4 && !(p.dbg & 16);
+            if (nxt) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
-                GC_LOAD_CHUNK(c + 1, buf ^ 1);
+                if (!ilv) GC_LOAD_CHUNK(c + 1, buf ^ 1);
             }
+            const float* __restrict__ Bc_n = sbase + (long)(c + 1) * p.CI_C * s_c;
+            const unsigned bl4_n = __builtin_amdgcn_readfirstlane(lds_addr(Bs + (buf ^ 1) * Bs_sz)) + 1024u * wave_u;
+            const float* __restrict__ Ac_n = Ag + (long)(gchunk + c + 1) * p.KCp * p.Mp;
+            const unsigned Adw_n = __builtin_amdgcn_readfirstlane(lds_addr(As + (buf ^ 1) * As_sz)) + 1024u * wave_u;
+            // slots of the next chunk this wave still has to issue: bits 0 .. NB-1 patch groups, NB .. weight groups (wave-uniform)
+            const unsigned slotmask = ilv ? (((1u << bit4) - 1u) | (((1u << ait) - 1u) << NB)) : 0u;
+            auto dma_slot = [&](auto S_) __attribute__((always_inline)) {
+                constexpr int sl = decltype(S_)::value;
+                // (no branch: a slot that is not due runs with EXEC = 0)
+                if constexpr (!ILV_TILE) return;
+                else if constexpr (sl < NB) gc_dma16_masked_s(Bc_n, boff[sl], bl4_n + 4096u * sl, vbits, slotmask & (1u << sl));
+                else if constexpr (sl < NB + A_IT) gc_dma16_cond_s(Ac_n, aoff[sl - NB], Adw_n + 4096u * (sl - NB), slotmask & (1u << sl));
+            };
+            static_assert(NB + A_IT <= NPAIR, "one DMA slot per k-pair position of a chunk");
             GC_T(1);
             // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
             const float* Ab = As + buf * As_sz + hi * BM + am;
@@ -431,18 +514,35 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                         __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
                         GC_MMA(ax, bx);
                         __builtin_amdgcn_sched_group_barrier(0x008, TM * JN, 0);
+                        dma_slot(std::integral_constant<int, kp>{});
                         GC_FETCH(kp + 2, ax, bx);
                         __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
                         GC_MMA(ay, by);
                         __builtin_amdgcn_sched_group_barrier(0x008, TM * JN, 0);
+                        dma_slot(std::integral_constant<int, kp + 1>{});
+                    }
+                });
+                // (a chunk with fewer k-pair positions than slots: the rest behind the matrix work)
+                static_for<NPAIR / 2>([&](auto KP2) {
+                    constexpr int kp = 2 * decltype(KP2)::value;
+                    if (kp >= npair) {
+                        dma_slot(std::integral_constant<int, kp>{});
+                        dma_slot(std::integral_constant<int, kp + 1>{});
                     }
                 });
             };
+            bool mma_ran = true;
             if (!(p.dbg & 4)) {
                 // (the 4-tile wave keeps ONE matrix path: with three, the register allocator moved its 128 accumulators between
                 // the paths' own ranges through scratch memory - a partly filled last tile is rare on the layers that use it)
                 if (jact == 1 && TN == 2) mma_chunk(std::integral_constant<int, 1>{});
                 else if (jact >= 1) mma_chunk(std::integral_constant<int, TN>{});
+                else mma_ran = false;
+            } else {
+                mma_ran = false;
+            }
+            if (!mma_ran) {      // a wave with nothing but padding columns still stages its share of the next chunk
+                static_for<NPAIR>([&](auto S_) { dma_slot(S_); });
             }
 #undef GC_FETCH
 #undef GC_MMA
@@ -1600,8 +1700,8 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     static const int dbg_env = getenv("SE_GC_DBG") ? atoi(getenv("SE_GC_DBG")) : 0;
     p.dbg = dbg_env;
     // patch offsets inside one staged chunk are 32-bit (the 64-bit part of an address is the per-block / per-chunk base)
-    SE_CHECK((double)p.CI_C * (double)std::max(p.s0_c, p.s1_c) + (double)p.Fin * (double)std::max(p.s0_f, p.s1_f) + p.Tin < 4.0e9,
-             "gc_launch: source plane too large for 32-bit patch offsets");
+    SE_CHECK((double)p.CI_C * (double)std::max(p.s0_c, p.s1_c) + (double)p.Fin * (double)std::max(p.s0_f, p.s1_f) + p.Tin < 1.0e9,
+             "gc_launch: source plane too large for 32-bit patch byte offsets");
     static const int pw4_env = getenv("SE_GC_PW4") ? atoi(getenv("SE_GC_PW4")) : 1;
     // 16 B staging groups: exact when no group straddles the end of a row (Tin % 4 == 0); for causal tap sets a straddling
     // group only feeds output frames >= Tin, which are never stored - then it merely has to stay inside mapped memory

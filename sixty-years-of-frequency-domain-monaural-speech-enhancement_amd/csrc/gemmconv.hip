@@ -193,6 +193,8 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
 #endif
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
+    // tiles that issue the next chunk's DMAs one per matrix-instruction group (see the K loop)
+    constexpr bool ILV_TILE = !RES && !(BM >= 128 && BN >= 128) && BN < 256;
     // small-M tiles do little MFMA work per staged K row, so they stage twice the K depth per barrier to keep the
     // global-load latency under the matrix work
     constexpr int KCP_MAX = gc_kcp_max(BM);
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     });
     unsigned boff[NB];
     unsigned vbits = 0;      // bit e set when patch element e lies inside the tensor (else it is a zero of the padding)
+    unsigned fullbits = 0;   // wave-uniform: bit e set when that holds for all 64 lanes of slot e
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -365,6 +368,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             /* non-causal taps: a 16 B group that straddles the end of its row is trimmed in LDS after it lands (bits 16..) */ \
             if (fixt) vbits |= (staged && (t < p.Tin) && (t + 4 > p.Tin)) ? (0x10000u << e) : 0u;   \
         });                                                                                        \
+        /* slots whose 64 lanes are all inside the tensor (every slot of an interior tile): staged without the EXEC detour */ \
+        /* (the tiles that spread their DMAs over the matrix loop stage through the masked form there: not worth the votes) */ \
+        fullbits = 0;                                                                              \
+        if constexpr (!ILV_TILE) {      /* (SE_GC_DBG=32: always the masked form, for the A/B measurement) */ \
+            if (!(p.dbg & 32)) static_for<NB>([&](auto E) {                                                           \
+                constexpr int e = decltype(E)::value;                                              \
+                if (e < bit4 && __builtin_amdgcn_ballot_w64((vbits >> e) & 1u) == ~0ull) fullbits |= 1u << e; \
+            });                                                                                    \
+        }                                                                                          \
     }
 // the frames >= Tin of a straddling group hold the head of the next row: the thread that staged the group zeroes them once
 // its own DMAs have landed (behind GC_WAIT_CHUNK, before the barrier that publishes the buffer)
@@ -387,10 +399,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
         const unsigned bb = __builtin_amdgcn_readfirstlane(lds_addr(Bs + (BUF) * Bs_sz));          \
         const unsigned bl = bb + 256u * wave_u, bl4 = bb + 1024u * wave_u;                         \
-        if (pw4) {                                                                                 \
+        if (pw4 && fullbits == (1u << bit4) - 1u) {     /* every group of the chunk inside the tensor: no EXEC detours */ \
             static_for<NB>([&](auto E) {                                                           \
                 constexpr int e = decltype(E)::value;                                              \
-                if (e < bit4) gc_dma16_masked_s(Bc, boff[e], bl4 + 4096u * e, vbits, 1u << e);      \
+                if (e < bit4) gc_dma16_s(Bc, boff[e], bl4 + 4096u * e);                            \
+            });                                                                                    \
+        } else if (pw4) {                                                                          \
+            static_for<NB>([&](auto E) {                                                           \
+                constexpr int e = decltype(E)::value;                                              \
+                if (e < bit4) gc_dma16_masked_s(Bc, boff[e], bl4 + 4096u * e, vbits, 1u << e);     \
             });                                                                                    \
         } else {                                                                                   \
             static_for<NB>([&](auto E) {                                                           \
@@ -461,7 +478,6 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // (4 B staging keeps the batch.  So do the 128 x 128 / x 256 and 64 x 256 tiles: with the slots inside their matrix
             // loop the register allocator parks two accumulator tiles in scratch memory between chunks - 168 registers are not
             // enough for 64 accumulators + the slots' operands; their chunks also carry 2 - 4 x the matrix work per DMA)
-            constexpr bool ILV_TILE = !RES && !(BM >= 128 && BN >= 128) && BN < 256;
             const bool ilv = ILV_TILE && nxt && pw4 && !(p.dbg & 16);
             if (nxt) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);

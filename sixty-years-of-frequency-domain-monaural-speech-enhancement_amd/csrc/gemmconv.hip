@@ -525,7 +525,12 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                 GC_FETCH(0, ax, bx);
                 static_for<NPAIR / 2>([&](auto KP2) {
                     constexpr int kp = 2 * decltype(KP2)::value;
-                    if (kp < npair) {
+                    // (the test against a copy the compiler cannot see through: as loop invariants of the chunk loop the eight
+                    // tests were hoisted, their masks ran out of SGPRs and every one came back through two v_readlane - vector
+                    // instructions on the matrix pipe's clock - per two k-pairs; now one s_cmp each)
+                    int np_ = npair;
+                    asm volatile("" : "+s"(np_));
+                    if (kp < np_) {
                         GC_FETCH(kp + 1, ay, by);
                         __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
                         GC_MMA(ax, bx);

@@ -86,9 +86,10 @@ inline Act4 act4(const float* p, int C, int F, int Tp) { return Act4{p, C, F, (l
 struct Profiler;
 // stats (optional): [B][dstC][Fout][ceil(T / 32)][2] partial sums of the stored output (GCParams::stats)
 // fz (optional, plans for which conv_folds_interaction() holds): the complex branch's tensor [B][2 * dstC][Fout][Tp] whose
-// interaction with this launch's output is folded into the store (GCParams::fz)
+// interaction with this launch's output is folded into the store (GCParams::fz); fz_planes = 3: fz is the REAL plane of a
+// three-plane tensor [B][3 * dstC][Fout][Tp] = [S | R | I] (gauss.h; the sum plane is the caller's to refresh)
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, float* fz = nullptr);
+              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, float* fz = nullptr, int fz_planes = 2);
 inline bool conv_folds_interaction(const GCPlan& pl) { return pl.p.Ws == nullptr && (pl.p.epi == EPI_ACT || pl.p.epi == EPI_ADD); }
 inline bool conv_folds_interaction(const DeconvPlan& pl) {
     if (pl.has_pair || pl.par.empty()) return false;
@@ -100,7 +101,7 @@ inline bool conv_folds_interaction(const DeconvPlan& pl) {
 // GCParams::tb_soft
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
                 int Tp, hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, int t_out = -1,
-                bool tb_soft = false, float* fz = nullptr);
+                bool tb_soft = false, float* fz = nullptr, int fz_planes = 2);
 bool conv_stats_supported(const GCPlan& pl);
 bool deconv_stats_supported(const DeconvPlan& pl);
 

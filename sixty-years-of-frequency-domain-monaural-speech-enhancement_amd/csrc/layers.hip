@@ -436,19 +436,19 @@ bool deconv_stats_supported(const DeconvPlan& pl) {
     return true;
 }
 
-static void set_fz(GCParams& p, float* fz, int dstC, int Fout, int Tp) {
+static void set_fz(GCParams& p, float* fz, int dstC, int Fout, int Tp, int planes) {
     p.fz = fz;
     p.fz_im = (long)dstC * Fout * Tp;
-    p.fz_b = 2 * p.fz_im;
+    p.fz_b = planes * p.fz_im;
     p.fz_c = (long)Fout * Tp;
     p.fz_f = Tp;
 }
 
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof, float* stats, int t_base, float* fz) {
+              hipStream_t st, Profiler* prof, float* stats, int t_base, float* fz, int fz_planes) {
     GCParams p = pl.p;
     p.t_base = t_base;
-    if (fz) set_fz(p, fz, dstC, Fout, Tp);
+    if (fz) set_fz(p, fz, dstC, Fout, Tp, fz_planes);
     if (stats) set_stats(p, stats, dstC, Fout, T);
     fill_src(p, s0, s1);
     p.Fin = s0.F;
@@ -465,7 +465,7 @@ void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int 
 }
 
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
-                int Tp, hipStream_t st, Profiler* prof, float* stats, int t_base, int t_out, bool tb_soft, float* fz) {
+                int Tp, hipStream_t st, Profiler* prof, float* stats, int t_base, int t_out, bool tb_soft, float* fz, int fz_planes) {
     if (t_out < 0) t_out = T;
     SE_CHECK(!fz || conv_folds_interaction(pl), "run_deconv: this plan cannot fold the branch interaction into its store");
     // (a BatchNorm attached to the class plans later is not in the pair; the few frames of a frame-online chunk go through
@@ -509,7 +509,7 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
         p.d_c = (long)Fout * Tp;
         p.d_f = Tp;
         if (const Ragged* rg = ragged_ctx()) p.tlen = rg->tlen;
-        if (fz) set_fz(p, fz, dstC, Fout, Tp);
+        if (fz) set_fz(p, fz, dstC, Fout, Tp, fz_planes);
         if (p.Q <= 0) continue;
         if (few && !stats && pl.par.size() == 2 && np < 2) {      // (a few frames: both classes in one thin launch if they qualify)
             ps[np] = p;

@@ -17,6 +17,7 @@
 //     frame covering both LSTMs (blockIdx.z) and all 2B sequences; r-i / r+i combinations are folded into the
 //     next layer's weights ([W,-W] / [W,W] two-source GEMMs).
 #include "rnn.h"
+#include "gauss.h"
 #include "../../include/se_engine.h"
 
 namespace se {
@@ -35,85 +36,9 @@ struct Bufs {
     float *X1 = nullptr, *G = nullptr, *H1 = nullptr, *H2 = nullptr, *C1 = nullptr, *C2 = nullptr, *P = nullptr, *K = nullptr;
 };
 
-// ---- Gauss' three-product complex (de)conv (measure it) -------------------------------------------------
-// The reference computes a complex conv as four real ones (complexnn: r2r - i2i, r2i + i2r); the engine runs them as ONE real
-// conv over the 2 x 2 block matrix.  Gauss: k1 = Wr (xr + xi), k2 = (Wi - Wr) xr, k3 = (Wr + Wi) xi, yr = k1 - k3, yi = k1 + k2 -
-// three real convs of half the rows and half the K: 3/4 of the matrix instructions.  Here as a GROUPED launch of the same
-// gc_kernel (blockIdx.z = product, sources = the planes [xr + xi | xr | xi] of a three-plane tensor, outputs k1..k3 in a scratch
-// tensor) and one elementwise pass that combines them, applies BatchNorm / bias / PReLU and writes the next layer's three planes.
-// tools/gcbench.cpp `gauss` (profiles/r04_gauss_gcbench.log): 128 -> 128 complex channels 0.81x the block GEMM's time, 64 -> 128
-// 0.87x, 32 -> 64 0.97x, 16 -> 32 1.28x (the combine pass is as big as the GEMM there) - so the layers with >= 128 complex output
-// channels take this path: encoder 3 - 5, decoder 0 - 1 (50 % of the step).  Rounding: the products are formed on sums of
-// weights / inputs - 4e-7 ... 1e-6 relative per layer against the four-product form (bar 1e-4 on the waveform).
-// x3 [B][3 C][P] planes (S | R | I): S = R + I
-__global__ __launch_bounds__(256) void gauss_sum_kernel(float* __restrict__ x3, long CP) {
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4, b = blockIdx.y;
-    if (i >= CP) return;
-    float* xb = x3 + b * 3 * CP;
-    if (i + 3 < CP && (CP & 3) == 0) {
-        const float4 r = *reinterpret_cast<const float4*>(xb + CP + i), m = *reinterpret_cast<const float4*>(xb + 2 * CP + i);
-        *reinterpret_cast<float4*>(xb + i) = make_float4(r.x + m.x, r.y + m.y, r.z + m.z, r.w + m.w);
-    } else {
-        for (long j = i; j < CP && j < i + 4; ++j) xb[j] = xb[CP + j] + xb[2 * CP + j];
-    }
-}
-// k [3][B][Co][F][T] -> y: yr = act((k1 - k3) sc[c] + sh[c]), yi = act((k1 + k2) sc[Co + c] + sh[Co + c]); planes of batch item b at
-// y + b ob + {oS, oR, oI} (oS < 0: no sum plane); frames >= tlen[b] are stored as zeros (ragged rows: the decoder looks ahead)
-__global__ __launch_bounds__(128) void gauss_combine_kernel(const float* __restrict__ k, float* __restrict__ y, int Co, int F, int T,
-                                                            long kz, long ob, long oS, long oR, long oI,
-                                                            const float* __restrict__ sc, const float* __restrict__ sh,
-                                                            const float* __restrict__ slope, const int* __restrict__ tlen) {
-    const int f = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
-    const long row = (((long)b * Co + c) * F + f) * T, orow = (long)b * ob + ((long)c * F + f) * T;
-    const float s_r = sc[c], h_r = sh[c], s_i = sc[Co + c], h_i = sh[Co + c], a_r = slope[c], a_i = slope[Co + c];
-    const int tv = tlen ? tlen[b] : T;
-    const bool v4 = (T & 3) == 0;
-    for (int t = threadIdx.x * 4; t < T; t += 512) {
-        float k1[4], k2[4], k3[4], yr[4], yi[4];
-        if (v4) {
-            *reinterpret_cast<float4*>(k1) = *reinterpret_cast<const float4*>(k + row + t);
-            *reinterpret_cast<float4*>(k2) = *reinterpret_cast<const float4*>(k + kz + row + t);
-            *reinterpret_cast<float4*>(k3) = *reinterpret_cast<const float4*>(k + 2 * kz + row + t);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int tt = min(t + j, T - 1);
-                k1[j] = k[row + tt]; k2[j] = k[kz + row + tt]; k3[j] = k[2 * kz + row + tt];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float r = (k1[j] - k3[j]) * s_r + h_r, m = (k1[j] + k2[j]) * s_i + h_i;
-            r = r >= 0.f ? r : a_r * r;
-            m = m >= 0.f ? m : a_i * m;
-            const bool live = t + j < tv;
-            yr[j] = live ? r : 0.f;
-            yi[j] = live ? m : 0.f;
-        }
-        if (v4) {
-            *reinterpret_cast<float4*>(y + orow + oR + t) = *reinterpret_cast<const float4*>(yr);
-            *reinterpret_cast<float4*>(y + orow + oI + t) = *reinterpret_cast<const float4*>(yi);
-            if (oS >= 0) *reinterpret_cast<float4*>(y + orow + oS + t) = make_float4(yr[0] + yi[0], yr[1] + yi[1], yr[2] + yi[2], yr[3] + yi[3]);
-        } else {
-            for (int j = 0; j < 4 && t + j < T; ++j) {
-                y[orow + oR + t + j] = yr[j];
-                y[orow + oI + t + j] = yi[j];
-                if (oS >= 0) y[orow + oS + t + j] = yr[j] + yi[j];
-            }
-        }
-    }
-}
-struct GaussLayer {
-    std::vector<GCPlan> pl;      // encoder: one grouped plan (Z = 3); decoder: one per output-parity class
-    float *sc = nullptr, *sh = nullptr, *slope = nullptr;      // [2 co] rows [real; imag]
-    int co = 0;
-    void free() {
-        for (auto& g : pl) gc_free_plan(g);
-        pl.clear();
-        for (float** p : {&sc, &sh, &slope})
-            if (*p) { (void)hipFree(*p); *p = nullptr; }
-    }
-};
+using gauss::GaussLayer;
+using gauss::gauss_sum_kernel;
+using gauss::gauss_combine_kernel;
 
 class Dccrn final : public Model {
   public:

@@ -15,6 +15,7 @@
 //     registers (T-branch: 401 x 401 online softmax per (b, f) with K/V tiles in LDS; F-branch: 4 x 4 per (b, t));
 //   * the dilated 3x3 conv pairs use the sigmoid and gate-product epilogues, `fusion` is one elementwise kernel.
 #include "rnn.h"
+#include "gauss.h"
 
 namespace se {
 
@@ -518,6 +519,8 @@ class Uformer final : public Model {
         }
         lnC.free();
         lnR.free();
+        for (auto& g : genc) g.free();
+        for (auto& g : gdec) g.free();
     }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, WIN}; }
     int64_t output_samples(int L) const override { return (int64_t)HOP * (L / HOP); }   // istft without length (:276)
@@ -562,6 +565,43 @@ class Uformer final : public Model {
             }
             decC[k] = make_deconv_plan(w, 2, 2, 0, act, sc, 401, 2 * ci);
             decR[k] = make_deconv_plan(r, 2, 2, 0, act, sr, 401, ci);
+        }
+        gauss_on = !(getenv("SE_UF_GAUSS") && atoi(getenv("SE_UF_GAUSS")) == 0);
+        if (gauss_on) {
+            // BatchNorm3d(C) (both parts alike) + the conv biases (real part b_r - b_i, imaginary b_r + b_i) + PReLU of a layer
+            auto tail = [&](gauss::GaussLayer& g, const std::string& p, const DenseW& wr, const DenseW& wi) {
+                const int co = wr.M;
+                const HostTensor &ga = sd.get(p + "1.weight", {co}), &be = sd.get(p + "1.bias", {co}), &mu = sd.get(p + "1.running_mean", {co}),
+                                 &va = sd.get(p + "1.running_var", {co});
+                std::vector<float> sc(2 * co), sh(2 * co);
+                for (int m = 0; m < 2 * co; ++m) {
+                    const int c = m % co;
+                    const float bias = m < co ? wr.bias[c] - wi.bias[c] : wr.bias[c] + wi.bias[c];
+                    const double k = (double)ga.data[c] / std::sqrt((double)va.data[c] + 1e-5);
+                    sc[m] = (float)k;
+                    sh[m] = (float)((double)be.data[c] - (double)mu.data[c] * k + (double)bias * k);
+                }
+                g.sc = to_device(sc);
+                g.sh = to_device(sh);
+                g.slope = to_device(prelu_slopes(sd.get(p + "2.weight"), 2 * co));
+            };
+            for (int j = 0; j < 2; ++j) {
+                const int k = 4 + j, ci = KN[k], co = KN[k + 1];
+                const std::string p = "encoder." + std::to_string(k) + ".";
+                DenseW wr = conv_weights(sd.get(p + "0.real_conv.weight", {co, ci, 5, 2}), &sd.get(p + "0.real_conv.bias", {co}), false);
+                DenseW wi = conv_weights(sd.get(p + "0.imag_conv.weight", {co, ci, 5, 2}), &sd.get(p + "0.imag_conv.bias", {co}), false);
+                gauss::make_conv_plans(genc[j], wr, wi, 401);
+                tail(genc[j], p, wr, wi);
+            }
+            for (int k = 0; k < 2; ++k) {
+                const int idx = NL - k, ci = KN[idx], co = KN[idx - 1];
+                const std::string p = "decoder." + std::to_string(k) + ".";
+                // input channels per part in the reference's cat order [skip (ci) | out (ci)] = (first source | second source)
+                DenseW wr = deconv_weights(sd.get(p + "0.real_conv.weight", {2 * ci, co, 5, 2}), &sd.get(p + "0.real_conv.bias", {co}), false);
+                DenseW wi = deconv_weights(sd.get(p + "0.imag_conv.weight", {2 * ci, co, 5, 2}), &sd.get(p + "0.imag_conv.bias", {co}), false);
+                gauss::make_deconv_plans(gdec[k], wr, wi, 0, ci, 401);
+                tail(gdec[k], p, wr, wi);
+            }
         }
         const std::string c = "conformer.";
         ffC[0].load(sd, c + "ff1_cplx.", true);
@@ -617,7 +657,12 @@ class Uformer final : public Model {
         float *c, *spec, *est, *frames, *mag0, *ph0, *xc, *xm;
         float *EC[NL], *ER[NL], *DC[NL], *DR[NL];
         float *XC[2], *XR[2], *t1, *t2, *t3, *pq;
+        float *EC5g, *XCg, *K;      // three-product layers: three-plane copies of the encoder's last output / the conformer's output, k1..k3
     } cur;
+    // encoder layers 4 - 5 and decoder layers 0 - 1 (>= 64 complex output channels at 128 / 256 complex inputs) as Gauss' three real
+    // products (gauss.h): EC[3], EC[4], DC[0] are then three-plane tensors [S | R | I] (SE_UF_GAUSS=0: block GEMMs)
+    gauss::GaussLayer genc[2], gdec[2];
+    bool gauss_on = false;
     GCPlan encC[NL], encR[NL];
     DeconvPlan decC[NL], decR[NL];
     FFBlock ffC[2], ffR[2];
@@ -644,19 +689,25 @@ class Uformer final : public Model {
         int F = 256;
         for (int k = 0; k < NL; ++k) {
             F /= 2;
-            b.EC[k] = a.alloc_f(BT * 2 * KN[k + 1] * F);
+            b.EC[k] = a.alloc_f(BT * ((gauss_on && (k == 3 || k == 4)) ? 3 : 2) * KN[k + 1] * F);
             b.ER[k] = a.alloc_f(BT * KN[k + 1] * F);
         }
         F = 4;
         for (int k = 0; k < NL; ++k) {
             F *= 2;
-            b.DC[k] = a.alloc_f(BT * 2 * KN[NL - k - 1] * F);
+            b.DC[k] = a.alloc_f(BT * ((gauss_on && k == 0) ? 3 : 2) * KN[NL - k - 1] * F);
             b.DR[k] = a.alloc_f(BT * KN[NL - k - 1] * F);
         }
         const size_t P = BT * 4;
         for (int j = 0; j < 2; ++j) {
             b.XC[j] = a.alloc_f(P * 2 * CC);
             b.XR[j] = a.alloc_f(P * CC);
+        }
+        b.EC5g = b.XCg = b.K = nullptr;
+        if (gauss_on) {
+            b.EC5g = a.alloc_f(P * 3 * CC);
+            b.XCg = a.alloc_f(P * 3 * CC);
+            b.K = a.alloc_f(BT * 3 * 1024);      // k1..k3 of the widest layer: 128 channels x 8 rows (64 x 16)
         }
         b.t1 = a.alloc_f(P * 2 * CC);
         b.t2 = a.alloc_f(P * 2 * CC);
@@ -685,6 +736,56 @@ class Uformer final : public Model {
     }
     void fusion(float* c, float* m, int B, long CP, hipStream_t st) {
         hipLaunchKernelGGL(uf_fusion_kernel, dim3((unsigned)((CP + 255) / 256), B), dim3(256), 0, st, c, m, CP);
+    }
+    // ---- three-product layers (gauss.h).  A three-plane tensor [B][3 C][F][T]: S = R + I at +0, R at + C F T, I at + 2 C F T
+    static Act4 view3(const float* t3, int C, int F, int T) {      // its [R | I] planes as a 2 C-channel tensor
+        return Act4{t3 + (long)C * F * T, 2 * C, F, 3L * C * F * T, (long)F * T, (long)T};
+    }
+    void gauss_sum(float* t3, int B, long CP, hipStream_t st) {
+        Profiler* pf = &ctx.prof;
+        const bool timed = pf->on;
+        if (timed) pf->begin(st);
+        hipLaunchKernelGGL(gauss::gauss_sum_kernel, dim3((unsigned)((CP / 4 + 255) / 256 + 1), B), dim3(256), 0, st, t3, CP);
+        SE_HIP(hipGetLastError());
+        if (timed) pf->end(st, 0.0);
+    }
+    void gauss_planes23(const float* x2, float* x3, int B, long CP, hipStream_t st) {
+        Profiler* pf = &ctx.prof;
+        const bool timed = pf->on;
+        if (timed) pf->begin(st);
+        hipLaunchKernelGGL(gauss::gauss_planes23_kernel, dim3((unsigned)((CP / 4 + 255) / 256 + 1), B), dim3(256), 0, st, x2, x3, CP);
+        SE_HIP(hipGetLastError());
+        if (timed) pf->end(st, 0.0);
+    }
+    // y = PReLU(BN(complex (de)conv(x))): the grouped launch(es) into b.K, then the combine pass.  src0 / src1: three-plane tensors of
+    // C0 / C1 complex channels; dst3: three-plane output (else [R | I])
+    void gauss_layer(const gauss::GaussLayer& g, Bufs& b, const float* src0, int C0, const float* src1, int C1, int Fin, int Fout, int T,
+                     float* dst, bool dst3, hipStream_t st) {
+        const int B = b.B, co = g.co;
+        Profiler* pf = &ctx.prof;
+        const long kz = (long)B * co * Fout * T;
+        const Ragged* rg = ragged_ctx();
+        for (const GCPlan& pl : g.pl) {
+            GCParams p = pl.p;
+            p.src0 = src0; p.C0 = C0; p.s0_b = 3L * C0 * Fin * T; p.s0_c = (long)Fin * T; p.s0_f = T; p.src0_z = (long)C0 * Fin * T;
+            if (src1) {
+                p.src1 = src1; p.C1 = C1; p.s1_b = 3L * C1 * Fin * T; p.s1_c = (long)Fin * T; p.s1_f = T; p.src1_z = (long)C1 * Fin * T;
+            } else {
+                p.src1 = nullptr; p.C1 = 0;
+            }
+            p.Fin = Fin; p.Tin = T; p.B = B; p.Tout = T;
+            p.Q = (Fout - p.po + p.so - 1) / p.so;
+            p.dst = b.K; p.d_b = (long)co * Fout * T; p.d_c = (long)Fout * T; p.d_f = T; p.dst_z = kz;
+            if (rg) p.tlen = rg->tlen;
+            gc_launch_prof(pl, p, st, pf);
+        }
+        const long CP = (long)co * Fout * T;
+        const bool timed = pf->on;
+        if (timed) pf->begin(st);
+        hipLaunchKernelGGL(gauss::gauss_combine_kernel, dim3(Fout, co, B), dim3(128), 0, st, b.K, dst, co, Fout, T, kz, dst3 ? 3 * CP : 2 * CP,
+                           -1L, dst3 ? CP : 0L, dst3 ? 2 * CP : CP, g.sc, g.sh, g.slope, rg ? rg->tlen : nullptr);
+        SE_HIP(hipGetLastError());
+        if (timed) pf->end(st, 0.0);
     }
     // LayerNorm over C of a [Bv][C][P] view
     void ln(const LnW& w, const float* x, float* y, int Bv, int C, long P, hipStream_t st, int post = 0, const float* slope = nullptr,
@@ -784,13 +885,24 @@ class Uformer final : public Model {
         int F = 256;
         for (int k = 0; k < NL; ++k) {
             F /= 2;
-            run_conv(encC[k], xc, nullptr, b.EC[k], 2 * KN[k + 1], F, B, T, T, st, pf);
+            const int co = KN[k + 1];
+            const long CPk = (long)co * F * T;
+            // three-plane outputs (inputs of the three-product layers 4 / 5 and skips of decoder layers 1 / 2): EC[3], EC[4]
+            const bool out3 = gauss_on && (k == 3 || k == 4);
+            float* ecR = out3 ? b.EC[k] + CPk : b.EC[k];          // the [R | I] planes
+            if (gauss_on && k >= 4) gauss_layer(genc[k - 4], b, b.EC[k - 1], KN[k], nullptr, 0, 2 * F, F, T, b.EC[k], out3, st);
+            else run_conv(encC[k], xc, nullptr, ecR, (out3 ? 3 : 2) * co, F, B, T, T, st, pf);      // (dstC only sets the batch stride)
             const bool fold = fold_env() && conv_folds_interaction(encR[k]);
-            run_conv(encR[k], xm, nullptr, b.ER[k], KN[k + 1], F, B, T, T, st, pf, nullptr, 0, fold ? b.EC[k] : nullptr);
-            if (!fold) fusion(b.EC[k], b.ER[k], B, (long)KN[k + 1] * F * T, st);
-            xc = act4(b.EC[k], 2 * KN[k + 1], F, T);
-            xm = act4(b.ER[k], KN[k + 1], F, T);
+            run_conv(encR[k], xm, nullptr, b.ER[k], co, F, B, T, T, st, pf, nullptr, 0, fold ? ecR : nullptr, out3 ? 3 : 2);
+            if (!fold) {
+                SE_CHECK(!out3, "Uformer: three-plane encoder tensors need the folded interaction (SE_UF_FOLD=0 with SE_UF_GAUSS=1)");
+                fusion(b.EC[k], b.ER[k], B, CPk, st);
+            }
+            if (out3) gauss_sum(b.EC[k], B, CPk, st);             // S = R + I of the tensor the interaction has just rewritten
+            xc = out3 ? view3(b.EC[k], co, F, T) : act4(b.EC[k], 2 * co, F, T);
+            xm = act4(b.ER[k], co, F, T);
         }
+        if (gauss_on) gauss_planes23(b.EC[NL - 1], b.EC5g, B, (long)CC * 4 * T, st);      // skip of decoder layer 0
         // ---- dilated dual-path conformer at [B][128][4][T] (dilated_dualpath_conformer.py:53-78)
         const long P = 4L * T, CP = (long)CC * P;
         const float *c = b.EC[NL - 1], *m = b.ER[NL - 1];
@@ -821,16 +933,35 @@ class Uformer final : public Model {
         m = b.XR[pp];
         // ---- decoder (:225-232): cat([skip, out]) two-source, fusion after every layer
         F = 4;
+        if (gauss_on) gauss_planes23(c, b.XCg, B, CP, st);
+        bool c3 = false;          // `c` is a three-plane tensor
         for (int k = 0; k < NL; ++k) {
             const int ci = KN[NL - k], co = KN[NL - k - 1];
-            Act4 s0 = act4(b.EC[NL - 1 - k], 2 * ci, F, T), s1 = act4(c, 2 * ci, F, T);
-            run_deconv(decC[k], s0, &s1, b.DC[k], 2 * co, 2 * F, B, T, T, st, pf);
-            Act4 r0 = act4(b.ER[NL - 1 - k], ci, F, T), r1 = act4(m, ci, F, T);
+            const int ek = NL - 1 - k;                             // the skip: encoder output ek
+            const bool skip3 = gauss_on && (ek == 3 || ek == 4);
+            const bool out3 = gauss_on && k == 0;                  // DC[0] feeds the three-product layer 1
+            const long CPo = (long)co * 2 * F * T;
+            float* dcR = out3 ? b.DC[k] + CPo : b.DC[k];
+            if (gauss_on && k < 2) {
+                const float* s0 = k == 0 ? b.EC5g : b.EC[ek];
+                const float* s1 = k == 0 ? b.XCg : b.DC[0];
+                gauss_layer(gdec[k], b, s0, ci, s1, ci, F, 2 * F, T, b.DC[k], out3, st);
+            } else {
+                Act4 s0 = skip3 ? view3(b.EC[ek], ci, F, T) : act4(b.EC[ek], 2 * ci, F, T);
+                Act4 s1 = c3 ? view3(c, ci, F, T) : act4(c, 2 * ci, F, T);
+                run_deconv(decC[k], s0, &s1, b.DC[k], 2 * co, 2 * F, B, T, T, st, pf);
+            }
+            Act4 r0 = act4(b.ER[ek], ci, F, T), r1 = act4(m, ci, F, T);
             const bool fold = fold_env() && conv_folds_interaction(decR[k]);
-            run_deconv(decR[k], r0, &r1, b.DR[k], co, 2 * F, B, T, T, st, pf, nullptr, 0, -1, false, fold ? b.DC[k] : nullptr);
+            run_deconv(decR[k], r0, &r1, b.DR[k], co, 2 * F, B, T, T, st, pf, nullptr, 0, -1, false, fold ? dcR : nullptr, out3 ? 3 : 2);
             F *= 2;
-            if (!fold) fusion(b.DC[k], b.DR[k], B, (long)co * F * T, st);
+            if (!fold) {
+                SE_CHECK(!out3, "Uformer: three-plane decoder tensors need the folded interaction (SE_UF_FOLD=0 with SE_UF_GAUSS=1)");
+                fusion(b.DC[k], b.DR[k], B, (long)co * F * T, st);
+            }
+            if (out3) gauss_sum(b.DC[k], B, CPo, st);
             c = b.DC[k];
+            c3 = out3;
             m = b.DR[k];
         }
         hipLaunchKernelGGL(uf_post_kernel, dim3((T + 255) / 256, NBIN, B), dim3(256), 0, st, c, m, b.mag0, b.ph0, b.est, T, ctx.p_out);

@@ -195,6 +195,12 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     constexpr int TN = BN / (WN * 32);
     // tiles that issue the next chunk's DMAs one per matrix-instruction group (see the K loop)
     constexpr bool ILV_TILE = !RES && !(BM >= 128 && BN >= 128) && BN < 256;
+    // the 128 x 256 tile (two workgroups per CU, FullSubNet's step GEMM: + 4 %) spreads eight slots.  The 128 x 128 and 64 x 256
+    // tiles do not: measured with compile-time chunk sizes and a single matrix path (the form that keeps their four accumulator
+    // tiles in place - with DMA asm in BOTH the full and the one-sub-tile path the allocator carried two accumulator sets, 200
+    // VGPRs) they ran 1 - 1.5 % SLOWER than with the batch (DCCRN 2 472 vs 2 510 utt/s): three workgroups per CU already hide
+    // one another's issue stalls, the per-slot EXEC detours are pure cost
+    constexpr bool ILV_BIG = !RES && BM >= 128 && BN >= 256;
     // small-M tiles do little MFMA work per staged K row, so they stage twice the K depth per barrier to keep the
     // global-load latency under the matrix work
     constexpr int KCP_MAX = gc_kcp_max(BM);
@@ -478,7 +484,11 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // (4 B staging keeps the batch.  So do the 128 x 128 / x 256 and 64 x 256 tiles: with the slots inside their matrix
             // loop the register allocator parks two accumulator tiles in scratch memory between chunks - 168 registers are not
             // enough for 64 accumulators + the slots' operands; their chunks also carry 2 - 4 x the matrix work per DMA)
-            const bool ilv = ILV_TILE && nxt && pw4 && !(p.dbg & 16);
+            // (the big tiles - ILV_BIG - spread only eight slots: the weight groups and the first patch groups, at the first eight
+            // k-pair positions, which every chunk of >= 16 K rows has; patch groups beyond go out as a short batch in front.  With
+            // a slot behind EVERY position and a clean-up loop for short chunks the register allocator parked two of their four
+            // accumulator tiles in scratch memory between chunks)
+            const bool ilv = (ILV_TILE || (ILV_BIG && p.KCp >= 16 && !(p.dbg & 64))) && nxt && pw4 && !(p.dbg & 16);
             if (nxt) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
                 if (!ilv) GC_LOAD_CHUNK(c + 1, buf ^ 1);
@@ -489,13 +499,22 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             const unsigned Adw_n = __builtin_amdgcn_readfirstlane(lds_addr(As + (buf ^ 1) * As_sz)) + 1024u * wave_u;
             // slots of the next chunk this wave still has to issue: bits 0 .. NB-1 patch groups, NB .. weight groups (wave-uniform)
             const unsigned slotmask = ilv ? (((1u << bit4) - 1u) | (((1u << ait) - 1u) << NB)) : 0u;
-            auto dma_slot = [&](auto S_) __attribute__((always_inline)) {
+            auto dma_issue = [&](auto S_) __attribute__((always_inline)) {      // slot sl: < NB patch group sl, else weight group sl - NB
                 constexpr int sl = decltype(S_)::value;
                 // (no branch: a slot that is not due runs with EXEC = 0)
-                if constexpr (!ILV_TILE) return;
-                else if constexpr (sl < NB) gc_dma16_masked_s(Bc_n, boff[sl], bl4_n + 4096u * sl, vbits, slotmask & (1u << sl));
+                if constexpr (sl < NB) gc_dma16_masked_s(Bc_n, boff[sl], bl4_n + 4096u * sl, vbits, slotmask & (1u << sl));
                 else if constexpr (sl < NB + A_IT) gc_dma16_cond_s(Ac_n, aoff[sl - NB], Adw_n + 4096u * (sl - NB), slotmask & (1u << sl));
             };
+            constexpr int BIG_B = 8 - A_IT;       // patch groups the big tiles issue inside the matrix loop
+            auto dma_slot = [&](auto S_) __attribute__((always_inline)) {       // k-pair position -> slot
+                constexpr int pos = decltype(S_)::value;
+                if constexpr (ILV_TILE) dma_issue(S_);
+                else if constexpr (ILV_BIG && pos < A_IT) dma_issue(std::integral_constant<int, NB + pos>{});
+                else if constexpr (ILV_BIG && pos < 8 && pos - A_IT < NB) dma_issue(std::integral_constant<int, pos - A_IT>{});
+            };
+            if constexpr (ILV_BIG && NB > BIG_B) {
+                static_for<NB - BIG_B>([&](auto E) { dma_issue(std::integral_constant<int, BIG_B + decltype(E)::value>{}); });
+            }
             static_assert(NB + A_IT <= NPAIR, "one DMA slot per k-pair position of a chunk");
             GC_T(1);
             // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
@@ -544,13 +563,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     }
                 });
                 // (a chunk with fewer k-pair positions than slots: the rest behind the matrix work)
-                static_for<NPAIR / 2>([&](auto KP2) {
-                    constexpr int kp = 2 * decltype(KP2)::value;
-                    if (kp >= npair) {
-                        dma_slot(std::integral_constant<int, kp>{});
-                        dma_slot(std::integral_constant<int, kp + 1>{});
-                    }
-                });
+                if constexpr (ILV_TILE) {
+                    static_for<NPAIR / 2>([&](auto KP2) {
+                        constexpr int kp = 2 * decltype(KP2)::value;
+                        if (kp >= npair) {
+                            dma_slot(std::integral_constant<int, kp>{});
+                            dma_slot(std::integral_constant<int, kp + 1>{});
+                        }
+                    });
+                }
             };
             bool mma_ran = true;
             if (!(p.dbg & 4)) {

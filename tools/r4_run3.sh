@@ -2,5 +2,4 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_dccrn.py -x -q -m gpu 2>&1 | tail -2
-timeout 900 python tools/sweep.py --models dccrn,fullsubnet,crn,uformer --batch 256 --steps 5 --no-profile 2>&1 | grep utt_per_s | cut -c1-75
+for d in 0 16 0 16; do echo "SE_GC_DBG=$d"; SE_GC_DBG=$d timeout 300 python tools/sweep.py --models dccrn --batch 256 --steps 6 2>&1 | tail -1 | cut -c1-200; done

@@ -1390,6 +1390,12 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
     GCPlan pl;
     GCParams& p = pl.p;
     pl.BM = M >= 96 ? 128 : (M >= 48 ? 64 : 32);
+    {   // memory-bound pointwise layers (<= 128 input channels, <= 384 rows: Uformer's conformer, the TCM blocks' 64 -> 256 layers) on
+        // 64-row tiles: twice the workgroups in flight, each small enough to spread its DMAs over the matrix loop
+        // (SE_GC_PW_BM64=k: input-channel limit, 0 = 128-row tiles; Uformer + 1.1 %, the others unchanged)
+        static const int pw64 = getenv("SE_GC_PW_BM64") ? atoi(getenv("SE_GC_PW_BM64")) : 128;
+        if (pw64 > 0 && taps.ntaps == 1 && Cin <= pw64 && M >= 96 && M <= 384 && epi != EPI_LSTM) pl.BM = 64;
+    }
     pl.BN = (tout_hint >= 96 || pl.BM == 32) ? 128 : 64;
     // distinct rows / dt span
     int dtmin = taps.dt[0], dtmax = taps.dt[0];

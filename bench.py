@@ -191,14 +191,18 @@ def run_other_configs(torch, local_rank, steps, configs=None):
             eng.enhance_batch(wav, out)
         torch.cuda.synchronize()
         k = max(steps, 20) if B == 1 else steps
-        t0 = time.perf_counter()
-        for _ in range(k):
-            eng.enhance_batch(wav, out)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / k
+        passes = []          # two timed passes of k steps; the faster one is reported, both are in the row (a pass of three steps
+        for _ in range(2):   # of a fresh engine now and then catches a clock dip: G2Net 4 374 vs 5 375 utt/s in one of this round's runs)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                eng.enhance_batch(wav, out)
+            torch.cuda.synchronize()
+            passes.append((time.perf_counter() - t0) / k)
+        dt = min(passes)
         assert bool(torch.isfinite(out).all()), name
         ups = B / dt
         rows.append({"config": cfg, "model": name, "batch": B, "steps": k, "utt_s": round(ups, 1), "ms_per_step": round(dt * 1e3, 3),
+                     "ms_per_step_passes": [round(v * 1e3, 3) for v in passes],
                      "x_realtime": round(ups * CLIP_SECONDS, 0), "gflop_per_utt": gflop,
                      "achieved": round(ups * gflop / 1e3, 2), "frac": round(ups * gflop / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)})
         del m, eng, wav, out
@@ -392,7 +396,8 @@ def main():
             if not args.no_zoo:
                 res["roofline"]["zoo"] = run_other_configs(torch, local_rank, 3, ZOO_CONFIGS)
             res["roofline"]["configs_note"] = ("whole decode path per config: utt/s x SURVEY 8(d) GFLOP per utterance against the "
-                                              "f32 MFMA peak; unprofiled steps timed by the host clock around a device sync")
+                                              "f32 MFMA peak; unprofiled steps timed by the host clock around a device sync; two passes per config, "
+                                              "the faster one reported, both in ms_per_step_passes")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(seed, p_in, p_out)
         print(json.dumps(res), flush=True)

@@ -136,22 +136,6 @@ __device__ __forceinline__ void gc_dma16_masked_s(const float* base, unsigned vo
         : "v"(vbits), "s"(lds_byte), "v"(voff), "s"(base), "s"(mask)
         : "memory", "vcc");
 }
-// unmasked lanes, but the whole instruction only when the wave-uniform `cond` is non-zero (EXEC = 0 otherwise: no branch
-// inside the matrix loop)
-__device__ __forceinline__ void gc_dma16_cond_s(const float* base, unsigned voff, unsigned lds_byte, unsigned cond) {
-    unsigned long long saved;
-    asm volatile(
-        "s_mov_b64 %0, exec\n\t"
-        "s_cmp_lg_u32 %1, 0\n\t"
-        "s_cselect_b64 exec, exec, 0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %4\n\t"
-        "s_mov_b64 exec, %0"
-        : "=&s"(saved)
-        : "s"(cond), "s"(lds_byte), "v"(voff), "s"(base)
-        : "memory", "scc");
-}
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
 }
@@ -193,14 +177,6 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
 #endif
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    // tiles that issue the next chunk's DMAs one per matrix-instruction group (see the K loop)
-    constexpr bool ILV_TILE = !RES && !(BM >= 128 && BN >= 128) && BN < 256;
-    // the 128 x 256 tile (two workgroups per CU, FullSubNet's step GEMM: + 4 %) spreads eight slots.  The 128 x 128 and 64 x 256
-    // tiles do not: measured with compile-time chunk sizes and a single matrix path (the form that keeps their four accumulator
-    // tiles in place - with DMA asm in BOTH the full and the one-sub-tile path the allocator carried two accumulator sets, 200
-    // VGPRs) they ran 1 - 1.5 % SLOWER than with the batch (DCCRN 2 472 vs 2 510 utt/s): three workgroups per CU already hide
-    // one another's issue stalls, the per-slot EXEC detours are pure cost
-    constexpr bool ILV_BIG = !RES && BM >= 128 && BN >= 256;
     // small-M tiles do little MFMA work per staged K row, so they stage twice the K depth per barrier to keep the
     // global-load latency under the matrix work
     constexpr int KCP_MAX = gc_kcp_max(BM);
@@ -375,9 +351,8 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             if (fixt) vbits |= (staged && (t < p.Tin) && (t + 4 > p.Tin)) ? (0x10000u << e) : 0u;   \
         });                                                                                        \
         /* slots whose 64 lanes are all inside the tensor (every slot of an interior tile): staged without the EXEC detour */ \
-        /* (the tiles that spread their DMAs over the matrix loop stage through the masked form there: not worth the votes) */ \
-        fullbits = 0;                                                                              \
-        if constexpr (!ILV_TILE) {      /* (SE_GC_DBG=32: always the masked form, for the A/B measurement) */ \
+        fullbits = 0;      /* (SE_GC_DBG=32: always the masked form, for the A/B measurement) */ \
+        {                                                                                          \
             if (!(p.dbg & 32)) static_for<NB>([&](auto E) {                                                           \
                 constexpr int e = decltype(E)::value;                                              \
                 if (e < bit4 && __builtin_amdgcn_ballot_w64((vbits >> e) & 1u) == ~0ull) fullbits |= 1u << e; \
@@ -474,48 +449,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     buf = 0;
                 }
             }
-            // the next chunk's DMAs: one instruction behind every group of matrix instructions (a slot = one 16 B / 4 B patch
-            // group or one 16 B weight group per lane).  Issued as one batch in front of the MFMAs, the 6 - 13 DMA
-            // instructions of a chunk stalled the wave at issue for half as long as its matrix work took (gcbench_timing:
-            // `load issue` 26 - 29 % of a block's life against 49 - 57 % `mfma`; the vector-memory queue fills and every
-            // further global_load_lds waits for a slot); spread over the matrix stream they find the queue drained
-            // (SE_GC_DBG=16: the batch in front, for the A/B measurement)
-            const bool nxt = !RES && c + 1 < nch && !(p.dbg & 1);
-            // (4 B staging keeps the batch.  So do the 128 x 128 / x 256 and 64 x 256 tiles: with the slots inside their matrix
-            // loop the register allocator parks two accumulator tiles in scratch memory between chunks - 168 registers are not
-            // enough for 64 accumulators + the slots' operands; their chunks also carry 2 - 4 x the matrix work per DMA)
-            // (the big tiles - ILV_BIG - spread only eight slots: the weight groups and the first patch groups, at the first eight
-            // k-pair positions, which every chunk of >= 16 K rows has; patch groups beyond go out as a short batch in front.  With
-            // a slot behind EVERY position and a clean-up loop for short chunks the register allocator parked two of their four
-            // accumulator tiles in scratch memory between chunks)
-            const bool ilv = (ILV_TILE || (ILV_BIG && p.KCp >= 16 && !(p.dbg & 64))) && nxt && pw4 && !(p.dbg & 16);
-            if (nxt) {
+            // (round 4 also tried the next chunk's DMAs one per matrix-instruction group instead of as a batch up front - gcbench_timing
+            // shows the batch stalling a wave at issue for half as long as its matrix work takes.  Measured on every tile, with a
+            // clean build as the baseline, it was a loss: the other workgroups of the CU already cover one another's issue stalls,
+            // and the slots' code - sixteen asm blocks per matrix path - cost the 64 x 64 / 128 x 32 / 32 x 128 tiles 20 - 40 % at small
+            // batches and 2 - 6 % at batch 256.  DESIGN.md 3.1)
+            if (!RES && c + 1 < nch && !(p.dbg & 1)) {
                 if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
-                if (!ilv) GC_LOAD_CHUNK(c + 1, buf ^ 1);
+                GC_LOAD_CHUNK(c + 1, buf ^ 1);
             }
-            const float* __restrict__ Bc_n = sbase + (long)(c + 1) * p.CI_C * s_c;
-            const unsigned bl4_n = __builtin_amdgcn_readfirstlane(lds_addr(Bs + (buf ^ 1) * Bs_sz)) + 1024u * wave_u;
-            const float* __restrict__ Ac_n = Ag + (long)(gchunk + c + 1) * p.KCp * p.Mp;
-            const unsigned Adw_n = __builtin_amdgcn_readfirstlane(lds_addr(As + (buf ^ 1) * As_sz)) + 1024u * wave_u;
-            // slots of the next chunk this wave still has to issue: bits 0 .. NB-1 patch groups, NB .. weight groups (wave-uniform)
-            const unsigned slotmask = ilv ? (((1u << bit4) - 1u) | (((1u << ait) - 1u) << NB)) : 0u;
-            auto dma_issue = [&](auto S_) __attribute__((always_inline)) {      // slot sl: < NB patch group sl, else weight group sl - NB
-                constexpr int sl = decltype(S_)::value;
-                // (no branch: a slot that is not due runs with EXEC = 0)
-                if constexpr (sl < NB) gc_dma16_masked_s(Bc_n, boff[sl], bl4_n + 4096u * sl, vbits, slotmask & (1u << sl));
-                else if constexpr (sl < NB + A_IT) gc_dma16_cond_s(Ac_n, aoff[sl - NB], Adw_n + 4096u * (sl - NB), slotmask & (1u << sl));
-            };
-            constexpr int BIG_B = 8 - A_IT;       // patch groups the big tiles issue inside the matrix loop
-            auto dma_slot = [&](auto S_) __attribute__((always_inline)) {       // k-pair position -> slot
-                constexpr int pos = decltype(S_)::value;
-                if constexpr (ILV_TILE) dma_issue(S_);
-                else if constexpr (ILV_BIG && pos < A_IT) dma_issue(std::integral_constant<int, NB + pos>{});
-                else if constexpr (ILV_BIG && pos < 8 && pos - A_IT < NB) dma_issue(std::integral_constant<int, pos - A_IT>{});
-            };
-            if constexpr (ILV_BIG && NB > BIG_B) {
-                static_for<NB - BIG_B>([&](auto E) { dma_issue(std::integral_constant<int, BIG_B + decltype(E)::value>{}); });
-            }
-            static_assert(NB + A_IT <= NPAIR, "one DMA slot per k-pair position of a chunk");
             GC_T(1);
             // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
             const float* Ab = As + buf * As_sz + hi * BM + am;
@@ -554,37 +496,18 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                         __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
                         GC_MMA(ax, bx);
                         __builtin_amdgcn_sched_group_barrier(0x008, TM * JN, 0);
-                        dma_slot(std::integral_constant<int, kp>{});
                         GC_FETCH(kp + 2, ax, bx);
                         __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
                         GC_MMA(ay, by);
                         __builtin_amdgcn_sched_group_barrier(0x008, TM * JN, 0);
-                        dma_slot(std::integral_constant<int, kp + 1>{});
                     }
                 });
-                // (a chunk with fewer k-pair positions than slots: the rest behind the matrix work)
-                if constexpr (ILV_TILE) {
-                    static_for<NPAIR / 2>([&](auto KP2) {
-                        constexpr int kp = 2 * decltype(KP2)::value;
-                        if (kp >= npair) {
-                            dma_slot(std::integral_constant<int, kp>{});
-                            dma_slot(std::integral_constant<int, kp + 1>{});
-                        }
-                    });
-                }
             };
-            bool mma_ran = true;
             if (!(p.dbg & 4)) {
                 // (the 4-tile wave keeps ONE matrix path: with three, the register allocator moved its 128 accumulators between
                 // the paths' own ranges through scratch memory - a partly filled last tile is rare on the layers that use it)
                 if (jact == 1 && TN == 2) mma_chunk(std::integral_constant<int, 1>{});
                 else if (jact >= 1) mma_chunk(std::integral_constant<int, TN>{});
-                else mma_ran = false;
-            } else {
-                mma_ran = false;
-            }
-            if (!mma_ran) {      // a wave with nothing but padding columns still stages its share of the next chunk
-                static_for<NPAIR>([&](auto S_) { dma_slot(S_); });
             }
 #undef GC_FETCH
 #undef GC_MMA
@@ -1653,17 +1576,18 @@ void gc_free_plan(GCPlan& pl) {
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool RES = false>
-static void gc_launch_e(const GCParams& p, hipStream_t stream) {
+static void gc_launch_e(const GCParams& p_in, hipStream_t stream) {
     // epilogue: 4*BM row parameters + one transposition strip per wave (rows x (cols + 4))
     const size_t epi = (size_t)(4 * (BM / WM) * 36) * sizeof(float);
-    const size_t lds = gc_lds_bytes(p, BM, epi, RES ? p.nbuf : 2);
+    const size_t lds = gc_lds_bytes(p_in, BM, epi, RES ? p_in.nbuf : 2);
     static bool attr_set[64] = {};
     if (first_on_device(attr_set)) {
         SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI, RES>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    const long nblk = (long)p.Z * p.B * p.Qt * p.n_ttiles * p.n_mtiles;
+    const long nblk = (long)p_in.Z * p_in.B * p_in.Qt * p_in.n_ttiles * p_in.n_mtiles;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
+    const GCParams& p = p_in;
     if constexpr ((EPI == EPI_ACT || EPI == EPI_ADD) && !RES) {
         if (p.fz) {          // branch interaction folded into the store (GCParams::fz)
             SE_CHECK(!p.trim && !p.stats, "gc_launch: no trimming / statistics variant of the kernel with the folded interaction");

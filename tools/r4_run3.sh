@@ -2,5 +2,6 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-timeout 900 python -m pytest tests/test_gpu_uformer.py tests/test_gpu_new_variants.py -x -q -m gpu 2>&1 | tail -2
-for k in 128 0 128 0; do echo "SE_GC_PW_BM64=$k"; SE_GC_PW_BM64=$k timeout 600 python tools/sweep.py --models uformer,dpcrn,gcrn,taylorsenet,crn,dccrn --batch 256 --steps 4 --no-profile 2>&1 | grep utt_per_s | cut -c1-75; done
+for lib in libse_4bfc897.so libse_engine.so libse_4bfc897.so libse_engine.so; do echo "== $lib"; SE_ENGINE_LIB=$ROOT/sixty-years-of-frequency-domain-monaural-speech-enhancement_amd/$lib timeout 300 python tools/sweep.py --models crn,dccrn,gcrn --batch 1 --steps 40 --no-profile 2>&1 | grep utt_per_s | cut -c1-75; done
+for b in 8 32; do for lib in libse_4bfc897.so libse_engine.so; do echo "B=$b $lib $(SE_ENGINE_LIB=$ROOT/sixty-years-of-frequency-domain-monaural-speech-enhancement_amd/$lib timeout 300 python tools/sweep.py --models dccrn,g2net --batch $b --steps 10 --no-profile 2>&1 | grep utt_per_s | cut -c28-60 | tr '\n' ' ')"; done; done
+for r in 1 2; do timeout 900 python tools/sweep.py --models dccrn,fullsubnet,uformer,g2net,dpcrn,crn --batch 256 --steps 4 --no-profile 2>&1 | grep utt_per_s | cut -c1-75; done

@@ -258,11 +258,13 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     if (EPI != EPI_LSTM && tid < BM) {
         const int m = min(m0 + tid, p.M - 1);
         epv[0] = bias ? bias[m] : 0.f;
+        // (identity and ReLU ride the PReLU form of the epilogue with slopes 1 and 0)
+        const float lin_slope = p.act == ACT_NONE ? 1.f : 0.f;
         if (EPI != EPI_GLU) {
-            epv[1] = p.slope ? p.slope[m] : 0.f;
+            epv[1] = (p.act == ACT_PRELU && p.slope) ? p.slope[m] : lin_slope;
         } else if (tid < BM / 2) {
             const int oc = min((m0 >> 1) + tid, (p.M >> 1) - 1);
-            epv[1] = p.slope ? p.slope[oc] : 0.f;
+            epv[1] = (p.act == ACT_PRELU && p.slope) ? p.slope[oc] : lin_slope;
             epv[2] = p.post_scale ? p.post_scale[oc] : 1.f;
             epv[3] = p.post_scale ? p.post_shift[oc] : 0.f;
         }
@@ -582,29 +584,48 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     }
                 }
             }
+            // The activation is chosen ONCE per column tile, not per value: as `act_apply(v, p.act, ..)` inside the unrolled loops
+            // every one of the 32 - 64 values of a tile carried the whole switch - libm's expm1f / log1pf / tanhf expansions - and the
+            // plain PReLU path hopped over them value by value: 22 500 instructions (180 KB) per kernel, a multiple of the
+            // instruction cache, fetched again by every workgroup.  LIN: identity / ReLU / PReLU as one `v >= 0 ? v : s v`.
+            auto write_strip = [&](auto ACT_) __attribute__((always_inline)) {
+                constexpr int ACT = decltype(ACT_)::value;      // -1: the linear family, else the activation itself
+                auto actf = [&](float v, float sl) __attribute__((always_inline)) -> float {
+                    if constexpr (ACT < 0) return v >= 0.f ? v : sl * v;
+                    else return act_apply(v, ACT, sl);
+                };
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (EPI != EPI_GLU) {
+                for (int i = 0; i < TM; ++i) {
+                    if (EPI != EPI_GLU) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
-                        float v = acc[i][j][r] + ep[mw + dm];
-                        v = act_apply(v, p.act, ep[BM + mw + dm]);
-                        strip[(4 * hi + dm) * OST + l31] = v;
-                    }
-                } else {
+                        for (int r = 0; r < 16; ++r) {
+                            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+                            const float v = acc[i][j][r] + ep[mw + dm];
+                            strip[(4 * hi + dm) * OST + l31] = actf(v, ep[BM + mw + dm]);
+                        }
+                    } else {
 #pragma unroll
-                    for (int r2 = 0; r2 < 8; ++r2) {
-                        const int r = 2 * r2;
-                        const int dm = i * 32 + (r & 3) + 8 * (r >> 2);      // even row (value), dm + 1 = its gate
-                        const float a = acc[i][j][r] + ep[mw + dm];
-                        const float g = acc[i][j][r + 1] + ep[mw + dm + 1];
-                        const int ol = (mw + dm) >> 1;
-                        float v = a * fsig_(g);          // hardware exp + reciprocal (as in the LSTM cells): the libm pair was ~15 % of a small-K GLU tile
-                        v = v * ep[2 * BM + ol] + ep[3 * BM + ol];
-                        strip[((4 * hi + dm) >> 1) * OST + l31] = act_apply(v, p.act, ep[BM + ol]);
+                        for (int r2 = 0; r2 < 8; ++r2) {
+                            const int r = 2 * r2;
+                            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);      // even row (value), dm + 1 = its gate
+                            const float a = acc[i][j][r] + ep[mw + dm];
+                            const float g = acc[i][j][r + 1] + ep[mw + dm + 1];
+                            const int ol = (mw + dm) >> 1;
+                            float v = a * fsig_(g);          // hardware exp + reciprocal (as in the LSTM cells): the libm pair was ~15 % of a small-K GLU tile
+                            v = v * ep[2 * BM + ol] + ep[3 * BM + ol];
+                            strip[((4 * hi + dm) >> 1) * OST + l31] = actf(v, ep[BM + ol]);
+                        }
                     }
                 }
+            };
+            switch (p.act) {
+                case ACT_NONE:
+                case ACT_RELU:
+                case ACT_PRELU: write_strip(std::integral_constant<int, -1>{}); break;      // (slopes 1 / 0 / the layer's: see `ep`)
+                case ACT_ELU: write_strip(std::integral_constant<int, ACT_ELU>{}); break;
+                case ACT_SOFTPLUS: write_strip(std::integral_constant<int, ACT_SOFTPLUS>{}); break;
+                case ACT_SIGMOID: write_strip(std::integral_constant<int, ACT_SIGMOID>{}); break;
+                default: write_strip(std::integral_constant<int, ACT_TANH>{}); break;
             }
             GC_WAVE_FENCE();
             // read back as rows: 8 lanes x 16 B cover the 32 columns of one row, 8 rows per wave instruction

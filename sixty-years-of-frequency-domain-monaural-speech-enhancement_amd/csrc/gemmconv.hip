@@ -630,7 +630,10 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             GC_WAVE_FENCE();
             // read back as rows: 8 lanes x 16 B cover the 32 columns of one row, 8 rows per wave instruction
             const int tg = t0 + wt * (TN * 32) + j * 32 + lc;
-#pragma unroll
+            // (a rolled loop where nothing indexes registers by `it`: eight copies of the store path - vector form, ragged mask,
+            // frame-by-frame tail - were 6 KB of instructions per kernel that every workgroup streamed through once)
+            constexpr int RB_UNROLL = (PRE || FZ) ? OROWS / 8 : 1;
+#pragma unroll RB_UNROLL
             for (int it = 0; it < OROWS / 8; ++it) {
                 const int row = it * 8 + lr, m = mo0 + row;
                 floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * OST + lc);

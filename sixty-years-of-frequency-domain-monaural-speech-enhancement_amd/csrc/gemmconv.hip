@@ -725,6 +725,9 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     cpa[i][j][g4] = p.first_step ? 0.f : cell[(long)(m >> 2) * p.d_c + tc];
                 }
             }
+        // (cell type and gate source are chosen once per workgroup, not inside each of the 32 - 64 unrolled cells)
+        auto cells = [&](auto GRU_, auto HGX_) __attribute__((always_inline)) {
+            constexpr bool GRU = decltype(GRU_)::value, HGX = decltype(HGX_)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -736,8 +739,8 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int m = min(mb + 8 * g4, p.M - 4);
-                    const float* gp = has_gx ? gx + (long)m * p.x_c + tc : gx + m;
-                    const long gs = has_gx ? p.x_c : 1;
+                    const float* gp = HGX ? gx + (long)m * p.x_c + tc : gx + m;
+                    const long gs = HGX ? p.x_c : 1;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) g[4 * g4 + k] = gp[(long)k * gs];
                     cp[g4] = cpa[i][j][g4];
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     // fast exp / reciprocal as in the persistent LSTM kernels (5 transcendentals per cell, 16 cells per lane
                     // and tile: libm's tanhf / expf made this the longest phase of a step block)
                     float cn, hn;
-                    if (p.gru) {
+                    if constexpr (GRU) {
                         // torch.nn.GRU: r = s(W_ir x + b_ir + W_hr h + b_hr), z likewise, n = tanh(W_in x + b_in + r (W_hn h + b_hn)),
                         // h' = (1 - z) n + z h.  Rows (r, z, n, -): gi / gf / gg hold the r / z / n sums, the aux row of the unused
                         // fourth gate carries b_hn (go = 0 + b_hn), `cell` keeps h for the next step
@@ -772,6 +775,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     }
                 }
             }
+    
+        };
+        if (p.gru) {
+            if (has_gx) cells(std::true_type{}, std::true_type{});
+            else cells(std::true_type{}, std::false_type{});
+        } else {
+            if (has_gx) cells(std::false_type{}, std::true_type{});
+            else cells(std::false_type{}, std::false_type{});
+        }
     }
 #ifdef GC_TIMING
     GC_T(5);

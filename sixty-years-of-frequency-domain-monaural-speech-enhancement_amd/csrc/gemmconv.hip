@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // and the slots' code - sixteen asm blocks per matrix path - cost the 64 x 64 / 128 x 32 / 32 x 128 tiles 20 - 40 % at small
             // batches and 2 - 6 % at batch 256.  DESIGN.md 3.1)
             if (!RES && c + 1 < nch && !(p.dbg & 1)) {
-                if (c + 2 == nch && tail != p.CI_C) GC_MAKE_DESC(tail);
+                if (__builtin_expect(c + 2 == nch && tail != p.CI_C, 0)) GC_MAKE_DESC(tail);      // (cold code out of the loop's way)
                 GC_LOAD_CHUNK(c + 1, buf ^ 1);
             }
             GC_T(1);
@@ -660,9 +660,9 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                 }
                 if (m < Mo) {
                     float* __restrict__ dp = dst + (long)m * p.d_c + tg;
-                    if (tg + 3 < p.Tout) {
+                    if (__builtin_expect(tg + 3 < p.Tout, 1)) {
                         if (EPI == EPI_ADD || EPI == EPI_MUL) v = (EPI == EPI_ADD) ? v + rvp[it] : v * rvp[it];
-                        if (tg + 3 >= tvalid) {      // rows of a ragged batch: frames past the row's own end are stored as zeros
+                        if (__builtin_expect(tg + 3 >= tvalid, 0)) {      // rows of a ragged batch: frames past the row's own end are stored as zeros
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[k] = (tg + k < tvalid) ? v[k] : 0.f;
                         }

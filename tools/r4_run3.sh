@@ -2,5 +2,4 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-timeout 900 python -m pytest tests/test_gpu_models.py -x -q -m gpu -k "fullsubnet or lstm" 2>&1 | tail -2
-for lib in libse_prev.so libse_engine.so libse_prev.so libse_engine.so; do echo "== $lib $(SE_ENGINE_LIB=$ROOT/sixty-years-of-frequency-domain-monaural-speech-enhancement_amd/$lib timeout 300 python tools/sweep.py --models fullsubnet --batch 128 --steps 4 --no-profile 2>&1 | grep utt_per_s | cut -c28-90)"; done
+for lib in libse_prev.so libse_engine.so libse_prev.so libse_engine.so; do echo "== $lib"; SE_ENGINE_LIB=$ROOT/sixty-years-of-frequency-domain-monaural-speech-enhancement_amd/$lib timeout 600 python tools/sweep.py --models dccrn,uformer,g2net,dpcrn,ctsnet --batch 256 --steps 4 --no-profile 2>&1 | grep utt_per_s | cut -c1-75; SE_ENGINE_LIB=$ROOT/sixty-years-of-frequency-domain-monaural-speech-enhancement_amd/$lib timeout 600 python tools/sweep.py --models dccrn,g2net --batch 4 --steps 20 --no-profile 2>&1 | grep utt_per_s | cut -c1-75; done

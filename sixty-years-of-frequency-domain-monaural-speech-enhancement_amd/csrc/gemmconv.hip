@@ -42,7 +42,9 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
-__device__ __forceinline__ float fsig_(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// (v_rcp_f32, 1 ulp: `__frcp_rn` is a correctly rounded division - ten vector instructions on the matrix pipe's clock, five
+// times per LSTM cell and twice per gated value)
+__device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 // GCParams::fz - one frame of the branch interaction (the same expressions as model_uformer.hip: uf_fusion_kernel)
 __device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long im) {
     const float re = zr[0], ii = zr[im];
@@ -52,7 +54,7 @@ __device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long 
     zr[im] = ii + s;
     return v + fsig_(cm);
 }
-__device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+__device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 // 16 B per lane global -> LDS copy without a register round trip (global_load_lds_dwordx4: lane l lands at
 // lds_base + 16*l, lds_base wave-uniform in M0).  Issued from inline asm on purpose: through the builtin the compiler

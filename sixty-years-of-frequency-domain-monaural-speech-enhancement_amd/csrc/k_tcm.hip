@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) g[i][j][r] = __frcp_rn(1.f + __expf(-g[i][j][r]));      // hardware exp / reciprocal, as in the gc_kernel GLU epilogue
+                for (int r = 0; r < 16; ++r) g[i][j][r] = __builtin_amdgcn_rcpf(1.f + __expf(-g[i][j][r]));      // hardware exp / reciprocal, as in the gc_kernel GLU epilogue
         head(h, a.hL, a.K);
         dconv(m, a.w2L);
 #pragma unroll

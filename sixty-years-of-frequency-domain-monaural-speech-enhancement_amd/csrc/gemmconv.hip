@@ -48,7 +48,7 @@ __device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1
 // GCParams::fz - one frame of the branch interaction (the same expressions as model_uformer.hip: uf_fusion_kernel)
 __device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long im) {
     const float re = zr[0], ii = zr[im];
-    const float cm = sqrtf(fmaxf(re * re + ii * ii, 1.1920928955078125e-07f));
+    const float cm = __builtin_amdgcn_sqrtf(fmaxf(re * re + ii * ii, 1.1920928955078125e-07f));      // v_sqrt_f32 (1 ulp)
     const float s = fsig_(v);
     zr[0] = re + s;
     zr[im] = ii + s;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                             floatx4 re = zre[it], ii = zim[it];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                const float cm = sqrtf(fmaxf(re[k] * re[k] + ii[k] * ii[k], 1.1920928955078125e-07f));
+                                const float cm = __builtin_amdgcn_sqrtf(fmaxf(re[k] * re[k] + ii[k] * ii[k], 1.1920928955078125e-07f));
                                 const float sg = fsig_(v[k]);
                                 re[k] += sg;
                                 ii[k] += sg;

@@ -2,4 +2,5 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-for lib in libse_prev.so libse_engine.so libse_prev.so libse_engine.so; do echo "== $lib"; SE_ENGINE_LIB=$ROOT/sixty-years-of-frequency-domain-monaural-speech-enhancement_amd/$lib timeout 600 python tools/sweep.py --models dccrn,uformer,g2net,dpcrn,ctsnet --batch 256 --steps 4 --no-profile 2>&1 | grep utt_per_s | cut -c1-75; SE_ENGINE_LIB=$ROOT/sixty-years-of-frequency-domain-monaural-speech-enhancement_amd/$lib timeout 600 python tools/sweep.py --models dccrn,g2net --batch 4 --steps 20 --no-profile 2>&1 | grep utt_per_s | cut -c1-75; done
+timeout 900 python -m pytest tests/test_gpu_uformer.py -x -q -m gpu 2>&1 | tail -2
+for r in 1 2; do timeout 300 python tools/sweep.py --models uformer --batch 256 --steps 5 --no-profile 2>&1 | grep utt_per_s | cut -c1-100; done

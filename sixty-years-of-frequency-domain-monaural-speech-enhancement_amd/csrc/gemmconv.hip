@@ -33,7 +33,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
         case ACT_PRELU: return v >= 0.f ? v : slope * v;
-        case ACT_ELU: return v > 0.f ? v : expm1f(v);
+        // (ELU's negative branch: hardware exp2 - libm's expm1f is ~40 instructions per value in CRN's / GCRN's conv epilogues;
+        // near zero, where exp(v) - 1 cancels, the series v + v^2 / 2 is exact to 2e-10)
+        case ACT_ELU: return v > 0.f ? v : (v > -1e-3f ? fmaf(0.5f * v, v, v) : __expf(v) - 1.f);
         case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
         case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case ACT_TANH: return tanhf(v);

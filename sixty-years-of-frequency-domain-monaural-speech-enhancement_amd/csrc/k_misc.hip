@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void elu_kernel(const float* __restrict__ x, f
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         const float v = x[i];
-        y[i] = v > 0.f ? v : expm1f(v);
+        y[i] = v > 0.f ? v : (v > -1e-3f ? fmaf(0.5f * v, v, v) : __expf(v) - 1.f);      // (as gemmconv.hip: act_apply)
     }
 }
 void launch_elu(const float* x, float* y, long n, hipStream_t s) {

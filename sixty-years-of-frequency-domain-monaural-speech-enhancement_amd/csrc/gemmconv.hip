@@ -30,23 +30,24 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// (v_rcp_f32, 1 ulp: `__frcp_rn` is a correctly rounded division - ten vector instructions on the matrix pipe's clock, five
+// times per LSTM cell and twice per gated value)
+__device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
         case ACT_PRELU: return v >= 0.f ? v : slope * v;
         // (ELU's negative branch: hardware exp2 - libm's expm1f is ~40 instructions per value in CRN's / GCRN's conv epilogues;
         // near zero, where exp(v) - 1 cancels, the series v + v^2 / 2 is exact to 2e-10)
         case ACT_ELU: return v > 0.f ? v : (v > -1e-3f ? fmaf(0.5f * v, v, v) : __expf(v) - 1.f);
-        case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
-        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        case ACT_TANH: return tanhf(v);
+        case ACT_SOFTPLUS: return v > 20.f ? v : __logf(1.f + __expf(v));      // (hardware exp2 / log2: absolute error < 1e-7)
+        case ACT_SIGMOID: return fsig_(v);
+        case ACT_TANH: return ftanh_(v);
         case ACT_RELU: return fmaxf(v, 0.f);
         default: return v;
     }
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
-// (v_rcp_f32, 1 ulp: `__frcp_rn` is a correctly rounded division - ten vector instructions on the matrix pipe's clock, five
-// times per LSTM cell and twice per gated value)
-__device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 // GCParams::fz - one frame of the branch interaction (the same expressions as model_uformer.hip: uf_fusion_kernel)
 __device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long im) {
     const float re = zr[0], ii = zr[im];
@@ -56,7 +57,6 @@ __device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long 
     zr[im] = ii + s;
     return v + fsig_(cm);
 }
-__device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 // 16 B per lane global -> LDS copy without a register round trip (global_load_lds_dwordx4: lane l lands at
 // lds_base + 16*l, lds_base wave-uniform in M0).  Issued from inline asm on purpose: through the builtin the compiler

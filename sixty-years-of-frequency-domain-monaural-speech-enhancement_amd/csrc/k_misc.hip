@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
     auto finish = [&](int i, float xv, float rv) {
         const int c = i / F, f = i - c * F;
         float y = (xv - mu) * rs * w[f * C + c] + bb[f * C + c];
-        if (post == 1) y = y / (1.f + expf(-y));
+        if (post == 1) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));      // swish on the hardware exp2 / reciprocal
         if (prelu_slope) y = y >= 0.f ? y : slope * y;
         if (res) y += rv;
         out[base + (long)i * T] = y;

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void uf_att_f_kernel(const float* __restrict__
         }
         float l = 0.f;
         for (int g = 0; g < F; ++g) {
-            e[g] = expf(e[g] - mx);
+            e[g] = __expf(e[g] - mx);
             l += e[g];
         }
         const float inv = 1.f / l;

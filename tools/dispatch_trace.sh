@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-dispatch kernel traces of tools/sweep.py (one model, 2 steps): gpurun_out/r4_trace/<model>_kernel_trace.csv
+# per-dispatch kernel traces of tools/sweep.py (one model, 2 steps): gpurun_out/r4_trace/<model>_b<B>_trace.csv; bash tools/dispatch_trace.sh "uformer 256" "crn 64"
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/r4_trace

@@ -273,6 +273,47 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 // y = PReLU((x - mu) * rs * g + bt) (+ r) over one plane, NU elements per thread in flight (r may alias y)
 __device__ __forceinline__ void norm_apply_pass(const float* __restrict__ xp, float* yp, const float* rp, int P, float muf,
                                                 float rs, float g, float bt, float sl) {
+    // 16 B accesses where the plane allows them: input, output (and residual) share their misalignment - a plane starts at an
+    // odd multiple of 4 B when P is odd - so a head of <= 3 values brings all of them to a 16 B boundary
+    if (((((size_t)xp ^ (size_t)yp) & 15) == 0) && (!rp || ((((size_t)xp ^ (size_t)rp) & 15) == 0))) {
+        const int head = min(P, (int)((4 - (((size_t)xp >> 2) & 3)) & 3));
+        auto one = [&](int k) {
+            float o = (xp[k] - muf) * rs * g + bt;
+            o = o >= 0.f ? o : sl * o;
+            yp[k] = rp ? o + rp[k] : o;
+        };
+        if ((int)threadIdx.x < head) one(threadIdx.x);
+        const int n4 = (P - head) >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(xp + head);
+        float4* y4 = reinterpret_cast<float4*>(yp + head);
+        const float4* r4 = rp ? reinterpret_cast<const float4*>(rp + head) : nullptr;
+        constexpr int NV = 4;
+        auto f4 = [&](float4 v, float4 r) {
+            float o[4] = {v.x, v.y, v.z, v.w}, q[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = (o[k] - muf) * rs * g + bt;
+                t = t >= 0.f ? t : sl * t;
+                o[k] = rp ? t + q[k] : t;
+            }
+            return make_float4(o[0], o[1], o[2], o[3]);
+        };
+        int i = threadIdx.x;
+        for (; i + (NV - 1) * 256 < n4; i += NV * 256) {
+            float4 v[NV], r[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                v[u] = x4[i + u * 256];
+                r[u] = r4 ? r4[i + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < NV; ++u) y4[i + u * 256] = f4(v[u], r[u]);
+        }
+        for (; i < n4; i += 256) y4[i] = f4(x4[i], r4 ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+        const int done = head + 4 * n4;
+        if (done + (int)threadIdx.x < P) one(done + threadIdx.x);
+        return;
+    }
     int i = threadIdx.x;
     for (; i + (NU - 1) * 256 < P; i += NU * 256) {
         float v[NU], r[NU];

@@ -59,7 +59,26 @@ def pmc_traffic():
     with open(cands[-1]) as f:            # the latest round's summary
         d = json.load(f)['gc_family']
     d['source'] = os.path.relpath(cands[-1], ROOT)
+    # the counters describe the kernels they were collected on: the summary carries a hash of the kernel sources the DCCRN
+    # decode runs through (tools/pmc_summary.py: csrc_sha16); when the tree's differ, the figure is STALE and the line says so
+    # instead of quoting it (there is no .git on the GPU box to ask for an ancestry check)
+    d['stale'] = d.get('csrc_sha16') != dccrn_csrc_sha16()
     return d
+
+
+DCCRN_KERNEL_SOURCES = ['gemmconv.hip', 'gemmconv.h', 'gauss.h', 'model_dccrn.hip', 'layers.hip', 'layers.h', 'k_lstm.hip',
+                        'k_misc.hip', 'k_stft2.hip', 'rnn.h', 'kernels.h', 'model.h', 'fastmath.h']
+
+
+def dccrn_csrc_sha16():
+    """sha256[:16] over the kernel sources of the DCCRN decode path (the files a PMC pass of this bench exercises)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, [d for d in os.listdir(ROOT) if d.endswith('_amd')][0], 'csrc')
+    for fn in DCCRN_KERNEL_SOURCES:
+        with open(os.path.join(csrc, fn), 'rb') as f:
+            h.update(fn.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
 
 
 def _host_cpu():
@@ -191,18 +210,18 @@ def run_other_configs(torch, local_rank, steps, configs=None):
             eng.enhance_batch(wav, out)
         torch.cuda.synchronize()
         k = max(steps, 20) if B == 1 else steps
-        passes = []          # two timed passes of k steps; the faster one is reported, both are in the row (a pass of three steps
-        for _ in range(2):   # of a fresh engine now and then catches a clock dip: G2Net 4 374 vs 5 375 utt/s in one of this round's runs)
+        passes = []          # two timed passes of k steps; their mean is reported, both are in the row (a pass of a fresh engine
+        for _ in range(2):   # now and then catches a clock dip: G2Net 4 374 vs 5 375 utt/s in one of round 4's runs)
             t0 = time.perf_counter()
             for _ in range(k):
                 eng.enhance_batch(wav, out)
             torch.cuda.synchronize()
             passes.append((time.perf_counter() - t0) / k)
-        dt = min(passes)
+        dt = sum(passes) / len(passes)          # the MEAN of the passes is the figure (a min-of-N is a selection)
         assert bool(torch.isfinite(out).all()), name
         ups = B / dt
         rows.append({"config": cfg, "model": name, "batch": B, "steps": k, "utt_s": round(ups, 1), "ms_per_step": round(dt * 1e3, 3),
-                     "ms_per_step_passes": [round(v * 1e3, 3) for v in passes],
+                     "ms_per_step_passes": [round(v * 1e3, 3) for v in passes], "utt_s_best_pass": round(B / min(passes), 1),
                      "x_realtime": round(ups * CLIP_SECONDS, 0), "gflop_per_utt": gflop,
                      "achieved": round(ups * gflop / 1e3, 2), "frac": round(ups * gflop / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)})
         del m, eng, wav, out
@@ -345,7 +364,8 @@ def main():
                                            "complex layers as three real products + sum / combine passes, counted in the family)",
                 "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": pmc['traffic_GB_per_launch'] if pmc and B == 256 else None,
+                "traffic": pmc['traffic_GB_per_launch'] if pmc and B == 256 and not pmc['stale'] else None,
+                "traffic_stale": bool(pmc and pmc['stale']),
                 "traffic_unit": "GB of HBM traffic per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 "
                                 "--pmc passes of this command at batch 256: %s)" % (pmc['source'] if pmc else 'profiles/'),
                 "algorithmic_GB_per_launch": round((rd_b + wr_b) / 1e9 / max(prof['gemm_launches'], 1), 3),
@@ -357,7 +377,10 @@ def main():
                                           "decoder layers 1-2 execute three (Gauss, DESIGN 3.6), so the matrix cores execute "
                                           "fewer flops than `achieved` prices: executed_mfma_tflop_per_step is the PMC count "
                                           "(SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, padded tile rows included)",
-                "executed_mfma_tflop_per_step": pmc.get('executed_mfma_tflop_per_step') if pmc and B == 256 else None,
+                "executed_mfma_tflop_per_step": pmc.get('executed_mfma_tflop_per_step') if pmc and B == 256 and not pmc['stale'] else None,
+                # like-for-like with rounds 1-3: the flops the matrix cores EXECUTE over the family's time
+                "executed_frac": (round(pmc['executed_mfma_tflop_per_step'] / (prof['gemm_ms'] * 1e-3) / F32_MFMA_PEAK_TFLOPS, 4)
+                                  if pmc and B == 256 and not pmc['stale'] and pmc.get('executed_mfma_tflop_per_step') else None),
                 "profiler_events_in_timed_region": True,
                 "traffic_source_commit": pmc.get('commit') if pmc else None,
                 "kernel_ms_per_step": round(prof['gemm_ms'], 3),
@@ -394,10 +417,10 @@ def main():
             rows = run_other_configs(torch, local_rank, max(3, min(args.steps, 10)))
             res["roofline"]["configs"] = rows[:2] + [head] + rows[2:]
             if not args.no_zoo:
-                res["roofline"]["zoo"] = run_other_configs(torch, local_rank, 3, ZOO_CONFIGS)
+                res["roofline"]["zoo"] = run_other_configs(torch, local_rank, 5, ZOO_CONFIGS)
             res["roofline"]["configs_note"] = ("whole decode path per config: utt/s x SURVEY 8(d) GFLOP per utterance against the "
                                               "f32 MFMA peak; unprofiled steps timed by the host clock around a device sync; two passes per config, "
-                                              "the faster one reported, both in ms_per_step_passes")
+                                              "their MEAN reported (utt_s, ms_per_step), both in ms_per_step_passes, the faster one in utt_s_best_pass")
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(seed, p_in, p_out)
         print(json.dumps(res), flush=True)

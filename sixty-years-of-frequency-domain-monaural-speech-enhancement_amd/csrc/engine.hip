@@ -245,12 +245,17 @@ int se_engine_finalize(se_engine* e) {
         e->plan_frames = e->model->stream_supported() ? std::max(Tr, e->model->stream_hc() + 16) : Tr;
         // a model's layout may depend on the batch (FullSubNet keeps a [T][4H][S] gate tensor below 16 clips and none from 16
         // on, so 15 clips need more than 16...42): the arena covers every batch a call may bring, not only the largest
+        // ... and a layout may depend on the window length: FullSubNet's frame-online windows (<= 64 frames) always keep the
+        // sub-band gate tensor, at every batch - a stream of 32 rows on an engine made for short clips needs more for a
+        // 58-frame chunk than the offline plan at plan_frames holds: the short-window plan is measured too
         size_t need = 0;
-        for (int bq : {e->ctx.max_batch, std::min(e->ctx.max_batch, 15)}) {
-            e->ctx.arena.measure_begin();
-            e->model->plan_buffers(bq, e->plan_frames);
-            need = std::max(need, e->ctx.arena.measure_end());
-        }
+        for (int bq : {e->ctx.max_batch, std::min(e->ctx.max_batch, 15)})
+            for (int tq : {e->plan_frames, std::min(e->plan_frames, 64)}) {
+                if (tq != e->plan_frames && !e->model->stream_supported()) continue;
+                e->ctx.arena.measure_begin();
+                e->model->plan_buffers(bq, tq);
+                need = std::max(need, e->ctx.arena.measure_end());
+            }
         e->ctx.arena.reserve(need + (1 << 20));
         gc_register_overread_range(e->ctx.arena.base(), e->ctx.arena.capacity());
         e->model->plan_buffers(e->ctx.max_batch, T);
@@ -260,12 +265,20 @@ int se_engine_finalize(se_engine* e) {
     });
 }
 
+// an offline decode re-carves the arena: it is ordered behind the last frame-online call made on ANOTHER hipStream (the event
+// stream_mark() recorded there), so that it cannot overwrite windows that call is still reading
+static void stream_order_wait(se_engine* e, hipStream_t st) {
+    se_engine::Stream& S = e->strm;
+    if (S.has_last && S.last_st != st && S.ev_order) SE_HIP(hipStreamWaitEvent(st, S.ev_order, 0));
+}
+
 int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32_t in_ndim, float* out_dev,
                void* stream) {
     if (!e) return 1;
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
+        stream_order_wait(e, static_cast<hipStream_t>(stream));
         SE_CHECK(in_dev && out_dev && in_shape, "null argument");
         e->ctx.prof_reset();
         e->model->forward(in_dev, in_shape, in_ndim, out_dev, static_cast<hipStream_t>(stream));
@@ -278,6 +291,7 @@ int se_uformer_forward(se_engine* e, const float* inputs_dev, const float* src_d
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
+        stream_order_wait(e, static_cast<hipStream_t>(stream));
         SE_CHECK(inputs_dev && output_dev, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples, "n_samples outside [n_fft, max_samples]");
@@ -293,6 +307,7 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
+        stream_order_wait(e, static_cast<hipStream_t>(stream));
         SE_CHECK(wav_in_dev && wav_out_dev, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples,
@@ -373,6 +388,7 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
     return guard(e, [&] {
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
+        stream_order_wait(e, static_cast<hipStream_t>(stream));
         SE_CHECK(wav_in_dev && wav_out_dev && lengths, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(e->model->ragged_supported(),
@@ -457,6 +473,15 @@ static void stream_process(se_engine* e, int t_end, bool last, float* out_dev, i
     }
 }
 
+// the last thing a stream call does on its hipStream: record the ordering event the NEXT se_stream_begin (possibly on another
+// hipStream) waits for, while the handle is certainly alive
+static void stream_mark(se_engine::Stream& S, hipStream_t st) {
+    if (!S.ev_order) SE_HIP(hipEventCreateWithFlags(&S.ev_order, hipEventDisableTiming));
+    SE_HIP(hipEventRecord(S.ev_order, st));
+    S.has_last = true;
+    S.last_st = st;
+}
+
 static int stream_begin_impl(se_engine* e, int32_t batch, int32_t max_chunk_frames, const float* c_dev, bool running, void* stream) {
     if (!e) return 1;
     return guard(e, [&] {
@@ -469,17 +494,9 @@ static int stream_begin_impl(se_engine* e, int32_t batch, int32_t max_chunk_fram
                  "front end overlap + look-ahead exceed the history the model keeps");
         hipStream_t st = static_cast<hipStream_t>(stream);
         se_engine::Stream& S = e->strm;
-        if (S.has_last && S.last_st != st) {
-            if (!S.ev_order) SE_HIP(hipEventCreateWithFlags(&S.ev_order, hipEventDisableTiming));
-            if (hipEventRecord(S.ev_order, S.last_st) == hipSuccess) {
-                SE_HIP(hipStreamWaitEvent(st, S.ev_order, 0));
-            } else {      // the caller has destroyed that hipStream in the meantime (its work was drained by the destroy)
-                (void)hipGetLastError();
-                SE_HIP(hipDeviceSynchronize());
-            }
-        }
-        S.has_last = true;
-        S.last_st = st;
+        // work of the previous stream on another hipStream: wait for the event that stream_mark() recorded behind ITS last
+        // call (the handle itself may have been destroyed since - it is never touched again)
+        if (S.has_last && S.last_st != st && S.ev_order) SE_HIP(hipStreamWaitEvent(st, S.ev_order, 0));
         S.max_chunk = std::max(1, std::min(max_chunk_frames > 0 ? max_chunk_frames : 16, e->plan_frames - e->model->stream_hc()));
         if (!S.wav) {
             SE_HIP(hipMalloc(&S.wav, (size_t)e->ctx.max_batch * e->ctx.max_samples * sizeof(float)));
@@ -503,6 +520,7 @@ static int stream_begin_impl(se_engine* e, int32_t batch, int32_t max_chunk_fram
         S.carve_B = S.carve_n = -1;
         e->model->stream_begin(batch, S.max_chunk, st);
         S.active = true;
+        stream_mark(S, st);
     });
 }
 
@@ -523,7 +541,6 @@ int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_
         SE_CHECK(S.batch == 1 || pitch >= n_new, "se_stream_push: input row pitch smaller than n_new");
         SE_CHECK(S.n_total + n_new <= e->ctx.max_samples, "stream longer than max_samples given at create");
         hipStream_t st = static_cast<hipStream_t>(stream);
-        S.last_st = st;
         const StftGeom& g = e->ctx.geom;
         if (n_new > 0)
             SE_HIP(hipMemcpy2DAsync(S.wav + S.n_total, (size_t)e->ctx.max_samples * sizeof(float), wav_dev,
@@ -542,6 +559,7 @@ int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_
         e->ctx.prof_reset();
         stream_process(e, std::max(t_avail, S.t_done), false, out_dev, out_pitch, &written, st);
         *n_out = written;
+        stream_mark(S, st);
     });
 }
 
@@ -554,7 +572,6 @@ int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_
         SE_CHECK(S.n_total >= e->ctx.geom.n_fft, "stream shorter than one FFT frame");
         SE_CHECK(out_pitch >= e->model->output_samples(S.n_total) - S.o_done, "output row pitch too small for the rest of the stream");
         int written = 0;
-        S.last_st = static_cast<hipStream_t>(stream);
         e->ctx.prof_reset();
         if (S.running)
             launch_stream_rms(S.wav, e->ctx.max_samples, S.batch, S.n_total, 0, S.sumsq, S.c, S.frame_inv, S.ring, S.t_done,
@@ -562,6 +579,7 @@ int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_
         stream_process(e, e->model->num_frames(S.n_total), true, out_dev, out_pitch, &written, static_cast<hipStream_t>(stream));
         *n_out = written;
         S.active = false;
+        stream_mark(S, static_cast<hipStream_t>(stream));
     });
 }
 

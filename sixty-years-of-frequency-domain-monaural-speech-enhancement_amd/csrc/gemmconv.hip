@@ -10,6 +10,7 @@
 // on row k+1: conflict-free for both operands at any tap offset.
 #include "gemmconv.h"
 #include "common.h"
+#include "fastmath.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -32,15 +33,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // (v_rcp_f32, 1 ulp: `__frcp_rn` is a correctly rounded division - ten vector instructions on the matrix pipe's clock, five
 // times per LSTM cell and twice per gated value)
-__device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+__device__ __forceinline__ float fsig_(float x) { return fm_sigmoid(x); }
+__device__ __forceinline__ float ftanh_(float x) { return fm_tanh(x); }
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     switch (act) {
         case ACT_PRELU: return v >= 0.f ? v : slope * v;
         // (ELU's negative branch: hardware exp2 - libm's expm1f is ~40 instructions per value in CRN's / GCRN's conv epilogues;
         // near zero, where exp(v) - 1 cancels, the series v + v^2 / 2 is exact to 2e-10)
-        case ACT_ELU: return v > 0.f ? v : (v > -1e-3f ? fmaf(0.5f * v, v, v) : __expf(v) - 1.f);
-        case ACT_SOFTPLUS: return v > 20.f ? v : __logf(1.f + __expf(v));      // (hardware exp2 / log2: absolute error < 1e-7)
+        case ACT_ELU: return v > 0.f ? v : fm_expm1(v);
+        case ACT_SOFTPLUS: return fm_softplus(v);      // (hardware exp2 / log2: absolute error < 1e-7)
         case ACT_SIGMOID: return fsig_(v);
         case ACT_TANH: return ftanh_(v);
         case ACT_RELU: return fmaxf(v, 0.f);
@@ -51,7 +52,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // GCParams::fz - one frame of the branch interaction (the same expressions as model_uformer.hip: uf_fusion_kernel)
 __device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long im) {
     const float re = zr[0], ii = zr[im];
-    const float cm = __builtin_amdgcn_sqrtf(fmaxf(re * re + ii * ii, 1.1920928955078125e-07f));      // v_sqrt_f32 (1 ulp)
+    const float cm = fm_sqrt(fmaxf(re * re + ii * ii, 1.1920928955078125e-07f));      // v_sqrt_f32 (1 ulp)
     const float s = fsig_(v);
     zr[0] = re + s;
     zr[im] = ii + s;
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                             floatx4 re = zre[it], ii = zim[it];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                const float cm = __builtin_amdgcn_sqrtf(fmaxf(re[k] * re[k] + ii[k] * ii[k], 1.1920928955078125e-07f));
+                                const float cm = fm_sqrt(fmaxf(re[k] * re[k] + ii[k] * ii[k], 1.1920928955078125e-07f));
                                 const float sg = fsig_(v[k]);
                                 re[k] += sg;
                                 ii[k] += sg;

@@ -28,8 +28,8 @@ __device__ __forceinline__ void static_for_l(F&& f) {
     }
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fm_sigmoid(x); }
+__device__ __forceinline__ float fast_tanh(float x) { return fm_tanh(x); }
 
 template <int H>
 __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistArgs a) {

@@ -35,8 +35,8 @@ __device__ __forceinline__ void static_for_c(F&& f) {
     }
 }
 
-__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+__device__ __forceinline__ float sigm(float x) { return fm_sigmoid(x); }
+__device__ __forceinline__ float tanhf_fast(float x) { return fm_tanh(x); }
 
 template <int H>
 __global__ __launch_bounds__(256, 1) void lstm_coop_kernel(const LstmCoopArgs a) {
@@ -599,8 +599,8 @@ __device__ __forceinline__ void c4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 
 // one hardware exp2 and one hardware reciprocal per activation (v_exp_f32 / v_rcp_f32, 1 ulp each): `__frcp_rn` is a correctly
 // rounded division - ten instructions - and a slot's tail is what the matrix pipe waits for
-__device__ __forceinline__ float sigm_hw(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896f * x)); }
-__device__ __forceinline__ float tanh_hw(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177793f * x)); }
+__device__ __forceinline__ float sigm_hw(float x) { return kExactMath ? fm_sigmoid(x) : fm_rcp(1.f + fm_exp2(-1.44269504088896f * x)); }
+__device__ __forceinline__ float tanh_hw(float x) { return kExactMath ? fm_tanh(x) : 1.f - 2.f * fm_rcp(1.f + fm_exp2(2.88539008177793f * x)); }
 // 16 B per lane global -> LDS with a wave-uniform 64-bit base and a 32-bit per-lane byte offset (no 64-bit vector address arithmetic per slot)
 __device__ __forceinline__ void c4_dma16s(const float* base, unsigned voff, unsigned lds_byte) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_byte), "v"(voff), "s"(base) : "memory");

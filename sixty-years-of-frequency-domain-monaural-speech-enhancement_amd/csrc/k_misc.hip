@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void layernorm_cf_kernel(const float* __restri
     auto finish = [&](int i, float xv, float rv) {
         const int c = i / F, f = i - c * F;
         float y = (xv - mu) * rs * w[f * C + c] + bb[f * C + c];
-        if (post == 1) y = y * __builtin_amdgcn_rcpf(1.f + __expf(-y));      // swish on the hardware exp2 / reciprocal
+        if (post == 1) y = y * fm_sigmoid(y);      // swish on the hardware exp2 / reciprocal
         if (prelu_slope) y = y >= 0.f ? y : slope * y;
         if (res) y += rv;
         out[base + (long)i * T] = y;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void elu_kernel(const float* __restrict__ x, f
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         const float v = x[i];
-        y[i] = v > 0.f ? v : (v > -1e-3f ? fmaf(0.5f * v, v, v) : __expf(v) - 1.f);      // (as gemmconv.hip: act_apply)
+        y[i] = v > 0.f ? v : fm_expm1(v);      // (as gemmconv.hip: act_apply)
     }
 }
 void launch_elu(const float* x, float* y, long n, hipStream_t s) {

@@ -306,12 +306,12 @@ __global__ __launch_bounds__(Shape<false>::NT) void stft2_kernel(const Stft2Args
             for (int s = 0; s < 2 * NB; ++s) {
                 const float m2 = vre[q][s] * vre[q][s] + vim[q][s] * vim[q][s];
                 const bool pos = !(m2 <= 1e-37f);                  // (below: the hardware square root flushes to zero; NaN / inf pass through)
-                const float m = pos ? __builtin_amdgcn_sqrtf(m2) : 0.f;       // v_sqrt_f32, 1 ulp
+                const float m = pos ? fm_sqrt(m2) : 0.f;       // v_sqrt_f32, 1 ulp
                 float mp = m;
                 if (cprs) {
                     float sc;
                     if (half) {
-                        sc = pos ? __builtin_amdgcn_rsqf(m) : 0.f;            // |X|^0.5 / |X| = |X|^-0.5
+                        sc = pos ? fm_rsq(m) : 0.f;            // |X|^0.5 / |X| = |X|^-0.5
                         mp = m * sc;
                     } else {
                         mp = powf(m, a.p_in);

@@ -30,12 +30,16 @@ namespace {
 
 constexpr int TCM_C = 64, TCM_CIO = 256, TCM_NW = 8;      // bottleneck channels, block in/out channels, waves per workgroup
 
-__device__ __forceinline__ float half_sum32(float v) {     // sum over the 32 lanes that share (lane >> 5)
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
+// sum over the 32 lanes that share (lane >> 5), on the DPP network: quad swaps, half-row and row mirrors give every lane its
+// 16-lane row's total, row_bcast15 then adds row 0's / row 2's total into rows 1 / 3 - the result is valid in lanes 16-31 and
+// 48-63 (callers read it from lane 31 of their half).  Five v_add_f32_dpp per sum; the `__shfl_xor` form of rounds 2-4 was five
+// ds_bpermute_b32 each - 640 LDS round trips per lane and InstanceNorm head, 20 of the 29 us the statistics took per block.
+__device__ __forceinline__ float half_sum32(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast15 into rows 1, 3
     return v;
 }
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }      // MFMA 32x32 D layout
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
                 v0 = v0 >= 0.f ? v0 : sl * v0;
                 vv1 = vv1 >= 0.f ? vv1 : sl * vv1;
                 const float s = half_sum32((in0 ? v0 : 0.f) + (in1 ? vv1 : 0.f));
-                if (l31 == 0) part[wave * TCM_C + row] = s;
+                if (l31 == 31) part[wave * TCM_C + row] = s;
             }
         __syncthreads();
         if (tid < TCM_C) {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
                 v0 = (v0 >= 0.f ? v0 : sl * v0) - mu;
                 vv1 = (vv1 >= 0.f ? vv1 : sl * vv1) - mu;
                 const float s = half_sum32((in0 ? v0 * v0 : 0.f) + (in1 ? vv1 * vv1 : 0.f));
-                if (l31 == 0) part[wave * TCM_C + row] = s;
+                if (l31 == 31) part[wave * TCM_C + row] = s;
             }
         __syncthreads();
         if (tid < TCM_C) {
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) g[i][j][r] = __builtin_amdgcn_rcpf(1.f + __expf(-g[i][j][r]));      // hardware exp / reciprocal, as in the gc_kernel GLU epilogue
+                for (int r = 0; r < 16; ++r) g[i][j][r] = fm_sigmoid(g[i][j][r]);      // hardware exp / reciprocal, as in the gc_kernel GLU epilogue
         head(h, a.hL, a.K);
         dconv(m, a.w2L);
 #pragma unroll
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
         w_store(0, w_load(a.w3, 8, 0, 0));
         __syncthreads();
         tcm_x16 acc[2][2];
+        wf4 xres[2][2][4];
         for (int c = 0; c < NC; ++c) {
             const int ps = c >> 1, half = c & 1;
             wf4 wn;
@@ -429,6 +434,22 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                // the residual rows of this pass (x, in the layout the strips are read back in) are requested HERE, ahead of
+                // the pass's 128 matrix instructions: issued in the epilogue they were 16 exposed HBM round trips per pass
+                // (rounds 2-4: ~36 us of a block's 172 with the matrix pipe idle)
+                if (a.strip && !(a.dbg & 64)) {
+                    const int lr = lane >> 3, lc = (lane & 7) * 4;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int tg = 32 * (wave + TCM_NW * j) + lc;
+                            if ((j == 1 && !v1) || tg + 3 >= T) continue;
+#pragma unroll
+                            for (int it = 0; it < 4; ++it)
+                                xres[mt][j][it] = *reinterpret_cast<const wf4*>(xb + (64 * ps + 32 * mt + it * 8 + lr) * T + tg);
+                        }
+                }
             }
             const float* wb = Ws + (c & 1) * (CK * 128) + lane;
             const float* A0 = Ah + (2 * half * CK) * Tp + ta0;
@@ -466,7 +487,7 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
                                 wf4 v = *reinterpret_cast<const wf4*>(strip + row * 36 + lc);
                                 const int o = (64 * ps + 32 * mt + row) * T + tg;
                                 if (tg + 3 < T) {
-                                    v += *reinterpret_cast<const wf4*>(xb + o);
+                                    v += xres[mt][j][it];          // (SE_TCM_DBG=64: not loaded - timing ablation only)
                                     *reinterpret_cast<wf4*>(yb + o) = v;
                                 } else {
 #pragma unroll

@@ -37,7 +37,7 @@ struct TcmStreamArgs {
     char* state; long state_stride; // per stream: double carry[3][2] | firL [64][K-1] | firR | cvL [64][(ks-1)*dil] | cvR
 };
 
-__device__ __forceinline__ float sigm_(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float sigm_(float v) { return 1.f / (1.f + fm_exp(-v)); }
 
 // Latency, not arithmetic, bounds a chunk of one or two frames (~75 K multiply-adds): every dependent global access is a
 // ~1 us round trip (first version, a load per loop iteration with runtime trip counts: 125 us per block; second, the whole

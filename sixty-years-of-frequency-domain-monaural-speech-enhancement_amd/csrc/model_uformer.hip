@@ -57,10 +57,10 @@ __global__ __launch_bounds__(256) void uf_fusion_kernel(float* __restrict__ cplx
     float* mp = mag + b * CP + r;
     const float re = cr[0], im = cr[CP], m = mp[0];
     const float cm = sqrtf(fmaxf(re * re + im * im, UEPS));
-    const float s = __frcp_rn(1.f + __expf(-m));
+    const float s = (1.f / (1.f + fm_exp(-m)));
     cr[0] = re + s;
     cr[CP] = im + s;
-    mp[0] = m + __frcp_rn(1.f + __expf(-cm));
+    mp[0] = m + (1.f / (1.f + fm_exp(-cm)));
 }
 
 // ---- attention along T (t_att_cplx.py:15-40, :58-67): pq [B][nh*48][F][T] rows (q,k,v) x 16 per head.
@@ -120,14 +120,14 @@ __global__ __launch_bounds__(256) void uf_att_t_kernel(const float* __restrict__
                     cm = fmaxf(cm, e[k]);
                 }
                 const float mn = fmaxf(mx, cm);
-                const float corr = __expf(mx - mn);
+                const float corr = fm_exp(mx - mn);
                 l *= corr;
 #pragma unroll
                 for (int d = 0; d < HD; ++d) o[d] *= corr;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int s = min(s0 + k, T - 1);
-                    const float pe = __expf(e[k] - mn);          // masked keys: exp(-3e38 - mn) = 0
+                    const float pe = fm_exp(e[k] - mn);          // masked keys: exp(-3e38 - mn) = 0
                     l += pe;
                     const float4* vp = reinterpret_cast<const float4*>(Vs + s * HD);
 #pragma unroll
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(256) void uf_att_t_mfma_kernel(const float* __restr
                 cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
                 cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
                 const float mn = fmaxf(mx[qt], cm);
-                const float corr = __expf(mx[qt] - mn);
+                const float corr = fm_exp(mx[qt] - mn);
                 float ps = 0.f;
                 uf_x4 pe;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    pe[i] = __expf(sc[i] - mn);          // masked keys: exp(-3e38 - mn) = 0
+                    pe[i] = fm_exp(sc[i] - mn);          // masked keys: exp(-3e38 - mn) = 0
                     ps += pe[i];
                 }
                 ps += __shfl_xor(ps, 16, 64);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void uf_att_f_kernel(const float* __restrict__
         }
         float l = 0.f;
         for (int g = 0; g < F; ++g) {
-            e[g] = __expf(e[g] - mx);
+            e[g] = fm_exp(e[g] - mx);
             l += e[g];
         }
         const float inv = 1.f / l;

@@ -408,6 +408,10 @@ inline bool lstm_stack_chunked_fm(const LstmBig* const* ly, int L, const float* 
     for (int l = 0; l < L; ++l)
         if (!ly[l]->has_fm || !ly[l]->whh_dev || ly[l]->H != H || (l > 0 && ly[l]->I != H)) return false;
     if (!lstm_coop_chunk_supported(H, S, L)) return false;
+    // the chunk kernel addresses G / out with 32-bit lane offsets over rows of T * S elements (launch_lstm_coop_chunk checks the same
+    // bound): batches of long clips (H = 1024: T * S >= ~244 k, e.g. 64 clips of 3 800 frames) go back to the per-layer path, whose
+    // launchers fall back by themselves
+    if ((double)T * S * 4 * H * 4 >= 4.0e9 || (double)T * S * H >= 4.0e9) return false;
     static const int chunk_env = getenv("SE_LSTM_CHUNK_T") ? atoi(getenv("SE_LSTM_CHUNK_T")) : 0;
     // chunk length: the pipeline runs (L - 1) chunks longer than the sequence, every launch costs ~3 steps' worth of launch + fill
     int Tc = chunk_env > 0 ? chunk_env : 48;                 // (measured at batch 64, T = 401: 24 / 36 / 48 / 64 -> CRN 4 907 / 5 022 / 5 281 / 5 204 utt/s)

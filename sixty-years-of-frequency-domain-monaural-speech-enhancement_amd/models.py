@@ -83,7 +83,7 @@ class DCCRN(_EngineModule):
                  kernel_num=(16, 32, 64, 128, 256, 256), **kw):
         cfg = (rnn_layers, rnn_units, win_len, win_inc, fft_len, masking_mode, use_clstm, use_cbn, kernel_size,
                tuple(kernel_num))
-        if cfg[:5] + cfg[6:] != (2, 256, 512, 128, 512, True, False, 5, (32, 64, 128, 256, 256, 256)) or masking_mode not in 'ECR':
+        if cfg[:5] + cfg[6:] != (2, 256, 512, 128, 512, True, False, 5, (32, 64, 128, 256, 256, 256)) or masking_mode not in ('E', 'C', 'R'):
             raise NotImplementedError("the engine builds the decode script's DCCRN configuration "
                                       "(dccrn_decode_vb.py:11) with masking_mode 'E', 'C' or 'R'; got " + repr(cfg))
         # masking_mode (DCCRN_cprs.py:205-223): SE_CFG_DCCRN_MASK_C = 32, SE_CFG_DCCRN_MASK_R = 64 (include/se_engine.h)

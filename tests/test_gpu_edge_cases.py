@@ -87,6 +87,35 @@ def test_fullsubnet_smaller_batch_fits_the_planned_arena():
     assert rms(y32[:12] - ys) < 1e-4
 
 
+def test_long_clips_at_batch_40_fall_back_from_the_chunked_lstm_pipeline():
+    """the layer pipeline over time chunks (rnn.h: lstm_stack_chunked_fm) addresses its gate / output
+    tensors with 32-bit lane offsets over rows of T * S elements; at H = 1024 that ends at T * S ~ 244 k (40 clips of 62 s:
+    T * S = 248 040).  The gate must send such a batch to the per-layer path (whose launchers fall back by themselves) instead
+    of throwing 'tensor too large for 32-bit lane offsets'; rows are compared with a one-clip engine on the same clip."""
+    torch = _torch()
+    from se_amd.models import MODEL_CLASSES
+    B, L = 40, 6200 * 160
+    clip = np.tile(synth.synth_clip(31, 'speech', 160000), 7)[:L].copy()
+    other = np.tile(synth.synth_clip(32, 'speech', 160000), 7)[:L].copy()
+    x = np.stack([clip if b % 2 == 0 else 0.6 * other for b in range(B)])
+    for name in ('crn', 'lstm'):
+        big = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(SEEDS[name])
+        y = big.enhance_batch(torch.from_numpy(x).cuda())
+        assert bool(torch.isfinite(y).all()), name
+        y0, y39 = y[0].cpu().numpy(), y[B - 1].cpu().numpy()
+        del big, y
+        torch.cuda.empty_cache()
+        one = MODEL_CLASSES[name](max_batch=1, max_samples=L).load_synthetic(SEEDS[name])
+        r0 = one.enhance_batch(torch.from_numpy(x[:1]).cuda()).cpu().numpy()[0]
+        r39 = one.enhance_batch(torch.from_numpy(x[B - 1:]).cuda()).cpu().numpy()[0]
+        del one
+        torch.cuda.empty_cache()
+        for got, ref in ((y0, r0), (y39, r39)):
+            e = rms(got - ref)
+            print(name, 'batch 40 x 62 s row vs one-clip engine: rms diff', e, 'rms', rms(ref))
+            assert e < 1e-4 and e < 5e-4 * max(rms(ref), 1e-3), (name, e)
+
+
 @pytest.mark.parametrize('name', ['crn', 'dccrn', 'g2net', 'fullsubnet'])
 def test_graph_replay_matches_eager(name):
     """SE_CFG_GRAPHS: the third call of a shape replays a captured hipGraph (first eager, second captures) and must

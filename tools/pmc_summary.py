@@ -61,6 +61,15 @@ def main():
     fam['traffic_GB_per_launch'] = round((fam['read_GB_per_step'] + fam['write_GB_per_step']) / fam['launches_per_step'], 4)
     fam['executed_mfma_tflop_per_step'] = round(sum(r['mfma_tflop_per_step'] for r in mf), 3)   # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512
     fam['commit'] = commit
+    # hash of the kernel sources the DCCRN decode runs through, as bench.py computes it: the bench quotes these counters only
+    # while the tree's sources still hash to the same value (else `traffic` is null and `traffic_stale` true)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        fam['csrc_sha16'] = bench.dccrn_csrc_sha16()
+    except Exception as ex:       # (summaries of other models do not need it)
+        fam['csrc_sha16'] = None
+        print('csrc hash unavailable:', ex, file=sys.stderr)
     res = {'steps': steps, 'gc_family': fam, 'kernels': rows}
     json.dump(res, open(out + '.json', 'w'), indent=1)
     with open(out + '.md', 'w') as f:

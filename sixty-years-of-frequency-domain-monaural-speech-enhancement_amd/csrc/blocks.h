@@ -7,8 +7,11 @@ namespace se {
 struct NormAct {
     float *g = nullptr, *b = nullptr, *s = nullptr;
     bool cum = false;      // CumulativeLayerNorm (`_new` variants: parameters `gain` / `bias`) instead of InstanceNorm
+    bool gain_nonzero = true;      // every channel's gain != 0: the norm can be folded into its consumers (a left-pad frame is
+                                   // staged as the raw value that normalises to zero, which a zero gain does not have)
     void load(const TrackedSD& sd, const std::string& in_key, const std::string& prelu_key) {
         cum = sd.has(in_key + "gain");
+        for (float v : sd.get(in_key + (cum ? "gain" : "weight")).data) gain_nonzero = gain_nonzero && v != 0.f;
         g = to_device(sd.get(in_key + (cum ? "gain" : "weight")).data);
         b = to_device(sd.get(in_key + "bias").data);
         s = to_device(sd.get(prelu_key + "weight").data);
@@ -62,6 +65,21 @@ inline void deconv_norm2d_prelu(const DeconvPlan& pl, const NormAct& n, const Ac
     }
     run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf);
     norm2d_prelu(n, y, out, B, C, Fout, T, st, res);
+}
+// The same two layers with the normalisation left to the CONSUMERS (round 5): the conv stores its raw output, its epilogue
+// statistics become the per-(b, c) parameters `nrm` ([B][C] float4, kernels.h: launch_instnorm_finalize) that consumers pass as
+// Act4::nrm (gc_kernel NRM applies InstanceNorm + PReLU to its B-operand fragments) - the plane is neither read nor written again.
+inline void conv_stats_nrm(const GCPlan& pl, const NormAct& n, const Act4& s0, const Act4* s1, float* y, float* nrm, int C, int Fout,
+                           int B, int T, hipStream_t st, Profiler* pf) {
+    float* stats = in_stats_scratch(B, C, Fout, T, st);
+    run_conv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
+    launch_instnorm_finalize(stats, Fout * ((T + 31) / 32), n.g, n.b, n.s, nrm, B, C, Fout * T, st);
+}
+inline void deconv_stats_nrm(const DeconvPlan& pl, const NormAct& n, const Act4& s0, const Act4* s1, float* y, float* nrm, int C,
+                             int Fout, int B, int T, hipStream_t st, Profiler* pf) {
+    float* stats = in_stats_scratch(B, C, Fout, T, st);
+    run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
+    launch_instnorm_finalize(stats, Fout * ((T + 31) / 32), n.g, n.b, n.s, nrm, B, C, Fout * T, st);
 }
 // PReLU -> norm -> shared FIR on x [B][C][T]
 inline void tcm_head(const NormAct& n, const float* fir, int K, const float* x, float* y, int B, int C, int T, hipStream_t st) {

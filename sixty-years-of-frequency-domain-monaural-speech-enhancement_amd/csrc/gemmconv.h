@@ -98,7 +98,18 @@ struct GCParams {
     // (b, channel, row, frame) become  re + sig(v), im + sig(v), v + sig(|re + i im|)  - the pair is rewritten in place
     float* fz;
     long fz_b, fz_c, fz_f, fz_im;
+    // optional (gc_nrm_supported(): EPI_ACT on 64-row tiles, causal taps, <= GC_NRM_MAXC input channels): the sources are RAW conv
+    // outputs whose InstanceNorm + PReLU has not been applied - per (b, channel) float4 {scale = rstd * gamma, shift = beta - mean *
+    // scale, slope - 1, x0 = -shift / scale} (k_misc.hip: instnorm_finalize_kernel).  The kernel applies
+    //   y = fma(x, scale, shift);  y + (slope - 1) * min(y, 0)
+    // to every B-operand fragment on its way from LDS to the matrix instruction, so the normalised tensor never exists in HBM
+    // (round 5: the stand-alone InstanceNorm passes of the U^2-Net levels were 13-15 % of a G2Net / TaylorSENet step).  Zero
+    // padding stays zero: K rows whose frequency row lies outside the plane get scale = shift = 0, left-pad frames are staged as x0.
+    // nullptr for a source: that source is consumed as it is.
+    const float* nrm0;
+    const float* nrm1;
 };
+constexpr int GC_NRM_MAXC = 128;
 
 // Device tables of one patch geometry (owned by the plan)
 struct GCGeom {
@@ -160,6 +171,8 @@ void gc_unregister_overread_range(const void* lo);
 // Launch: p must have src/dst pointers, strides, B/Q/Tout/Fin/Tin/C0/C1 filled in.
 // true when launches of this plan can emit the per-tile statistics of GCParams::stats
 bool gc_stats_supported(const GCPlan& pl);
+// true when launches of this plan can normalise their sources on the fly (GCParams::nrm0 / nrm1)
+bool gc_nrm_supported(const GCPlan& pl);
 void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream);
 // two launches that would both take the thin path (the frequency-parity classes of a transposed conv on a few frames) as one;
 // false: nothing was launched

@@ -174,7 +174,8 @@ __device__ __forceinline__ float dpp_add8(float x) {
 // per chunk (16 for a 64 x 320 TCM conv, whose matrix work is a few hundred cycles).
 // TRIM: the launch stages 16 B groups under taps that look ahead in time (GC_TRIM_TAIL).  A variant of its own: the mere
 // presence of the LDS stores in the K loop costs the other launches 2-10 % (gcbench, 32- / 64-row tiles most).
-template <int BM, int BN, int WM, int WN, int EPI, bool RES = false, bool TRIM = false, bool FZ = false>
+// NRM: the sources are raw conv outputs, their InstanceNorm + PReLU is applied to the B-operand fragments (GCParams::nrm0 / nrm1)
+template <int BM, int BN, int WM, int WN, int EPI, bool RES = false, bool TRIM = false, bool FZ = false, bool NRM = false>
 __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (BM <= 32 ? 4 : 2) : gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {   // (FZ: room for the prefetched pair; 128 x 256: 128 accumulators per lane)
 #ifdef GC_TIMING
     unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -251,6 +252,10 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     int* tabl = reinterpret_cast<int*>(smem + max(nbuf * (As_sz + Bs_sz), STRIPS));
     int* koff_lds = tabl + GC_TAB_KOFF;
     float* ep = reinterpret_cast<float*>(tabl + GC_TAB_KOFF + KCP_MAX + 8);      // [4 * BM]
+    // NRM: per input channel {scale, shift, slope - 1, x0} of this batch row, and per K row of a staged chunk the same with
+    // scale = shift = 0 where the row's frequency tap lies outside the plane (double-buffered with the chunks)
+    floatx4* nrmC = reinterpret_cast<floatx4*>(ep + 4 * BM);                     // [GC_NRM_MAXC]
+    floatx4* nrmK = nrmC + GC_NRM_MAXC;                                          // [2][KCP_MAX] + 2 (the pipeline reads one pair ahead)
     GC_T(7);      /* kernel entry .. index decode */
     // one barrier for both block-wide LDS initialisations: the tap table (its global load is in flight while the patch
     // buffers are cleared) and the zeros of the padding (masked DMA lanes never touch their LDS words again)
@@ -274,6 +279,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             epv[3] = p.post_scale ? p.post_shift[oc] : 0.f;
         }
     }
+    if constexpr (NRM) {
+        if (tid < p.C0 + p.C1) {
+            const bool s1 = tid >= p.C0;
+            const float* __restrict__ np_ = s1 ? p.nrm1 : p.nrm0;
+            floatx4 v = {1.f, 0.f, 0.f, 0.f};
+            if (np_) v = reinterpret_cast<const floatx4*>(np_)[(long)b * (s1 ? p.C1 : p.C0) + (s1 ? tid - p.C0 : tid)];
+            nrmC[tid] = v;
+        }
+    }
     for (int i = tid; i < nbuf * Bs_sz / 4; i += 256) reinterpret_cast<floatx4*>(Bs)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     if (tid < GC_TAB_KOFF + KCP_MAX + 8) tabl[tid] = tabv;
     if (EPI != EPI_LSTM && tid < BM) {
@@ -290,6 +304,21 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             constexpr int kp = decltype(KP)::value;
             koffv[kp] = koff_lds[2 * kp + hi];
         });
+    }
+
+    // NRM, chunk-invariant part of the per-K-row parameters: thread k < KCP_MAX serves K row k = (cil, tap) - its channel inside
+    // the chunk and whether its frequency row lies inside the plane (block-uniform per row; padded K rows count as outside);
+    // threads < CI_C * nrows also own one patch row each for the left-pad frames of the first time tile
+    int nk_cil = 0, pb_cil = 0;
+    bool nk_ok = false;
+    const int npadL = NRM ? max(0, -(t0 + p.dtmin)) : 0;       // staged columns in front of frame 0 (block-uniform, multiple of 4)
+    if constexpr (NRM) {
+        if (tid < KCP_MAX) {
+            nk_cil = tid / p.ntaps;
+            const int f = q * p.si + tabl[tabl[GC_MAX_ROWS + tid - nk_cil * p.ntaps]];
+            nk_ok = tid < p.KC && f >= 0 && f < p.Fin;
+        }
+        pb_cil = tid / p.nrows;
     }
 
     // ---- chunk-invariant staging descriptors (all staging loops have uniform bounds: no exec masking)
@@ -382,6 +411,24 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     }
 #define GC_LOAD_CHUNK(CH, BUF)                                                                     \
     {                                                                                              \
+        if constexpr (NRM) {                                                                       \
+            /* the buffer is free (its readers passed the last barrier): its K-row parameters and, in the first time tile, */ \
+            /* the left-pad frames as the value the normalisation maps to zero (the masked DMA never touches them)        */ \
+            const int cb_ = (CH) * p.CI_C, co_ = seg ? p.C0 : 0;                                   \
+            if (tid < KCP_MAX) {                                                                   \
+                floatx4 v_ = nrmC[min(cb_ + nk_cil, Cseg - 1) + co_];                              \
+                if (!nk_ok) {                                                                      \
+                    v_[0] = 0.f;                                                                   \
+                    v_[1] = 0.f;                                                                   \
+                }                                                                                  \
+                nrmK[(BUF) * KCP_MAX + tid] = v_;                                                  \
+            }                                                                                      \
+            if (npadL > 0 && tid < rows) {                                                         \
+                const float x0_ = nrmC[min(cb_ + pb_cil, Cseg - 1) + co_][3];                      \
+                float* d_ = Bs + (BUF) * Bs_sz + tid * p.Wp;                                       \
+                for (int w_ = 0; w_ < npadL; w_ += 4) *reinterpret_cast<floatx4*>(d_ + w_) = floatx4{x0_, x0_, x0_, x0_}; \
+            }                                                                                      \
+        }                                                                                          \
         /* both operands go global -> LDS by DMA: no staging registers, no ds_write phase; the activation patch first */ \
         /* (HBM latency), the weights (L2-resident) behind it                                                        */ \
         const float* __restrict__ Bc = sbase + (long)(CH) * p.CI_C * s_c;                          \
@@ -469,6 +516,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
             const float* Ab = As + buf * As_sz + hi * BM + am;
             const float* Bb = Bs + buf * Bs_sz + bn;
+            const floatx4* nkb = nrmK + buf * KCP_MAX + hi;       // (NRM) parameters of K row 2 kp + hi
             const int npair = p.KCp >> 1;
             // software pipeline, depth 1: the operands of k-pair kp+1 are fetched (ds_read2_b32) before the MFMAs of
             // k-pair kp issue; sched_group_barrier pins "2 DS reads, then 4 MFMAs" so the LDS latency sits under
@@ -480,6 +528,13 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         else o_ = koff_lds[2 * (KP) + hi];                                                         \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) AR[i] = Ab[(2 * (KP)) * BM + i * 32];       \
         _Pragma("unroll") for (int j = 0; j < JN; ++j) BR[j] = Bb[o_ + j * 32];                    \
+        if constexpr (NRM) {                                                                       \
+            const floatx4 pr_ = nkb[2 * (KP)];                                                     \
+            _Pragma("unroll") for (int j = 0; j < JN; ++j) {                                       \
+                const float t_ = fmaf(BR[j], pr_[0], pr_[1]);                                      \
+                BR[j] = fmaf(fminf(t_, 0.f), pr_[2], t_);                                          \
+            }                                                                                      \
+        }                                                                                          \
     }
 #define GC_MMA(AR, BR)                                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
@@ -499,14 +554,19 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     int np_ = npair;
                     asm volatile("" : "+s"(np_));
                     if (kp < np_) {
+                        // (NRM: one more DS read - the K rows' parameters - and three vector instructions per B value, placed
+                        // behind the matrix instructions of the k-pair in flight)
+                        constexpr int NDS = (TM + 1) / 2 + (JN + 1) / 2 + (NRM ? 1 : 0);
                         GC_FETCH(kp + 1, ay, by);
-                        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
                         GC_MMA(ax, bx);
                         __builtin_amdgcn_sched_group_barrier(0x008, TM * JN, 0);
+                        if constexpr (NRM) __builtin_amdgcn_sched_group_barrier(0x002, 3 * JN, 0);
                         GC_FETCH(kp + 2, ax, bx);
-                        __builtin_amdgcn_sched_group_barrier(0x100, (TM + 1) / 2 + (JN + 1) / 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
                         GC_MMA(ay, by);
                         __builtin_amdgcn_sched_group_barrier(0x008, TM * JN, 0);
+                        if constexpr (NRM) __builtin_amdgcn_sched_group_barrier(0x002, 3 * JN, 0);
                     }
                 });
             };
@@ -1183,7 +1243,7 @@ static long gc_thin_blocks(const GCParams& p) {
     const int n = p.Tout - p.t_base;
     // (layers with <= 4 output channels have the packed matrix too: a one-frame launch of the direct kernel walks its whole K
     // in one thread per output - 20-40 us; the fused parity pair of a transposed conv only exists there)
-    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.stats) return 0;
+    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.stats || p.nrm0 || p.nrm1) return 0;
     if (p.epi != EPI_ACT && p.epi != EPI_ADD && p.epi != EPI_MUL && p.epi != EPI_GLU && p.epi != EPI_LSTM) return 0;
     if (p.epi == EPI_LSTM && (p.M & 3)) return 0;
     const long nblk = (long)((p.M + 7) >> 3) * p.Q * p.B;
@@ -1303,7 +1363,8 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes, int nbuf = 2) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
-    return std::max((size_t)nbuf * (as + bs) * 4, epi_bytes) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64;
+    const size_t nrm = (p.nrm0 || p.nrm1) ? (size_t)(GC_NRM_MAXC + 2 * gc_kcp_max(BM) + 2) * 16 : 0;      // gc_kernel NRM: nrmC + nrmK
+    return std::max((size_t)nbuf * (as + bs) * 4, epi_bytes) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64 + nrm;
 }
 
 // Device tables of one patch geometry (row stride Wp): frequency rows / tap table / K-row patch offsets, and the
@@ -1643,6 +1704,21 @@ static void gc_launch_e(const GCParams& p_in, hipStream_t stream) {
         }
     }
     SE_CHECK(!p.fz, "gc_launch: this kernel variant cannot fold the branch interaction into its store");
+    if constexpr (EPI == EPI_ACT && BM == 64 && !RES) {
+        if (p.nrm0 || p.nrm1) {      // sources normalised on the fly (GCParams::nrm0 / nrm1)
+            SE_CHECK(!p.trim && p.causal && !p.qt2 && p.Z == 1 && p.C0 + p.C1 <= GC_NRM_MAXC,
+                     "gc_launch: on-the-fly InstanceNorm needs causal taps, one-row tiles and <= 128 input channels");
+            static bool attr_nrm[64] = {};
+            if (first_on_device(attr_nrm)) {
+                SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI, false, false, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN, EPI, false, false, false, true>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
+            SE_HIP(hipGetLastError());
+            return;
+        }
+    }
+    SE_CHECK(!p.nrm0 && !p.nrm1, "gc_launch: this kernel variant cannot normalise its sources on the fly");
     if constexpr (EPI == EPI_ACT && !RES) {
         if (p.trim) {
             static bool attr_trim[64] = {};
@@ -1677,7 +1753,7 @@ static void gc_launch_t(const GCParams& p, hipStream_t stream) {
 // all chunks of a source resident in LDS at once (gc_kernel RES): launches of at most one workgroup per CU whose staging fits
 static bool gc_resident_fits(GCParams& p, int BM, int BM_div_WM) {
     static const int res_env = getenv("SE_GC_RES") ? atoi(getenv("SE_GC_RES")) : 1;
-    if (!res_env || p.trim || p.epi == EPI_LSTM || p.fz) return false;
+    if (!res_env || p.trim || p.epi == EPI_LSTM || p.fz || p.nrm0 || p.nrm1) return false;
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     const int nch0 = p.C0 > 0 ? (p.C0 + p.CI_C - 1) / p.CI_C : 0, nch1 = p.C1 > 0 ? (p.C1 + p.CI_C - 1) / p.CI_C : 0;
     int nb = std::max(std::max(nch0, nch1), 1);
@@ -1690,6 +1766,11 @@ static bool gc_resident_fits(GCParams& p, int BM, int BM_div_WM) {
     if (nb <= 2) return false;
     p.nbuf = nb;
     return true;
+}
+
+bool gc_nrm_supported(const GCPlan& pl) {
+    static const bool on = !(getenv("SE_IN_FOLD") && atoi(getenv("SE_IN_FOLD")) == 0);
+    return on && !pl.p.Ws && pl.p.epi == EPI_ACT && pl.BM == 64 && pl.p.causal && pl.p.Z == 1 && pl.p.C0 + pl.p.C1 <= GC_NRM_MAXC;
 }
 
 bool gc_stats_supported(const GCPlan& pl) {
@@ -1733,6 +1814,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     if (gc_thin_launch(p, stream)) return;
     if (p.Ws) {
         SE_CHECK(!p.fz, "gc_launch: the direct (<= 4 channel) path cannot fold the branch interaction into its store");
+        SE_CHECK(!p.nrm0 && !p.nrm1, "gc_launch: the direct (<= 4 channel) path cannot normalise its sources on the fly");
         if (p.M <= 1) gc_small_launch<1>(p, pl.small, stream);
         else if (p.M <= 2) gc_small_launch<2>(p, pl.small, stream);
         else gc_small_launch<4>(p, pl.small, stream);
@@ -1820,7 +1902,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
         static const long qt2_min = getenv("SE_GC_QT2_MIN") ? atol(getenv("SE_GC_QT2_MIN")) : 4096;
         const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
         if (qt2_env && pl.qt2.BN == 64 && pl.BN == 128 && p.Q >= 2 && !p.stats && p.pad_lo == 0 && p.epi != EPI_LSTM &&
-            nblk >= qt2_min) {
+            !p.nrm0 && !p.nrm1 && nblk >= qt2_min) {
             GCParams pa = p;
             pa.qt2 = 1;
             pa.qq_off = pl.qt2_qoff;

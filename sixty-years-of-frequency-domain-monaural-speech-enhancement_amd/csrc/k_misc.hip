@@ -449,6 +449,102 @@ void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, c
                        C, P);
     SE_HIP(hipGetLastError());
 }
+// ---- InstanceNorm folded into the consumers (round 5) ---------------------------------------------------------------------------
+// The epilogue statistics of a conv (GCParams::stats) -> the per-(b, c) parameters its CONSUMERS apply on the fly
+// (GCParams::nrm0 / nrm1): float4 {scale = rstd * gamma, shift = beta - mean * scale, slope - 1, x0 = -shift / scale}.  One wave
+// per (b, c) plane combines the nslot (sum, sum of squares) pairs in fp64 in a fixed order, like instnorm_prelu_stats_kernel.
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ stats, int nslot, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ slope,
+                                                                float* __restrict__ nrm, int C, int P, int planes) {
+    const int pl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pl >= planes) return;
+    const float2* sp = reinterpret_cast<const float2*>(stats) + (long)pl * nslot;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < nslot; i += 64) {
+        const float2 v = sp[i];
+        s += v.x;
+        q += v.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        q += __shfl_down(q, o, 64);
+    }
+    if (lane == 0) {
+        const int c = pl % C;
+        const double mu = s / P, var = fmax(q / P - mu * mu, 0.0);
+        const double sc = (1.0 / sqrt(var + 1e-5)) * (double)gamma[c], sh = (double)beta[c] - mu * sc;
+        // x0: the raw value that normalises to (numerically) zero - what a left-pad frame is staged as.  A zero gain has no such
+        // value; the fold is not used for such a layer (blocks.h checks gamma at load time), the field is then unused
+        reinterpret_cast<float4*>(nrm)[pl] = make_float4((float)sc, (float)sh, (slope ? slope[c] : 1.f) - 1.f, sc != 0.0 ? (float)(-sh / sc) : 0.f);
+    }
+}
+void launch_instnorm_finalize(const float* stats, int nslot, const float* gamma, const float* beta, const float* slope, float* nrm,
+                              int B, int C, int P, hipStream_t s) {
+    SE_CHECK(!ragged_ctx(), "epilogue statistics cannot be length-masked: ragged batches take the norm's own statistics pass");
+    const int planes = B * C;
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((planes + 3) / 4), dim3(256), 0, s, stats, nslot, gamma, beta, slope, nrm, C, P,
+                       planes);
+    SE_HIP(hipGetLastError());
+}
+// y = f_a(xa) + f_b(xb) over one (b, c) plane per block, f = the on-the-fly normalisation of gc_kernel NRM (same two fused
+// multiply-adds, so a value is the same whether a conv consumes it from the raw tensor or from this pass's output): the last
+// decoder level of a U^2-Net module + the module's residual (TaylorSENet.py:489-494), whose sum is what the NEXT module reads.
+// nb = nullptr: y = f_a(xa).  y may alias xa or xb.
+__global__ __launch_bounds__(256) void instnorm_apply2_kernel(const float* xa, const float* __restrict__ na, const float* xb,
+                                                              const float* __restrict__ nb, float* y, int P) {
+    const long base = (long)blockIdx.x * P;
+    const float4 pa = reinterpret_cast<const float4*>(na)[blockIdx.x];
+    const float4 pb = nb ? reinterpret_cast<const float4*>(nb)[blockIdx.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto f = [](float x, const float4& p) {
+        const float t = fmaf(x, p.x, p.y);
+        return fmaf(fminf(t, 0.f), p.z, t);
+    };
+    const float* ap = xa + base;
+    const bool two = nb != nullptr;
+    const float* bp = two ? xb + base : ap;
+    float* yp = y + base;
+    auto one = [&](int k) { yp[k] = f(ap[k], pa) + (two ? f(bp[k], pb) : 0.f); };
+    // 16 B accesses: the tensors share their misalignment (a plane starts at an odd multiple of 4 B when P is odd), so a head of
+    // <= 3 values brings all of them to a 16 B boundary (as norm_apply_pass)
+    if (((((size_t)ap ^ (size_t)yp) | ((size_t)ap ^ (size_t)bp)) & 15) == 0) {
+        const int head = min(P, (int)((4 - (((size_t)ap >> 2) & 3)) & 3));
+        if ((int)threadIdx.x < head) one(threadIdx.x);
+        const int n4 = (P - head) >> 2;
+        const float4* a4 = reinterpret_cast<const float4*>(ap + head);
+        const float4* b4 = reinterpret_cast<const float4*>(bp + head);
+        float4* y4 = reinterpret_cast<float4*>(yp + head);
+        auto f4 = [&](const float4& va, const float4& vb) {
+            float4 o;
+            o.x = f(va.x, pa) + (two ? f(vb.x, pb) : 0.f);
+            o.y = f(va.y, pa) + (two ? f(vb.y, pb) : 0.f);
+            o.z = f(va.z, pa) + (two ? f(vb.z, pb) : 0.f);
+            o.w = f(va.w, pa) + (two ? f(vb.w, pb) : 0.f);
+            return o;
+        };
+        constexpr int NV = 4;
+        int i = threadIdx.x;
+        for (; i + (NV - 1) * 256 < n4; i += NV * 256) {
+            float4 va[NV], vb[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                va[u] = a4[i + u * 256];
+                vb[u] = two ? b4[i + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < NV; ++u) y4[i + u * 256] = f4(va[u], vb[u]);
+        }
+        for (; i < n4; i += 256) y4[i] = f4(a4[i], two ? b4[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+        const int done = head + 4 * n4;
+        if (done + (int)threadIdx.x < P) one(done + threadIdx.x);
+        return;
+    }
+    for (int i = threadIdx.x; i < P; i += 256) one(i);
+}
+void launch_instnorm_apply2(const float* xa, const float* na, const float* xb, const float* nb, float* y, int B, int C, int P,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(instnorm_apply2_kernel, dim3(B * C), dim3(256), 0, s, xa, na, xb, nb, y, P);
+    SE_HIP(hipGetLastError());
+}
 void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
                            int C, int P, hipStream_t s, const float* res, int T) {
     if (const Ragged* rg = ragged_ctx()) {

@@ -194,6 +194,12 @@ void launch_zero_tail(float* x, int B, long rows, int T, hipStream_t s);
 // own frame count
 void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const float* beta, const float* slope, int B,
                            int C, int P, hipStream_t s, const float* res = nullptr, int T = 0);
+// InstanceNorm folded into the consumers: statistics -> per-(b, c) {scale, shift, slope - 1, x0} (GCParams::nrm0 / nrm1), and the
+// elementwise pass y = f_a(xa) (+ f_b(xb)) for tensors that still have to exist normalised
+void launch_instnorm_finalize(const float* stats, int nslot, const float* gamma, const float* beta, const float* slope, float* nrm,
+                              int B, int C, int P, hipStream_t s);
+void launch_instnorm_apply2(const float* xa, const float* na, const float* xb, const float* nb, float* y, int B, int C, int P,
+                            hipStream_t s);
 // statistics from the producing conv (nslot (sum, sum of squares) pairs per (b, c) plane, GCParams::stats)
 void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, const float* beta, const float* slope,
                                  const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res = nullptr);

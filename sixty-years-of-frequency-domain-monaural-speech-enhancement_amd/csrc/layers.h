@@ -80,6 +80,14 @@ struct Act4 {          // a view of an activation tensor
     const float* p = nullptr;
     int C = 0, F = 0;
     long sb = 0, sc = 0, sf = 0;   // element strides; t stride 1
+    // optional: the tensor is a RAW conv output whose InstanceNorm + PReLU the consumer applies on the fly - [B][C] float4
+    // parameters (GCParams::nrm0 / nrm1; only for plans with conv_nrm_supported())
+    const float* nrm = nullptr;
+    Act4 with_nrm(const float* n) const {
+        Act4 a = *this;
+        a.nrm = n;
+        return a;
+    }
 };
 inline Act4 act4(const float* p, int C, int F, int Tp) { return Act4{p, C, F, (long)C * F * Tp, (long)F * Tp, (long)Tp}; }
 
@@ -103,6 +111,8 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
                 int Tp, hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, int t_out = -1,
                 bool tb_soft = false, float* fz = nullptr, int fz_planes = 2);
 bool conv_stats_supported(const GCPlan& pl);
+bool conv_nrm_supported(const GCPlan& pl);
+bool deconv_nrm_supported(const DeconvPlan& pl);
 bool deconv_stats_supported(const DeconvPlan& pl);
 
 // HIP-event timing of the dominant kernel family (gemmconv launches) on the launch stream.

@@ -410,6 +410,8 @@ static void fill_src(GCParams& p, const Act4& s0, const Act4* s1) {
     p.s0_b = s0.sb;
     p.s0_c = s0.sc;
     p.s0_f = s0.sf;
+    p.nrm0 = s0.nrm;
+    p.nrm1 = s1 ? s1->nrm : nullptr;
     if (s1) {
         p.src1 = s1->p;
         p.C1 = s1->C;
@@ -433,6 +435,14 @@ bool conv_stats_supported(const GCPlan& pl) { return gc_stats_supported(pl); }
 bool deconv_stats_supported(const DeconvPlan& pl) {
     for (const auto& g : pl.par)
         if (!gc_stats_supported(g)) return false;
+    return true;
+}
+
+bool conv_nrm_supported(const GCPlan& pl) { return gc_nrm_supported(pl); }
+bool deconv_nrm_supported(const DeconvPlan& pl) {
+    if (pl.has_pair || pl.par.empty()) return false;
+    for (const auto& g : pl.par)
+        if (!gc_nrm_supported(g)) return false;
     return true;
 }
 

@@ -185,7 +185,7 @@ class G2Net final : public Model {
         b.hx = a.alloc_f(BT * 256);
         b.X[0] = a.alloc_f(BT * 256);
         b.X[1] = a.alloc_f(BT * 256);
-        b.us.alloc(a, BT);
+        b.us.alloc(a, BT, B);
         b.ts.h = a.alloc_f(BT * 64);
         b.ts.a = a.alloc_f(BT * 64);
         b.ts.r = a.alloc_f(BT * 64);

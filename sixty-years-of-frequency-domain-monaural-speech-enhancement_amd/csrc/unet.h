@@ -84,12 +84,14 @@ inline ConvIN load_gate2_conv_in(const TrackedSD& sd, const std::string& p, int 
 struct UnetScratch {
     float* lev[5] = {};     // encoder levels 1..4 of the nested U-Net
     float* dec[5] = {};     // decoder outputs at levels 0..3
-    void alloc(Arena& a, size_t BT) {
+    float* nrm[10] = {};    // [B][64] float4 each: on-the-fly InstanceNorm parameters of the module's raw tensors (UnetModule::run)
+    void alloc(Arena& a, size_t BT, int B) {
         const int F[5] = {79, 39, 19, 9, 4};
         for (int i = 0; i < 5; ++i) {
             lev[i] = a.alloc_f(BT * 64 * F[i]);
             dec[i] = a.alloc_f(BT * 64 * F[i]);
         }
+        for (auto& n : nrm) n = a.alloc_f((size_t)B * 64 * 4);
     }
 };
 
@@ -137,9 +139,55 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
     }
     int out_F(int Fin) const { return de ? (Fin - 1) * 2 + k1f : (Fin - k1f) / 2 + 1; }
 
+    // every nested (de)conv can hand statistics to its consumers and normalise its own sources on the fly
+    bool fold_ok() const {
+        bool ok = !(de ? in_d.na.cum : in_c.na.cum) && (de ? in_d.na.gain_nonzero : in_c.na.gain_nonzero) &&
+                  (de ? deconv_stats_supported(in_d.plan) : conv_stats_supported(in_c.plan));
+        for (int i = 0; i < scale && ok; ++i)
+            ok = !enco[i].na.cum && !deco[i].na.cum && enco[i].na.gain_nonzero && deco[i].na.gain_nonzero &&
+                 conv_stats_supported(enco[i].plan) && conv_nrm_supported(enco[i].plan) && deconv_stats_supported(deco[i].plan) &&
+                 deconv_nrm_supported(deco[i].plan);
+        return ok;
+    }
+    // InstanceNorm + PReLU of every tensor inside the module applied by its consumers (gc_kernel NRM): the nested U-Net's tensors
+    // exist only raw; ONE elementwise pass remains - the module's output, PReLU(IN(last deconv)) + PReLU(IN(in_conv)), which the
+    // next module reads.  Rounds 2-4 made a read + write pass over every level (2 * scale + 1 passes, 13-15 % of a step).
+    void run_folded(const Act4& in0, const Act4* in1, float* out, const UnetScratch& s, int B, int T, hipStream_t st,
+                    Profiler* pf) const {
+        const int F0 = out_F(in0.F);
+        if (de) deconv_stats_nrm(in_d.plan, in_d.na, in0, in1, out, s.nrm[0], 64, F0, B, T, st, pf);
+        else conv_stats_nrm(in_c.plan, in_c.na, in0, in1, out, s.nrm[0], 64, F0, B, T, st, pf);
+        int Fs[6];
+        Fs[0] = F0;
+        float* xs[5];
+        xs[0] = out;
+        auto lvl = [](int F) { return F >= 79 ? 0 : F >= 39 ? 1 : F >= 19 ? 2 : F >= 9 ? 3 : 4; };
+        for (int i = 0; i < scale; ++i) {
+            Fs[i + 1] = (Fs[i] - 3) / 2 + 1;
+            float* y = s.lev[lvl(Fs[i + 1])];
+            conv_stats_nrm(enco[i].plan, enco[i].na, act4(xs[i], 64, Fs[i], T).with_nrm(s.nrm[i]), nullptr, y, s.nrm[i + 1], 64,
+                           Fs[i + 1], B, T, st, pf);
+            xs[i + 1] = y;
+        }
+        const float* x = xs[scale];
+        const float* nx = s.nrm[scale];
+        for (int i = 0; i < scale; ++i) {
+            const int Fi = Fs[scale - i], Fo = Fs[scale - i - 1];
+            float* y = s.dec[lvl(Fo)];
+            const Act4 a0 = act4(x, 64, Fi, T).with_nrm(nx);
+            const Act4 a1 = act4(xs[scale - i], 64, Fi, T).with_nrm(s.nrm[scale - i]);
+            float* ny = s.nrm[5 + i];
+            deconv_stats_nrm(deco[i].plan, deco[i].na, a0, i == 0 ? nullptr : &a1, y, ny, 64, Fo, B, T, st, pf);
+            if (i + 1 == scale) launch_instnorm_apply2(y, ny, out, s.nrm[0], out, B, 64, Fo * T, st);      // + the module's residual
+            x = y;
+            nx = ny;
+        }
+    }
+
     // in0 (+ optional in1 concatenated on channels), both with F = Fin  ->  out [B][64][out_F][T]
     void run(const Act4& in0, const Act4* in1, float* out, const UnetScratch& s, int B, int T, hipStream_t st,
              Profiler* pf) const {
+        if (in_stats_enabled() && fold_ok()) return run_folded(in0, in1, out, s, B, T, st, pf);
         const int F0 = out_F(in0.F);
         if (de) {
             deconv_norm2d_prelu(in_d.plan, in_d.na, in0, in1, out, out, 64, F0, B, T, st, pf);

@@ -230,6 +230,13 @@ __global__ __launch_bounds__(512) void tcm_fused_kernel(const TcmFusedArgs a) {
         } else {
         // pass 1: mean of PReLU(src) per channel
         const bool in0 = tj0 < Tv, in1 = v1 && tj1 < Tv;
+        if (a.dbg & 2) {          // (ablation: identity normalisation, so that the decode stays finite)
+            if (tid < TCM_C) {
+                prm[1 * TCM_C + tid] = 1.f;
+                prm[2 * TCM_C + tid] = 0.f;
+            }
+            __syncthreads();
+        }
         if (!(a.dbg & 2)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)

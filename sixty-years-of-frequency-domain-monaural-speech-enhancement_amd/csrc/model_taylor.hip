@@ -75,6 +75,7 @@ class TaylorSENet final : public Model {
     }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
     int padded_samples(int L) const override { return ((L + HOP - 1) / HOP) * HOP; }   // taylorsenet_decode_vb.py:31-35
+    bool graph_capturable() const override { return false; }      // network() forks the separate encoder onto a second stream
 
     void finalize(const TrackedSD& sd) override {
         zen.load(sd, "zeroorderblock.en.", 2);
@@ -162,7 +163,7 @@ class TaylorSENet final : public Model {
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *est, *frames, *ens[5], *sens[5], *dx[4], *dlast, *gain, *zero, *hx, *hob, *X[2];
-        UnetScratch us;
+        UnetScratch us, us2;      // us2: the separate encoder's own scratch (it runs on a second stream next to the zero-order block)
         TcmScratch ts;
     } cur;
     U2Encoder zen, sen;
@@ -198,6 +199,7 @@ class TaylorSENet final : public Model {
         b.X[0] = a.alloc_f(BT * 256);
         b.X[1] = a.alloc_f(BT * 256);
         b.us.alloc(a, BT, B);
+        b.us2.alloc(a, BT, B);
         b.ts.h = a.alloc_f(BT * 64);
         b.ts.a = a.alloc_f(BT * 64);
         b.ts.r = a.alloc_f(BT * 64);
@@ -211,6 +213,19 @@ class TaylorSENet final : public Model {
         const int B = b.B, T = b.T;
         Profiler* pf = &ctx.prof;
         const long n2 = (long)B * 2 * NBIN * T;
+        // The separate encoder (:78-82) reads only the spectrum: offline it runs on a second stream NEXT TO the zero-order block
+        // (fork / join through events, as FullSubNet's column ranges do).  Both are long chains of launches of which the deep
+        // U^2-Net levels fill a fraction of the chip each (F = 4 ... 19: one to three rounds of workgroups, a tail per launch) -
+        // two independent chains fill each other's tails.  SE_TAYLOR_FORK=0: one stream.
+        static const bool fork_env = !(getenv("SE_TAYLOR_FORK") && atoi(getenv("SE_TAYLOR_FORK")) == 0);
+        const bool fork = fork_env && !stream_ctx();
+        if (fork) {
+            hipStream_t s2 = ctx.aux_stream(0);
+            SE_HIP(hipEventRecord(ctx.ev_fork, st));
+            SE_HIP(hipStreamWaitEvent(s2, ctx.ev_fork, 0));
+            sen.run(act4(b.spec, 2, NBIN, T), b.sens, b.us2, B, T, s2, &ctx.aux_prof[0]);
+            SE_HIP(hipEventRecord(ctx.ev_join[0], s2));
+        }
         // ---- zero-order block (:139-153)
         zen.run(act4(b.spec, 2, NBIN, T), b.ens, b.us, B, T, st, pf);
         const float* x = ztcm.run(b.ens[4], b.X, b.ts, B, T, st, pf);      // [B][64*4][T] view of the bottleneck
@@ -232,7 +247,8 @@ class TaylorSENet final : public Model {
         hipLaunchKernelGGL(taylor_zero_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b.gain, b.spec, b.zero, b.est,
                            plane, tot);
         // ---- separate encoder (:78-82) and the high-order recurrence (:84-93); `zero` doubles as pre_term
-        sen.run(act4(b.spec, 2, NBIN, T), b.sens, b.us, B, T, st, pf);
+        if (fork) SE_HIP(hipStreamWaitEvent(st, ctx.ev_join[0], 0));
+        else sen.run(act4(b.spec, 2, NBIN, T), b.sens, b.us, B, T, st, pf);
         float fact = 1.f;
         for (int k = 0; k < 3; ++k) {
             GCParams p = h_in[k].p;      // in_conv over cat(feature_head [B][256][T], pre [B][322][T])

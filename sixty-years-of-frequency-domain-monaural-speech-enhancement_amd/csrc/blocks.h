@@ -28,6 +28,10 @@ struct NormAct {
 inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int C, int F, int T, hipStream_t st,
                          const float* res = nullptr) {
     if (n.cum) {
+        if (res && !stream_ctx()) {       // offline: the residual rides on the apply pass (k_misc.hip: cln_apply_plane_kernel)
+            launch_cln(x, y, n.g, n.b, nullptr, n.s, nullptr, 0, B, C, F, T, st, res);
+            return;
+        }
         launch_cln(x, y == res ? const_cast<float*>(x) : y, n.g, n.b, nullptr, n.s, nullptr, 0, B, C, F, T, st);
         if (res) launch_add(res, y == res ? x : y, y, (long)B * C * F * T, st);
     } else {

@@ -734,6 +734,81 @@ __global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict_
     }
 }
 
+// Offline form of the apply pass for the 2-D norms of the U-Net levels (no pre-activation, no FIR): one workgroup per (b, c) plane
+// of F * T contiguous values, the utterance's per-frame (mean, rstd) in LDS, 16 B accesses with four of them in flight per thread
+// (cln_apply_kernel above walks eight rows of one column with one 4 B load in flight: 8.7 ms per G2Net_new step for the traffic
+// the InstanceNorm pass of the base model moved in 6.3), and the residual of the module's last level added here instead of by
+// an add_kernel pass behind it (4 % / 7 % of a G2Net_new / TaylorSENet_new step).  res may alias y.
+__global__ __launch_bounds__(256) void cln_apply_plane_kernel(const float* x, float* y, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gain,
+                                                              const float* __restrict__ bias, const float* __restrict__ post_slope,
+                                                              const float* res, int C, int F, int T) {
+    extern __shared__ float cl_sm[];      // mu [T], rs [T]
+    const int c = blockIdx.x % C, b = blockIdx.x / C, tid = threadIdx.x;
+    float* mu = cl_sm;
+    float* rs = cl_sm + T;
+    for (int t = tid; t < T; t += 256) {
+        mu[t] = mean[(long)b * T + t];
+        rs[t] = rstd[(long)b * T + t];
+    }
+    __syncthreads();
+    const int P = F * T;
+    const float* xp = x + (long)blockIdx.x * P;
+    float* yp = y + (long)blockIdx.x * P;
+    const float* rp = res ? res + (long)blockIdx.x * P : nullptr;
+    const float g = gain[c], bt = bias[c], sl = post_slope ? post_slope[c] : 1.f;
+    auto one = [&](float v, int t, float r) {
+        float o = (v - mu[t]) * rs[t] * g + bt;
+        o = o >= 0.f ? o : sl * o;
+        return rp ? o + r : o;
+    };
+    if (((((size_t)xp ^ (size_t)yp) & 15) == 0) && (!rp || ((((size_t)xp ^ (size_t)rp) & 15) == 0))) {
+        const int head = min(P, (int)((4 - (((size_t)xp >> 2) & 3)) & 3));
+        if (tid < head) yp[tid] = one(xp[tid], tid % T, rp ? rp[tid] : 0.f);
+        const int n4 = (P - head) >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(xp + head);
+        float4* y4 = reinterpret_cast<float4*>(yp + head);
+        const float4* r4 = rp ? reinterpret_cast<const float4*>(rp + head) : nullptr;
+        auto f4 = [&](float4 v, float4 r, int t) {        // t: frame of the first element (< T); the group may wrap into the next row
+            float in[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r.x, r.y, r.z, r.w}, o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int tk = t + k;
+                tk = tk >= T ? tk - T : tk;
+                o[k] = one(in[k], tk, rr[k]);
+            }
+            return make_float4(o[0], o[1], o[2], o[3]);
+        };
+        constexpr int NV = 4;
+        const int step1 = 1024 % T;                    // frames one 256-thread sweep of 16 B groups advances, mod T
+        int i = tid;
+        int t = (head + 4 * tid) % T;
+        for (; i + (NV - 1) * 256 < n4; i += NV * 256) {
+            float4 v[NV], r[NV];
+            int tu[NV];
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                v[u] = x4[i + u * 256];
+                r[u] = r4 ? r4[i + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+                tu[u] = t;
+                t += step1;
+                t = t >= T ? t - T : t;
+            }
+#pragma unroll
+            for (int u = 0; u < NV; ++u) y4[i + u * 256] = f4(v[u], r[u], tu[u]);
+        }
+        for (; i < n4; i += 256) {
+            y4[i] = f4(x4[i], r4 ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f), t);
+            t += step1;
+            t = t >= T ? t - T : t;
+        }
+        const int done = head + 4 * n4;
+        if (done + tid < P) yp[done + tid] = one(xp[done + tid], (done + tid) % T, rp ? rp[done + tid] : 0.f);
+        return;
+    }
+    for (int i = tid; i < P; i += 256) yp[i] = one(xp[i], i % T, rp ? rp[i] : 0.f);
+}
+
 // Frame-online windows are a few columns wide: one workgroup per utterance does the three passes in one launch (sums in
 // double precision like the kernels above, the same serial scan; the order inside a column's row sum differs).
 __global__ __launch_bounds__(256) void cln_window_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -921,7 +996,8 @@ __global__ __launch_bounds__(256) void cln_window_reg_kernel(const float* __rest
 }
 
 void launch_cln(const float* x, float* y, const float* gain, const float* bias, const float* pre_slope,
-                const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s) {
+                const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s, const float* res) {
+    SE_CHECK(!res || (K <= 0 && !pre_slope), "cLN: the residual rides on the plain 2-D form only");
     // per-(b, t) statistics live in a small engine-lifetime buffer (grown on first use, never on the steady-state path)
     const size_t need = (size_t)B * T * (2 * sizeof(double) + 2 * sizeof(float));
     char* stat = device_scratch(1, need, s);
@@ -974,6 +1050,13 @@ void launch_cln(const float* x, float* y, const float* gain, const float* bias, 
     }
     hipLaunchKernelGGL(cln_stats_kernel, dim3((T + 63) / 64, B), dim3(256), 0, s, x, pre_slope, sum, sq, R, F, T, 0, 64);
     hipLaunchKernelGGL(cln_scan_kernel, dim3(B), dim3(256), (size_t)T * 16, s, sum, sq, mean, rstd, R, T, 0, 0L, 0, nullptr);
+    static const bool plane_on = !(getenv("SE_CLN_PLANE") && atoi(getenv("SE_CLN_PLANE")) == 0);
+    if (K <= 0 && !pre_slope && (plane_on || res)) {
+        hipLaunchKernelGGL(cln_apply_plane_kernel, dim3(B * C), dim3(256), (size_t)T * 8, s, x, y, mean, rstd, gain, bias, post_slope,
+                           res, C, F, T);
+        SE_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(cln_apply_kernel, dim3((T + 255) / 256, (R + 7) / 8, B), dim3(256), 0, s, x, y, mean, rstd, gain,
                        bias, pre_slope, post_slope, fir, K, R, F, T, 0, 0L);
     SE_HIP(hipGetLastError());

@@ -243,8 +243,10 @@ void launch_tcm_chain(const TcmStreamW* const* f, const TcmFusedHeads* hd, const
 // CumulativeLayerNorm2d / 1d of the `_new` variants (CTSNet_new/Step1_network.py:213-286): frame t is normalised by the
 // statistics of all C*F values of frames 0..t;  x [B][C][F][T] (F = 1 for 1-D), gain / bias [C].
 //   y = FIR_K( cLN( PReLU_pre(x) ) )   (TCM branch head, K > 0, not in place)   or   y = PReLU_post( cLN(x) )
+// res (optional, offline, plain 2-D form only; may alias y): y = PReLU_post( cLN(x) ) + res
 void launch_cln(const float* x, float* y, const float* gain, const float* bias, const float* pre_slope,
-                const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s);
+                const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s,
+                const float* res = nullptr);
 
 // y = a + b (n elements);  y may alias a
 void launch_add(const float* a, const float* b, float* y, long n, hipStream_t s);

@@ -48,8 +48,21 @@ inline bool in_stats_enabled() {
 inline float* in_stats_scratch(int B, int C, int F, int T, hipStream_t st) {
     return reinterpret_cast<float*>(device_scratch(2, (size_t)B * C * F * ((T + 31) / 32) * 2 * sizeof(float), st));
 }
+inline bool cln_stats_enabled() {
+    static const bool on = !(getenv("SE_CLN_STATS") && atoi(getenv("SE_CLN_STATS")) == 0);
+    return on && !ragged_ctx() && !stream_ctx();
+}
+inline float* cln_parts_scratch(int B, int Fout, int T, hipStream_t st) {
+    return reinterpret_cast<float*>(device_scratch(7, (size_t)B * Fout * T * 2 * sizeof(float), st));
+}
 inline void conv_norm2d_prelu(const GCPlan& pl, const NormAct& n, const Act4& s0, const Act4* s1, float* y, float* out, int C,
                               int Fout, int B, int T, hipStream_t st, Profiler* pf, const float* res = nullptr) {
+    if (n.cum && cln_stats_enabled() && conv_stats_supported(pl) && pl.p.n_mtiles == 1) {      // cLN: per-frame sums from the epilogue
+        float* parts = cln_parts_scratch(B, Fout, T, st);
+        run_conv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, parts, 0, nullptr, 2, true);
+        launch_cln_parts(y, out, n.g, n.b, n.s, parts, B, C, Fout, T, st, res);
+        return;
+    }
     if (!n.cum && in_stats_enabled() && conv_stats_supported(pl)) {
         float* stats = in_stats_scratch(B, C, Fout, T, st);
         run_conv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
@@ -61,6 +74,14 @@ inline void conv_norm2d_prelu(const GCPlan& pl, const NormAct& n, const Act4& s0
 }
 inline void deconv_norm2d_prelu(const DeconvPlan& pl, const NormAct& n, const Act4& s0, const Act4* s1, float* y, float* out,
                                 int C, int Fout, int B, int T, hipStream_t st, Profiler* pf, const float* res = nullptr) {
+    bool one_mtile = !pl.has_pair && !pl.par.empty();
+    for (const auto& g : pl.par) one_mtile = one_mtile && g.p.n_mtiles == 1;       // (a one-tap parity class of <= 128 input channels runs on 64-row tiles)
+    if (n.cum && cln_stats_enabled() && deconv_stats_supported(pl) && one_mtile) {
+        float* parts = cln_parts_scratch(B, Fout, T, st);
+        run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, parts, 0, -1, false, nullptr, 2, true);
+        launch_cln_parts(y, out, n.g, n.b, n.s, parts, B, C, Fout, T, st, res);
+        return;
+    }
     if (!n.cum && in_stats_enabled() && deconv_stats_supported(pl)) {
         float* stats = in_stats_scratch(B, C, Fout, T, st);
         run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);

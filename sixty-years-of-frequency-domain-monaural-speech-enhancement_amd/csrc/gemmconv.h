@@ -92,6 +92,12 @@ struct GCParams {
     // the InstanceNorm that follows does not have to read the plane for its statistics (blocks.h: conv_norm2d_prelu)
     float* stats;
     long st_b, st_c, st_f;   // float strides of the statistics tensor
+    // optional (same tile configurations, one m-tile): per (b, output frequency row, frame) the (sum, sum of squares) over ALL
+    // output channels of the values this launch stores - [B][Fout][Tout][2] floats - for the CumulativeLayerNorm behind the layer
+    // (k_misc.hip: cln_scan_parts_kernel sums the rows and scans the frames; the norm's own statistics pass over the tensor -
+    // 6 % of a G2Net_new / TaylorSENet_new step - is not launched)
+    float* cstats;
+    long cs_b, cs_f;
     // optional (EPI_ACT / EPI_ADD on the MFMA path; Uformer's interaction of the two branches, fusion.py:13-19, folded into
     // the magnitude branch's last launch): fz = the complex branch's tensor, real plane at fz, imaginary plane fz_im floats
     // behind it, laid out like dst with its own strides.  The stored value v and the complex pair (re, im) at the same

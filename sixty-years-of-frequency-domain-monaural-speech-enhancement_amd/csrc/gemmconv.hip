@@ -256,6 +256,8 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     // scale = shift = 0 where the row's frequency tap lies outside the plane (double-buffered with the chunks)
     floatx4* nrmC = reinterpret_cast<floatx4*>(ep + 4 * BM);                     // [GC_NRM_MAXC]
     floatx4* nrmK = nrmC + GC_NRM_MAXC;                                          // [2][KCP_MAX] + 2 (the pipeline reads one pair ahead)
+    // GCParams::cstats: per-wave-row column sums of the block's tile, [WM][BN][2] floats, combined in a fixed order after a barrier
+    float* cpart = NRM ? reinterpret_cast<float*>(nrmK + 2 * KCP_MAX + 2) : ep + 4 * BM;
     GC_T(7);      /* kernel entry .. index decode */
     // one barrier for both block-wide LDS initialisations: the tap table (its global load is in flight while the patch
     // buffers are cleared) and the zeros of the padding (masked DMA lanes never touch their LDS words again)
@@ -698,10 +700,21 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // (a rolled loop where nothing indexes registers by `it`: eight copies of the store path - vector form, ragged mask,
             // frame-by-frame tail - were 6 KB of instructions per kernel that every workgroup streamed through once)
             constexpr int RB_UNROLL = (PRE || FZ) ? OROWS / 8 : 1;
+            float ccs[GC_STATS ? 4 : 1] = {}, ccq[GC_STATS ? 4 : 1] = {};      // GCParams::cstats: this lane's 4 frames over its rows
 #pragma unroll RB_UNROLL
             for (int it = 0; it < OROWS / 8; ++it) {
                 const int row = it * 8 + lr, m = mo0 + row;
                 floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * OST + lc);
+                if constexpr (GC_STATS) {
+                    if (p.cstats && m < Mo) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float xk = (tg + k < p.Tout) ? v[k] : 0.f;
+                            ccs[k] += xk;
+                            ccq[k] = fmaf(xk, xk, ccq[k]);
+                        }
+                    }
+                }
                 if constexpr (GC_STATS) {
                     // statistics of the stored values for the InstanceNorm behind this layer: the 8 lanes that hold one
                     // row of the 32-column sub-tile add up their 4 frames each (frames >= Tout masked), fixed order
@@ -760,6 +773,27 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     }
                 }
             }
+            if constexpr (GC_STATS) {
+                if (p.cstats) {
+                    // the 8 lanes (lane >> 3 = row within 8) that hold the same 4 frames: lanes l, l ^ 8, l ^ 16, l ^ 32, fixed order
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int o = 8; o < 64; o <<= 1) {
+                            ccs[k] += __shfl_xor(ccs[k], o, 64);
+                            ccq[k] += __shfl_xor(ccq[k], o, 64);
+                        }
+                    }
+                    if (lane < 8) {
+                        float* cp_ = cpart + ((wm * BN) + wt * (TN * 32) + j * 32 + lc) * 2;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            cp_[2 * k] = ccs[k];
+                            cp_[2 * k + 1] = ccq[k];
+                        }
+                    }
+                }
+            }
         };
         epi_tile(std::integral_constant<int, 0>{});
         if constexpr (TN > 1) epi_tile(std::integral_constant<int, 1>{});
@@ -768,6 +802,25 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             epi_tile(std::integral_constant<int, 3>{});
         }
         static_assert(TN == 1 || TN == 2 || TN == 4, "epilogue: column tiles per wave");
+        if constexpr (GC_STATS) {
+            if (p.cstats) {      // (block-uniform) the wave rows' partial column sums -> one (sum, sum of squares) per frame of this row
+                __syncthreads();
+                for (int col = tid; col < BN; col += 256) {
+                    float a = 0.f, c2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) {
+                        a += cpart[(w * BN + col) * 2];
+                        c2 += cpart[(w * BN + col) * 2 + 1];
+                    }
+                    const int t = t0 + col;
+                    if (t < p.Tout && fo < p.so * p.Q + p.po) {
+                        float* cg = p.cstats + (long)b * p.cs_b + (long)fo * p.cs_f + 2 * t;
+                        cg[0] = a;
+                        cg[1] = c2;
+                    }
+                }
+            }
+        }
     } else {   // EPI_LSTM
         // a lane's 16 accumulators of one MFMA tile are the i,f,g,o gates of 4 cells: all 16 gate pre-activations and
         // the 4 cell states are fetched by unconditional (clamped) loads in one batch, then the cells update
@@ -1243,7 +1296,7 @@ static long gc_thin_blocks(const GCParams& p) {
     const int n = p.Tout - p.t_base;
     // (layers with <= 4 output channels have the packed matrix too: a one-frame launch of the direct kernel walks its whole K
     // in one thread per output - 20-40 us; the fused parity pair of a transposed conv only exists there)
-    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.stats || p.nrm0 || p.nrm1) return 0;
+    if (!thin_env || (p.Ws && p.pair) || n > GC_THIN_NT || p.Z > 1 || p.stats || p.cstats || p.nrm0 || p.nrm1) return 0;
     if (p.epi != EPI_ACT && p.epi != EPI_ADD && p.epi != EPI_MUL && p.epi != EPI_GLU && p.epi != EPI_LSTM) return 0;
     if (p.epi == EPI_LSTM && (p.M & 3)) return 0;
     const long nblk = (long)((p.M + 7) >> 3) * p.Q * p.B;
@@ -1364,7 +1417,8 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
 static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes, int nbuf = 2) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
     const size_t nrm = (p.nrm0 || p.nrm1) ? (size_t)(GC_NRM_MAXC + 2 * gc_kcp_max(BM) + 2) * 16 : 0;      // gc_kernel NRM: nrmC + nrmK
-    return std::max((size_t)nbuf * (as + bs) * 4, epi_bytes) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64 + nrm;
+    const size_t cst = p.cstats ? (size_t)4 * 256 * 2 * 4 : 0;                                            // GCParams::cstats: cpart [WM][BN][2], WM * BN <= 1024... (<= 4 x 256)
+    return std::max((size_t)nbuf * (as + bs) * 4, epi_bytes) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64 + nrm + cst;
 }
 
 // Device tables of one patch geometry (row stride Wp): frequency rows / tap table / K-row patch offsets, and the
@@ -1753,7 +1807,7 @@ static void gc_launch_t(const GCParams& p, hipStream_t stream) {
 // all chunks of a source resident in LDS at once (gc_kernel RES): launches of at most one workgroup per CU whose staging fits
 static bool gc_resident_fits(GCParams& p, int BM, int BM_div_WM) {
     static const int res_env = getenv("SE_GC_RES") ? atoi(getenv("SE_GC_RES")) : 1;
-    if (!res_env || p.trim || p.epi == EPI_LSTM || p.fz || p.nrm0 || p.nrm1) return false;
+    if (!res_env || p.trim || p.epi == EPI_LSTM || p.fz || p.nrm0 || p.nrm1 || p.cstats) return false;
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     const int nch0 = p.C0 > 0 ? (p.C0 + p.CI_C - 1) / p.CI_C : 0, nch1 = p.C1 > 0 ? (p.C1 + p.CI_C - 1) / p.CI_C : 0;
     int nb = std::max(std::max(nch0, nch1), 1);
@@ -1786,7 +1840,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     if (p.tb_soft) p.t_base &= ~3;
     const int tb = p.t_base, Tspan = p.Tout - tb;
     SE_CHECK(tb >= 0 && (tb & 3) == 0 && Tspan > 0, "gc_launch: first output frame must be a multiple of 4 below Tout");
-    SE_CHECK(tb == 0 || !p.stats, "gc_launch: the statistics epilogue needs whole rows");
+    SE_CHECK(tb == 0 || (!p.stats && !p.cstats), "gc_launch: the statistics epilogue needs whole rows");
     p.n_ttiles = (Tspan + pl.BN - 1) / pl.BN;
     p.Qt = p.Q;
     p.qt2 = 0;
@@ -1809,6 +1863,10 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     p.pw4 = (pw4_env && p.desc4 && (p.Tin % 4 == 0 || ((p.causal || trim_ok) && gc_overread_ok(p.src0) && gc_overread_ok(p.src1)))) ? 1 : 0;
     p.trim = (p.pw4 && !p.causal && p.Tin % 4 != 0) ? 1 : 0;
     SE_CHECK(!p.stats || gc_stats_supported(pl), "gc_launch: this tile configuration has no statistics epilogue");
+    SE_CHECK(!p.cstats || (gc_stats_supported(pl) && p.n_mtiles == 1 && p.Z == 1),
+             "gc_launch: column statistics need a statistics tile configuration and one m-tile (M " + std::to_string(p.M) + ", BM " +
+                 std::to_string(pl.BM) + ", m-tiles " + std::to_string(p.n_mtiles) + ", epilogue " + std::to_string(p.epi) + ", direct " +
+                 std::to_string(p.Ws != nullptr) + ")");
     SE_CHECK(p.pw4 || p.CI_C * p.nrows * p.Wp <= gc_bld_max(pl.BM) * 256,
              "pointwise layer with a row length that is not a multiple of 4 needs its sources inside the engine arena");
     if (gc_thin_launch(p, stream)) return;
@@ -1901,7 +1959,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
         static const int qt2_env = getenv("SE_GC_QT2") ? atoi(getenv("SE_GC_QT2")) : 1;
         static const long qt2_min = getenv("SE_GC_QT2_MIN") ? atol(getenv("SE_GC_QT2_MIN")) : 4096;
         const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
-        if (qt2_env && pl.qt2.BN == 64 && pl.BN == 128 && p.Q >= 2 && !p.stats && p.pad_lo == 0 && p.epi != EPI_LSTM &&
+        if (qt2_env && pl.qt2.BN == 64 && pl.BN == 128 && p.Q >= 2 && !p.stats && !p.cstats && p.pad_lo == 0 && p.epi != EPI_LSTM &&
             !p.nrm0 && !p.nrm1 && nblk >= qt2_min) {
             GCParams pa = p;
             pa.qt2 = 1;

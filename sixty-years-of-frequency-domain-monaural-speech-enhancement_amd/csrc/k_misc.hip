@@ -700,6 +700,53 @@ __global__ __launch_bounds__(256) void cln_scan_kernel(const double* __restrict_
     }
 }
 
+// The scan with the per-frame sums handed over by the producing conv's epilogue (GCParams::cstats: parts [B][F][T][2] floats - per
+// output row and frame the sums over all channels): the rows are added in double precision in row order, then the serial scan as above
+__global__ __launch_bounds__(256) void cln_scan_parts_kernel(const float* __restrict__ parts, int F, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int R, int T) {
+    extern __shared__ double sc[];       // [2][T]
+    const int b = blockIdx.x;
+    const float2* pb = reinterpret_cast<const float2*>(parts) + (long)b * F * T;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        double a = 0.0, q = 0.0;
+        int f = 0;
+        for (; f + 7 < F; f += 8) {           // eight rows in flight (one workgroup per utterance: the loads' latency is the pass)
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pb[(long)(f + u) * T + t];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a += v[u].x;
+                q += v[u].y;
+            }
+        }
+        for (; f < F; ++f) {
+            const float2 v = pb[(long)f * T + t];
+            a += v.x;
+            q += v.y;
+        }
+        sc[t] = a;
+        sc[T + t] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, q = 0.0;
+        for (int t = 0; t < T; ++t) {
+            a += sc[t];
+            q += sc[T + t];
+            sc[t] = a;
+            sc[T + t] = q;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const double cnt = (double)R * (double)(t + 1), mu = sc[t] / cnt;
+        const double var = (sc[T + t] - 2.0 * mu * sc[t]) / cnt + mu * mu;
+        mean[(long)b * T + t] = (float)mu;
+        rstd[(long)b * T + t] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
 __global__ __launch_bounds__(256) void cln_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gain, const float* __restrict__ bias,
@@ -1059,6 +1106,21 @@ void launch_cln(const float* x, float* y, const float* gain, const float* bias, 
     }
     hipLaunchKernelGGL(cln_apply_kernel, dim3((T + 255) / 256, (R + 7) / 8, B), dim3(256), 0, s, x, y, mean, rstd, gain,
                        bias, pre_slope, post_slope, fir, K, R, F, T, 0, 0L);
+    SE_HIP(hipGetLastError());
+}
+
+// offline 2-D cLN + PReLU (+ residual) behind a conv that emitted its per-frame sums (GCParams::cstats): scan + apply, no statistics pass
+void launch_cln_parts(const float* x, float* y, const float* gain, const float* bias, const float* post_slope, const float* parts,
+                      int B, int C, int F, int T, hipStream_t s, const float* res) {
+    SE_CHECK(!stream_ctx() && !ragged_ctx(), "cLN from epilogue statistics: offline equal-length batches only");
+    SE_CHECK((size_t)T * 16 <= 60000, "utterance too long for the LDS-resident cLN scan");
+    const size_t need = (size_t)B * T * (2 * sizeof(double) + 2 * sizeof(float));
+    char* stat = device_scratch(1, need, s);
+    float* mean = (float*)((double*)stat + 2 * (size_t)B * T);
+    float* rstd = mean + (size_t)B * T;
+    hipLaunchKernelGGL(cln_scan_parts_kernel, dim3(B), dim3(256), (size_t)T * 16, s, parts, F, mean, rstd, C * F, T);
+    hipLaunchKernelGGL(cln_apply_plane_kernel, dim3(B * C), dim3(256), (size_t)T * 8, s, x, y, mean, rstd, gain, bias, post_slope, res, C,
+                       F, T);
     SE_HIP(hipGetLastError());
 }
 

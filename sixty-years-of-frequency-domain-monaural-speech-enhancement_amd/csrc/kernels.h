@@ -248,6 +248,10 @@ void launch_cln(const float* x, float* y, const float* gain, const float* bias, 
                 const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s,
                 const float* res = nullptr);
 
+// the offline 2-D form behind a conv whose epilogue emitted the per-frame sums (parts [B][F][T][2], GCParams::cstats)
+void launch_cln_parts(const float* x, float* y, const float* gain, const float* bias, const float* post_slope, const float* parts,
+                      int B, int C, int F, int T, hipStream_t s, const float* res = nullptr);
+
 // y = a + b (n elements);  y may alias a
 void launch_add(const float* a, const float* b, float* y, long n, hipStream_t s);
 

@@ -96,8 +96,11 @@ struct Profiler;
 // fz (optional, plans for which conv_folds_interaction() holds): the complex branch's tensor [B][2 * dstC][Fout][Tp] whose
 // interaction with this launch's output is folded into the store (GCParams::fz); fz_planes = 3: fz is the REAL plane of a
 // three-plane tensor [B][3 * dstC][Fout][Tp] = [S | R | I] (gauss.h; the sum plane is the caller's to refresh)
+// colstats: `stats` is [B][Fout][T][2] - per (b, output row, frame) sums over all output channels (GCParams::cstats, for a
+// CumulativeLayerNorm behind the layer) - instead of the per-channel partials of an InstanceNorm
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, float* fz = nullptr, int fz_planes = 2);
+              hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, float* fz = nullptr, int fz_planes = 2,
+              bool colstats = false);
 inline bool conv_folds_interaction(const GCPlan& pl) { return pl.p.Ws == nullptr && (pl.p.epi == EPI_ACT || pl.p.epi == EPI_ADD); }
 inline bool conv_folds_interaction(const DeconvPlan& pl) {
     if (pl.has_pair || pl.par.empty()) return false;
@@ -109,7 +112,7 @@ inline bool conv_folds_interaction(const DeconvPlan& pl) {
 // GCParams::tb_soft
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
                 int Tp, hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, int t_out = -1,
-                bool tb_soft = false, float* fz = nullptr, int fz_planes = 2);
+                bool tb_soft = false, float* fz = nullptr, int fz_planes = 2, bool colstats = false);
 bool conv_stats_supported(const GCPlan& pl);
 bool conv_nrm_supported(const GCPlan& pl);
 bool deconv_nrm_supported(const DeconvPlan& pl);

@@ -431,6 +431,12 @@ static void set_stats(GCParams& p, float* stats, int dstC, int Fout, int T) {
     p.st_c = (long)Fout * p.st_f;
     p.st_b = (long)dstC * p.st_c;
 }
+// GCParams::cstats: [B][Fout][T][2]
+static void set_cstats(GCParams& p, float* cstats, int Fout, int T) {
+    p.cstats = cstats;
+    p.cs_f = 2L * T;
+    p.cs_b = (long)Fout * p.cs_f;
+}
 bool conv_stats_supported(const GCPlan& pl) { return gc_stats_supported(pl); }
 bool deconv_stats_supported(const DeconvPlan& pl) {
     for (const auto& g : pl.par)
@@ -455,11 +461,12 @@ static void set_fz(GCParams& p, float* fz, int dstC, int Fout, int Tp, int plane
 }
 
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof, float* stats, int t_base, float* fz, int fz_planes) {
+              hipStream_t st, Profiler* prof, float* stats, int t_base, float* fz, int fz_planes, bool colstats) {
     GCParams p = pl.p;
     p.t_base = t_base;
     if (fz) set_fz(p, fz, dstC, Fout, Tp, fz_planes);
-    if (stats) set_stats(p, stats, dstC, Fout, T);
+    if (stats && colstats) set_cstats(p, stats, Fout, T);
+    else if (stats) set_stats(p, stats, dstC, Fout, T);
     fill_src(p, s0, s1);
     p.Fin = s0.F;
     p.Tin = T;
@@ -475,7 +482,8 @@ void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int 
 }
 
 void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T,
-                int Tp, hipStream_t st, Profiler* prof, float* stats, int t_base, int t_out, bool tb_soft, float* fz, int fz_planes) {
+                int Tp, hipStream_t st, Profiler* prof, float* stats, int t_base, int t_out, bool tb_soft, float* fz, int fz_planes,
+                bool colstats) {
     if (t_out < 0) t_out = T;
     SE_CHECK(!fz || conv_folds_interaction(pl), "run_deconv: this plan cannot fold the branch interaction into its store");
     // (a BatchNorm attached to the class plans later is not in the pair; the few frames of a frame-online chunk go through
@@ -505,7 +513,8 @@ void run_deconv(const DeconvPlan& pl, const Act4& s0, const Act4* s1, float* dst
     const GCPlan* gp[2] = {nullptr, nullptr};
     for (const auto& g : pl.par) {
         GCParams p = g.p;
-        if (stats) set_stats(p, stats, dstC, Fout, T);
+        if (stats && colstats) set_cstats(p, stats, Fout, T);
+        else if (stats) set_stats(p, stats, dstC, Fout, T);
         fill_src(p, s0, s1);
         p.Fin = s0.F;
         p.Tin = T;

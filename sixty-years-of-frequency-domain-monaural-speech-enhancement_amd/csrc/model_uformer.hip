@@ -329,6 +329,79 @@ __global__ __launch_bounds__(256) void uf_att_f_kernel(const float* __restrict__
     }
 }
 
+// The same attention on the matrix cores (round 5; the north star names f_att next to t_att).  The problem is 4 x 4 per (b, t, head) -
+// four frequency bins attend to four - which is exactly the block shape of v_mfma_f32_4x4x1_16b_f32: SIXTEEN independent 4 x 4 x 1
+// products per instruction.  A wave owns 16 consecutive frames of one utterance (block <-> frame, lane = 4 * block + j):
+//   S^T[g][fq] = sum_d k[g][d] q[fq][d]     A row g = k[g][d], B column fq = q[fq][d] / 4, 16 steps over d in 4 accumulator chains
+//                                           (a dependent 4x4x1 issues at half rate, tools/mfma4bench.cpp);
+//   D: lane (block, fq), register g  ->  all four scores of query fq sit in ONE lane: the softmax needs no cross-lane step, and the
+//   probabilities are already the B operand (column fq, step g) of
+//   O^T[d][fq] = sum_g v[g][d] p[g][fq]     A row d' = v[g][4 db + d'], four row blocks db, accumulated over the heads with the
+//                                           sign of the complex product folded into p (f_att_cplx.py:31-88).
+// Every q / k / v element is loaded exactly once (4 x 64 B per wave instruction).
+__global__ __launch_bounds__(256) void uf_att_f_mfma_kernel(const float* __restrict__ pq, float* __restrict__ out, int T, int nh,
+                                                            int ngroups) {
+    constexpr int F = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (grp >= ngroups) return;
+    const int blk = lane >> 2, j = lane & 3;
+    const int t = grp * 16 + blk, tc = min(t, T - 1);
+    const long P = (long)F * T;
+    const float* base = pq + (long)b * nh * 48 * P + (long)j * T + tc;       // row j of every (head, dim) plane at this lane's frame
+    uf_x4 accr[4], acci[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) accr[db] = acci[db] = uf_x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < nh; ++h) {
+        const float* hq = base + (long)h * 48 * P;
+        float qv[HD], kv[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            qv[d] = hq[(long)d * P] * 0.25f;                  // / hidden_channel ** 0.5
+            kv[d] = hq[(long)(HD + d) * P];
+        }
+        uf_x4 sc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sc[c] = uf_x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < HD; ++d) sc[d & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(kv[d], qv[d], sc[d & 3], 0, 0, 0);
+        float e[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e[g] = (sc[0][g] + sc[1][g]) + (sc[2][g] + sc[3][g]);
+        const float mx = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
+        float l = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            e[g] = fm_exp(e[g] - mx);
+            l += e[g];
+        }
+        const float sg = (nh == 1) ? 1.f : ((h == 0 || (h >= 4 && h < 7)) ? 1.f : -1.f);
+        const float inv = sg / l;
+        const bool to_r = nh == 1 || h < 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float pg = e[g] * inv;
+            const float* vg = hq + (long)(2 * HD) * P + (long)(g - j) * T;       // row g (this lane's base points at row j)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const float vv = vg[(long)(4 * db + j) * P];                     // A row d' = j of row block db: v[g][4 db + j]
+                if (to_r) accr[db] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv, pg, accr[db], 0, 0, 0);
+                else acci[db] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv, pg, acci[db], 0, 0, 0);
+            }
+        }
+    }
+    if (t >= T) return;
+    const int nout = nh == 1 ? 1 : 2;
+    float* ob = out + (long)b * nout * HD * P + (long)j * T + t;                 // lane (block, fq = j): every dim of query row fq
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ob[(long)(4 * db + i) * P] = accr[db][i];
+            if (nout == 2) ob[(long)(HD + 4 * db + i) * P] = acci[db][i];
+        }
+}
+
 // ---- :236-262  sigmoid magnitude mask, tanh complex-magnitude mask + phase add, average, polar -> RI [B][2][257][T]
 __global__ __launch_bounds__(256) void uf_post_kernel(const float* __restrict__ dc, const float* __restrict__ dm,
                                                       const float* __restrict__ mag0, const float* __restrict__ ph0,
@@ -830,7 +903,14 @@ class Uformer final : public Model {
             }
         } else {
             SE_CHECK(F <= 8, "F-attention kernel is built for the 4-bin bottleneck");
-            hipLaunchKernelGGL(uf_att_f_kernel, dim3((T + 255) / 256, F, B), dim3(256), 0, st, b.pq, b.t2, F, T, a.nh);
+            // SE_UF_ATT_F_MFMA=0: the VALU kernel of rounds 1-4 (one thread per query)
+            static const bool fmfma = !(getenv("SE_UF_ATT_F_MFMA") && atoi(getenv("SE_UF_ATT_F_MFMA")) == 0);
+            if (fmfma && F == 4) {
+                const int ng = (T + 15) / 16;
+                hipLaunchKernelGGL(uf_att_f_mfma_kernel, dim3((ng + 3) / 4, B), dim3(256), 0, st, b.pq, b.t2, T, a.nh, ng);
+            } else {
+                hipLaunchKernelGGL(uf_att_f_kernel, dim3((T + 255) / 256, F, B), dim3(256), 0, st, b.pq, b.t2, F, T, a.nh);
+            }
         }
         ln(a.ln2, b.t2, b.t1, m * B, HD, P, st);
         pw(a.trans, b.t1, m * HD, b.t3, m * CC, nullptr, B, P, st);

@@ -38,6 +38,9 @@ enum Epi : int {
     EPI_GLU = 2,     // rows are pair-interleaved (2j, 2j+1): dst[j] = (a+bias) * sigmoid(g+bias)
     EPI_ADD = 3,     // dst = act(acc + bias) + res   (res laid out like dst)
     EPI_MUL = 4,     // dst = act(acc + bias) * aux   (gated TCM branches, CTSNet/Step1_network.py:184)
+    EPI_CMB = 5,     // dst = prelu((aux +- acc) * post_scale + post_shift): the last two of Gauss' three products finish the complex
+                     // layer in their own store (aux = k1; GCParams::cmb_neg bit z: minus; per-z rows of post_scale / post_shift /
+                     // slope at stride ps_z) - gauss.h
 };
 
 // launches that produce at most this many frames per row go to the thin kernel (frame-online chunks)
@@ -52,6 +55,8 @@ struct GCParams {
     const float* post_shift;
     const float* bias_pad;   // bias for output rows fo < pad_lo (a zero-padded frequency row: no conv bias, only the folded BN shift)
     int pad_lo;
+    long ps_z;               // EPI_CMB: per-z element stride of post_scale / post_shift / slope
+    int cmb_neg;             // EPI_CMB: bit z set -> dst = f(aux - acc), else f(aux + acc)
     const float* src0;
     const float* src1;
     float* dst;

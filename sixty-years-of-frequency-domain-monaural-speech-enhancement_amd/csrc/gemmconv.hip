@@ -272,7 +272,11 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         epv[0] = bias ? bias[m] : 0.f;
         // (identity and ReLU ride the PReLU form of the epilogue with slopes 1 and 0)
         const float lin_slope = p.act == ACT_NONE ? 1.f : 0.f;
-        if (EPI != EPI_GLU) {
+        if (EPI == EPI_CMB) {
+            epv[0] = p.post_shift[(long)z * p.ps_z + m];
+            epv[1] = p.slope ? p.slope[(long)z * p.ps_z + m] : 1.f;
+            epv[2] = p.post_scale[(long)z * p.ps_z + m];
+        } else if (EPI != EPI_GLU) {
             epv[1] = (p.act == ACT_PRELU && p.slope) ? p.slope[m] : lin_slope;
         } else if (tid < BM / 2) {
             const int oc = min((m0 >> 1) + tid, (p.M >> 1) - 1);
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             ep[2 * BM + tid] = epv[2];
             ep[3 * BM + tid] = epv[3];
         }
+        if (EPI == EPI_CMB) ep[2 * BM + tid] = epv[2];
     }
     __syncthreads();
     if constexpr (KOFF_REGS) {
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     constexpr int OST = 32 + 4;                                    // LDS row stride of the strip (one 32-column MFMA tile wide)
     float* strip = smem + wave * (TM * 32 * OST);
 #define GC_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-    if (EPI == EPI_ACT || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_GLU) {
+    if (EPI == EPI_ACT || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_GLU || EPI == EPI_CMB) {
         const int mw = wm * (TM * 32) + 4 * hi;                 // first tile row of this lane
         const int lr = lane >> 3, lc = (lane & 7) * 4;           // read-back role: (row within 8, 4 consecutive t)
         const int mo0 = (EPI == EPI_GLU ? (m0 >> 1) : m0) + wm * OROWS;      // first output row of the strip
@@ -626,7 +631,8 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         // p.tlen (ragged batches, layers in front of operators that look ahead): frames >= tlen[b] of the output are zeros
         const int tvalid = p.tlen ? p.tlen[b] : 0x7fffffff;
         const float* __restrict__ res =
-            (EPI == EPI_ADD || EPI == EPI_MUL) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fow * p.x_f : nullptr;
+            (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_CMB) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fow * p.x_f : nullptr;
+        const float cmb_sg = (EPI == EPI_CMB && ((p.cmb_neg >> z) & 1)) ? -1.f : 1.f;
         float* __restrict__ fzb = FZ ? p.fz + (long)b * p.fz_b + (long)fow * p.fz_f : nullptr;      // FZ: GCParams::fz (its own instantiations: the
                                                                                                       // extra live registers of the epilogue spill in the 128-row tile otherwise)
         // (one column tile per call, its index a compile-time constant: with the interaction operands in the body the unroller
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // residual / interaction operands of this column tile: all of a wave's loads issued here, ahead of the transposition
             // (one load -> wait -> store per 8 rows left an EPI_ADD tile waiting on 8 HBM round trips in a row: the pointwise
             // layers of Uformer's conformer ran at 0.22 of the matrix peak)
-            constexpr bool PRE = (EPI == EPI_ADD || EPI == EPI_MUL);
+            constexpr bool PRE = (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_CMB);
             const int tgp = t0 + wt * (TN * 32) + j * 32 + lc;
             floatx4 rvp[PRE ? OROWS / 8 : 1], zre[FZ ? OROWS / 8 : 1], zim[FZ ? OROWS / 8 : 1];
             if ((PRE || FZ) && tgp + 3 < p.Tout && Mo > 0) {
@@ -663,7 +669,13 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                 };
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    if (EPI != EPI_GLU) {
+                    if (EPI == EPI_CMB) {        // raw products: scale / shift / PReLU follow the sum with k1 in the read-back
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+                            strip[(4 * hi + dm) * OST + l31] = acc[i][j][r];
+                        }
+                    } else if (EPI != EPI_GLU) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
@@ -740,6 +752,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     float* __restrict__ dp = dst + (long)m * p.d_c + tg;
                     if (__builtin_expect(tg + 3 < p.Tout, 1)) {
                         if (EPI == EPI_ADD || EPI == EPI_MUL) v = (EPI == EPI_ADD) ? v + rvp[it] : v * rvp[it];
+                        if (EPI == EPI_CMB) {
+                            const int rt = wm * (TM * 32) + row;
+                            const float sh_ = ep[rt], sl_ = ep[BM + rt], sc_ = ep[2 * BM + rt];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float u = fmaf(fmaf(cmb_sg, v[k], rvp[it][k]), sc_, sh_);
+                                v[k] = u >= 0.f ? u : sl_ * u;
+                            }
+                        }
                         if (__builtin_expect(tg + 3 >= tvalid, 0)) {      // rows of a ragged batch: frames past the row's own end are stored as zeros
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[k] = (tg + k < tvalid) ? v[k] : 0.f;
@@ -766,6 +787,11 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                                 float o = v[k];
                                 if (EPI == EPI_ADD) o += res[(long)m * p.x_c + tg + k];
                                 if (EPI == EPI_MUL) o *= res[(long)m * p.x_c + tg + k];
+                                if (EPI == EPI_CMB) {
+                                    const int rt = wm * (TM * 32) + row;
+                                    const float u = fmaf(fmaf(cmb_sg, o, res[(long)m * p.x_c + tg + k]), ep[2 * BM + rt], ep[rt]);
+                                    o = u >= 0.f ? u : ep[BM + rt] * u;
+                                }
                                 o = (tg + k < tvalid) ? o : 0.f;
                                 if (FZ) o = gc_fuse1(o, fzb + (long)m * p.fz_c + tg + k, p.fz_im);
                                 dp[k] = o;
@@ -1797,6 +1823,10 @@ static void gc_launch_t(const GCParams& p, hipStream_t stream) {
         case EPI_ADD: gc_launch_e<BM, BN, WM, WN, EPI_ADD, RES>(p, stream); break;
         case EPI_MUL: gc_launch_e<BM, BN, WM, WN, EPI_MUL, RES>(p, stream); break;
         case EPI_GLU: gc_launch_e<BM, BN, WM, WN, EPI_GLU, RES>(p, stream); break;
+        case EPI_CMB:
+            if constexpr (!RES && BM >= 64) gc_launch_e<BM, BN, WM, WN, EPI_CMB>(p, stream);
+            else SE_CHECK(false, "no resident-K / 32-row form of the combine epilogue");
+            break;
         case EPI_LSTM:
             if constexpr (!RES) gc_launch_e<BM, BN, WM, WN, EPI_LSTM>(p, stream);
             else SE_CHECK(false, "no resident-K form of the LSTM step");
@@ -1807,7 +1837,7 @@ static void gc_launch_t(const GCParams& p, hipStream_t stream) {
 // all chunks of a source resident in LDS at once (gc_kernel RES): launches of at most one workgroup per CU whose staging fits
 static bool gc_resident_fits(GCParams& p, int BM, int BM_div_WM) {
     static const int res_env = getenv("SE_GC_RES") ? atoi(getenv("SE_GC_RES")) : 1;
-    if (!res_env || p.trim || p.epi == EPI_LSTM || p.fz || p.nrm0 || p.nrm1 || p.cstats) return false;
+    if (!res_env || p.trim || p.epi == EPI_LSTM || p.epi == EPI_CMB || p.fz || p.nrm0 || p.nrm1 || p.cstats) return false;
     const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;
     const int nch0 = p.C0 > 0 ? (p.C0 + p.CI_C - 1) / p.CI_C : 0, nch1 = p.C1 > 0 ? (p.C1 + p.CI_C - 1) / p.CI_C : 0;
     int nb = std::max(std::max(nch0, nch1), 1);

@@ -835,6 +835,10 @@ class Uformer final : public Model {
     void gauss_layer(const gauss::GaussLayer& g, Bufs& b, const float* src0, int C0, const float* src1, int C1, int Fin, int Fout, int T,
                      float* dst, bool dst3, hipStream_t st) {
         const int B = b.B, co = g.co;
+        // SE_GAUSS_CMB=0: three products into scratch + the combine pass (round 4).  Rows of whole 16 B groups only (the combine
+        // epilogue has no trimming variant; PadFrames gives every offline decode such rows)
+        static const bool cmb_env = !(getenv("SE_GAUSS_CMB") && atoi(getenv("SE_GAUSS_CMB")) == 0);
+        const bool cmb = cmb_env && T % 4 == 0 && co >= 64;
         Profiler* pf = &ctx.prof;
         const long kz = (long)B * co * Fout * T;
         const Ragged* rg = ragged_ctx();
@@ -850,9 +854,32 @@ class Uformer final : public Model {
             p.Q = (Fout - p.po + p.so - 1) / p.so;
             p.dst = b.K; p.d_b = (long)co * Fout * T; p.d_c = (long)Fout * T; p.d_f = T; p.dst_z = kz;
             if (rg) p.tlen = rg->tlen;
+            if (cmb) {
+                // k1 = Wr (xr + xi) alone, then k2 / k3 as a grouped launch of two whose epilogue (EPI_CMB) reads k1 and stores the
+                // finished planes: I = f(k1 + k2), R = f(k1 - k3) - no k2 / k3 scratch, no combine pass (round 4: 5 % of a step)
+                GCParams p1 = p;
+                p1.Z = 1;
+                p1.tlen = nullptr;
+                gc_launch_prof(pl, p1, st, pf);
+                GCParams q = p;
+                q.Z = 2;
+                q.A = pl.p.A + pl.p.A_z;
+                q.src0 = p.src0 + p.src0_z;
+                if (src1) q.src1 = p.src1 + p.src1_z;
+                q.epi = EPI_CMB;
+                q.bias = nullptr;
+                q.aux = b.K; q.x_b = p.d_b; q.x_c = p.d_c; q.x_f = p.d_f; q.aux_z = 0;
+                q.post_scale = g.sc + co; q.post_shift = g.sh + co; q.slope = g.slope + co; q.ps_z = -co;
+                q.cmb_neg = 2;                                   // z = 0: I = f(k1 + k2); z = 1: R = f(k1 - k3)
+                const long CPo = (long)co * Fout * T, oR = dst3 ? CPo : 0L, oI = dst3 ? 2 * CPo : CPo;
+                q.dst = dst + oI; q.dst_z = oR - oI; q.d_b = (dst3 ? 3 : 2) * CPo;
+                gc_launch_prof(pl, q, st, pf);
+                continue;
+            }
             gc_launch_prof(pl, p, st, pf);
         }
         const long CP = (long)co * Fout * T;
+        if (cmb) return;      // (the sum plane of a three-plane output is refreshed by the caller, behind the folded interaction)
         const bool timed = pf->on;
         if (timed) pf->begin(st);
         hipLaunchKernelGGL(gauss::gauss_combine_kernel, dim3(Fout, co, B), dim3(128), 0, st, b.K, dst, co, Fout, T, kz, dst3 ? 3 * CP : 2 * CP,

@@ -249,15 +249,18 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     // lookup is a short LDS read instead of a dependent global load in the block prologue
     // LDS map: [staging buffers | epilogue strips (aliased)] [tap table] [per-row epilogue parameters]
     constexpr int STRIPS = 4 * (TM * 32) * 36;       // floats of the four per-wave epilogue transposition strips
-    int* tabl = reinterpret_cast<int*>(smem + max(nbuf * (As_sz + Bs_sz), STRIPS));
+    // (GCParams::cstats: 2 048 floats of partial column sums behind the strips, see `cpart` - the host sizes the area the same way)
+    int* tabl = reinterpret_cast<int*>(smem + max(nbuf * (As_sz + Bs_sz), STRIPS + (p.cstats ? 2048 : 0)));
     int* koff_lds = tabl + GC_TAB_KOFF;
     float* ep = reinterpret_cast<float*>(tabl + GC_TAB_KOFF + KCP_MAX + 8);      // [4 * BM]
     // NRM: per input channel {scale, shift, slope - 1, x0} of this batch row, and per K row of a staged chunk the same with
     // scale = shift = 0 where the row's frequency tap lies outside the plane (double-buffered with the chunks)
     floatx4* nrmC = reinterpret_cast<floatx4*>(ep + 4 * BM);                     // [GC_NRM_MAXC]
     floatx4* nrmK = nrmC + GC_NRM_MAXC;                                          // [2][KCP_MAX] + 2 (the pipeline reads one pair ahead)
-    // GCParams::cstats: per-wave-row column sums of the block's tile, [WM][BN][2] floats, combined in a fixed order after a barrier
-    float* cpart = NRM ? reinterpret_cast<float*>(nrmK + 2 * KCP_MAX + 2) : ep + 4 * BM;
+    // GCParams::cstats: partial column sums of the block's tile, [WM][4 row groups][BN][2] floats (<= 8 KB), combined in a fixed
+    // order after a barrier.  Behind the epilogue strips INSIDE the (by then dead) staging area: as 8 KB of their own they pushed the
+    // 64 x 256 tile from three to two workgroups per CU (+ 6 ... 23 % per launch in the first form of this epilogue)
+    float* cpart = smem + STRIPS;
     GC_T(7);      /* kernel entry .. index decode */
     // one barrier for both block-wide LDS initialisations: the tap table (its global load is in flight while the patch
     // buffers are cleared) and the zeros of the padding (masked DMA lanes never touch their LDS words again)
@@ -801,17 +804,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             }
             if constexpr (GC_STATS) {
                 if (p.cstats) {
-                    // the 8 lanes (lane >> 3 = row within 8) that hold the same 4 frames: lanes l, l ^ 8, l ^ 16, l ^ 32, fixed order
+                    // the 8 lanes (lane >> 3 = row within 8) that hold the same 4 frames: lanes l and l ^ 8 meet on the DPP network
+                    // (row_ror:8), the four pairs (lane >> 4) go to LDS and are added with the wave rows' partials below
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                        for (int o = 8; o < 64; o <<= 1) {
-                            ccs[k] += __shfl_xor(ccs[k], o, 64);
-                            ccq[k] += __shfl_xor(ccq[k], o, 64);
-                        }
+                        ccs[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ccs[k]), 0x128, 0xF, 0xF, true));
+                        ccq[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ccq[k]), 0x128, 0xF, 0xF, true));
                     }
-                    if (lane < 8) {
-                        float* cp_ = cpart + ((wm * BN) + wt * (TN * 32) + j * 32 + lc) * 2;
+                    if (!(lane & 8)) {
+                        float* cp_ = cpart + (((wm * 4 + (lane >> 4)) * BN) + wt * (TN * 32) + j * 32 + lc) * 2;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             cp_[2 * k] = ccs[k];
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                 for (int col = tid; col < BN; col += 256) {
                     float a = 0.f, c2 = 0.f;
 #pragma unroll
-                    for (int w = 0; w < WM; ++w) {
+                    for (int w = 0; w < 4 * WM; ++w) {
                         a += cpart[(w * BN + col) * 2];
                         c2 += cpart[(w * BN + col) * 2 + 1];
                     }
@@ -1443,8 +1444,8 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
 static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes, int nbuf = 2) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
     const size_t nrm = (p.nrm0 || p.nrm1) ? (size_t)(GC_NRM_MAXC + 2 * gc_kcp_max(BM) + 2) * 16 : 0;      // gc_kernel NRM: nrmC + nrmK
-    const size_t cst = p.cstats ? (size_t)4 * 256 * 2 * 4 : 0;                                            // GCParams::cstats: cpart [WM][BN][2], WM * BN <= 1024... (<= 4 x 256)
-    return std::max((size_t)nbuf * (as + bs) * 4, epi_bytes) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64 + nrm + cst;
+    const size_t cst = p.cstats ? (size_t)4 * 256 * 2 * 4 : 0;      // GCParams::cstats: cpart [WM][4][BN][2] <= 8 KB, behind the strips inside the staging area
+    return std::max((size_t)nbuf * (as + bs) * 4, epi_bytes + cst) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64 + nrm;
 }
 
 // Device tables of one patch geometry (row stride Wp): frequency rows / tap table / K-row patch offsets, and the

@@ -14,6 +14,12 @@ for step in "$@"; do
     parity)
       (cd $ROOT && timeout 900 python tools/parity_record.py --out $OUT/r05_parity.json > $OUT/parity.log 2>&1; tail -2 $OUT/parity.log
        SE_ENGINE_LIB=$PKG/libse_engine_exact.so timeout 900 python tools/parity_record.py --out $OUT/r05_parity_exact.json > $OUT/parity_exact.log 2>&1; tail -2 $OUT/parity_exact.log) ;;
+    parityx)
+      (cd $ROOT && SE_ENGINE_LIB=$PKG/libse_engine_exact.so timeout 900 python tools/parity_record.py --out $OUT/r05_parity_exact.json > $OUT/parity_exact.log 2>&1; tail -1 $OUT/parity_exact.log) ;;
+    measure)
+      bash $ROOT/tools/measure_round.sh r05 ;;
+    pmc)
+      bash $ROOT/tools/pmc_models.sh r05 "$a $b" ;;
     prof)
       D=$OUT/prof_${a}_b${b}
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o s -- python $ROOT/tools/sweep.py --models $a --batch $b --steps 3 --no-profile > $D.log 2>&1

@@ -24,3 +24,23 @@ def test_reference_fixtures_with_the_ab_switches_thrown():
            os.path.join(ROOT, 'tests', 'test_gpu_models.py')]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# round 5: the norm folds, the combine epilogue, the matrix-core frequency attention and TaylorSENet's second stream all have
+# their round-4 paths behind a switch; the Gauss layers' scratch + combine form is reached with SE_GAUSS_CMB=0 while
+# SE_DCCRN_GAUSS / SE_UF_GAUSS stay on (above they are off)
+SWITCHES_R5 = {
+    'SE_IN_FOLD': '0', 'SE_CLN_STATS': '0', 'SE_CLN_PLANE': '0', 'SE_GAUSS_CMB': '0', 'SE_UF_ATT_F_MFMA': '0', 'SE_TAYLOR_FORK': '0',
+}
+
+
+@pytest.mark.gpu
+def test_reference_fixtures_with_the_round5_switches_thrown():
+    env = dict(os.environ, **SWITCHES_R5)
+    cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+           os.path.join(ROOT, 'tests', 'test_gpu_full_fixture.py'), os.path.join(ROOT, 'tests', 'test_gpu_new_variants.py'),
+           os.path.join(ROOT, 'tests', 'test_gpu_dccrn.py'), os.path.join(ROOT, 'tests', 'test_gpu_uformer.py'),
+           os.path.join(ROOT, 'tests', 'test_gpu_b256_fixture.py'), '-k',
+           'g2net or taylor or ctsnet or dccrn or uformer']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

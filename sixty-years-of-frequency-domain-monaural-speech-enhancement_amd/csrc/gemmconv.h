@@ -57,6 +57,8 @@ struct GCParams {
     int pad_lo;
     long ps_z;               // EPI_CMB: per-z element stride of post_scale / post_shift / slope
     int cmb_neg;             // EPI_CMB: bit z set -> dst = f(aux - acc), else f(aux + acc)
+    const float* cmb_i;      // EPI_CMB, optional (with cmb_s): the OTHER finished plane (I, laid out like dst) ...
+    float* cmb_s;            // ... and where their sum goes: S = dst + I, the third plane of a three-plane tensor (gauss.h)
     const float* src0;
     const float* src1;
     float* dst;

@@ -636,6 +636,9 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         const float* __restrict__ res =
             (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_CMB) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fow * p.x_f : nullptr;
         const float cmb_sg = (EPI == EPI_CMB && ((p.cmb_neg >> z) & 1)) ? -1.f : 1.f;
+        // EPI_CMB with the sum plane: this launch finishes R, reads the finished I and writes S = R + I beside it
+        const float* __restrict__ cmbi = (EPI == EPI_CMB && p.cmb_s) ? p.cmb_i + (long)b * p.d_b + (long)fow * p.d_f : nullptr;
+        float* __restrict__ cmbs = (EPI == EPI_CMB && p.cmb_s) ? p.cmb_s + (long)b * p.d_b + (long)fow * p.d_f : nullptr;
         float* __restrict__ fzb = FZ ? p.fz + (long)b * p.fz_b + (long)fow * p.fz_f : nullptr;      // FZ: GCParams::fz (its own instantiations: the
                                                                                                       // extra live registers of the epilogue spill in the 128-row tile otherwise)
         // (one column tile per call, its index a compile-time constant: with the interaction operands in the body the unroller
@@ -648,12 +651,13 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // layers of Uformer's conformer ran at 0.22 of the matrix peak)
             constexpr bool PRE = (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_CMB);
             const int tgp = t0 + wt * (TN * 32) + j * 32 + lc;
-            floatx4 rvp[PRE ? OROWS / 8 : 1], zre[FZ ? OROWS / 8 : 1], zim[FZ ? OROWS / 8 : 1];
+            floatx4 rvp[PRE ? OROWS / 8 : 1], zre[FZ ? OROWS / 8 : 1], zim[FZ ? OROWS / 8 : 1], ivp[EPI == EPI_CMB ? OROWS / 8 : 1];
             if ((PRE || FZ) && tgp + 3 < p.Tout && Mo > 0) {
 #pragma unroll
                 for (int it = 0; it < OROWS / 8; ++it) {
                     const int m = min(mo0 + it * 8 + lr, Mo - 1);      // clamped: rows past M are loaded, not used
                     if (PRE) rvp[it] = *reinterpret_cast<const floatx4*>(res + (long)m * p.x_c + tgp);
+                    if (EPI == EPI_CMB && cmbi) ivp[it] = *reinterpret_cast<const floatx4*>(cmbi + (long)m * p.d_c + tgp);
                     if (FZ) {
                         zre[it] = *reinterpret_cast<const floatx4*>(fzb + (long)m * p.fz_c + tgp);
                         zim[it] = *reinterpret_cast<const floatx4*>(fzb + (long)m * p.fz_c + tgp + p.fz_im);
@@ -783,6 +787,14 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                             *reinterpret_cast<floatx4*>(zr + p.fz_im) = ii;
                         }
                         *reinterpret_cast<floatx4*>(dp) = v;
+                        if (EPI == EPI_CMB && cmbs) {
+                            floatx4 s4 = v + ivp[it];
+                            if (__builtin_expect(tg + 3 >= tvalid, 0)) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) s4[k] = (tg + k < tvalid) ? s4[k] : 0.f;
+                            }
+                            *reinterpret_cast<floatx4*>(cmbs + (long)m * p.d_c + tg) = s4;
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
@@ -798,6 +810,10 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                                 o = (tg + k < tvalid) ? o : 0.f;
                                 if (FZ) o = gc_fuse1(o, fzb + (long)m * p.fz_c + tg + k, p.fz_im);
                                 dp[k] = o;
+                                if (EPI == EPI_CMB && cmbs) {
+                                    const float iv = cmbi[(long)m * p.d_c + tg + k];
+                                    cmbs[(long)m * p.d_c + tg + k] = (tg + k < tvalid) ? o + iv : 0.f;
+                                }
                             }
                     }
                 }

@@ -111,6 +111,7 @@ struct GCParams {
     // (b, channel, row, frame) become  re + sig(v), im + sig(v), v + sig(|re + i im|)  - the pair is rewritten in place
     float* fz;
     long fz_b, fz_c, fz_f, fz_im;
+    long fz_s;               // != 0 (three-plane tensors, gauss.h): the rewritten pair's sum re + im is stored fz_s floats from the real plane
     // optional (gc_nrm_supported(): EPI_ACT on 64-row tiles, causal taps, <= GC_NRM_MAXC input channels): the sources are RAW conv
     // outputs whose InstanceNorm + PReLU has not been applied - per (b, channel) float4 {scale = rstd * gamma, shift = beta - mean *
     // scale, slope - 1, x0 = -shift / scale} (k_misc.hip: instnorm_finalize_kernel).  The kernel applies

@@ -50,12 +50,13 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
 }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 // GCParams::fz - one frame of the branch interaction (the same expressions as model_uformer.hip: uf_fusion_kernel)
-__device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long im) {
+__device__ __forceinline__ float gc_fuse1(float v, float* __restrict__ zr, long im, long so = 0) {
     const float re = zr[0], ii = zr[im];
     const float cm = fm_sqrt(fmaxf(re * re + ii * ii, 1.1920928955078125e-07f));      // v_sqrt_f32 (1 ulp)
     const float s = fsig_(v);
     zr[0] = re + s;
     zr[im] = ii + s;
+    if (so) zr[so] = (re + s) + (ii + s);      // the sum plane of a three-plane tensor (GCParams::fz_s)
     return v + fsig_(cm);
 }
 
@@ -785,6 +786,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                             }
                             *reinterpret_cast<floatx4*>(zr) = re;
                             *reinterpret_cast<floatx4*>(zr + p.fz_im) = ii;
+                            if (p.fz_s) *reinterpret_cast<floatx4*>(zr + p.fz_s) = re + ii;      // S = R + I of a three-plane tensor
                         }
                         *reinterpret_cast<floatx4*>(dp) = v;
                         if (EPI == EPI_CMB && cmbs) {
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                                     o = u >= 0.f ? u : ep[BM + rt] * u;
                                 }
                                 o = (tg + k < tvalid) ? o : 0.f;
-                                if (FZ) o = gc_fuse1(o, fzb + (long)m * p.fz_c + tg + k, p.fz_im);
+                                if (FZ) o = gc_fuse1(o, fzb + (long)m * p.fz_c + tg + k, p.fz_im, p.fz_s);
                                 dp[k] = o;
                                 if (EPI == EPI_CMB && cmbs) {
                                     const float iv = cmbi[(long)m * p.d_c + tg + k];

@@ -101,6 +101,8 @@ struct Profiler;
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
               hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, float* fz = nullptr, int fz_planes = 2,
               bool colstats = false);
+// true: a folded interaction into a three-plane tensor (fz_planes = 3) also stores its sum plane S = R + I
+bool conv_fold_writes_sum();
 inline bool conv_folds_interaction(const GCPlan& pl) { return pl.p.Ws == nullptr && (pl.p.epi == EPI_ACT || pl.p.epi == EPI_ADD); }
 inline bool conv_folds_interaction(const DeconvPlan& pl) {
     if (pl.has_pair || pl.par.empty()) return false;

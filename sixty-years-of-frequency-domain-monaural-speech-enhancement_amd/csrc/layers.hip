@@ -458,6 +458,13 @@ static void set_fz(GCParams& p, float* fz, int dstC, int Fout, int Tp, int plane
     p.fz_b = planes * p.fz_im;
     p.fz_c = (long)Fout * Tp;
     p.fz_f = Tp;
+    // three planes [S | R | I] (fz = the R plane): the epilogue that rewrites R and I stores S = R + I as well - no gauss_sum pass
+    static const bool fzs = !(getenv("SE_UF_FOLD_SUM") && atoi(getenv("SE_UF_FOLD_SUM")) == 0);
+    p.fz_s = (planes == 3 && fzs) ? -p.fz_im : 0;
+}
+bool conv_fold_writes_sum() {
+    static const bool fzs = !(getenv("SE_UF_FOLD_SUM") && atoi(getenv("SE_UF_FOLD_SUM")) == 0);
+    return fzs;
 }
 
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,

@@ -1005,7 +1005,7 @@ class Uformer final : public Model {
                 SE_CHECK(!out3, "Uformer: three-plane encoder tensors need the folded interaction (SE_UF_FOLD=0 with SE_UF_GAUSS=1)");
                 fusion(b.EC[k], b.ER[k], B, CPk, st);
             }
-            if (out3) gauss_sum(b.EC[k], B, CPk, st);             // S = R + I of the tensor the interaction has just rewritten
+            if (out3 && !(fold && conv_fold_writes_sum())) gauss_sum(b.EC[k], B, CPk, st);      // S = R + I of the tensor the interaction has just rewritten (else: stored by the fold's epilogue)
             xc = out3 ? view3(b.EC[k], co, F, T) : act4(b.EC[k], 2 * co, F, T);
             xm = act4(b.ER[k], co, F, T);
         }
@@ -1066,7 +1066,7 @@ class Uformer final : public Model {
                 SE_CHECK(!out3, "Uformer: three-plane decoder tensors need the folded interaction (SE_UF_FOLD=0 with SE_UF_GAUSS=1)");
                 fusion(b.DC[k], b.DR[k], B, (long)co * F * T, st);
             }
-            if (out3) gauss_sum(b.DC[k], B, CPo, st);
+            if (out3 && !(fold && conv_fold_writes_sum())) gauss_sum(b.DC[k], B, CPo, st);
             c = b.DC[k];
             c3 = out3;
             m = b.DR[k];

@@ -70,6 +70,11 @@ enum se_model_id {
  * spec_i mask_i).  At most one of the two bits. */
 #define SE_CFG_DCCRN_MASK_C 32
 #define SE_CFG_DCCRN_MASK_R 64
+/* G2Net / TaylorSENet: the constructor's repeat count, bits 8-11 of se_config.flags.
+ *   gaf_base(..., stage_num = n)      G2Net_VB/gaf_net_320.py:27,55-58  (n GAF stages `gafs.<s>.`, 1 <= n <= 8)
+ *   TaylorSENet(..., order_num = n)   TaylorSENet/TaylorSENet.py:27,66-70 (n high-order blocks `highorderblock_list.<k>.`, 0 <= n <= 8)
+ * 0 in the field = the decode scripts' value (3 for both: G2Net_VB/com_decode.py:23, TaylorSENet/taylorsenet_decode_vb.py:11-13). */
+#define SE_CFG_REPEATS(n) ((((n) + 1) & 15) << 8)
 
 typedef struct se_config {
     int32_t model;        /* enum se_model_id */

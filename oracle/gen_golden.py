@@ -466,10 +466,10 @@ def gen_ctsnet(ref_dir='CTSNet', tag=''):
     save_full('ctsnet' + tag, 209, lambda w: enh(w, 0.5, 2.0))
 
 
-def gen_taylorsenet(ref_dir='TaylorSENet', tag=''):
+def gen_taylorsenet(ref_dir='TaylorSENet', tag='', order_num=3):
     mod = import_ref(ref_dir, 'TaylorSENet')
     model = mod.TaylorSENet(cin=2, k1=(1, 3), k2=(2, 3), c=64, kd1=5, cd1=64, d_feat=256, dilations=[1, 2, 5, 9], p=2,
-                            fft_num=320, order_num=3, intra_connect='cat', inter_connect='cat', is_causal=True,
+                            fft_num=320, order_num=order_num, intra_connect='cat', inter_connect='cat', is_causal=True,
                             is_conformer=False, is_u2=True, is_param_share=False, is_encoder_share=False)
     schema, _ = load_synth(model, 19)
     save_schema('taylorsenet' + tag, schema)
@@ -496,13 +496,14 @@ def gen_taylorsenet(ref_dir='TaylorSENet', tag=''):
         return (y / c).numpy()
     wav = synth.synth_clip(10, 'speech', 6000)
     save('taylorsenet' + tag, x=x, y=y, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
-    save_full('taylorsenet' + tag, 210, lambda w: enh(w, 0.5, 2.0))
+    if order_num == 3:      # (the other constructor values: the small fixture only)
+        save_full('taylorsenet' + tag, 210, lambda w: enh(w, 0.5, 2.0))
 
 
-def gen_g2net(ref_dir='G2Net_VB', tag=''):
+def gen_g2net(ref_dir='G2Net_VB', tag='', stage_num=3):
     install_stubs()
     mod = import_ref(ref_dir, 'gaf_net_320')
-    model = mod.gaf_base(3, 64, 2, 4, 4, [1, 2, 5, 9], 256 + 161 * 2, 256, 256, (2, 3), (1, 3), 64, 'cat', 3,
+    model = mod.gaf_base(3, 64, 2, 4, 4, [1, 2, 5, 9], 256 + 161 * 2, 256, 256, (2, 3), (1, 3), 64, 'cat', stage_num,
                          is_aux=False, encoder_type='U2Net', tcm_type='full-band')
     schema, _ = load_synth(model, 20)
     save_schema('g2net' + tag, schema)
@@ -529,7 +530,8 @@ def gen_g2net(ref_dir='G2Net_VB', tag=''):
         return (yy * c).numpy()
     wav = synth.synth_clip(11, 'speech', 6000)
     save('g2net' + tag, x=x, y=y, y0=y0, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
-    save_full('g2net' + tag, 211, lambda w: enh(w, 0.5, 2.0))
+    if stage_num == 3:      # (the other constructor values: the small fixture only)
+        save_full('g2net' + tag, 211, lambda w: enh(w, 0.5, 2.0))
 
 
 def gen_uformer():
@@ -588,7 +590,18 @@ def gen_g2net_new():
     gen_g2net('G2Net_new', '_new')
 
 
-GENS = {'stft': gen_stft, 'dccrn_mask': gen_dccrn_mask, 'fullsubnet_cum': gen_fullsubnet_cum, 'fullsubnet_gru': gen_fullsubnet_gru, 'ctsnet_new': gen_ctsnet_new, 'taylorsenet_new': gen_taylorsenet_new, 'g2net_new': gen_g2net_new, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
+def gen_repeat_counts():
+    """Constructor values the decode scripts do not use: gaf_base(stage_num = 2 / 4) (gaf_net_320.py:27,55-58) and
+    TaylorSENet(order_num = 1 / 4) (TaylorSENet.py:27,66-70); one cLN flavour of each."""
+    gen_g2net(tag='_s2', stage_num=2)
+    gen_g2net(tag='_s4', stage_num=4)
+    gen_g2net('G2Net_new', '_new_s2', stage_num=2)
+    gen_taylorsenet(tag='_o1', order_num=1)
+    gen_taylorsenet(tag='_o4', order_num=4)
+    gen_taylorsenet('TaylorSENet_new', '_new_o1', order_num=1)
+
+
+GENS = {'repeat_counts': gen_repeat_counts, 'stft': gen_stft, 'dccrn_mask': gen_dccrn_mask, 'fullsubnet_cum': gen_fullsubnet_cum, 'fullsubnet_gru': gen_fullsubnet_gru, 'ctsnet_new': gen_ctsnet_new, 'taylorsenet_new': gen_taylorsenet_new, 'g2net_new': gen_g2net_new, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

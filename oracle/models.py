@@ -535,8 +535,16 @@ def _tcms(sd, p, x, n=2, dils=(1, 2, 5, 9)):
     return x
 
 
-def taylorsenet_forward(sd, inputs, order_num=3):
-    """TaylorSENet.forward (:66-94): [B,2,T,161] -> [B,2,T,161]."""
+def _module_list_len(sd, prefix):
+    """len() of the ModuleList whose entries are `prefix<i>.` in a state dict (0 if absent)."""
+    return 1 + max((int(k[len(prefix):].split('.', 1)[0]) for k in sd if k.startswith(prefix)), default=-1)
+
+
+def taylorsenet_forward(sd, inputs, order_num=None):
+    """TaylorSENet.forward (:66-94): [B,2,T,161] -> [B,2,T,161].  order_num (:27,66-70): as many high-order blocks as
+    the state dict holds (3 in the decode script, taylorsenet_decode_vb.py:11-13)."""
+    if order_num is None:
+        order_num = _module_list_len(sd, 'highorderblock_list.')
     mag = np.sqrt(inputs[:, 0] ** 2 + inputs[:, 1] ** 2)
     ph = np.arctan2(inputs[:, -1], inputs[:, 0])
     # ZeroOrderBlock (:139-153)
@@ -612,8 +620,11 @@ def _g2_tcm_seq(sd, p, x, n_out_idx=2, dils=(1, 2, 5, 9)):
     return nn.conv1d(x, sd[f'{p}{n_out_idx}.weight'], sd[f'{p}{n_out_idx}.bias'])
 
 
-def g2net_forward(sd, inpt, stage_num=3):
-    """gaf_base.forward (:73-87): [B,2,T,161] -> list of stage outputs [B,2,161,T]."""
+def g2net_forward(sd, inpt, stage_num=None):
+    """gaf_base.forward (:73-87): [B,2,T,161] -> list of stage outputs [B,2,161,T].  stage_num (:27,55-58): as many GAF
+    stages as the state dict holds (3 in the decode script, com_decode.py:23)."""
+    if stage_num is None:
+        stage_num = _module_list_len(sd, 'gafs.')
     B, _, T, _ = inpt.shape
     x = inpt
     for i, scale in enumerate((4, 3, 2, 1)):                     # U2Net_Encoder (:277-304)

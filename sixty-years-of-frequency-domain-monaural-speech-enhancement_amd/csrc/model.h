@@ -12,6 +12,11 @@ struct EngineCtx {
     int max_batch = 1, max_samples = 64000;
     float p_in = 1.f, p_out = 1.f;
     int flags = 0;          // se_config.flags
+    // SE_CFG_REPEATS(n) (include/se_engine.h): gaf_base's stage_num / TaylorSENet's order_num; `dflt` = the decode script's
+    int repeats(int dflt) const {
+        const int v = (flags >> 8) & 15;
+        return v ? v - 1 : dflt;
+    }
     StftGeom geom{0, 0, 0};
     Arena arena;
     Profiler prof;

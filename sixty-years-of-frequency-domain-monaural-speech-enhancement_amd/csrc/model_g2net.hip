@@ -14,7 +14,7 @@ namespace se {
 
 namespace {
 
-constexpr int NFFT = 320, HOP = 160, NBIN = 161, NDIL = 4, NSTAGE = 3;
+constexpr int NFFT = 320, HOP = 160, NBIN = 161, NDIL = 4;
 constexpr int DIL[NDIL] = {1, 2, 5, 9};
 
 // x_next = gain * pre + resi ; gain [B][161][T], pre / resi / out [B][2][161][T]
@@ -94,7 +94,11 @@ class G2Net final : public Model {
 
     void finalize(const TrackedSD& sd) override {
         en.load(sd, "en.", 2, UNET_G2NET, 2);
-        for (int s = 0; s < NSTAGE; ++s) st_[s].load(sd, "gafs." + std::to_string(s) + ".");
+        // stage_num (gaf_net_320.py:27,55-58): 3 in the decode script (com_decode.py:23), others through SE_CFG_REPEATS
+        const int nstage = ctx.repeats(3);
+        SE_CHECK(nstage >= 1 && nstage <= 8, "G2Net: stage_num outside [1, 8]");
+        st_.resize(nstage);
+        for (int s = 0; s < nstage; ++s) st_[s].load(sd, "gafs." + std::to_string(s) + ".");
         cum = en.last.na.cum;
     }
 
@@ -162,7 +166,7 @@ class G2Net final : public Model {
         TcmScratch ts;
     } cur;
     U2Encoder en;
-    GafStage st_[NSTAGE];
+    std::vector<GafStage> st_;
 
     Bufs& bufs(int B, int T) {
         if (cur.B == B && cur.T == T) return cur;
@@ -211,7 +215,7 @@ class G2Net final : public Model {
         const float* feat = b.ens[4];            // [B][256][T]
         const float* pre = b.spec;               // inpt.transpose(-2,-1) is the engine layout already (:78)
         const long plane = (long)NBIN * T, tot = plane * B;
-        for (int s = 0; s < NSTAGE; ++s) {
+        for (int s = 0; s < (int)st_.size(); ++s) {
             gate_in(st_[s].gin, feat, pre, b.hx, B, T, st);
             st_[s].glance.run(b.hx, b.X, b.ts, b.gain, plane, B, T, st, pf);
             gate_in(st_[s].fin, feat, pre, b.hx, B, T, st);

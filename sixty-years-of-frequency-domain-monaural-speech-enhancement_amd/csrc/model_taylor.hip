@@ -67,7 +67,7 @@ class TaylorSENet final : public Model {
         zlast.free();
         gc_free_plan(zgain);
         ztcm.free();
-        for (int k = 0; k < 3; ++k) {
+        for (size_t k = 0; k < htcm.size(); ++k) {
             gc_free_plan(h_in[k]);
             gc_free_plan(h_out[k]);
             htcm[k].free();
@@ -89,7 +89,13 @@ class TaylorSENet final : public Model {
             DenseW d = conv_weights(w, &sd.get("zeroorderblock.de.last_conv.3.bias", {1}), true);
             zgain = make_conv_plan(d, 1, 0, 0, 1, 1, ACT_SIGMOID, {}, EPI_ACT, 401);
         }
-        for (int k = 0; k < 3; ++k) {    // HighOrderBlock (:155-214)
+        // order_num (TaylorSENet.py:27,66-70): 3 in the decode script (taylorsenet_decode_vb.py:11-13), others through SE_CFG_REPEATS
+        const int norder = ctx.repeats(3);
+        SE_CHECK(norder >= 0 && norder <= 8, "TaylorSENet: order_num outside [0, 8]");
+        h_in.resize(norder);
+        h_out.resize(norder);
+        htcm.resize(norder);
+        for (int k = 0; k < norder; ++k) {    // HighOrderBlock (:155-214)
             const std::string p = "highorderblock_list." + std::to_string(k) + ".";
             auto c1 = [&](const std::string& key, int co, int ci) {
                 HostTensor w4 = sd.get(key + "weight", {co, ci, 1});
@@ -169,8 +175,10 @@ class TaylorSENet final : public Model {
     U2Encoder zen, sen;
     UnetModule zde[4];
     DeconvIN zlast;
-    GCPlan zgain, h_in[3], h_out[3];
-    TcmStack ztcm, htcm[3];
+    GCPlan zgain;
+    std::vector<GCPlan> h_in, h_out;
+    TcmStack ztcm;
+    std::vector<TcmStack> htcm;
 
     Bufs& bufs(int B, int T) {
         if (cur.B == B && cur.T == T) return cur;
@@ -250,7 +258,7 @@ class TaylorSENet final : public Model {
         if (fork) SE_HIP(hipStreamWaitEvent(st, ctx.ev_join[0], 0));
         else sen.run(act4(b.spec, 2, NBIN, T), b.sens, b.us, B, T, st, pf);
         float fact = 1.f;
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < (int)htcm.size(); ++k) {
             GCParams p = h_in[k].p;      // in_conv over cat(feature_head [B][256][T], pre [B][322][T])
             p.src0 = b.sens[4]; p.s0_b = 256L * T; p.s0_c = T; p.s0_f = 0; p.C0 = 256;
             p.src1 = b.zero; p.s1_b = 2L * NBIN * T; p.s1_c = T; p.s1_f = 0; p.C1 = 2 * NBIN;

@@ -4,16 +4,29 @@ Same class names, constructor arguments, `load_state_dict` key schema, `eval()/c
 `forward()` tensor shapes as the reference `nn.Module`s, but every forward runs in the HIP engine
 (libse_engine.so) - these classes hold no parameters and do no arithmetic themselves.
 """
+import functools
+
 import numpy as np
 
 from . import schemas, synth
 from .engine import Engine
 
 
+class _class_or_instance_method:
+    """f(cls, self) reachable both as Class.f() (self = None) and instance.f()."""
+
+    def __init__(self, f):
+        self.f = f
+
+    def __get__(self, obj, cls):
+        return functools.partial(self.f, cls if obj is None else type(obj), obj)
+
+
 class _EngineModule:
     """Common plumbing: lazy engine creation, strict state-dict load, torch-like call surface."""
     _model = None          # key into _lib.MODEL_IDS
     _schema = None         # key into schemas.SCHEMAS (defaults to _model)
+    _repeat_prefix = None  # ModuleList whose length is a constructor argument (stage_num / order_num), decode-script value 3
     p_in = 1.0             # magnitude exponents the decode script applies around the network
     p_out = 1.0
 
@@ -30,9 +43,12 @@ class _EngineModule:
         self.engine = None
 
     # -- reference-compatible surface -------------------------------------------------------------
-    @classmethod
-    def state_dict_schema(cls):
-        return schemas.SCHEMAS[cls._schema or cls._model]()
+    @_class_or_instance_method
+    def state_dict_schema(cls, self):
+        """Class.state_dict_schema(): the decode script's configuration; instance.state_dict_schema(): this instance's."""
+        base = schemas.SCHEMAS[cls._schema or cls._model]()
+        n = getattr(self, '_repeats', 3)
+        return base if cls._repeat_prefix is None or n == 3 else schemas.repeat_variant(base, cls._repeat_prefix, n)
 
     def load_state_dict(self, sd, strict=True):
         assert strict, "the engine only supports strict loads (as every reference decode script does)"
@@ -221,15 +237,23 @@ class CTSNet:
 class TaylorSENet(_EngineModule):
     """TaylorSENet/TaylorSENet.py:8 as built at taylorsenet_decode_vb.py:11-13.  forward: RI [B,2,T,161] -> RI."""
     _model = 'taylorsenet'
+    _repeat_prefix = 'highorderblock_list.'
 
     def __init__(self, cin=2, k1=(1, 3), k2=(2, 3), c=64, kd1=3, cd1=64, d_feat=256, dilations=(1, 2, 5, 9), p=2,
                  fft_num=320, order_num=3, intra_connect='cat', inter_connect='add', is_causal=True, is_conformer=False,
                  is_u2=True, is_param_share=False, is_encoder_share=False, **kw):
         cfg = (cin, tuple(k1), tuple(k2), c, kd1, cd1, d_feat, tuple(dilations), p, fft_num, order_num, intra_connect,
                inter_connect, is_causal, is_conformer, is_u2, is_param_share, is_encoder_share)
-        if cfg != (2, (1, 3), (2, 3), 64, 5, 64, 256, (1, 2, 5, 9), 2, 320, 3, 'cat', 'cat', True, False, True, False, False):
-            raise NotImplementedError("the engine builds the decode script's TaylorSENet configuration; got " + repr(cfg))
+        if (cfg[:10] + cfg[11:] != (2, (1, 3), (2, 3), 64, 5, 64, 256, (1, 2, 5, 9), 2, 320, 'cat', 'cat', True, False, True, False,
+                                     False) or not 0 <= order_num <= 8):
+            raise NotImplementedError("the engine builds the decode script's TaylorSENet configuration with order_num in "
+                                      "[0, 8]; got " + repr(cfg))
+        # order_num (TaylorSENet.py:27,66-70): SE_CFG_REPEATS(n) = (n + 1) << 8 (include/se_engine.h)
+        self._repeats = order_num
+        if order_num != 3:
+            kw['flags'] = kw.get('flags', 0) | ((order_num + 1) << 8)
         super().__init__(**kw)
+
 
 
 def _taylor(**kw):
@@ -242,15 +266,23 @@ class gaf_base(_EngineModule):
     """G2Net_VB/gaf_net_320.py:10 as built at com_decode.py:23.  forward: RI [B,2,T,161] -> list of stage outputs;
     the engine returns the list with only the LAST stage ([B,2,161,T]) materialised - the decode script uses [-1]."""
     _model = 'g2net'
+    _repeat_prefix = 'gafs.'
 
     def __init__(self, kd1=3, cd1=64, tcm_num=2, sub_g1=4, sub_g2=4, dilas=(1, 2, 5, 9), ci=256 + 161 * 2, co1=256,
                  co2=256, k1=(2, 3), k2=(1, 3), c=64, intra_connect='cat', stage_num=3, is_causal=True, is_aux=True,
                  encoder_type='U2Net', tcm_type='full-band', **kw):
         cfg = (kd1, cd1, tcm_num, tuple(dilas), ci, co1, co2, tuple(k1), tuple(k2), c, intra_connect, stage_num,
                is_causal, is_aux, encoder_type, tcm_type)
-        if cfg != (3, 64, 2, (1, 2, 5, 9), 578, 256, 256, (2, 3), (1, 3), 64, 'cat', 3, True, False, 'U2Net', 'full-band'):
-            raise NotImplementedError("the engine builds the decode script's gaf_base configuration; got " + repr(cfg))
+        if (cfg[:11] + cfg[12:] != (3, 64, 2, (1, 2, 5, 9), 578, 256, 256, (2, 3), (1, 3), 64, 'cat', True, False, 'U2Net', 'full-band')
+                or not 1 <= stage_num <= 8):
+            raise NotImplementedError("the engine builds the decode script's gaf_base configuration with stage_num in [1, 8]; "
+                                      "got " + repr(cfg))
+        # stage_num (gaf_net_320.py:27,55-58): SE_CFG_REPEATS(n) = (n + 1) << 8 (include/se_engine.h)
+        self._repeats = stage_num
+        if stage_num != 3:
+            kw['flags'] = kw.get('flags', 0) | ((stage_num + 1) << 8)
         super().__init__(**kw)
+
 
     def forward(self, x):
         B, _, T, F = x.shape

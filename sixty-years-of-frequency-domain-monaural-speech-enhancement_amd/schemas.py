@@ -252,6 +252,30 @@ def uformer_schema():
     return _from_data('uformer')
 
 
+def repeat_variant(schema, prefix, n):
+    """The schema of a constructor whose ModuleList `prefix<i>.` holds n equal blocks instead of the captured count
+    (gaf_base(stage_num = n): `gafs.`, gaf_net_320.py:55-58; TaylorSENet(order_num = n): `highorderblock_list.`,
+    TaylorSENet.py:66-70).  Blocks keep their place in state_dict() order; block i >= the captured count copies the last one."""
+    blocks, out, emitted = OrderedDict(), OrderedDict(), False
+    for k in schema:
+        if k.startswith(prefix):
+            idx, rest = k[len(prefix):].split('.', 1)
+            blocks.setdefault(int(idx), []).append(rest)
+    have = len(blocks)
+    for k, v in schema.items():
+        if not k.startswith(prefix):
+            out[k] = v
+            continue
+        if emitted:
+            continue
+        emitted = True
+        for i in range(n):
+            src = min(i, have - 1)
+            for rest in blocks[src]:
+                out[f'{prefix}{i}.{rest}'] = schema[f'{prefix}{src}.{rest}']
+    return out
+
+
 def cln_variant(schema):
     """The `*_new` flavour of a schema: every InstanceNorm (a 1-D `weight` with a sibling 1-D `bias`) becomes a
     CumulativeLayerNorm with `gain` / `bias` of shape [1,C,1,1] (2-D) or [1,C,1] (inside a TCM), same position

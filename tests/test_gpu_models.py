@@ -216,3 +216,38 @@ def test_recurrence_forms_agree(name):
         e = float(np.sqrt(np.mean((outs[B] - ref) ** 2)))
         print(name, 'batch', B, 'vs batch 20: rms err', e, 'rms', float(np.sqrt(np.mean(ref ** 2))))
         assert e < 1e-6 + 2e-5 * float(np.sqrt(np.mean(ref ** 2))), (name, B, e)
+
+
+def _variant(name, n, **kw):
+    from se_amd import models, models_new
+    mod = models_new if '_new' in name else models
+    if name.startswith('g2net'):
+        return mod.gaf_base(3, 64, 2, 4, 4, [1, 2, 5, 9], 256 + 161 * 2, 256, 256, (2, 3), (1, 3), 64, 'cat', n, is_aux=False,
+                            encoder_type='U2Net', tcm_type='full-band', **kw)
+    return mod.TaylorSENet(cin=2, k1=(1, 3), k2=(2, 3), c=64, kd1=5, cd1=64, d_feat=256, dilations=[1, 2, 5, 9], p=2, fft_num=320,
+                           order_num=n, intra_connect='cat', inter_connect='cat', is_causal=True, is_conformer=False, is_u2=True,
+                           is_param_share=False, is_encoder_share=False, **kw)
+
+
+@pytest.mark.parametrize('name,n,seed', [('g2net_s2', 2, 20), ('g2net_s4', 4, 20), ('g2net_new_s2', 2, 20), ('taylorsenet_o1', 1, 19),
+                                         ('taylorsenet_o4', 4, 19), ('taylorsenet_new_o1', 1, 19)])
+def test_stage_num_and_order_num_match_reference_fixtures(name, n, seed):
+    """gaf_base(stage_num = n) (G2Net_VB/gaf_net_320.py:27,55-58) and TaylorSENet(order_num = n) (TaylorSENet/TaylorSENet.py:27,
+    66-70) with values the decode scripts do not use (SE_CFG_REPEATS): forward and the compressed decode against fixtures of
+    the imported reference built with the same value; a state dict of another count is rejected by the strict load."""
+    torch = _torch()
+    G = load_golden(name)
+    m = _variant(name, n, max_batch=2, max_samples=8000, p_in=0.5, p_out=2.0).load_synthetic(seed)
+    y = m(torch.from_numpy(G['x']).cuda())
+    y = (y[-1] if isinstance(y, list) else y).cpu().numpy()
+    err = rms(y - G['y'])
+    print(name, 'forward rms err', err, 'rms ref', rms(G['y']))
+    assert y.shape == G['y'].shape and err < 2e-5 * max(rms(G['y']), 1.0)
+    wav = torch.from_numpy(np.stack([G['wav'], G['wav'][::-1].copy()])).cuda()
+    e = m.enhance_batch(wav).cpu().numpy()
+    err = rms(e[0] - G['enh_cprs'])
+    print(name, 'decode rms err', err, 'rms ref', rms(G['enh_cprs']))
+    assert err < 1e-4 and err < 5e-4 * max(rms(G['enh_cprs']), 1e-3)
+    other = _variant(name, 3, max_batch=1, max_samples=8000)
+    with pytest.raises(RuntimeError):
+        other.load_state_dict(synth.synth_state_dict(m.state_dict_schema(), seed))

@@ -232,3 +232,27 @@ def test_cln_variants_are_causal_and_instance_norm_bases_are_not(name):
         full, part = fwd(sd, x), fwd(sd, head)
         err = rms(out_frames(full, cut) - out_frames(part, cut)) / max(rms(full), 1e-9)
         assert (err < 1e-7) if causal else (err > 1e-4), (variant, err)      # (sums in another order: ~1e-9)
+
+
+@pytest.mark.parametrize('name,seed', [('g2net_s2', 20), ('g2net_s4', 20), ('g2net_new_s2', 20)])
+def test_g2net_stage_num_matches_reference(name, seed):
+    """gaf_base(stage_num = 2 / 4) (G2Net_VB/gaf_net_320.py:27,55-58) - constructor values no decode script uses."""
+    G = load_golden(name)
+    sd = _sd(name, seed)
+    ys = M.g2net_forward(sd, G['x'])
+    assert len(ys) == int(name[-1])
+    assert rms(ys[-1] - G['y']) < 5e-6 * max(rms(G['y']), 1.0)
+    assert rms(ys[0] - G['y0']) < 5e-6 * max(rms(G['y0']), 1.0)
+    e = D.enhance_g2net(sd, G['wav'], 0.5, 2.0)
+    assert rms(e - G['enh_cprs']) < 1e-5 * max(rms(G['enh_cprs']), 1e-3)
+
+
+@pytest.mark.parametrize('name,seed', [('taylorsenet_o1', 19), ('taylorsenet_o4', 19), ('taylorsenet_new_o1', 19)])
+def test_taylorsenet_order_num_matches_reference(name, seed):
+    """TaylorSENet(order_num = 1 / 4) (TaylorSENet/TaylorSENet.py:27,66-70)."""
+    G = load_golden(name)
+    sd = _sd(name, seed)
+    y = M.taylorsenet_forward(sd, G['x'])
+    assert rms(y - G['y']) < 5e-6 * max(rms(G['y']), 1.0), rms(y - G['y'])
+    e = D.enhance_taylorsenet(sd, G['wav'], 0.5, 2.0)
+    assert rms(e - G['enh_cprs']) < 1e-5 * max(rms(G['enh_cprs']), 1e-3)

@@ -75,6 +75,10 @@ enum se_model_id {
  *   TaylorSENet(..., order_num = n)   TaylorSENet/TaylorSENet.py:27,66-70 (n high-order blocks `highorderblock_list.<k>.`, 0 <= n <= 8)
  * 0 in the field = the decode scripts' value (3 for both: G2Net_VB/com_decode.py:23, TaylorSENet/taylorsenet_decode_vb.py:11-13). */
 #define SE_CFG_REPEATS(n) ((((n) + 1) & 15) << 8)
+/* CTSNet: Step2_net(X, R) (CTSNet/Step2_network.py:13-21: R groups `tcm_list.<r>.` of X gated blocks `glu_list.<i>.`, dilation 2^i):
+ * R in SE_CFG_REPEATS (1 <= R <= 8), X in bits 12-15 (1 <= X <= 6); 0 in a field = the decode script's 3 / 6
+ * (two_stage_com_decode_vb.py:14). */
+#define SE_CFG_REPEATS2(n) ((((n) + 1) & 15) << 12)
 
 typedef struct se_config {
     int32_t model;        /* enum se_model_id */

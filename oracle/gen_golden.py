@@ -427,12 +427,13 @@ def gen_gcrn():
     save_full('gcrn', 208, lambda w: _enhance_librosa_family(model, w, 'ri', 0.5, 2.0))
 
 
-def gen_ctsnet(ref_dir='CTSNet', tag=''):
+def gen_ctsnet(ref_dir='CTSNet', tag='', X=6, R=3):
     m1 = import_ref(ref_dir, 'Step1_network').Step1_net()
     sch1, _ = load_synth(m1, 17)
-    m2 = import_ref(ref_dir, 'Step2_network').Step2_net(X=6, R=3)
+    m2 = import_ref(ref_dir, 'Step2_network').Step2_net(X=X, R=R)
     sch2, _ = load_synth(m2, 18)
-    save_schema('cts_step1' + tag, sch1)
+    if (X, R) == (6, 3):
+        save_schema('cts_step1' + tag, sch1)
     save_schema('cts_step2' + tag, sch2)
     rng = np.random.default_rng(11)
     x1 = np.abs(rng.standard_normal((2, 40, 161))).astype(np.float32)
@@ -462,6 +463,9 @@ def gen_ctsnet(ref_dir='CTSNet', tag=''):
         y = torch.istft(de.T, 320, 160, 320, window=torch.hann_window(320, dtype=torch.float64))[:wav_len]
         return (y / c).numpy()
     wav = synth.synth_clip(9, 'speech', 8000)
+    if (X, R) != (6, 3):      # (another constructor value: the second stage's fixture and the chained decode only)
+        save('ctsnet' + tag, x2=x2, y2=y2, wav=wav, enh_cprs=enh(wav, 0.5, 2.0))
+        return
     save('ctsnet' + tag, x1=x1, y1=y1, x2=x2, y2=y2, wav=wav, enh=enh(wav, 1.0, 1.0), enh_cprs=enh(wav, 0.5, 2.0))
     save_full('ctsnet' + tag, 209, lambda w: enh(w, 0.5, 2.0))
 
@@ -599,6 +603,9 @@ def gen_repeat_counts():
     gen_taylorsenet(tag='_o1', order_num=1)
     gen_taylorsenet(tag='_o4', order_num=4)
     gen_taylorsenet('TaylorSENet_new', '_new_o1', order_num=1)
+    # Step2_net(X, R) (CTSNet/Step2_network.py:13-21)
+    gen_ctsnet(tag='_x4r2', X=4, R=2)
+    gen_ctsnet('CTSNet_new', '_new_x5r4', X=5, R=4)
 
 
 GENS = {'repeat_counts': gen_repeat_counts, 'stft': gen_stft, 'dccrn_mask': gen_dccrn_mask, 'fullsubnet_cum': gen_fullsubnet_cum, 'fullsubnet_gru': gen_fullsubnet_gru, 'ctsnet_new': gen_ctsnet_new, 'taylorsenet_new': gen_taylorsenet_new, 'g2net_new': gen_g2net_new, 'uformer': gen_uformer, 'g2net': gen_g2net, 'taylorsenet': gen_taylorsenet, 'ctsnet': gen_ctsnet, 'gcrn': gen_gcrn, 'fullsubnet': gen_fullsubnet, 'lstm': gen_lstm, 'crn': gen_crn, 'dpcrn': gen_dpcrn, 'dccrn': gen_dccrn}

@@ -427,8 +427,13 @@ def cts_step1_forward(sd, x):
     return _cts_decoder(sd, 'de.de.', 'de.de6.', x, skips, True)
 
 
-def cts_step2_forward(sd, inpt, R=3, X=6):
-    """Step2_net.forward (Step2_network.py:23-38): [B,4,T,161] -> [B,2,T,161]."""
+def cts_step2_forward(sd, inpt, R=None, X=None):
+    """Step2_net.forward (Step2_network.py:23-38): [B,4,T,161] -> [B,2,T,161].  R groups of X gated blocks (:13-21): as many
+    as the state dict holds (3 x 6 in the decode script, two_stage_com_decode_vb.py:14)."""
+    if R is None:
+        R = _module_list_len(sd, 'tcm_list.')
+    if X is None:
+        X = _module_list_len(sd, 'tcm_list.0.glu_list.')
     x, skips = _cts_encoder(sd, 'en.en_module.', inpt)
     B, _, T, _ = x.shape
     x = np.transpose(x, (0, 1, 3, 2)).reshape(B, -1, T)

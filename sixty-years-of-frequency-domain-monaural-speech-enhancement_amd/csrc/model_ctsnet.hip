@@ -14,7 +14,7 @@ namespace se {
 
 namespace {
 
-constexpr int NFFT = 320, HOP = 160, NBIN = 161, NTCM = 18;
+constexpr int NFFT = 320, HOP = 160, NBIN = 161;
 constexpr int EF[5] = {79, 39, 19, 9, 4}, DF[5] = {9, 19, 39, 79, 161};
 
 struct GatedEncoder {
@@ -100,6 +100,7 @@ class CtsNet final : public Model {
         if (has1) {
             en1.load(sd, "step1.en.en.", 1);
             de1.load(sd, "step1.de.de.", "step1.de.de6.", true);
+            tcm1.resize(18);
             for (int k = 0; k < 3; ++k)
                 for (int i = 0; i < 6; ++i)
                     tcm1[k * 6 + i].load(sd, "step1.tcm" + std::to_string(k + 1) + ".tcm_list." + std::to_string(i) + ".", 1 << i,
@@ -109,9 +110,14 @@ class CtsNet final : public Model {
             en2.load(sd, "step2.en.en_module.", 4);
             de2r.load(sd, "step2.de_r.de_list.", "step2.de_r.de6.", false);
             de2i.load(sd, "step2.de_i.de_list.", "step2.de_i.de6.", false);
-            for (int r = 0; r < 3; ++r)
-                for (int i = 0; i < 6; ++i)
-                    tcm2[r * 6 + i].load(sd, "step2.tcm_list." + std::to_string(r) + ".glu_list." + std::to_string(i) + ".", 1 << i,
+            // Step2_net(X, R) (Step2_network.py:13-21): 6 / 3 in the decode script, others through SE_CFG_REPEATS2 / SE_CFG_REPEATS
+            R2 = ctx.repeats(3);
+            X2 = ((ctx.flags >> 12) & 15) ? ((ctx.flags >> 12) & 15) - 1 : 6;      // SE_CFG_REPEATS2(X)
+            SE_CHECK(R2 >= 1 && R2 <= 8 && X2 >= 1 && X2 <= 6, "Step2_net: R outside [1, 8] or X outside [1, 6]");
+            tcm2.resize((size_t)R2 * X2);
+            for (int r = 0; r < R2; ++r)
+                for (int i = 0; i < X2; ++i)
+                    tcm2[r * X2 + i].load(sd, "step2.tcm_list." + std::to_string(r) + ".glu_list." + std::to_string(i) + ".", 1 << i,
                                          "ori_conv", "att_ori", 4, 2 * (1 << i) - 1, 5);
         }
         cum = (has1 ? en1.na[0].cum : true) && (has2 ? en2.na[0].cum : true);
@@ -202,7 +208,8 @@ class CtsNet final : public Model {
     bool has1 = false, has2 = false;
     GatedEncoder en1, en2;
     GatedDecoder de1, de2r, de2i;
-    TcmBlock tcm1[NTCM], tcm2[NTCM];
+    std::vector<TcmBlock> tcm1, tcm2;
+    int R2 = 3, X2 = 6;
 
     Bufs& bufs(int B, int T) {
         if (cur.B == B && cur.T == T) return cur;
@@ -233,12 +240,12 @@ class CtsNet final : public Model {
     }
 
     // x = E[4] viewed as [B][256][T]; returns the accumulated TCM output in b.acc
-    void tcm_stack(Bufs& b, const TcmBlock* blocks, hipStream_t st) {
+    void tcm_stack(Bufs& b, const TcmBlock* blocks, int groups, int per, hipStream_t st) {
         const int B = b.B, T = b.T;
         const long n = (long)B * 256 * T;
         const float* x = b.E[4];
-        for (int g = 0; g < 3; ++g) {
-            x = run_tcm_chain(blocks + g * 6, 6, x, b.X, b.ts, B, T, st, &ctx.prof);
+        for (int g = 0; g < groups; ++g) {
+            x = run_tcm_chain(blocks + g * per, per, x, b.X, b.ts, B, T, st, &ctx.prof);
             if (g == 0) SE_HIP(hipMemcpyAsync(b.acc, x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
             else launch_add(b.acc, x, b.acc, n, st);
         }
@@ -246,13 +253,13 @@ class CtsNet final : public Model {
 
     void step1(Bufs& b, const float* mag, float* est, hipStream_t st) {      // Step1_network.py:21-40
         en1.run(act4(mag, 1, NBIN, b.T), nullptr, b.E, b.B, b.T, st, &ctx.prof);
-        tcm_stack(b, tcm1, st);
+        tcm_stack(b, tcm1.data(), 3, 6, st);
         de1.run(b.acc, b.E, b.D, est, (long)NBIN * b.T, b.B, b.T, st, &ctx.prof);
     }
     void step2(Bufs& b, const float* spec, const float* s1, float* est, hipStream_t st) {   // Step2_network.py:23-38
         Act4 a1 = act4(s1, 2, NBIN, b.T);
         en2.run(act4(spec, 2, NBIN, b.T), &a1, b.E, b.B, b.T, st, &ctx.prof);
-        tcm_stack(b, tcm2, st);
+        tcm_stack(b, tcm2.data(), R2, X2, st);
         de2r.run(b.acc, b.E, b.D, est, 2L * NBIN * b.T, b.B, b.T, st, &ctx.prof);
         de2i.run(b.acc, b.E, b.D, est + (long)NBIN * b.T, 2L * NBIN * b.T, b.B, b.T, st, &ctx.prof);
     }

@@ -179,7 +179,7 @@ class _CtsStage(_EngineModule):
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
         self._sd = {self._prefix + k: v for k, v in sd.items()}
         self.engine = Engine('ctsnet', self._device, self._max_batch, self._max_samples, self.p_in, self.p_out,
-                             graphs=self._graphs)
+                             graphs=self._graphs, flags=self._flags)
         self.engine.load_state_dict(self._sd)
         return self
 
@@ -196,9 +196,20 @@ class Step2_net(_CtsStage):
     _schema = 'cts_step2'
 
     def __init__(self, X=6, R=3, **kw):
+        if not (1 <= X <= 6 and 1 <= R <= 8):
+            raise NotImplementedError("the engine builds Step2_net(X, R) with X in [1, 6] and R in [1, 8] (the decode "
+                                      "script's: X=6, R=3)")
+        # R groups of X gated blocks (Step2_network.py:13-21): SE_CFG_REPEATS(R) | SE_CFG_REPEATS2(X) (include/se_engine.h)
+        self._xr = (X, R)
         if (X, R) != (6, 3):
-            raise NotImplementedError("the engine builds the decode script's Step2_net(X=6, R=3)")
+            kw['flags'] = kw.get('flags', 0) | ((R + 1) << 8) | ((X + 1) << 12)
         super().__init__(**kw)
+
+    @_class_or_instance_method
+    def state_dict_schema(cls, self):
+        X, R = getattr(self, '_xr', (6, 3))
+        base = schemas.cts_step2_schema(X, R)
+        return schemas.cln_variant(base) if (cls._schema or '').endswith('_new') else base
 
     def forward(self, x):
         B, _, T, F = x.shape
@@ -210,8 +221,9 @@ class CTSNet:
 
     _stages = (Step1_net, Step2_net)
 
-    def __init__(self, **kw):
+    def __init__(self, X=6, R=3, **kw):
         self._kw = {k: v for k, v in kw.items() if v is not None}
+        self._stage2 = self._stages[1](X=X, R=R)      # Step2_net(X, R): validates, knows its key schema and flag bits
         self.engine = None
 
     def load_state_dicts(self, sd1, sd2):
@@ -219,13 +231,14 @@ class CTSNet:
         sd = {'step1.' + k: v for k, v in sd1.items()}
         sd.update({'step2.' + k: v for k, v in sd2.items()})
         self.engine = Engine('ctsnet', kw.get('device', 0), kw.get('max_batch', 1), kw.get('max_samples', 64000),
-                             kw.get('p_in', 1.0), kw.get('p_out', 1.0), graphs=kw.get('graphs', False))
+                             kw.get('p_in', 1.0), kw.get('p_out', 1.0), graphs=kw.get('graphs', False),
+                             flags=kw.get('flags', 0) | self._stage2._flags)
         self.engine.load_state_dict(sd)
         return self
 
     def load_synthetic(self, seed1=17, seed2=18):
         return self.load_state_dicts(synth.synth_state_dict(self._stages[0].state_dict_schema(), seed1),
-                                     synth.synth_state_dict(self._stages[1].state_dict_schema(), seed2))
+                                     synth.synth_state_dict(self._stage2.state_dict_schema(), seed2))
 
     def enhance_batch(self, wav):
         return self.engine.enhance_batch(wav)

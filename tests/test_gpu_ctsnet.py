@@ -43,3 +43,22 @@ def test_two_stage_decode_matches_reference(p_in, p_out, key):
     print('ctsnet decode rms err', e, rms(G[key]))
     assert y.shape[1] == G[key].shape[0]
     assert e < 1e-4 and e < 5e-4 * max(rms(G[key]), 1e-3)
+
+
+@pytest.mark.parametrize('tag,X,R', [('_x4r2', 4, 2), ('_new_x5r4', 5, 4)])
+def test_step2_x_r_matches_reference_fixture(tag, X, R):
+    """Step2_net(X, R) (CTSNet/Step2_network.py:13-21; SE_CFG_REPEATS / SE_CFG_REPEATS2) with values the decode script does not
+    use: the stage alone and the chained compressed decode against fixtures of the imported reference built with them."""
+    import torch
+    from se_amd import models, models_new
+    mod = models_new if '_new' in tag else models
+    G = load_golden('ctsnet' + tag)
+    m2 = mod.Step2_net(X=X, R=R, max_batch=2, max_samples=8000).load_synthetic(18)
+    e2 = rms(m2(torch.from_numpy(G['x2']).cuda()).cpu().numpy() - G['y2'])
+    print('step2', tag, 'rms err', e2, rms(G['y2']))
+    assert e2 < 2e-5 * max(rms(G['y2']), 1.0)
+    net = mod.CTSNet(X=X, R=R, max_batch=2, max_samples=8000, p_in=0.5, p_out=2.0).load_synthetic(17, 18)
+    wav = torch.from_numpy(np.stack([G['wav'], synth.synth_clip(77, 'white', 8000)])).cuda()
+    e = rms(net.enhance_batch(wav).cpu().numpy()[0] - G['enh_cprs'])
+    print('ctsnet', tag, 'decode rms err', e, rms(G['enh_cprs']))
+    assert e < 1e-4 and e < 5e-4 * max(rms(G['enh_cprs']), 1e-3)

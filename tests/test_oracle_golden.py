@@ -256,3 +256,14 @@ def test_taylorsenet_order_num_matches_reference(name, seed):
     assert rms(y - G['y']) < 5e-6 * max(rms(G['y']), 1.0), rms(y - G['y'])
     e = D.enhance_taylorsenet(sd, G['wav'], 0.5, 2.0)
     assert rms(e - G['enh_cprs']) < 1e-5 * max(rms(G['enh_cprs']), 1e-3)
+
+
+@pytest.mark.parametrize('tag,new,X,R', [('_x4r2', '', 4, 2), ('_new_x5r4', '_new', 5, 4)])
+def test_ctsnet_step2_x_r_matches_reference(tag, new, X, R):
+    """Step2_net(X, R) (CTSNet/Step2_network.py:13-21) with values the decode script does not use."""
+    G = load_golden('ctsnet' + tag)
+    sd1, sd2 = _sd('cts_step1' + new, 17), _sd('cts_step2' + tag, 18)
+    assert sum(k.endswith('.glu_list.0.in_conv.weight') for k in sd2) == R and f'tcm_list.0.glu_list.{X - 1}.in_conv.weight' in sd2
+    assert rms(M.cts_step2_forward(sd2, G['x2']) - G['y2']) < 5e-6 * max(rms(G['y2']), 1.0)
+    e = D.enhance_ctsnet(sd1, sd2, G['wav'], 0.5, 2.0)
+    assert rms(e - G['enh_cprs']) < 1e-5 * max(rms(G['enh_cprs']), 1e-3)

@@ -38,3 +38,19 @@ def test_repeat_count_schema_matches_reference(name, n):
         models.gaf_base(stage_num=9, is_aux=False)
     with pytest.raises(NotImplementedError):
         models._taylor.__globals__['TaylorSENet'](kd1=5, inter_connect='cat', order_num=9)
+
+
+@pytest.mark.parametrize('tag,X,R', [('_x4r2', 4, 2), ('_new_x5r4', 5, 4)])
+def test_step2_x_r_schema_matches_reference(tag, X, R):
+    """Step2_net(X, R) (CTSNet/Step2_network.py:13-21): key schema and flag bits of a configuration the decode script does not use."""
+    from se_amd import models, models_new
+    m = (models_new if '_new' in tag else models).Step2_net(X=X, R=R)
+    ref, mine = load_schema('cts_step2' + tag), m.state_dict_schema()
+    assert list(mine.keys()) == list(ref.keys())
+    for k in ref:
+        assert tuple(mine[k][0]) == tuple(ref[k][0]) and mine[k][1] == ref[k][1], k
+    assert m._flags & 0xFF00 == ((R + 1) << 8) | ((X + 1) << 12)
+    assert list(type(m).state_dict_schema().keys()) == list(load_schema('cts_step2' + ('_new' if '_new' in tag else '')).keys())
+    for bad in ((7, 3), (6, 9), (0, 3)):
+        with pytest.raises(NotImplementedError):
+            models.Step2_net(X=bad[0], R=bad[1])

@@ -11,6 +11,7 @@
 //   * inter-frame LSTM (over T, :77-82): transposed to time-major [T][128][B*4], same persistent kernel;
 //   * LayerNorm([4,128]) + residual fused in one kernel; complex mask + decode-script decompress fused.
 #include "rnn.h"
+#include "k_lstm_short.h"
 
 namespace se {
 
@@ -28,7 +29,8 @@ class Dpcrn final : public Model {
         for (auto& p : inter_in) gc_free_plan(p);
         gc_free_plan(intra_fc);
         gc_free_plan(inter_fc);
-        for (float* d : {intra_whh[0], intra_whh[1], inter_whh[0], inter_whh[1], ln_w[0], ln_b[0], ln_w[1], ln_b[1]})
+        for (float* d : {intra_whh[0], intra_whh[1], inter_whh[0], inter_whh[1], ln_w[0], ln_b[0], ln_w[1], ln_b[1], intra_wih[0],
+                         intra_wih[1], intra_bias[0], intra_bias[1]})
             if (d) (void)hipFree(d);
     }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
@@ -50,6 +52,8 @@ class Dpcrn final : public Model {
             std::vector<float> w = f.whh.w;
             w.insert(w.end(), r.whh.w.begin(), r.whh.w.end());             // [2][256][64]
             intra_whh[l] = to_device(w);
+            intra_wih[l] = to_device(both.w);                              // [2][256][128] and [2][256]: the fused short-sequence kernel
+            intra_bias[l] = to_device(both.bias);
             LstmW t = load_lstm(sd, "dprnn.inter_rnn.", l, "", CH, CH);
             inter_in[l] = make_pointwise_plan(t.wih, ACT_NONE, {}, ctx.max_batch * NF);
             inter_whh[l] = to_device(t.whh.w);
@@ -186,6 +190,7 @@ class Dpcrn final : public Model {
     GCPlan enc[5], intra_in[2], inter_in[2], intra_fc, inter_fc;
     DeconvPlan dec[5];
     float *intra_whh[2] = {nullptr, nullptr}, *inter_whh[2] = {nullptr, nullptr};
+    float *intra_wih[2] = {nullptr, nullptr}, *intra_bias[2] = {nullptr, nullptr};
     float *ln_w[2] = {nullptr, nullptr}, *ln_b[2] = {nullptr, nullptr};
 
     Bufs& bufs(int B, int T) {
@@ -232,7 +237,23 @@ class Dpcrn final : public Model {
         const long plane = (long)NF * T;            // one channel
         // ---- intra: BiLSTM(128 -> 64 x2, 2 layers) over F for every (b, t)
         const float* lin = x;
-        for (int l = 0; l < 2; ++l) {
+        // many short sequences: input projection and recurrence in one kernel, no gate tensor (k_lstm_short.hip; SE_LSTM_SHORT=0:
+        // the projection GEMM + the persistent kernel below).  Frame-online chunks of a few frames keep the two-launch form.
+        const bool fused_intra = lstm_short_supported(64, CH, NF) && (long)B * T >= 4096;
+        for (int l = 0; l < 2 && fused_intra; ++l) {
+            LstmShortArgs a{};
+            a.x = lin; a.x_o = (long)CH * plane; a.x_c = plane; a.x_t = T;
+            a.wih = intra_wih[l]; a.whh = intra_whh[l]; a.bias = intra_bias[l];
+            a.wih_z = 256L * CH; a.whh_z = 256L * 64; a.bias_z = 256;
+            a.out = b.Hi[l]; a.out_o = (long)CH * plane; a.out_z = 64L * plane; a.out_t = T; a.out_row = plane;
+            a.T = NF; a.S = T; a.Z = 2; a.O = B; a.reverse = 2;
+            const bool timed = pf && pf->on;
+            if (timed) pf->begin(st);
+            launch_lstm_short(a, st);
+            if (timed) pf->end(st, 2.0 * 2 * 256 * (double)(CH + 64) * NF * B * T);
+            lin = b.Hi[l];
+        }
+        for (int l = 0; l < 2 && !fused_intra; ++l) {
             // Gi[b][dir*256 + row][f][t]
             run_pointwise(intra_in[l], lin, (long)CH * plane, plane, b.Gi, 512L * plane, plane, B, (int)plane, st, pf);
             LstmPersistArgs a{};

@@ -62,6 +62,8 @@ struct GCParams {
     const float* src0;
     const float* src1;
     float* dst;
+    float* dst_elu;          // EPI_GLU, optional: a second tensor laid out like dst that receives ELU(stored value) - GCRN's decoders
+                             // read elu(e_k) of every encoder output beside e_k itself (GCRN_noncprs.py:147-157); gc_kernel only
     const float* aux;        // EPI_LSTM: gate pre-activations gx; EPI_ADD: residual
     float* cell;             // EPI_LSTM: cell state, laid out like dst (channels = M/4), updated in place
     long A_z, bias_z, src0_z, src1_z, dst_z, aux_z, cell_z;   // per-z (blockIdx.z) element strides

@@ -640,6 +640,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         // EPI_CMB with the sum plane: this launch finishes R, reads the finished I and writes S = R + I beside it
         const float* __restrict__ cmbi = (EPI == EPI_CMB && p.cmb_s) ? p.cmb_i + (long)b * p.d_b + (long)fow * p.d_f : nullptr;
         float* __restrict__ cmbs = (EPI == EPI_CMB && p.cmb_s) ? p.cmb_s + (long)b * p.d_b + (long)fow * p.d_f : nullptr;
+        float* __restrict__ delu = (EPI == EPI_GLU && p.dst_elu) ? p.dst_elu + (long)b * p.d_b + (long)fow * p.d_f : nullptr;      // GCParams::dst_elu
         float* __restrict__ fzb = FZ ? p.fz + (long)b * p.fz_b + (long)fow * p.fz_f : nullptr;      // FZ: GCParams::fz (its own instantiations: the
                                                                                                       // extra live registers of the epilogue spill in the 128-row tile otherwise)
         // (one column tile per call, its index a compile-time constant: with the interaction operands in the body the unroller
@@ -789,6 +790,12 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                             if (p.fz_s) *reinterpret_cast<floatx4*>(zr + p.fz_s) = re + ii;      // S = R + I of a three-plane tensor
                         }
                         *reinterpret_cast<floatx4*>(dp) = v;
+                        if (EPI == EPI_GLU && delu) {
+                            floatx4 e4;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) e4[k] = v[k] > 0.f ? v[k] : fm_expm1(v[k]);
+                            *reinterpret_cast<floatx4*>(delu + (long)m * p.d_c + tg) = e4;
+                        }
                         if (EPI == EPI_CMB && cmbs) {
                             floatx4 s4 = v + ivp[it];
                             if (__builtin_expect(tg + 3 >= tvalid, 0)) {
@@ -812,6 +819,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                                 o = (tg + k < tvalid) ? o : 0.f;
                                 if (FZ) o = gc_fuse1(o, fzb + (long)m * p.fz_c + tg + k, p.fz_im, p.fz_s);
                                 dp[k] = o;
+                                if (EPI == EPI_GLU && delu) delu[(long)m * p.d_c + tg + k] = o > 0.f ? o : fm_expm1(o);
                                 if (EPI == EPI_CMB && cmbs) {
                                     const float iv = cmbi[(long)m * p.d_c + tg + k];
                                     cmbs[(long)m * p.d_c + tg + k] = (tg + k < tvalid) ? o + iv : 0.f;
@@ -1363,7 +1371,7 @@ static long gc_thin_blocks(const GCParams& p) {
     return nblk;
 }
 static bool gc_thin_launch(const GCParams& p, hipStream_t stream) {
-    const long nblk = p.fz ? 0 : gc_thin_blocks(p);          // (GCParams::fz: MFMA kernel only)
+    const long nblk = (p.fz || p.dst_elu) ? 0 : gc_thin_blocks(p);          // (GCParams::fz / dst_elu: MFMA kernel only)
     if (nblk <= 0) return false;
     const int n = p.Tout - p.t_base;
     dim3 grid((unsigned)nblk);
@@ -1884,6 +1892,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     // p.t_base (default 0): first output frame of the launch - frame-online chunks only produce the frames behind their
     // history columns.  A multiple of 4, so that the 16 B staging groups keep their alignment to frame 0.
     SE_CHECK(p.C0 == pl.p.C0 && p.C1 == pl.p.C1, "gc_launch: source channel split differs from the plan");
+    SE_CHECK(!p.dst_elu || (p.epi == EPI_GLU && p.Z == 1), "gc_launch: the second (ELU) store belongs to the gated epilogue");
     if (p.epi == EPI_LSTM && p.first_step && p.C1 == 0) p.C0 = 0;       // h_{-1} = 0: no matrix work (a step that also projects its input keeps both)
     if (p.t_base > 0 && gc_thin_launch(p, stream)) return;       // (any first frame)
     if (p.tb_soft) p.t_base &= ~3;
@@ -1921,6 +1930,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
     if (gc_thin_launch(p, stream)) return;
     if (p.Ws) {
         SE_CHECK(!p.fz, "gc_launch: the direct (<= 4 channel) path cannot fold the branch interaction into its store");
+        SE_CHECK(!p.dst_elu, "gc_launch: the direct (<= 4 channel) path has no second (ELU) store");
         SE_CHECK(!p.nrm0 && !p.nrm1, "gc_launch: the direct (<= 4 channel) path cannot normalise its sources on the fly");
         if (p.M <= 1) gc_small_launch<1>(p, pl.small, stream);
         else if (p.M <= 2) gc_small_launch<2>(p, pl.small, stream);

@@ -100,7 +100,7 @@ struct Profiler;
 // CumulativeLayerNorm behind the layer) - instead of the per-channel partials of an InstanceNorm
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
               hipStream_t st, Profiler* prof = nullptr, float* stats = nullptr, int t_base = 0, float* fz = nullptr, int fz_planes = 2,
-              bool colstats = false);
+              bool colstats = false, float* dst_elu = nullptr);      // dst_elu: GCParams::dst_elu (gated layers on the matrix path)
 // true: a folded interaction into a three-plane tensor (fz_planes = 3) also stores its sum plane S = R + I
 bool conv_fold_writes_sum();
 inline bool conv_folds_interaction(const GCPlan& pl) { return pl.p.Ws == nullptr && (pl.p.epi == EPI_ACT || pl.p.epi == EPI_ADD); }

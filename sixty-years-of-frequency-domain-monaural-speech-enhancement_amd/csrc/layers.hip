@@ -468,9 +468,10 @@ bool conv_fold_writes_sum() {
 }
 
 void run_conv(const GCPlan& pl, const Act4& s0, const Act4* s1, float* dst, int dstC, int Fout, int B, int T, int Tp,
-              hipStream_t st, Profiler* prof, float* stats, int t_base, float* fz, int fz_planes, bool colstats) {
+              hipStream_t st, Profiler* prof, float* stats, int t_base, float* fz, int fz_planes, bool colstats, float* dst_elu) {
     GCParams p = pl.p;
     p.t_base = t_base;
+    p.dst_elu = dst_elu;
     if (fz) set_fz(p, fz, dstC, Fout, Tp, fz_planes);
     if (stats && colstats) set_cstats(p, stats, Fout, T);
     else if (stats) set_stats(p, stats, dstC, Fout, T);

@@ -215,11 +215,16 @@ class Gcrn final : public Model {
         // (frame-online chunk: nothing here has an extent in time, so only the n new columns are produced)
         const int tb = n_stream > 0 ? T - n_stream : 0;
         Act4 x = act4(b.spec, 2, NBIN, T);
+        // elu(e_k), the skip tensors as the decoders read them (:147-157), leaves with e_k from the encoder layer's own epilogue
+        // (GCParams::dst_elu; SE_GCRN_ELU_FOLD=0 and frame-online chunks - thin kernels - : a pass of its own)
+        static const bool elu_fold_env = !(getenv("SE_GCRN_ELU_FOLD") && atoi(getenv("SE_GCRN_ELU_FOLD")) == 0);
+        const bool elu_fold = elu_fold_env && n_stream == 0 && !enc[0].p.Ws;
         for (int k = 0; k < 5; ++k) {
-            run_conv(enc[k], x, nullptr, b.E[k], EC[k + 1], EF[k], B, T, T, st, pf, nullptr, tb);
+            run_conv(enc[k], x, nullptr, b.E[k], EC[k + 1], EF[k], B, T, T, st, pf, nullptr, tb, nullptr, 2, false,
+                     (elu_fold && k < 4) ? b.EE[k] : nullptr);
             x = act4(b.E[k], EC[k + 1], EF[k], T);
         }
-        for (int k = 0; k < 4; ++k) launch_elu(b.E[k], b.EE[k], (long)B * EC[k + 1] * EF[k] * T, st);
+        for (int k = 0; k < 4 && !elu_fold; ++k) launch_elu(b.E[k], b.EE[k], (long)B * EC[k + 1] * EF[k] * T, st);
         // ---- GLSTM, time-major [T][1024][B]
         const long S = B;
         if (n_stream > 0) {

@@ -31,6 +31,7 @@ def test_reference_fixtures_with_the_ab_switches_thrown():
 # SE_DCCRN_GAUSS / SE_UF_GAUSS stay on (above they are off)
 SWITCHES_R5 = {
     'SE_IN_FOLD': '0', 'SE_CLN_STATS': '0', 'SE_CLN_PLANE': '0', 'SE_GAUSS_CMB': '0', 'SE_UF_ATT_F_MFMA': '0', 'SE_TAYLOR_FORK': '0',
+    'SE_GCRN_ELU_FOLD': '0',   # GCRN: elu(e_k) as a pass of its own instead of a second store of the encoder layers' epilogue
     'SE_LSTM_SHORT': '0',      # DPCRN's intra-frame BiLSTM as projection GEMM + persistent recurrence (k_lstm.hip) instead of k_lstm_short.hip
 }
 
@@ -42,6 +43,6 @@ def test_reference_fixtures_with_the_round5_switches_thrown():
            os.path.join(ROOT, 'tests', 'test_gpu_full_fixture.py'), os.path.join(ROOT, 'tests', 'test_gpu_new_variants.py'),
            os.path.join(ROOT, 'tests', 'test_gpu_dccrn.py'), os.path.join(ROOT, 'tests', 'test_gpu_uformer.py'),
            os.path.join(ROOT, 'tests', 'test_gpu_b256_fixture.py'), '-k',
-           'g2net or taylor or ctsnet or dccrn or uformer or dpcrn']
+           'g2net or taylor or ctsnet or dccrn or uformer or dpcrn or gcrn']
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -129,9 +129,10 @@ struct Profiler {
     double fscale = 1.0;    // algorithmic / executed frames: PadFrames runs a batch with the frame count rounded up to whole 16 B
                             // groups; the FLOPs reported are those of the clip's own frame count, not of the padding
     long launches = 0;
+    std::vector<double> fls;      // FLOPs per timed launch (SE_PROF_DUMP=1: total_ms() prints one line per launch, tools/profl.py)
     void begin(hipStream_t st);
     void end(hipStream_t st, double fl);
-    void reset() { used = 0; flops = 0.0; launches = 0; }
+    void reset() { used = 0; flops = 0.0; launches = 0; fls.clear(); }
     double total_ms();
     ~Profiler();
 };

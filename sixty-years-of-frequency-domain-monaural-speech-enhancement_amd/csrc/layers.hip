@@ -337,6 +337,7 @@ void Profiler::end(hipStream_t st, double fl) {
     used += 2;
     flops += fl * fscale;
     launches += 1;
+    fls.push_back(fl * fscale);
 }
 double Profiler::total_ms() {
     double tot = 0.0;
@@ -345,6 +346,9 @@ double Profiler::total_ms() {
         float ms = 0.f;
         SE_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
         tot += ms;
+        static const bool dump = getenv("SE_PROF_DUMP") != nullptr;      // per-launch lines for tools/profl.py
+        if (dump && i / 2 < fls.size())
+            fprintf(stderr, "PROFL %zu %.4f ms %.2f GFLOP %.1f TF/s\n", i / 2, ms, fls[i / 2] * 1e-9, fls[i / 2] / (ms * 1e9));
     }
     return tot;
 }

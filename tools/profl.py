@@ -1,3 +1,10 @@
+#!/usr/bin/env python
+"""Per-launch view of the tap-table GEMM family of one model: groups the `PROFL` lines the engine's profiler prints under
+SE_PROF_DUMP=1 (one per timed launch: HIP-event ms, algorithmic GFLOP) by launch shape - where a model's family time sits and
+at what TFLOP/s.
+
+  SE_PROF_DUMP=1 python tools/sweep.py --models ctsnet --batch 256 --steps 2 2>&1 | python tools/profl.py
+"""
 import sys,collections
 rows=[]
 for l in sys.stdin:

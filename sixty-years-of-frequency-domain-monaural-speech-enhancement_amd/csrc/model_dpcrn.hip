@@ -238,8 +238,10 @@ class Dpcrn final : public Model {
         // ---- intra: BiLSTM(128 -> 64 x2, 2 layers) over F for every (b, t)
         const float* lin = x;
         // many short sequences: input projection and recurrence in one kernel, no gate tensor (k_lstm_short.hip; SE_LSTM_SHORT=0:
-        // the projection GEMM + the persistent kernel below).  Frame-online chunks of a few frames keep the two-launch form.
-        const bool fused_intra = lstm_short_supported(64, CH, NF) && (long)B * T >= 4096;
+        // the projection GEMM + the persistent kernel below).  Frame-online windows of a few frames keep the two-launch form
+        // (measured at 1 / 16 streams x 1 / 8 frames: 2-3 % faster per push there; one whole clip: the same either way).
+        static const long short_min = getenv("SE_LSTM_SHORT_MIN") ? atol(getenv("SE_LSTM_SHORT_MIN")) : 256;      // (utterance, frame) pairs
+        const bool fused_intra = lstm_short_supported(64, CH, NF) && (long)B * T >= short_min;
         for (int l = 0; l < 2 && fused_intra; ++l) {
             LstmShortArgs a{};
             a.x = lin; a.x_o = (long)CH * plane; a.x_c = plane; a.x_t = T;

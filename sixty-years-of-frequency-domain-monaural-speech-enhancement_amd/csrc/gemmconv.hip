@@ -1109,41 +1109,50 @@ __global__ __launch_bounds__(256) void gc_small_lds_kernel(const GCParams p, con
                                             : p.src0 + (long)z * p.src0_z + (long)b * p.s0_b;
         const long s_c = seg ? p.s1_c : p.s0_c, s_f = seg ? p.s1_f : p.s0_f;
         const float* __restrict__ Wc = W + (long)(seg ? p.C0 : 0) * p.ntaps * MM;
+        // The next chunk's patch rows and weights travel in registers while the current chunk's taps run: a wave owns <= SRB rows
+        // of a chunk (CC * NR <= 23 rows at the 24 KB patch budget), SWN loads each - issued right after the previous chunk's values
+        // went to LDS, written behind the barrier that ends the current chunk's reads.  (Round 5, ablations SE_GC_DBG 64 / 128: the
+        // staging was 85 % of this kernel at 2.2 TB/s - one row per wave in flight - against a third for the taps.)
+        constexpr int SRB = 6, SWN = (SWT + 63) / 64, SWW = (8 * GC_MAX_TAPS * MM + 255) / 256;
+        float sv[SRB][SWN], wv[SWW];
+        auto issue = [&](int c0n) {
+            const int ccn = min(CC, C - c0n);
+#pragma unroll
+            for (int i = 0; i < SRB; ++i) {
+                const int row = min(wave + 4 * i, ccn * NR - 1);
+                const int c = row / NR, r = row - c * NR;
+                const float* __restrict__ sp = src + (long)(c0n + c) * s_c + (long)min(max(f0 + r, 0), p.Fin - 1) * s_f;
+#pragma unroll
+                for (int k = 0; k < SWN; ++k) sv[i][k] = sp[min(max(tb + lane + 64 * k, 0), p.Tin - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < SWW; ++k) wv[k] = Wc[(long)c0n * p.ntaps * MM + min(tid + 256 * k, ccn * p.ntaps * MM - 1)];
+        };
+        issue(0);
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += CC) {
             const int cc = min(CC, C - c0);
             __syncthreads();                         // the previous chunk has been consumed (and s_off is visible)
-            for (int e = tid; e < cc * p.ntaps * MM; e += 256) s_w[e] = Wc[(long)c0 * p.ntaps * MM + e];
+#pragma unroll
+            for (int k = 0; k < SWW; ++k)
+                if (tid + 256 * k < cc * p.ntaps * MM) s_w[tid + 256 * k] = wv[k];
             // stage [cc][NR][SWT]: a wave takes whole rows, 64 consecutive frames per load; outside the plane: zeros
-            // (four rows = 20 loads per wave in flight before the first LDS write: one row at a time left a CU with ~15 KB under
-            // way per memory round trip - 2.2 TB/s over the chip, 85 % of the kernel's time with the taps themselves at a third)
-            constexpr int SRB = 4, SWN = (SWT + 63) / 64;
-            for (int row0 = wave; row0 < cc * NR; row0 += 4 * SRB) {
-                float sv[SRB][SWN];
 #pragma unroll
-                for (int i = 0; i < SRB; ++i) {
-                    const int row = min(row0 + 4 * i, cc * NR - 1);
+            for (int i = 0; i < SRB; ++i) {
+                const int row = wave + 4 * i;
+                if (row < cc * NR) {
                     const int c = row / NR, r = row - c * NR;
-                    const float* __restrict__ sp = src + (long)(c0 + c) * s_c + (long)min(max(f0 + r, 0), p.Fin - 1) * s_f;
+                    const int fi = f0 + r;
+                    const bool rok = fi >= 0 && fi < p.Fin;
+                    float* __restrict__ dp = patch + c * plane + r * SWT;
 #pragma unroll
-                    for (int k = 0; k < SWN; ++k) sv[i][k] = sp[min(max(tb + lane + 64 * k, 0), p.Tin - 1)];
-                }
-#pragma unroll
-                for (int i = 0; i < SRB; ++i) {
-                    const int row = row0 + 4 * i;
-                    if (row < cc * NR) {
-                        const int c = row / NR, r = row - c * NR;
-                        const int fi = f0 + r;
-                        const bool rok = fi >= 0 && fi < p.Fin;
-                        float* __restrict__ dp = patch + c * plane + r * SWT;
-#pragma unroll
-                        for (int k = 0; k < SWN; ++k) {
-                            const int w = lane + 64 * k, ti = tb + w;
-                            if (w < SWT) dp[w] = (rok && ti >= 0 && ti < p.Tin) ? sv[i][k] : 0.f;
-                        }
+                    for (int k = 0; k < SWN; ++k) {
+                        const int w = lane + 64 * k, ti = tb + w;
+                        if (w < SWT) dp[w] = (rok && ti >= 0 && ti < p.Tin) ? sv[i][k] : 0.f;
                     }
                 }
             }
+            if (c0 + CC < C) issue(c0 + CC);
             __syncthreads();
             for (int c = 0; c < cc; ++c) {
                 const float* __restrict__ pc = patch + c * plane + tid;
@@ -1442,7 +1451,8 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
     static const int lds_env = getenv("SE_GC_SMALL_LDS") ? atoi(getenv("SE_GC_SMALL_LDS")) : 1;
     const int NR = (SQB - 1) * p.si + (sg.dfmax - sg.dfmin) + 1;
     static const int small_kb = getenv("SE_GC_SMALL_KB") ? atoi(getenv("SE_GC_SMALL_KB")) : 24;       // LDS budget of the staged patch (KB): 2-channel chunks, 6-7 workgroups per CU (40 KB: DCCRN -0.4 %, CTSNet -1.7 %)
-    const int CC = std::min(8, (int)((size_t)small_kb * 1024 / ((size_t)NR * SWT * sizeof(float))));      // <= 8: s_w holds 8 channels
+    // <= 8: s_w holds 8 channels; <= 24 patch rows per chunk: a wave carries 6 rows of the next chunk in registers (gc_small_lds_kernel)
+    const int CC = std::min(std::min(8, 24 / std::max(NR, 1)), (int)((size_t)small_kb * 1024 / ((size_t)NR * SWT * sizeof(float))));
     const long nblk8 = (long)((p.Tout + 255) / 256) * ((p.Q + SQB - 1) / SQB) * p.B * p.Z;
     // (worth it from three frequency rows per output row on: with one or two the plain kernel's caches do as well - CRN /
     // DPCRN last layers measured 1-3 % slower here, DCCRN's 5-tap deconv 1 % faster with a third of the fetches)

@@ -283,11 +283,22 @@ def main():
     local_rank %= ndev
     torch.cuda.set_device(local_rank)
     use_pg = world > 1 or args.force_pg
+    distinct_devices = 1
     if use_pg:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group(args.backend, rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local_rank) if args.backend == 'nccl' else None)
+        # one rank = one GPU: every rank names the device it sits on (uuid / PCI bus id where torch exposes them); over
+        # nccl (= RCCL) the ranks must sit on `world` DISTINCT devices - the line then carries `rccl_ranks` so that a scaling
+        # record shows how many ranks the collective library really saw (VERDICT r5 next #7c)
+        props = torch.cuda.get_device_properties(local_rank)
+        me = (os.uname().nodename, local_rank, str(getattr(props, 'uuid', '')), str(getattr(props, 'pci_bus_id', '')))
+        devs = [None] * world
+        dist.all_gather_object(devs, me)
+        distinct_devices = len(set(devs))
+        if args.backend == 'nccl':
+            assert distinct_devices == world, f"RCCL group of {world} ranks on {distinct_devices} distinct device(s): {devs}"
 
     B, p_in, p_out, seed = args.batch, 0.5, 2.0, 14
     model = DCCRN(rnn_units=256, masking_mode='E', use_clstm=True, kernel_num=[32, 64, 128, 256, 256, 256],
@@ -347,6 +358,8 @@ def main():
             "value": round(value, 2), "unit": "utt/s",
             "rtf": round(dt / (utts * CLIP_SECONDS), 8), "x_realtime": round(value * CLIP_SECONDS, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "rccl_ranks": world if (use_pg and args.backend == 'nccl') else 0,
+            "collective": ({"backend": args.backend, "ranks": world, "distinct_devices": distinct_devices} if use_pg else None),
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded speech-like clips; random-init DCCRN weights)",

@@ -124,6 +124,13 @@ struct GCParams {
     // nullptr for a source: that source is consumed as it is.
     const float* nrm0;
     const float* nrm1;
+    // per launch (gc_launch; equal-length offline batches, causal taps with <= 4 frames of look-back, 16 B staging groups): the
+    // column tiles run over the batch rows' 32-frame UNITS flattened - unit u = b * flat_upr + (t >> 5) - instead of over one
+    // row's frames, so that only the very last tile of a (z, q) plane is partly filled: a T = 401 row is 13 units, which the
+    // 64 x 256 tile (8 units) covered with 2 tiles = 16 slots (81 %), the 64 x 128 / 32 x 128 tiles (4 units) with 4 tiles.
+    // A unit is staged with its own halo (32 + 4 columns of LDS per patch row), its own batch row and first frame.
+    int flat_upr;            // units per row (0: off)
+    int flat_units;          // B * flat_upr
 };
 constexpr int GC_NRM_MAXC = 128;
 
@@ -158,6 +165,9 @@ struct GCPlan {
     bool tail_split = false; // tail[0] may be used as a separate launch for the last time tile
     GCTail tail[3];          // [0]: 32-column geometry for a mostly empty last time tile; [1]: 64-column geometry of the whole layer for small launches; [2]: 256-column geometry of a 64-row layer for big launches
     GCTail qt2;              // two-row geometry: 2 output rows x 64 frames per tile (BN = 0: unused)
+    GCTail flat[2];          // unit-flattened geometries (GCParams::flat_upr): [0] 128 columns = 4 units, [1] 256 columns = 8 units of a
+                             // 64-row layer; Wp = units x flat_uw (BN = 0: unused)
+    int flat_uw = 0;         // LDS columns per unit and patch row: 32 (pointwise) or 36 (causal taps, <= 4 frames of look-back)
     int qt2_nrows = 0, qt2_qoff = 0;
     float* dBias = nullptr;
     float* dSlope = nullptr;

@@ -176,7 +176,9 @@ __device__ __forceinline__ float dpp_add8(float x) {
 // TRIM: the launch stages 16 B groups under taps that look ahead in time (GC_TRIM_TAIL).  A variant of its own: the mere
 // presence of the LDS stores in the K loop costs the other launches 2-10 % (gcbench, 32- / 64-row tiles most).
 // NRM: the sources are raw conv outputs, their InstanceNorm + PReLU is applied to the B-operand fragments (GCParams::nrm0 / nrm1)
-template <int BM, int BN, int WM, int WN, int EPI, bool RES = false, bool TRIM = false, bool FZ = false, bool NRM = false>
+// FLATW > 0 (GCParams::flat_upr): the tile's columns are BN / 32 consecutive 32-frame UNITS of the batch rows flattened, each staged
+// with its own halo - FLATW = LDS columns per unit and patch row (32: pointwise layers, 36: causal taps that look back <= 4 frames)
+template <int BM, int BN, int WM, int WN, int EPI, bool RES = false, bool TRIM = false, bool FZ = false, bool NRM = false, int FLATW = 0>
 __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (BM <= 32 ? 4 : 2) : gc_blocks_per_cu(BM)) void gc_kernel(const GCParams p) {   // (FZ: room for the prefetched pair; 128 x 256: 128 accumulators per lane)
 #ifdef GC_TIMING
     unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -184,6 +186,10 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
 #endif
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
+    constexpr bool FLAT = FLATW > 0;
+    constexpr int UW = FLAT ? FLATW : 32;            // LDS columns between the 32-column sub-tiles of a wave
+    constexpr int UPT = BN / 32;                     // units per tile
+    static_assert(!FLAT || (!RES && !TRIM && !FZ && EPI != EPI_LSTM), "flattened column tiles: plain offline variants only");
     // small-M tiles do little MFMA work per staged K row, so they stage twice the K depth per barrier to keep the
     // global-load latency under the matrix work
     constexpr int KCP_MAX = gc_kcp_max(BM);
@@ -230,12 +236,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     // two-row tiles (p.qt2, gc_launch): the tile's columns are 2 output rows x BN / 2 frames - neighbouring output rows share
     // most of their input rows (5 taps at stride 2: 7 staged rows instead of 10), so a chunk stages ~30 % fewer bytes for the
     // same matrix work.  The waves of the upper column half take the second row; only block-level scalars differ.
-    const bool qt2 = p.qt2 != 0;
+    const bool qt2 = !FLAT && p.qt2 != 0;
     const int q = (rest % p.Qt) << (qt2 ? 1 : 0);
     rest /= p.Qt;
-    const int b = rest % p.B;
-    const int z = rest / p.B;
-    const int t0 = p.t_base + ttile * (qt2 ? BN / 2 : BN);
+    // FLAT: `b` is the batch row of the tile's FIRST unit (the 64-bit bases are taken there, a unit of the next row adds its
+    // batch stride to the 32-bit offsets), `t0` the first frame of that unit; every unit has its own entry in `utab`
+    const int u0 = FLAT ? ttile * UPT : 0;
+    const int b = FLAT ? u0 / p.flat_upr : rest % p.B;
+    const int z = FLAT ? rest : rest / p.B;
+    const int t0 = FLAT ? p.t_base + (u0 - b * p.flat_upr) * 32 : p.t_base + ttile * (qt2 ? BN / 2 : BN);
     const int m0 = mt * BM;
 
     const float* __restrict__ Ag = p.A + (long)z * p.A_z + m0;
@@ -256,8 +265,12 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     float* ep = reinterpret_cast<float*>(tabl + GC_TAB_KOFF + KCP_MAX + 8);      // [4 * BM]
     // NRM: per input channel {scale, shift, slope - 1, x0} of this batch row, and per K row of a staged chunk the same with
     // scale = shift = 0 where the row's frequency tap lies outside the plane (double-buffered with the chunks)
-    floatx4* nrmC = reinterpret_cast<floatx4*>(ep + 4 * BM);                     // [GC_NRM_MAXC]
-    floatx4* nrmK = nrmC + GC_NRM_MAXC;                                          // [2][KCP_MAX] + 2 (the pipeline reads one pair ahead)
+    // (FLAT: a tile's units may lie in two batch rows - both rows' channel parameters, and per buffer both rows' K-row parameters)
+    constexpr int NRMB = FLAT ? 2 : 1;
+    floatx4* nrmC = reinterpret_cast<floatx4*>(ep + 4 * BM);                     // [NRMB][GC_NRM_MAXC]
+    floatx4* nrmK = nrmC + NRMB * GC_NRM_MAXC;                                   // [2][NRMB][KCP_MAX] + 2 (the pipeline reads one pair ahead)
+    // FLAT: per unit k of the tile {batch row - b, first frame, valid, -}
+    int* utab = reinterpret_cast<int*>(nrmC + (NRM ? NRMB * GC_NRM_MAXC + 2 * NRMB * KCP_MAX + 2 : 0));
     // GCParams::cstats: partial column sums of the block's tile, [WM][4 row groups][BN][2] floats (<= 8 KB), combined in a fixed
     // order after a barrier.  Behind the epilogue strips INSIDE the (by then dead) staging area: as 8 KB of their own they pushed the
     // 64 x 256 tile from three to two workgroups per CU (+ 6 ... 23 % per launch in the first form of this epilogue)
@@ -290,12 +303,23 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         }
     }
     if constexpr (NRM) {
-        if (tid < p.C0 + p.C1) {
-            const bool s1 = tid >= p.C0;
+        const int ct_ = p.C0 + p.C1;
+        if (tid < NRMB * ct_) {
+            const int db_ = tid >= ct_ ? 1 : 0, ch_ = tid - db_ * ct_;
+            const bool s1 = ch_ >= p.C0;
             const float* __restrict__ np_ = s1 ? p.nrm1 : p.nrm0;
             floatx4 v = {1.f, 0.f, 0.f, 0.f};
-            if (np_) v = reinterpret_cast<const floatx4*>(np_)[(long)b * (s1 ? p.C1 : p.C0) + (s1 ? tid - p.C0 : tid)];
-            nrmC[tid] = v;
+            if (np_) v = reinterpret_cast<const floatx4*>(np_)[(long)min(b + db_, p.B - 1) * (s1 ? p.C1 : p.C0) + (s1 ? ch_ - p.C0 : ch_)];
+            nrmC[db_ * GC_NRM_MAXC + ch_] = v;
+        }
+    }
+    if constexpr (FLAT) {
+        if (tid < UPT) {
+            const int u_ = u0 + tid, bk_ = u_ / p.flat_upr;
+            utab[4 * tid + 0] = bk_ - b;
+            utab[4 * tid + 1] = p.t_base + (u_ - bk_ * p.flat_upr) * 32;
+            utab[4 * tid + 2] = u_ < p.flat_units ? 1 : 0;
+            utab[4 * tid + 3] = 0;
         }
     }
     for (int i = tid; i < nbuf * Bs_sz / 4; i += 256) reinterpret_cast<floatx4*>(Bs)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -322,12 +346,13 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     // threads < CI_C * nrows also own one patch row each for the left-pad frames of the first time tile
     int nk_cil = 0, pb_cil = 0;
     bool nk_ok = false;
-    const int npadL = NRM ? max(0, -(t0 + p.dtmin)) : 0;       // staged columns in front of frame 0 (block-uniform, multiple of 4)
+    const int npadL = (NRM && !FLAT) ? max(0, -(t0 + p.dtmin)) : 0;       // staged columns in front of frame 0 (block-uniform, multiple of 4; FLAT: per unit, see GC_LOAD_CHUNK)
     if constexpr (NRM) {
-        if (tid < KCP_MAX) {
-            nk_cil = tid / p.ntaps;
-            const int f = q * p.si + tabl[tabl[GC_MAX_ROWS + tid - nk_cil * p.ntaps]];
-            nk_ok = tid < p.KC && f >= 0 && f < p.Fin;
+        if (tid < NRMB * KCP_MAX) {
+            const int kr_ = tid & (KCP_MAX - 1);      // K row (FLAT: threads KCP_MAX.. serve the second batch row's copy)
+            nk_cil = kr_ / p.ntaps;
+            const int f = q * p.si + tabl[tabl[GC_MAX_ROWS + kr_ - nk_cil * p.ntaps]];
+            nk_ok = kr_ < p.KC && f >= 0 && f < p.Fin;
         }
         pb_cil = tid / p.nrows;
     }
@@ -359,9 +384,10 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     const int wq = (qt2 && WN >= 2) ? wn / WNT : 0;     // output row of this wave inside the tile
     const int wt = (qt2 && WN >= 2) ? wn % WNT : wn;    // its 32 * TN-frame strip inside the row
     const int am = wm * (TM * 32) + l31;      // A column base inside the tile
-    const int bn = wq * p.qq_off + wt * (TN * 32) + l31;      // B column base inside the staged patch
-    // 32-column sub-tiles of this wave with a frame below Tout (wave-uniform)
-    const int jact = (q + wq >= p.Q) ? 0 : max(0, min(TN, (p.Tout - t0 - wt * (TN * 32) + 31) >> 5));
+    const int bn = FLAT ? wn * (TN * UW) + l31 : wq * p.qq_off + wt * (TN * 32) + l31;      // B column base inside the staged patch
+    // 32-column sub-tiles of this wave with a frame below Tout (wave-uniform; FLAT: units below the end of the batch)
+    const int jact = FLAT ? max(0, min(TN, p.flat_units - u0 - wn * TN))
+                          : (q + wq >= p.Q) ? 0 : max(0, min(TN, (p.Tout - t0 - wt * (TN * 32) + 31) >> 5));
 
     int gchunk = 0;          // global chunk counter (weights are packed segment after segment)
     int buf = 0;
@@ -387,13 +413,17 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             const int w = d_ & 0xfff, r = (d_ >> 12) & 0xf, cil = (d_ >> 16) & 0x7fff;             \
             const bool staged = (d_ >> 31) != 0;                                                   \
             const int f = q * p.si + tabl[staged ? r : 0];                                         \
-            const int t = t0 + p.dtmin + w;                                                        \
+            /* FLAT: column w of the patch row belongs to unit w / UW - its own batch row, first frame and validity */ \
+            const int uk_ = FLAT ? min(w / UW, UPT - 1) : 0;                                       \
+            const int t = FLAT ? utab[4 * uk_ + 1] + p.dtmin + (w - uk_ * UW) : t0 + p.dtmin + w;  \
+            const bool uok_ = !FLAT || utab[4 * uk_ + 2] != 0;                                     \
+            const unsigned ub_ = (FLAT && uok_) ? (unsigned)utab[4 * uk_] * sb32 : 0u;             \
             const int fc = f < 0 ? 0 : (f >= p.Fin ? p.Fin - 1 : f);                               \
             const int tc = t < 0 ? 0 : (t >= p.Tin ? p.Tin - 1 : t);                               \
             const int cc = cil < lim_ ? cil : lim_ - 1;                                            \
-            boff[e] = staged ? 4u * ((unsigned)cc * sc32 + (unsigned)fc * sf32 + (unsigned)tc) : 0u;   /* bytes */ \
+            boff[e] = staged ? 4u * (ub_ + (unsigned)cc * sc32 + (unsigned)fc * sf32 + (unsigned)tc) : 0u;   /* bytes */ \
             /* pw4: the slot is a group of 4 frames; never straddles frame 0, may straddle Tin (see gc_launch)   */ \
-            vbits |= (staged && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? (1u << e) : 0u; \
+            vbits |= (staged && uok_ && (cil < lim_) && (f >= 0) && (f < p.Fin) && (t >= 0) && (t < p.Tin)) ? (1u << e) : 0u; \
             /* non-causal taps: a 16 B group that straddles the end of its row is trimmed in LDS after it lands (bits 16..) */ \
             if (fixt) vbits |= (staged && (t < p.Tin) && (t + 4 > p.Tin)) ? (0x10000u << e) : 0u;   \
         });                                                                                        \
@@ -426,18 +456,31 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             /* the buffer is free (its readers passed the last barrier): its K-row parameters and, in the first time tile, */ \
             /* the left-pad frames as the value the normalisation maps to zero (the masked DMA never touches them)        */ \
             const int cb_ = (CH) * p.CI_C, co_ = seg ? p.C0 : 0;                                   \
-            if (tid < KCP_MAX) {                                                                   \
-                floatx4 v_ = nrmC[min(cb_ + nk_cil, Cseg - 1) + co_];                              \
+            if (tid < NRMB * KCP_MAX) {                                                            \
+                const int db_ = tid >= KCP_MAX ? 1 : 0;                                            \
+                floatx4 v_ = nrmC[db_ * GC_NRM_MAXC + min(cb_ + nk_cil, Cseg - 1) + co_];          \
                 if (!nk_ok) {                                                                      \
                     v_[0] = 0.f;                                                                   \
                     v_[1] = 0.f;                                                                   \
                 }                                                                                  \
-                nrmK[(BUF) * KCP_MAX + tid] = v_;                                                  \
+                nrmK[(BUF) * (NRMB * KCP_MAX) + tid] = v_;                                         \
             }                                                                                      \
             if (npadL > 0 && tid < rows) {                                                         \
                 const float x0_ = nrmC[min(cb_ + pb_cil, Cseg - 1) + co_][3];                      \
                 float* d_ = Bs + (BUF) * Bs_sz + tid * p.Wp;                                       \
                 for (int w_ = 0; w_ < npadL; w_ += 4) *reinterpret_cast<floatx4*>(d_ + w_) = floatx4{x0_, x0_, x0_, x0_}; \
+            }                                                                                      \
+            if constexpr (FLAT) {      /* every unit that starts a row: its halo columns (frames < 0) as that row's x0 */ \
+                if (tid < rows && p.dtmin < 0) {                                                   \
+                    _Pragma("unroll") for (int k_ = 0; k_ < UPT; ++k_) {                           \
+                        if (utab[4 * k_ + 1] + p.dtmin < 0 && utab[4 * k_ + 2]) {                  \
+                            const float x0_ = nrmC[utab[4 * k_] * GC_NRM_MAXC + min(cb_ + pb_cil, Cseg - 1) + co_][3]; \
+                            float* d_ = Bs + (BUF) * Bs_sz + tid * p.Wp + k_ * UW;                 \
+                            for (int w_ = 0; w_ < -(utab[4 * k_ + 1] + p.dtmin); w_ += 4)          \
+                                *reinterpret_cast<floatx4*>(d_ + w_) = floatx4{x0_, x0_, x0_, x0_}; \
+                        }                                                                          \
+                    }                                                                              \
+                }                                                                                  \
             }                                                                                      \
         }                                                                                          \
         /* both operands go global -> LDS by DMA: no staging registers, no ds_write phase; the activation patch first */ \
@@ -479,6 +522,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             (seg ? p.src1 + (long)z * p.src1_z + (long)b * p.s1_b : p.src0 + (long)z * p.src0_z + (long)b * p.s0_b);
         const long s_c = seg ? p.s1_c : p.s0_c, s_f = seg ? p.s1_f : p.s0_f;
         const unsigned sc32 = (unsigned)s_c, sf32 = (unsigned)s_f;      // patch offsets inside one chunk fit 32 bits
+        const unsigned sb32 = (unsigned)(seg ? p.s1_b : p.s0_b);        // (FLAT: a unit of the next batch row; gc_launch checks the range)
         const int nch = (Cseg + p.CI_C - 1) / p.CI_C;
         const int tail = Cseg - (nch - 1) * p.CI_C;       // channels in the last chunk
 
@@ -527,7 +571,13 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // ---- MFMA over the staged chunk: two k-pairs (8 MFMAs at TM = TN = 2) per operand fetch
             const float* Ab = As + buf * As_sz + hi * BM + am;
             const float* Bb = Bs + buf * Bs_sz + bn;
-            const floatx4* nkb = nrmK + buf * KCP_MAX + hi;       // (NRM) parameters of K row 2 kp + hi
+            const floatx4* nkb = nrmK + buf * (NRMB * KCP_MAX) + hi;       // (NRM) parameters of K row 2 kp + hi
+            // (FLAT) the batch row (0 / 1 relative to the tile's first) of each of this wave's units, as offsets into nrmK
+            int nkd[FLAT && NRM ? TN : 1];
+            if constexpr (FLAT && NRM) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) nkd[j] = utab[4 * min(wn * TN + j, UPT - 1)] * KCP_MAX;
+            }
             const int npair = p.KCp >> 1;
             // software pipeline, depth 1: the operands of k-pair kp+1 are fetched (ds_read2_b32) before the MFMAs of
             // k-pair kp issue; sched_group_barrier pins "2 DS reads, then 4 MFMAs" so the LDS latency sits under
@@ -538,10 +588,17 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         if constexpr (KOFF_REGS) o_ = koffv[(KP) < NPAIR ? (KP) : NPAIR - 1];                      \
         else o_ = koff_lds[2 * (KP) + hi];                                                         \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) AR[i] = Ab[(2 * (KP)) * BM + i * 32];       \
-        _Pragma("unroll") for (int j = 0; j < JN; ++j) BR[j] = Bb[o_ + j * 32];                    \
-        if constexpr (NRM) {                                                                       \
+        _Pragma("unroll") for (int j = 0; j < JN; ++j) BR[j] = Bb[o_ + j * UW];                    \
+        if constexpr (NRM && !FLAT) {                                                              \
             const floatx4 pr_ = nkb[2 * (KP)];                                                     \
             _Pragma("unroll") for (int j = 0; j < JN; ++j) {                                       \
+                const float t_ = fmaf(BR[j], pr_[0], pr_[1]);                                      \
+                BR[j] = fmaf(fminf(t_, 0.f), pr_[2], t_);                                          \
+            }                                                                                      \
+        }                                                                                          \
+        if constexpr (NRM && FLAT) {                                                               \
+            _Pragma("unroll") for (int j = 0; j < JN; ++j) {                                       \
+                const floatx4 pr_ = nkb[2 * (KP) + nkd[j]];                                        \
                 const float t_ = fmaf(BR[j], pr_[0], pr_[1]);                                      \
                 BR[j] = fmaf(fminf(t_, 0.f), pr_[2], t_);                                          \
             }                                                                                      \
@@ -567,7 +624,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     if (kp < np_) {
                         // (NRM: one more DS read - the K rows' parameters - and three vector instructions per B value, placed
                         // behind the matrix instructions of the k-pair in flight)
-                        constexpr int NDS = (TM + 1) / 2 + (JN + 1) / 2 + (NRM ? 1 : 0);
+                        constexpr int NDS = (TM + 1) / 2 + (JN + 1) / 2 + (NRM ? (FLAT ? JN : 1) : 0);
                         GC_FETCH(kp + 1, ay, by);
                         __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
                         GC_MMA(ax, bx);
@@ -648,18 +705,28 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         auto epi_tile = [&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             if (j > 0) GC_WAVE_FENCE();                          // the previous column tile has been read back
+            // FLAT: this column tile is one unit - its own batch row (an offset on every per-row pointer), first frame and validity
+            const int uk = FLAT ? min(wn * TN + j, UPT - 1) : 0;
+            const long dbJ = FLAT ? utab[4 * uk] : 0;
+            const int tj0 = FLAT ? utab[4 * uk + 1] : t0 + wt * (TN * 32) + j * 32;
+            const int MoJ = (!FLAT || utab[4 * uk + 2]) ? Mo : 0;
+            float* __restrict__ dstJ = dst + dbJ * p.d_b;
+            const float* __restrict__ resJ = res ? res + dbJ * p.x_b : nullptr;
+            const float* __restrict__ cmbiJ = cmbi ? cmbi + dbJ * p.d_b : nullptr;
+            float* __restrict__ cmbsJ = cmbs ? cmbs + dbJ * p.d_b : nullptr;
+            float* __restrict__ deluJ = delu ? delu + dbJ * p.d_b : nullptr;
             // residual / interaction operands of this column tile: all of a wave's loads issued here, ahead of the transposition
             // (one load -> wait -> store per 8 rows left an EPI_ADD tile waiting on 8 HBM round trips in a row: the pointwise
             // layers of Uformer's conformer ran at 0.22 of the matrix peak)
             constexpr bool PRE = (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_CMB);
-            const int tgp = t0 + wt * (TN * 32) + j * 32 + lc;
+            const int tgp = tj0 + lc;
             floatx4 rvp[PRE ? OROWS / 8 : 1], zre[FZ ? OROWS / 8 : 1], zim[FZ ? OROWS / 8 : 1], ivp[EPI == EPI_CMB ? OROWS / 8 : 1];
-            if ((PRE || FZ) && tgp + 3 < p.Tout && Mo > 0) {
+            if ((PRE || FZ) && tgp + 3 < p.Tout && MoJ > 0) {
 #pragma unroll
                 for (int it = 0; it < OROWS / 8; ++it) {
-                    const int m = min(mo0 + it * 8 + lr, Mo - 1);      // clamped: rows past M are loaded, not used
-                    if (PRE) rvp[it] = *reinterpret_cast<const floatx4*>(res + (long)m * p.x_c + tgp);
-                    if (EPI == EPI_CMB && cmbi) ivp[it] = *reinterpret_cast<const floatx4*>(cmbi + (long)m * p.d_c + tgp);
+                    const int m = min(mo0 + it * 8 + lr, MoJ - 1);      // clamped: rows past M are loaded, not used
+                    if (PRE) rvp[it] = *reinterpret_cast<const floatx4*>(resJ + (long)m * p.x_c + tgp);
+                    if (EPI == EPI_CMB && cmbiJ) ivp[it] = *reinterpret_cast<const floatx4*>(cmbiJ + (long)m * p.d_c + tgp);
                     if (FZ) {
                         zre[it] = *reinterpret_cast<const floatx4*>(fzb + (long)m * p.fz_c + tgp);
                         zim[it] = *reinterpret_cast<const floatx4*>(fzb + (long)m * p.fz_c + tgp + p.fz_im);
@@ -717,7 +784,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             }
             GC_WAVE_FENCE();
             // read back as rows: 8 lanes x 16 B cover the 32 columns of one row, 8 rows per wave instruction
-            const int tg = t0 + wt * (TN * 32) + j * 32 + lc;
+            const int tg = tj0 + lc;
             // (a rolled loop where nothing indexes registers by `it`: eight copies of the store path - vector form, ragged mask,
             // frame-by-frame tail - were 6 KB of instructions per kernel that every workgroup streamed through once)
             constexpr int RB_UNROLL = (PRE || FZ) ? OROWS / 8 : 1;
@@ -727,7 +794,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                 const int row = it * 8 + lr, m = mo0 + row;
                 floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * OST + lc);
                 if constexpr (GC_STATS) {
-                    if (p.cstats && m < Mo) {
+                    if (p.cstats && m < MoJ) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float xk = (tg + k < p.Tout) ? v[k] : 0.f;
@@ -750,15 +817,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                         s = dpp_add8(s);
                         q = dpp_add8(q);
                         const int tb = tg - lc;                  // first frame of the sub-tile
-                        if ((lane & 7) == 0 && m < Mo && tb < p.Tout) {
-                            float* sp = p.stats + (long)b * p.st_b + (long)m * p.st_c + (long)fow * p.st_f + (tb >> 5) * 2;
+                        if ((lane & 7) == 0 && m < MoJ && tb < p.Tout) {
+                            float* sp = p.stats + (long)(b + dbJ) * p.st_b + (long)m * p.st_c + (long)fow * p.st_f + (tb >> 5) * 2;
                             sp[0] = s;
                             sp[1] = q;
                         }
                     }
                 }
-                if (m < Mo) {
-                    float* __restrict__ dp = dst + (long)m * p.d_c + tg;
+                if (m < MoJ) {
+                    float* __restrict__ dp = dstJ + (long)m * p.d_c + tg;
                     if (__builtin_expect(tg + 3 < p.Tout, 1)) {
                         if (EPI == EPI_ADD || EPI == EPI_MUL) v = (EPI == EPI_ADD) ? v + rvp[it] : v * rvp[it];
                         if (EPI == EPI_CMB) {
@@ -790,39 +857,39 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                             if (p.fz_s) *reinterpret_cast<floatx4*>(zr + p.fz_s) = re + ii;      // S = R + I of a three-plane tensor
                         }
                         *reinterpret_cast<floatx4*>(dp) = v;
-                        if (EPI == EPI_GLU && delu) {
+                        if (EPI == EPI_GLU && deluJ) {
                             floatx4 e4;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) e4[k] = v[k] > 0.f ? v[k] : fm_expm1(v[k]);
-                            *reinterpret_cast<floatx4*>(delu + (long)m * p.d_c + tg) = e4;
+                            *reinterpret_cast<floatx4*>(deluJ + (long)m * p.d_c + tg) = e4;
                         }
-                        if (EPI == EPI_CMB && cmbs) {
+                        if (EPI == EPI_CMB && cmbsJ) {
                             floatx4 s4 = v + ivp[it];
                             if (__builtin_expect(tg + 3 >= tvalid, 0)) {
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) s4[k] = (tg + k < tvalid) ? s4[k] : 0.f;
                             }
-                            *reinterpret_cast<floatx4*>(cmbs + (long)m * p.d_c + tg) = s4;
+                            *reinterpret_cast<floatx4*>(cmbsJ + (long)m * p.d_c + tg) = s4;
                         }
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (tg + k < p.Tout) {
                                 float o = v[k];
-                                if (EPI == EPI_ADD) o += res[(long)m * p.x_c + tg + k];
-                                if (EPI == EPI_MUL) o *= res[(long)m * p.x_c + tg + k];
+                                if (EPI == EPI_ADD) o += resJ[(long)m * p.x_c + tg + k];
+                                if (EPI == EPI_MUL) o *= resJ[(long)m * p.x_c + tg + k];
                                 if (EPI == EPI_CMB) {
                                     const int rt = wm * (TM * 32) + row;
-                                    const float u = fmaf(fmaf(cmb_sg, o, res[(long)m * p.x_c + tg + k]), ep[2 * BM + rt], ep[rt]);
+                                    const float u = fmaf(fmaf(cmb_sg, o, resJ[(long)m * p.x_c + tg + k]), ep[2 * BM + rt], ep[rt]);
                                     o = u >= 0.f ? u : ep[BM + rt] * u;
                                 }
                                 o = (tg + k < tvalid) ? o : 0.f;
                                 if (FZ) o = gc_fuse1(o, fzb + (long)m * p.fz_c + tg + k, p.fz_im, p.fz_s);
                                 dp[k] = o;
-                                if (EPI == EPI_GLU && delu) delu[(long)m * p.d_c + tg + k] = o > 0.f ? o : fm_expm1(o);
-                                if (EPI == EPI_CMB && cmbs) {
-                                    const float iv = cmbi[(long)m * p.d_c + tg + k];
-                                    cmbs[(long)m * p.d_c + tg + k] = (tg + k < tvalid) ? o + iv : 0.f;
+                                if (EPI == EPI_GLU && deluJ) deluJ[(long)m * p.d_c + tg + k] = o > 0.f ? o : fm_expm1(o);
+                                if (EPI == EPI_CMB && cmbsJ) {
+                                    const float iv = cmbiJ[(long)m * p.d_c + tg + k];
+                                    cmbsJ[(long)m * p.d_c + tg + k] = (tg + k < tvalid) ? o + iv : 0.f;
                                 }
                             }
                     }
@@ -865,9 +932,11 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                         a += cpart[(w * BN + col) * 2];
                         c2 += cpart[(w * BN + col) * 2 + 1];
                     }
-                    const int t = t0 + col;
-                    if (t < p.Tout && fo < p.so * p.Q + p.po) {
-                        float* cg = p.cstats + (long)b * p.cs_b + (long)fo * p.cs_f + 2 * t;
+                    const int ukc = FLAT ? col >> 5 : 0;      // FLAT: the column's unit - its batch row and first frame
+                    const int t = FLAT ? utab[4 * ukc + 1] + (col & 31) : t0 + col;
+                    const long bc = FLAT ? b + utab[4 * ukc] : b;
+                    if (t < p.Tout && fo < p.so * p.Q + p.po && (!FLAT || utab[4 * ukc + 2])) {
+                        float* cg = p.cstats + bc * p.cs_b + (long)fo * p.cs_f + 2 * t;
                         cg[0] = a;
                         cg[1] = c2;
                     }
@@ -1494,7 +1563,8 @@ static void gc_small_launch(const GCParams& p, const GCSmallGeom& sg, hipStream_
 // ------------------------------------------------------------------------------------------------
 static size_t gc_lds_bytes(const GCParams& p, int BM, size_t epi_bytes, int nbuf = 2) {
     const size_t as = (size_t)((p.KCp * (BM / 4) + 255) / 256) * 1024, bs = (size_t)((p.CI_C * p.nrows * p.Wp + 255) / 256) * 256;
-    const size_t nrm = (p.nrm0 || p.nrm1) ? (size_t)(GC_NRM_MAXC + 2 * gc_kcp_max(BM) + 2) * 16 : 0;      // gc_kernel NRM: nrmC + nrmK
+    const size_t nrb = p.flat_upr ? 2 : 1;      // FLAT: parameters of two batch rows
+    const size_t nrm = ((p.nrm0 || p.nrm1) ? (size_t)(nrb * GC_NRM_MAXC + 2 * nrb * gc_kcp_max(BM) + 2) * 16 : 0) + (p.flat_upr ? 128 : 0);      // gc_kernel NRM: nrmC + nrmK; FLAT: utab
     const size_t cst = p.cstats ? (size_t)4 * 256 * 2 * 4 : 0;      // GCParams::cstats: cpart [WM][4][BN][2] <= 8 KB, behind the strips inside the staging area
     return std::max((size_t)nbuf * (as + bs) * 4, epi_bytes + cst) + (GC_TAB_KOFF + GC_MAX_KCP + 8) * 4 + (size_t)4 * BM * 4 + 64 + nrm;
 }
@@ -1676,6 +1746,23 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
             pl.tail[2].Wp = 256;
             pl.tail[2].g = gc_build_geom(taps, rows, dtmin, p.nrows, 256, cic, p.KC, gc_bld_max(pl.BM));
         }
+        // unit-flattened geometries (GCParams::flat_upr): every 32-frame unit of the tile with its own halo
+        static const int flat_env = getenv("SE_GC_FLAT") ? atoi(getenv("SE_GC_FLAT")) : 1;
+        if (flat_env && pl.BM == 64 && pl.BN == 128 && epi != EPI_LSTM && p.causal && dtmin >= -4 && Z == 1) {
+            const int uw = 32 - dtmin;      // 32 or 36
+            pl.flat_uw = uw;
+            const int nbk = gc_bld_max(pl.BM);
+            if ((long)cic * p.nrows * 4 * uw <= (long)nbk * 256 * 4) {
+                pl.flat[0].BN = 128;
+                pl.flat[0].Wp = 4 * uw;
+                pl.flat[0].g = gc_build_geom(taps, rows, dtmin, p.nrows, 4 * uw, cic, p.KC, nbk);
+            }
+            if (pl.BM == 64 && (long)cic * p.nrows * 8 * uw <= 4608) {      // (5 x 256 groups, 3 workgroups' LDS - as the plain 64 x 256 tile)
+                pl.flat[1].BN = 256;
+                pl.flat[1].Wp = 8 * uw;
+                pl.flat[1].g = gc_build_geom(taps, rows, dtmin, p.nrows, 8 * uw, cic, p.KC, nbk);
+            }
+        }
         if (pl.BN == 128 && (pl.BM == 64 || pl.BM == 128) && epi != EPI_LSTM) {
             pl.tail[1].BN = 64;
             pl.tail[1].Wp = 64 + (dtmax - dtmin);
@@ -1795,6 +1882,12 @@ void gc_free_plan(GCPlan& pl) {
         if (t.g.desc4) (void)hipFree(t.g.desc4);
         t = GCTail{};
     }
+    for (auto& t : pl.flat) {
+        if (t.g.tab) (void)hipFree(t.g.tab);
+        if (t.g.desc) (void)hipFree(t.g.desc);
+        if (t.g.desc4) (void)hipFree(t.g.desc4);
+        t = GCTail{};
+    }
     pl.dWs = nullptr;
     pl.dDesc = nullptr;
     if (pl.dBias) (void)hipFree(pl.dBias);
@@ -1809,6 +1902,39 @@ void gc_free_plan(GCPlan& pl) {
     pl.dA = pl.dBias = pl.dSlope = nullptr;
 }
 
+// kernel variants with unit-flattened column tiles (GCParams::flat_upr) that are instantiated: the tiles whose last time tile
+// of a T = 401 row is mostly padding, for the epilogues the zoo uses on them
+// (64-row tiles only.  Measured in round 6 on one box, batch 256, T = 401, flattened against plain tiles with identical output
+// hashes: 64 -> 64 channels at F = 79 on the 64 x 256 tile 3.43 -> 3.17 ms; 32 -> 32 channels on the 32 x 128 tile 1.13 -> 1.26 ms -
+// that tile is bound by its staging, not by matrix slots, and a unit's own halo is 9 % more bytes; 64 -> 128 channels on the
+// 128 x 128 tile 5.61 -> 5.63 ms against three full tiles + the 32-column tail launch, CTSNet as a whole 3 138 -> 3 017 utt/s)
+constexpr bool gc_flat_inst(int BM, int BN, int EPI, int UWv) {
+    const bool tile = BM == 64 && (BN == 256 || BN == 128);
+    if (!tile) return false;
+    if (UWv == 36) return EPI == EPI_ACT || EPI == EPI_GLU || (EPI == EPI_CMB && BN == 256);
+    if (UWv == 32) return EPI == EPI_ACT || (EPI == EPI_ADD && BN == 128);
+    return false;
+}
+static bool gc_flat_supported(int BM, int BN, int epi, int uw) {
+    switch (epi) {
+        case EPI_ACT: return gc_flat_inst(BM, BN, EPI_ACT, uw);
+        case EPI_ADD: return gc_flat_inst(BM, BN, EPI_ADD, uw);
+        case EPI_GLU: return gc_flat_inst(BM, BN, EPI_GLU, uw);
+        case EPI_CMB: return gc_flat_inst(BM, BN, EPI_CMB, uw);
+        default: return false;
+    }
+}
+template <int BM, int BN, int WM, int WN, int EPI, bool NRMv, int UWv>
+static void gc_launch_flat_k(const GCParams& p, long nblk, size_t lds, hipStream_t stream) {
+    static bool attr_fl[64] = {};
+    if (first_on_device(attr_fl)) {
+        SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI, false, false, false, NRMv, UWv>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipLaunchKernelGGL((gc_kernel<BM, BN, WM, WN, EPI, false, false, false, NRMv, UWv>), dim3((unsigned)nblk), dim3(256), lds, stream, p);
+    SE_HIP(hipGetLastError());
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, bool RES = false>
 static void gc_launch_e(const GCParams& p_in, hipStream_t stream) {
     // epilogue: 4*BM row parameters + one transposition strip per wave (rows x (cols + 4))
@@ -1819,9 +1945,43 @@ static void gc_launch_e(const GCParams& p_in, hipStream_t stream) {
         SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gc_kernel<BM, BN, WM, WN, EPI, RES>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    const long nblk = (long)p_in.Z * p_in.B * p_in.Qt * p_in.n_ttiles * p_in.n_mtiles;
+    const long nblk = (long)p_in.Z * (p_in.flat_upr ? 1 : p_in.B) * p_in.Qt * p_in.n_ttiles * p_in.n_mtiles;
     SE_CHECK(nblk > 0 && nblk < (1L << 31), "grid size");
     const GCParams& p = p_in;
+    if (p.flat_upr) {        // unit-flattened column tiles (gc_launch decided; only the instantiated variants get here)
+        const int uw = p.Wp / (BN / 32);
+        SE_CHECK(!RES && !p.fz && !p.trim && !p.tlen && !p.qt2 && p.pw4 && p.t_base == 0, "gc_launch: flattened tiles on a launch they do not cover");
+        const bool nrm = p.nrm0 || p.nrm1;
+        if constexpr (!RES && gc_flat_inst(BM, BN, EPI, 36)) {
+            if (uw == 36) {
+                if constexpr (EPI == EPI_ACT && BM == 64) {
+                    if (nrm) {
+                        SE_CHECK(p.causal && p.Z == 1 && p.C0 + p.C1 <= GC_NRM_MAXC, "gc_launch: on-the-fly InstanceNorm needs causal taps and <= 128 input channels");
+                        gc_launch_flat_k<BM, BN, WM, WN, EPI, true, 36>(p, nblk, lds, stream);
+                        return;
+                    }
+                }
+                SE_CHECK(!nrm, "gc_launch: this flattened variant cannot normalise its sources on the fly");
+                gc_launch_flat_k<BM, BN, WM, WN, EPI, false, 36>(p, nblk, lds, stream);
+                return;
+            }
+        }
+        if constexpr (!RES && gc_flat_inst(BM, BN, EPI, 32)) {
+            if (uw == 32) {
+                if constexpr (EPI == EPI_ACT && BM == 64) {
+                    if (nrm) {
+                        SE_CHECK(p.causal && p.Z == 1 && p.C0 + p.C1 <= GC_NRM_MAXC, "gc_launch: on-the-fly InstanceNorm needs causal taps and <= 128 input channels");
+                        gc_launch_flat_k<BM, BN, WM, WN, EPI, true, 32>(p, nblk, lds, stream);
+                        return;
+                    }
+                }
+                SE_CHECK(!nrm, "gc_launch: this flattened variant cannot normalise its sources on the fly");
+                gc_launch_flat_k<BM, BN, WM, WN, EPI, false, 32>(p, nblk, lds, stream);
+                return;
+            }
+        }
+        SE_CHECK(false, "gc_launch: no flattened variant of this kernel");
+    }
     if constexpr ((EPI == EPI_ACT || EPI == EPI_ADD) && !RES) {
         if (p.fz) {          // branch interaction folded into the store (GCParams::fz)
             SE_CHECK(!p.trim && !p.stats, "gc_launch: no trimming / statistics variant of the kernel with the folded interaction");
@@ -1997,6 +2157,48 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
                 gc_launch_t<128, 64, 4, 1>(pa, stream);
             }
             return;
+        }
+    }
+    // unit-flattened column tiles (GCParams::flat_upr): equal-length offline batches whose rows do not fill their last time tile.
+    // T = 401 is 13 units of 32 frames: 2 tiles of 256 / 4 tiles of 128 columns per row hold 16, the flattened batch needs
+    // 13 B / 8 (or / 4) tiles - 19 % fewer workgroups for the same stored values
+    {
+        static const int flat_env = getenv("SE_GC_FLAT") ? atoi(getenv("SE_GC_FLAT")) : 1;
+        static const long flat_min = getenv("SE_GC_FLAT_MIN") ? atol(getenv("SE_GC_FLAT_MIN")) : 1024;
+        static const long wide_min = getenv("SE_GC_WIDE_MIN") ? atol(getenv("SE_GC_WIDE_MIN")) : 6144;
+        const long nblk = (long)p.Z * p.B * p.Q * p.n_ttiles * p.n_mtiles;      // (128-column tiles)
+        const int upr = (Tspan + 31) / 32;
+        const double sbmax = 4.0 * (double)std::max(p.s0_b, p.s1_b);
+        // (A/B switch: SE_GC_FLAT_QT2=0 keeps the two-row tiles where they apply)
+        static const int flat_qt2 = getenv("SE_GC_FLAT_QT2") ? atoi(getenv("SE_GC_FLAT_QT2")) : 1;
+        static const int qt2_env_f = getenv("SE_GC_QT2") ? atoi(getenv("SE_GC_QT2")) : 1;
+        static const long qt2_min_f = getenv("SE_GC_QT2_MIN") ? atol(getenv("SE_GC_QT2_MIN")) : 4096;
+        const bool would_qt2 = qt2_env_f && pl.qt2.BN == 64 && pl.BN == 128 && p.Q >= 2 && !p.stats && !p.cstats && p.pad_lo == 0 &&
+                               !p.nrm0 && !p.nrm1 && nblk >= qt2_min_f;
+        if (flat_env && pl.BM == 64 && pl.flat_uw && tb == 0 && !p.tlen && p.pw4 && !p.trim && !p.fz && p.Z == 1 && nblk >= flat_min && p.B > 1 &&
+            true) {
+            // tile width as the plain path would choose it
+            const bool wide = pl.BM == 64 && pl.flat[1].BN == 256 && nblk >= wide_min && gc_flat_supported(64, 256, p.epi, pl.flat_uw);
+            const GCTail& fg = wide ? pl.flat[1] : pl.flat[0];
+            const int upt = wide ? 8 : 4;
+            const long tiles_plain = (long)p.B * ((Tspan + 32 * upt - 1) / (32 * upt));
+            const long tiles_flat = ((long)p.B * upr + upt - 1) / upt;
+            // (a unit of a later batch row adds (rows ahead) x batch stride to a 32-bit byte offset)
+            const double span = ((double)(upt + upr - 1) / upr + 1.0) * sbmax;
+            if (fg.BN && gc_flat_supported(pl.BM, fg.BN, p.epi, pl.flat_uw) && tiles_flat * 100 <= tiles_plain * 94 && span < 3.0e9 &&
+                (wide || flat_qt2 || !would_qt2)) {
+                GCParams pa = p;
+                pa.flat_upr = upr;
+                pa.flat_units = p.B * upr;
+                pa.n_ttiles = (int)tiles_flat;
+                pa.Wp = fg.Wp;
+                pa.tab = fg.g.tab;
+                pa.desc = fg.g.desc;
+                pa.desc4 = fg.g.desc4;
+                if (wide) gc_launch_t<64, 256, 1, 4>(pa, stream);
+                else gc_launch_t<64, 128, 2, 2>(pa, stream);
+                return;
+            }
         }
     }
     // big launches of a 64-row layer: 64 x 256 tiles when the patch goes in 16 B groups (4 x fewer slots), the rows fill the

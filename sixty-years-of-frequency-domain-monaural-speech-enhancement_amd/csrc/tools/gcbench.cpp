@@ -316,5 +316,14 @@ int main(int argc, char** argv) {
 #endif
     printf("Cin=%d Cout=%d Fin=%d B=%d T=%d BM=%d BN=%d CI_C=%d KCp=%d: %.3f ms  %.1f TFLOP/s\n", Cin, Cout, Fin, B, T, pl.BM, pl.BN,
            pl.p.CI_C, pl.p.KCp, ms, fl / ms / 1e9);
+    {   // FNV-1a over the output bytes: two runs with different tilings (SE_GC_FLAT=0 / 1, ...) must print the same value - every
+        // output is the same fmaf chain over K whatever tile computed it
+        std::vector<float> ho(nout);
+        SE_HIP(hipMemcpy(ho.data(), dout, nout * 4, hipMemcpyDeviceToHost));
+        unsigned long long h = 1469598103934665603ull;
+        const unsigned* u = reinterpret_cast<const unsigned*>(ho.data());
+        for (size_t i = 0; i < nout; ++i) { h ^= u[i]; h *= 1099511628211ull; }
+        printf("output hash %016llx\n", h);
+    }
     return 0;
 }

@@ -36,9 +36,19 @@ def test_bench_self_launches_two_ranks_from_a_bare_shell():
     assert r['steps'] == 2 and r['warmup'] == 1 and r['scaling'] == 'weak'
 
 
+def test_bench_self_launches_eight_ranks_from_a_bare_shell():
+    """The launch shape of the driver's last scaling point (N = 8) on the one GPU this box has: eight self-launched ranks share
+    the device, three timed steps so that both GatherPipe slots wrap, gather over gloo (RCCL refuses ranks that share a device)."""
+    r = _run(['--gpus', '8', '--batch', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-profile', '--backend', 'gloo'],
+             env={'SE_BENCH_SHARE_GPU': '1'}, timeout=900)
+    assert r['n_gpus'] == 8 and r['config']['global_batch'] == 16 and r['value'] > 0
+    assert r['collective'] == {'backend': 'gloo', 'ranks': 8, 'distinct_devices': 1} and r['rccl_ranks'] == 0
+
+
 def test_bench_single_rank_gather_over_rccl():
     r = _run(['--gpus', '1', '--batch', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--force-pg'])
     assert r['n_gpus'] == 1 and r['value'] > 0
+    assert r['rccl_ranks'] == 1 and r['collective']['backend'] == 'nccl' and r['collective']['distinct_devices'] == 1
 
 
 def test_bench_rejects_more_ranks_than_gpus():

@@ -70,12 +70,13 @@ def _worker(rank, world, port, n_items, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_items', [6, 7])
-def test_sharded_decode_gather_gloo(tmp_path, n_items):
-    """The N > 1 path of bench.py / decode: contiguous utterance shards, gather to rank 0 (even and uneven)."""
+@pytest.mark.parametrize('world,n_items', [(2, 6), (2, 7), (4, 8), (4, 11), (8, 16), (8, 21), (8, 5)])
+def test_sharded_decode_gather_gloo(tmp_path, world, n_items):
+    """The N > 1 path of bench.py / decode: contiguous utterance shards, gather to rank 0 - even and uneven shards at 2, 4 and
+    8 ranks (the driver's scaling run launches N = 1, 2, 4, 8), and fewer items than ranks (empty shards)."""
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 1000) + n_items
-    mp.spawn(_worker, args=(2, port, n_items, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 1000) + 3 * n_items + world
+    mp.spawn(_worker, args=(world, port, n_items, str(tmp_path)), nprocs=world, join=True)
     out = torch.load(os.path.join(str(tmp_path), 'out.pt'))
     ref = torch.arange(n_items * 5, dtype=torch.float32).reshape(n_items, 5) * 2.0 + 1.0
     assert torch.equal(out, ref)
@@ -100,14 +101,17 @@ def _pipe_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_gather_pipe_gloo(tmp_path):
-    """bench.py's steady-state gather (double-buffered, asynchronous): rank 0 holds every rank's rows of the last batch."""
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_gather_pipe_gloo(tmp_path, world):
+    """bench.py's steady-state gather (double-buffered, asynchronous; 5 batches, so both send slots wrap twice): rank 0 holds
+    every rank's rows of the last batch - at the 2, 4 and 8 ranks of the driver's scaling run."""
     import torch.multiprocessing as mp
-    port = 30500 + (os.getpid() % 1000)
-    mp.spawn(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 30500 + (os.getpid() % 1000) + world
+    mp.spawn(_pipe_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     rows = torch.load(os.path.join(str(tmp_path), 'pipe.pt'))
-    assert rows.shape == (2, 3, 4)
-    assert torch.equal(rows[0], torch.full((3, 4), 400.0)) and torch.equal(rows[1], torch.full((3, 4), 401.0))
+    assert rows.shape == (world, 3, 4)
+    for r in range(world):
+        assert torch.equal(rows[r], torch.full((3, 4), 400.0 + r))
 
 
 def test_decode_driver_batch_plan():

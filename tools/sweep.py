@@ -85,6 +85,7 @@ def main():
                     help='also decode N clips of N distinct lengths (VoiceBank+DEMAND-like: 1.2 - 9.8 s, median ~2.5 s) '
                          'through the driver\'s batch plan + se_enhance_ragged')
     ap.add_argument('--models', type=str, default='lstm,crn,gcrn,dpcrn,dccrn,fullsubnet,ctsnet,g2net,taylorsenet,uformer')
+    ap.add_argument('--fsn-max-batch', type=int, default=128, help='largest FullSubNet batch (batch sweeps around 128 raise it)')
     args = ap.parse_args()
     import torch
     from se_amd import synth
@@ -93,7 +94,7 @@ def main():
     wav = torch.from_numpy(np.tile(base, ((B + 7) // 8, 1))[:B].copy()).cuda()
     B0 = B
     for name in args.models.split(','):
-        B = min(B0, 128) if name == 'fullsubnet' else B0       # 257 * B sub-band sequences: 256 clips do not fit 288 GB
+        B = min(B0, args.fsn_max_batch) if name == 'fullsubnet' else B0       # 257 * B sub-band sequences: 256 clips do not fit 288 GB
         if B != wav.shape[0]:
             wav = torch.from_numpy(np.tile(base, ((B + 7) // 8, 1))[:B].copy()).cuda()
         m = build(name, B)

@@ -29,7 +29,7 @@ for step in "$@"; do
     profl)
       (export SE_PROF_DUMP=1 ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 2 --fsn-max-batch 256 2>&1 | python $ROOT/tools/profl.py > $OUT/profl_${a}_b${b}${c:+_${c//[=,]/_}}.txt; head -14 $OUT/profl_${a}_b${b}${c:+_${c//[=,]/_}}.txt) ;;
     dbg)
-      (export ${c//,/ }; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 5 --no-profile --fsn-max-batch 256 2>&1 | grep utt_per_s | cut -c1-100 | sed "s/^/[$c] /") ;;
+      (export SE_R6=1 ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 5 --no-profile --fsn-max-batch 256 2>&1 | grep utt_per_s | cut -c1-100 | sed "s/^/[$c] /") ;;
     fsnsweep)
       : > $OUT/r06_fsn_batch_sweep.jsonl
       for B in $(seq $a $b); do
@@ -40,6 +40,10 @@ for step in "$@"; do
       (export SE_R6=1 ${c:+${c//,/ }}; $PKG/gcbench step $a $b 2>&1 | tail -1 | sed "s/^/[${c:-}] /") ;;
     gcb)   # gcb:<"Cin Cout Fin B T">:<env=val,..>
       (export SE_R6=1 ${b:+${b//,/ }}; $PKG/gcbench $a 2>&1 | tail -2 | tr '\n' ' ' | sed "s/^/[${b:-}] /"; echo) ;;
+    gcbp)   # the previous build's gcbench (same-box A/B of a kernel change)
+      (export SE_R6=1 ${b:+${b//,/ }}; $PKG/gcbench_prev $a 2>&1 | tail -2 | tr '\n' ' ' | sed "s/^/[prev ${b:-}] /"; echo) ;;
+    dbgp)   # dbgp:<model>:<B>[:env]: the previous build of the library
+      (export SE_ENGINE_LIB=$PKG/libse_engine_prev.so ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 5 --no-profile --fsn-max-batch 256 2>&1 | grep utt_per_s | cut -c1-100 | sed "s/^/[prev ${c:-}] /") ;;
     gcbt)   # gcbt:<"Cin Cout Fin B T">:<env=val,..>  (phase-timing build)
       (export SE_R6=1 ${b:+${b//,/ }}; $PKG/gcbench_timing $a 2>&1 | tail -4 | cut -c1-400 | sed "s/^/[${b:-}] /") ;;
     stept)

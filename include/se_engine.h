@@ -194,6 +194,27 @@ int se_istft(se_engine* e, const float* spec_dev, int32_t batch, int32_t n_frame
 int32_t se_num_frames(const se_engine* e, int32_t n_samples);
 int32_t se_num_bins(const se_engine* e);
 
+/* The two halves of a decode loop's body around `model(feat)` as stage hooks of their own (se_frontend /
+ * se_backend), so that the front end and the mask / decompress stage can be diffed against the oracle alone.
+ *   se_frontend: c = sqrt(L / sum x^2); x * c (+ the script's tail pad); STFT; |X|^p_in e^{j angle X} with the engine's p_in
+ *                (e.g. DCCRN/dccrn_decode_vb.py:26-42, LSTM/lstm_decode_vb.py:33-38, GCRN/gcrn_decode_vb.py:35-46).
+ *                wav_dev [batch][pitch] -> c_dev [batch], spec_dev [batch][2][F][T]  (T = se_num_frames(n_samples)).
+ *   se_backend : network output -> estimated spectrum -> |S|^p_out e^{j angle S} (the engine's p_out) -> iSTFT -> / c.
+ *                kind SE_BACKEND_RI   : est_dev [batch][2][F][T] IS the estimated spectrum (complex-mapping scripts:
+ *                                       GCRN/gcrn_decode_vb.py:47-58, DCCRN/dccrn_decode_vb.py:45-62); spec_dev unused
+ *                     SE_BACKEND_MAG  : est_dev [batch][F][T] is a magnitude, the phase is the noisy spectrum's
+ *                                       (LSTM/lstm_decode_vb.py:47-52, CRN/crn_decode_vb.py:46-52)
+ *                     SE_BACKEND_CMASK: est_dev [batch][2][F][T] is a complex ratio mask applied to spec_dev
+ *                                       (FullSubNet/fullsubnet_sa_decode_vb.py:56-72, DPCRN/DPCRN.py:33-42)
+ *                spec_dev: the front end's output (kinds MAG / CMASK); c_dev may be NULL (no division); n_out samples per row. */
+#define SE_BACKEND_RI 0
+#define SE_BACKEND_MAG 1
+#define SE_BACKEND_CMASK 2
+int se_frontend(se_engine* e, const float* wav_dev, int64_t pitch, int32_t batch, int32_t n_samples, float* c_dev,
+                float* spec_dev, void* stream);
+int se_backend(se_engine* e, int32_t kind, const float* est_dev, const float* spec_dev, int32_t batch, int32_t n_frames,
+               const float* c_dev, float* wav_dev, int64_t pitch, int32_t n_out, void* stream);
+
 /* Kernel time of the dominant kernel family (f32-MFMA implicit-GEMM convolution) inside the last
  * se_enhance_batch / se_forward, measured with HIP events on the stream each launch runs on (the caller's `stream` and the
  * engine's auxiliary streams: launches that overlap on two streams both count); enabled by se_set_profiling(e, 1).
@@ -226,7 +247,7 @@ int se_pcm16_encode(const float* in_dev, int64_t in_pitch, int32_t batch, int32_
                     void* stream);
 
 /* ABI version of this header. */
-int32_t se_abi_version(void);   /* 2: se_enhance_ragged, se_get_stage_profile, se_stream_*; 3: se_uformer_forward, se_pcm16_*; 4: se_stream_begin_running */
+int32_t se_abi_version(void);   /* 2: se_enhance_ragged, se_get_stage_profile, se_stream_*; 3: se_uformer_forward, se_pcm16_*; 4: se_stream_begin_running; 5: se_frontend, se_backend */
 
 #ifdef __cplusplus
 }

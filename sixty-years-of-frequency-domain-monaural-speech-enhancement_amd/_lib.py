@@ -19,7 +19,7 @@ SYMBOLS = [
     'se_engine_finalize', 'se_forward', 'se_enhance_batch', 'se_output_samples', 'se_rms_scale', 'se_stft',
     'se_istft', 'se_num_frames', 'se_num_bins', 'se_set_profiling', 'se_get_profile', 'se_resample',
     'se_resample_samples', 'se_enhance_ragged', 'se_get_stage_profile', 'se_stream_begin', 'se_stream_begin_running', 'se_stream_push', 'se_stream_flush',
-    'se_uformer_forward', 'se_pcm16_decode', 'se_pcm16_encode',
+    'se_uformer_forward', 'se_pcm16_decode', 'se_pcm16_encode', 'se_frontend', 'se_backend',
 ]
 
 
@@ -67,6 +67,8 @@ def load():
     lib.se_rms_scale.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     lib.se_stft.argtypes = [vp, vp, i64, i32, i32, vp, f32, vp, vp]
     lib.se_istft.argtypes = [vp, vp, i32, i32, vp, vp, i64, i32, vp]
+    lib.se_frontend.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp]
+    lib.se_backend.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, i64, i32, vp]
     lib.se_num_frames.restype = i32
     lib.se_num_frames.argtypes = [vp, i32]
     lib.se_num_bins.restype = i32

@@ -1,6 +1,7 @@
 // Building blocks shared by the TCM / gated-U-Net models (CTSNet, TaylorSENet, G2Net).
 #pragma once
 #include "rnn.h"
+#include <cmath>
 
 namespace se {
 
@@ -11,7 +12,8 @@ struct NormAct {
                                    // staged as the raw value that normalises to zero, which a zero gain does not have)
     void load(const TrackedSD& sd, const std::string& in_key, const std::string& prelu_key) {
         cum = sd.has(in_key + "gain");
-        for (float v : sd.get(in_key + (cum ? "gain" : "weight")).data) gain_nonzero = gain_nonzero && v != 0.f;
+        // (a tiny gain makes that raw value -shift / scale overflow: below 1e-6 the layer keeps the stand-alone pass)
+        for (float v : sd.get(in_key + (cum ? "gain" : "weight")).data) gain_nonzero = gain_nonzero && std::fabs(v) >= 1e-6f;
         g = to_device(sd.get(in_key + (cum ? "gain" : "weight")).data);
         b = to_device(sd.get(in_key + "bias").data);
         s = to_device(sd.get(prelu_key + "weight").data);

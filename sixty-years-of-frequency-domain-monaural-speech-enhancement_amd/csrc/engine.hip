@@ -25,6 +25,8 @@ struct se_engine {
     std::vector<GraphEntry> graphs;
     std::vector<std::pair<int, int>> warmed;
     float *stage_in = nullptr, *stage_out = nullptr;
+    float* hook_buf = nullptr;     // se_backend: the decompressed spectrum between the mask stage and the iSTFT (grows, never shrinks)
+    size_t hook_cap = 0;
     // se_enhance_ragged: per-row sizes (len | lpad | tlen | olen, max_batch ints each) go host -> device through a small
     // ring of pinned slots, so back-to-back calls never wait for each other's copy
     static constexpr int RAG_SLOTS = 8;
@@ -117,7 +119,7 @@ int se_pcm16_encode(const float* in_dev, int64_t in_pitch, int32_t batch, int32_
     });
 }
 
-int32_t se_abi_version(void) { return 4; }
+int32_t se_abi_version(void) { return 5; }
 
 const char* se_last_error(const se_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 
@@ -193,6 +195,7 @@ int se_engine_destroy(se_engine* e) {
     if (e->rag_dev) (void)hipFree(e->rag_dev);
     for (auto& ev : e->rag_ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->hook_buf) (void)hipFree(e->hook_buf);
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     if (e->ctx.arena.base()) gc_unregister_overread_range(e->ctx.arena.base());
@@ -271,6 +274,21 @@ static void stream_order_wait(se_engine* e, hipStream_t st) {
     se_engine::Stream& S = e->strm;
     if (S.has_last && S.last_st != st && S.ev_order) SE_HIP(hipStreamWaitEvent(st, S.ev_order, 0));
 }
+// ... and the other direction: EVERY call that enqueues work on the arena - offline decodes as well - leaves the
+// ordering event behind its last launch, also when it throws after enqueueing, so that a se_stream_begin issued on another
+// hipStream right after an offline decode cannot re-carve or zero-fill the arena under it
+static void stream_mark(se_engine::Stream& S, hipStream_t st);
+struct StreamMarkScope {
+    se_engine* e;
+    hipStream_t st;
+    StreamMarkScope(se_engine* e_, hipStream_t st_) : e(e_), st(st_) {}
+    ~StreamMarkScope() {
+        try {
+            stream_mark(e->strm, st);
+        } catch (const std::exception&) {      // (a failed record leaves the previous event in place)
+        }
+    }
+};
 
 int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32_t in_ndim, float* out_dev,
                void* stream) {
@@ -279,6 +297,7 @@ int se_forward(se_engine* e, const float* in_dev, const int64_t* in_shape, int32
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         stream_order_wait(e, static_cast<hipStream_t>(stream));
+        StreamMarkScope sms(e, static_cast<hipStream_t>(stream));
         SE_CHECK(in_dev && out_dev && in_shape, "null argument");
         e->ctx.prof_reset();
         e->model->forward(in_dev, in_shape, in_ndim, out_dev, static_cast<hipStream_t>(stream));
@@ -292,6 +311,7 @@ int se_uformer_forward(se_engine* e, const float* inputs_dev, const float* src_d
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         stream_order_wait(e, static_cast<hipStream_t>(stream));
+        StreamMarkScope sms(e, static_cast<hipStream_t>(stream));
         SE_CHECK(inputs_dev && output_dev, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples, "n_samples outside [n_fft, max_samples]");
@@ -308,6 +328,7 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         stream_order_wait(e, static_cast<hipStream_t>(stream));
+        StreamMarkScope sms(e, static_cast<hipStream_t>(stream));
         SE_CHECK(wav_in_dev && wav_out_dev, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(n_samples >= e->ctx.geom.n_fft && n_samples <= e->ctx.max_samples,
@@ -389,6 +410,7 @@ int se_enhance_ragged(se_engine* e, const float* wav_in_dev, int64_t in_pitch, i
         SE_CHECK(e->finalized, "engine not finalized");
         e->strm.carve_B = -1;          // (any decode re-carves the arena: a stream running on this handle zero-fills its next windows)
         stream_order_wait(e, static_cast<hipStream_t>(stream));
+        StreamMarkScope sms(e, static_cast<hipStream_t>(stream));
         SE_CHECK(wav_in_dev && wav_out_dev && lengths, "null argument");
         SE_CHECK(batch >= 1 && batch <= e->ctx.max_batch, "batch exceeds max_batch given at create");
         SE_CHECK(e->model->ragged_supported(),
@@ -541,6 +563,7 @@ int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_
         SE_CHECK(S.batch == 1 || pitch >= n_new, "se_stream_push: input row pitch smaller than n_new");
         SE_CHECK(S.n_total + n_new <= e->ctx.max_samples, "stream longer than max_samples given at create");
         hipStream_t st = static_cast<hipStream_t>(stream);
+        StreamMarkScope sms(e, st);
         const StftGeom& g = e->ctx.geom;
         if (n_new > 0)
             SE_HIP(hipMemcpy2DAsync(S.wav + S.n_total, (size_t)e->ctx.max_samples * sizeof(float), wav_dev,
@@ -559,7 +582,6 @@ int se_stream_push(se_engine* e, const float* wav_dev, int64_t pitch, int32_t n_
         e->ctx.prof_reset();
         stream_process(e, std::max(t_avail, S.t_done), false, out_dev, out_pitch, &written, st);
         *n_out = written;
-        stream_mark(S, st);
     });
 }
 
@@ -572,6 +594,7 @@ int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_
         SE_CHECK(S.n_total >= e->ctx.geom.n_fft, "stream shorter than one FFT frame");
         SE_CHECK(out_pitch >= e->model->output_samples(S.n_total) - S.o_done, "output row pitch too small for the rest of the stream");
         int written = 0;
+        StreamMarkScope sms(e, static_cast<hipStream_t>(stream));
         e->ctx.prof_reset();
         if (S.running)
             launch_stream_rms(S.wav, e->ctx.max_samples, S.batch, S.n_total, 0, S.sumsq, S.c, S.frame_inv, S.ring, S.t_done,
@@ -579,7 +602,6 @@ int se_stream_flush(se_engine* e, float* out_dev, int64_t out_pitch, int32_t* n_
         stream_process(e, e->model->num_frames(S.n_total), true, out_dev, out_pitch, &written, static_cast<hipStream_t>(stream));
         *n_out = written;
         S.active = false;
-        stream_mark(S, static_cast<hipStream_t>(stream));
     });
 }
 
@@ -610,6 +632,46 @@ int se_istft(se_engine* e, const float* spec_dev, int32_t batch, int32_t n_frame
     return guard(e, [&] {
         launch_istft(e->ctx.geom, spec_dev, batch, n_frames, n_frames, nullptr, c_dev, wav_dev, pitch, n_out,
                      static_cast<hipStream_t>(stream));
+    });
+}
+
+int se_frontend(se_engine* e, const float* wav_dev, int64_t pitch, int32_t batch, int32_t n_samples, float* c_dev,
+                float* spec_dev, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(wav_dev && c_dev && spec_dev, "null argument");
+        SE_CHECK(batch >= 1 && n_samples >= e->ctx.geom.n_fft && pitch >= n_samples, "se_frontend: bad shape");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        launch_rms_scale(wav_dev, batch, n_samples, pitch, c_dev, st);
+        const int Lpad = e->model->padded_samples(n_samples);
+        const int T = 1 + Lpad / e->ctx.geom.hop;
+        launch_stft(e->ctx.geom, wav_dev, pitch, batch, n_samples, Lpad, c_dev, e->ctx.p_in, spec_dev, nullptr, T, T, st);
+    });
+}
+
+int se_backend(se_engine* e, int32_t kind, const float* est_dev, const float* spec_dev, int32_t batch, int32_t n_frames,
+               const float* c_dev, float* wav_dev, int64_t pitch, int32_t n_out, void* stream) {
+    if (!e) return 1;
+    return guard(e, [&] {
+        SE_CHECK(est_dev && wav_dev, "null argument");
+        SE_CHECK(kind == SE_BACKEND_RI || kind == SE_BACKEND_MAG || kind == SE_BACKEND_CMASK, "se_backend: unknown kind");
+        SE_CHECK(kind == SE_BACKEND_RI || spec_dev, "se_backend: this kind needs the front end's spectrum");
+        SE_CHECK(batch >= 1 && n_frames >= 1 && n_out >= 1 && pitch >= n_out, "se_backend: bad shape");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int F = e->ctx.geom.F();
+        const size_t need = (size_t)batch * 2 * F * n_frames * sizeof(float);
+        if (need > e->hook_cap) {
+            SE_HIP(hipStreamSynchronize(st));       // (an earlier call on this stream may still read the old buffer)
+            if (e->hook_buf) SE_HIP(hipFree(e->hook_buf));
+            e->hook_buf = nullptr;
+            e->hook_cap = 0;
+            SE_HIP(hipMalloc(&e->hook_buf, need));
+            e->hook_cap = need;
+        }
+        if (kind == SE_BACKEND_RI) launch_polar_pow(est_dev, e->hook_buf, batch, F, n_frames, e->ctx.p_out, st);
+        else if (kind == SE_BACKEND_MAG) launch_mag_phase(est_dev, spec_dev, e->hook_buf, batch, F, n_frames, e->ctx.p_out, st);
+        else launch_cmask_apply(est_dev, spec_dev, e->hook_buf, batch, F, n_frames, e->ctx.p_out, st);
+        launch_istft(e->ctx.geom, e->hook_buf, batch, n_frames, n_frames, nullptr, c_dev, wav_dev, pitch, n_out, st);
     });
 }
 

@@ -150,7 +150,12 @@ __global__ __launch_bounds__(256, 1) void lstm_short_kernel(const LstmShortArgs 
     if (NV > 1) load_x(pl);
     __syncthreads();
     project(xs[0], acc, std::integral_constant<int, 0>{}, nothing);
-    if (NV > 1) store_x(xs[1]);
+    if (NV > 1) {
+        store_x(xs[1]);
+    } else {      // a single (tile, step): the projection "of the next pair" below reads xs[1] - defined values, result unused
+#pragma unroll
+        for (int j = 0; j < I / 16; ++j) xs[1][(xcg + 16 * j) * LS_N + xn] = 0.f;
+    }
     advance(pl);
     __syncthreads();
 

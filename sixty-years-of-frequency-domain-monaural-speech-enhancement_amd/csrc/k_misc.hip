@@ -821,7 +821,10 @@ __global__ __launch_bounds__(256) void cln_apply_plane_kernel(const float* x, fl
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 int tk = t + k;
-                tk = tk >= T ? tk - T : tk;
+                if (tk >= T) {      // (T <= 2 - a one- or two-frame spectrogram through se_forward: the group wraps more than once)
+                    tk -= T;
+                    if (tk >= T) tk %= T;
+                }
                 o[k] = one(in[k], tk, rr[k]);
             }
             return make_float4(o[0], o[1], o[2], o[3]);

@@ -12,6 +12,13 @@ struct EngineCtx {
     int max_batch = 1, max_samples = 64000;
     float p_in = 1.f, p_out = 1.f;
     int flags = 0;          // se_config.flags
+    // hipGraph replay asked for (SE_CFG_GRAPHS, or SE_GRAPH=1 / 0 in the environment): models that would fork work onto an
+    // auxiliary stream stay on the caller's stream then, so that the decode can be captured (graphs were silently
+    // dropped for TaylorSENet, the most launch-heavy model)
+    bool graphs_wanted() const {
+        static const int graphs_env = getenv("SE_GRAPH") ? atoi(getenv("SE_GRAPH")) : -1;
+        return graphs_env >= 0 ? graphs_env != 0 : (flags & 1 /* SE_CFG_GRAPHS */) != 0;
+    }
     // SE_CFG_REPEATS(n) (include/se_engine.h): gaf_base's stage_num / TaylorSENet's order_num; `dflt` = the decode script's
     int repeats(int dflt) const {
         const int v = (flags >> 8) & 15;
@@ -86,6 +93,21 @@ struct TrackedSD {
 inline int pad_frames_mult(int model_default = 4) {
     static const int m = getenv("SE_PAD_FRAMES_TO") ? std::max(4, atoi(getenv("SE_PAD_FRAMES_TO")) & ~3) : 0;
     return m ? m : model_default;
+}
+// The cLN (`_new`) variants are causal end to end - every InstanceNorm of the base directories is a CumulativeLayerNorm
+// (CTSNet_new/Step1_network.py:213-286) - so frames behind a clip's last one never reach a frame the iSTFT reads: an
+// equal-length offline batch runs with its rows zero-extended to whole 128 B lines (T = 401 -> 416).  Rows of 401 floats put
+// three of four rows off 16 B alignment: every 16 B staging group and every 16 B store of the conv family straddles its
+// segment (round 6, `gcbench ... 401` vs `416`: the store-bound 2 -> 64 layer 1.11 -> 0.84 ms, the memory pipeline of a
+// 64 -> 64 layer alone - SE_GC_DBG=4 - 1.17 -> 0.81 ms).  SE_CLN_PAD=n: multiple (default 32, 1 = off).
+inline int causal_work_frames(int T, bool causal_all) {
+    static const int m = getenv("SE_CLN_PAD") ? std::max(1, atoi(getenv("SE_CLN_PAD"))) : 32;
+    if (!causal_all || m <= 1 || ragged_ctx() || stream_ctx()) return T;
+    return (T + m - 1) / m * m;
+}
+inline int causal_frame_multiple(bool causal_all) {
+    static const int m = getenv("SE_CLN_PAD") ? std::max(1, atoi(getenv("SE_CLN_PAD"))) : 32;
+    return causal_all ? std::max(4, (m + 3) & ~3) : 4;
 }
 struct PadFrames {
     Ragged rg;

@@ -75,7 +75,9 @@ class TaylorSENet final : public Model {
     }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
     int padded_samples(int L) const override { return ((L + HOP - 1) / HOP) * HOP; }   // taylorsenet_decode_vb.py:31-35
-    bool graph_capturable() const override { return false; }      // network() forks the separate encoder onto a second stream
+    // network() forks the separate encoder onto a second stream - unless hipGraph replay is asked for: then it stays on one
+    // stream and the decode is captured (fork and graphs are mutually exclusive per engine)
+    bool graph_capturable() const override { return ctx.graphs_wanted(); }
 
     void finalize(const TrackedSD& sd) override {
         zen.load(sd, "zeroorderblock.en.", 2);
@@ -125,14 +127,17 @@ class TaylorSENet final : public Model {
         launch_transpose_akt(b.est, out, NBIN, 2 * B, T, T, (long)NBIN * T, NBIN, (long)T * NBIN, st);
     }
 
+    int frame_multiple() const override { return causal_frame_multiple(cum); }
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int Lpad = padded_samples(L), T = 1 + Lpad / HOP;
-        Bufs& b = bufs(B, T);
+        const int Tw = causal_work_frames(T, cum);          // cLN weights: rows zero-extended to whole 128 B lines (model.h)
+        Bufs& b = bufs(B, Tw);
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // :27-28
-        launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, nullptr, T, T, st);   // :30-41
+        if (Tw != T) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
+        launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, nullptr, T, Tw, st);  // :30-41
         network(b, st);                                                                            // :42
-        launch_polar_pow(b.est, b.est, B, NBIN, T, ctx.p_out, st);                                 // :44-45
-        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :48-51
+        launch_polar_pow(b.est, b.est, B, NBIN, Tw, ctx.p_out, st);                                // :44-45
+        launch_istft(ctx.geom, b.est, B, T, Tw, b.frames, b.c, out, out_pitch, L, st);             // :48-51
     }
 
     // ---- frame-online mode (TaylorSENet_new: cumulative LayerNorms only).  Windows of SH history columns + n new frames
@@ -226,7 +231,7 @@ class TaylorSENet final : public Model {
         // U^2-Net levels fill a fraction of the chip each (F = 4 ... 19: one to three rounds of workgroups, a tail per launch) -
         // two independent chains fill each other's tails.  SE_TAYLOR_FORK=0: one stream.
         static const bool fork_env = !(getenv("SE_TAYLOR_FORK") && atoi(getenv("SE_TAYLOR_FORK")) == 0);
-        const bool fork = fork_env && !stream_ctx();
+        const bool fork = fork_env && !stream_ctx() && !ctx.graphs_wanted();
         if (fork) {
             hipStream_t s2 = ctx.aux_stream(0);
             SE_HIP(hipEventRecord(ctx.ev_fork, st));

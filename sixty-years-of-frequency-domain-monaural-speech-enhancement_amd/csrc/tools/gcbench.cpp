@@ -262,15 +262,19 @@ int main(int argc, char** argv) {
         return bench_gauss(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 501);
     int Cin = argc > 1 ? atoi(argv[1]) : 128, Cout = argc > 2 ? atoi(argv[2]) : 256, Fin = argc > 3 ? atoi(argv[3]) : 32;
     int B = argc > 4 ? atoi(argv[4]) : 64, T = argc > 5 ? atoi(argv[5]) : 501;
-    int Fout = Fin / 2;
+    // [nkf nkt]: kernel extent in frequency x time (default 5 x 2, DCCRN; 3 x 1 = G2Net's nested U-Net, 3 x 2 = TaylorSENet's);
+    // stride 2 in frequency, causal in time, no frequency padding for the 3-tap kernels
+    const int nkf = argc > 6 ? atoi(argv[6]) : 5, nkt = argc > 7 ? atoi(argv[7]) : 2;
+    const int pf = nkf == 5 ? 2 : 0;
+    int Fout = nkf == 5 ? Fin / 2 : (Fin - nkf) / 2 + 1;
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
     DenseW d;
-    d.M = Cout; d.Cin = Cin; d.nkf = 5; d.nkt = 2;
-    d.w.resize((size_t)Cout * Cin * 10);
+    d.M = Cout; d.Cin = Cin; d.nkf = nkf; d.nkt = nkt;
+    d.w.resize((size_t)Cout * Cin * nkf * nkt);
     for (auto& v : d.w) v = U(rng) * 0.05f;
     d.bias.assign(Cout, 0.1f);
-    GCPlan pl = make_conv_plan(d, 2, 2, 1, 1, 1, ACT_PRELU, std::vector<float>(Cout, 0.25f), EPI_ACT, T);
+    GCPlan pl = make_conv_plan(d, 2, pf, nkt - 1, 1, 1, ACT_PRELU, std::vector<float>(Cout, 0.25f), EPI_ACT, T);
     size_t nin = (size_t)B * Cin * Fin * T, nout = (size_t)B * Cout * Fout * T;
     std::vector<float> hin(nin);
     for (auto& v : hin) v = U(rng);
@@ -296,7 +300,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e1, 0);
     SE_HIP(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
-    double fl = 2.0 * Cout * Cin * 10.0 * B * Fout * T;
+    double fl = 2.0 * Cout * Cin * (double)(nkf * nkt) * B * Fout * T;
 #ifdef GC_TIMING
     {
         SE_HIP(hipMemset(dt, 0, 128));

@@ -239,6 +239,32 @@ class Engine:
                                        C.c_void_p(wav.data_ptr()), wav.stride(0), n_out, self._stream()))
         return wav
 
+    BACKEND_KINDS = {'ri': 0, 'mag': 1, 'cmask': 2}
+
+    def frontend(self, wav):
+        """se_frontend: (c [B], spec [B,2,F,T]) - unit-RMS scale, tail pad, STFT and |X|^p_in e^{j angle X} of the decode loop."""
+        import torch
+        B, L = wav.shape
+        T, F = self.num_frames(L), self.num_bins()
+        c = torch.empty(B, dtype=torch.float32, device=wav.device)
+        spec = torch.empty((B, 2, F, T), dtype=torch.float32, device=wav.device)
+        self._check(self._lib.se_frontend(self._h, C.c_void_p(wav.data_ptr()), wav.stride(0), B, L, C.c_void_p(c.data_ptr()),
+                                          C.c_void_p(spec.data_ptr()), self._stream()))
+        return c, spec
+
+    def backend(self, kind, est, n_out, spec=None, c=None):
+        """se_backend: the mask / decompress stage + iSTFT + / c alone.  kind 'ri' (est = estimated spectrum [B,2,F,T]),
+        'mag' (est = magnitude [B,F,T], noisy phase from spec), 'cmask' (est = complex ratio mask [B,2,F,T] on spec)."""
+        import torch
+        assert est.is_contiguous() and (spec is None or spec.is_contiguous())
+        B, T = est.shape[0], est.shape[-1]
+        wav = torch.empty((B, n_out), dtype=torch.float32, device=est.device)
+        self._check(self._lib.se_backend(self._h, self.BACKEND_KINDS[kind], C.c_void_p(est.data_ptr()),
+                                         C.c_void_p(spec.data_ptr()) if spec is not None else None, B, T,
+                                         C.c_void_p(c.data_ptr()) if c is not None else None, C.c_void_p(wav.data_ptr()),
+                                         wav.stride(0), n_out, self._stream()))
+        return wav
+
     # ------------------------------------------------------------------ profiling
     def set_profiling(self, on):
         self._check(self._lib.se_set_profiling(self._h, 1 if on else 0))

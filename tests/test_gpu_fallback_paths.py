@@ -46,3 +46,52 @@ def test_reference_fixtures_with_the_round5_switches_thrown():
            'g2net or taylor or ctsnet or dccrn or uformer or dpcrn or gcrn']
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# round 6: unit-flattened column tiles of the 64-row layers (GCParams::flat_upr) are the default from 1 024 workgroups on - the
+# batch-256 fixtures run them; here the same fixtures with the plain tiles
+SWITCHES_R6 = {'SE_GC_FLAT': '0'}
+
+
+@pytest.mark.gpu
+def test_reference_fixtures_with_the_round6_switches_thrown():
+    env = dict(os.environ, **SWITCHES_R6)
+    cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+           os.path.join(ROOT, 'tests', 'test_gpu_b256_fixture.py'), '-k', 'g2net or taylor or uformer or dpcrn or gcrn']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+_LSTM_SHORT_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import se_amd
+from se_amd.models import dpcrn
+B, T = int(sys.argv[1]), int(sys.argv[2])
+m = dpcrn(max_batch=B, max_samples=160 * (T - 1) + 320).load_synthetic(13)
+rng = np.random.default_rng(5)
+x = torch.from_numpy(rng.standard_normal((B, 2, T, 161)).astype(np.float32)).cuda()
+y = m(x).cpu().numpy()
+np.save(sys.argv[3], y)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,T', [(3, 87), (1, 257), (5, 53), (2, 200)])
+def test_lstm_short_kernel_against_projection_plus_persistent_path(tmp_path, B, T):
+    """`lstm_short_kernel` (DPCRN's intra-frame BiLSTM: 4 steps, both directions, input projection inside) against the
+    two-launch form it replaced (`SE_LSTM_SHORT=0`: projection GEMM + `lstm_persist_kernel`) on sequence counts B * T that are
+    NOT multiples of its 16-sequence tile (261, 257, 265) and one that is (400), through `se_forward`."""
+    import numpy as np
+    outs = []
+    for k, extra in enumerate(({}, {'SE_LSTM_SHORT': '0'})):
+        f = str(tmp_path / ('y%d.npy' % k))
+        r = subprocess.run([sys.executable, '-c', _LSTM_SHORT_CHILD % ROOT, str(B), str(T), f], env=dict(os.environ, **extra),
+                           cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(np.load(f))
+    a, b = outs
+    assert a.shape == b.shape == (B, 2, T, 161) and np.isfinite(a).all()
+    err = float(np.sqrt(np.mean((a - b) ** 2))) / max(float(np.sqrt(np.mean(b ** 2))), 1e-12)
+    print('lstm_short vs two-launch form, B', B, 'T', T, 'relative rms', err)
+    assert err < 2e-5

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.se_abi_version() == 4
+    assert lib.se_abi_version() == 5
 
 
 def test_engine_fails_loudly_without_gpu():

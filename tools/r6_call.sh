@@ -30,6 +30,8 @@ for step in "$@"; do
       (export SE_PROF_DUMP=1 ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 2 --fsn-max-batch 256 2>&1 | python $ROOT/tools/profl.py > $OUT/profl_${a}_b${b}${c:+_${c//[=,]/_}}.txt; head -14 $OUT/profl_${a}_b${b}${c:+_${c//[=,]/_}}.txt) ;;
     dbg)
       (export SE_R6=1 ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 5 --no-profile --fsn-max-batch 256 2>&1 | grep utt_per_s | cut -c1-100 | sed "s/^/[$c] /") ;;
+    len)   # len:<model>:<B>:<samples>[,env=val..]
+      (IFS=, read -r smp envs <<< "$c"; export SE_R6=1 ${envs:+${envs//;/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 5 --no-profile --samples $smp 2>&1 | grep utt_per_s | cut -c1-100 | sed "s/^/[L=$smp $envs] /") ;;
     fsnsweep)
       : > $OUT/r06_fsn_batch_sweep.jsonl
       for B in $(seq $a $b); do

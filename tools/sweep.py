@@ -18,10 +18,13 @@ GFLOP = {'lstm': 17.5, 'crn': 17.3, 'gcrn': 13.2, 'dpcrn': 4.8, 'dccrn': 53.4, '
          'g2net': 10.7, 'taylorsenet': 31.3, 'uformer': 27.5}      # SURVEY 8(d), per 4 s utterance
 
 
+SAMPLES = 64000
+
+
 def build(name, B):
     import se_amd  # noqa: F401
     from se_amd import models, models_new
-    kw = dict(max_batch=B, max_samples=64000)
+    kw = dict(max_batch=B, max_samples=SAMPLES)
     if name == 'ctsnet':
         return models.CTSNet(**kw).load_synthetic(17, 18)
     if name == 'ctsnet_new':
@@ -85,12 +88,15 @@ def main():
                     help='also decode N clips of N distinct lengths (VoiceBank+DEMAND-like: 1.2 - 9.8 s, median ~2.5 s) '
                          'through the driver\'s batch plan + se_enhance_ragged')
     ap.add_argument('--models', type=str, default='lstm,crn,gcrn,dpcrn,dccrn,fullsubnet,ctsnet,g2net,taylorsenet,uformer')
+    ap.add_argument('--samples', type=int, default=64000, help='clip length (64 000 = 4 s: 401 frames at hop 160; 66 400: 416 frames)')
     ap.add_argument('--fsn-max-batch', type=int, default=128, help='largest FullSubNet batch (batch sweeps around 128 raise it)')
     args = ap.parse_args()
+    global SAMPLES
+    SAMPLES = args.samples
     import torch
     from se_amd import synth
     B = args.batch
-    base = synth.synth_batch(8, 'speech', 64000, seed0=100)
+    base = synth.synth_batch(8, 'speech', args.samples, seed0=100)
     wav = torch.from_numpy(np.tile(base, ((B + 7) // 8, 1))[:B].copy()).cuda()
     B0 = B
     for name in args.models.split(','):
@@ -99,7 +105,7 @@ def main():
             wav = torch.from_numpy(np.tile(base, ((B + 7) // 8, 1))[:B].copy()).cuda()
         m = build(name, B)
         eng = m.engine
-        out = torch.empty((B, eng.output_samples(64000)), dtype=torch.float32, device='cuda')
+        out = torch.empty((B, eng.output_samples(args.samples)), dtype=torch.float32, device='cuda')
         eng.enhance_batch(wav, out)
         torch.cuda.synchronize()
         eng.enhance_batch(wav, out)          # second call of the shape (captures the graph when SE_GRAPH=1)

@@ -45,7 +45,9 @@ inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int 
 // the two-kernel sequence for the cumulative-LayerNorm variants and for tile configurations without the epilogue.
 inline bool in_stats_enabled() {
     static const bool on = !(getenv("SE_IN_STATS") && atoi(getenv("SE_IN_STATS")) == 0);
-    return on && !ragged_ctx();      // per-tile partial sums cannot be cut at a row's own frame count
+    // (round 6: the epilogue cuts its partial sums at the row's own frame count - gc_kernel `tstat` - and the norm kernels divide
+    // by it, so ragged batches and the padded equal-length batches of model.h PadFrames keep the epilogue statistics and the fold)
+    return on;
 }
 inline float* in_stats_scratch(int B, int C, int F, int T, hipStream_t st) {
     return reinterpret_cast<float*>(device_scratch(2, (size_t)B * C * F * ((T + 31) / 32) * 2 * sizeof(float), st));
@@ -68,7 +70,7 @@ inline void conv_norm2d_prelu(const GCPlan& pl, const NormAct& n, const Act4& s0
     if (!n.cum && in_stats_enabled() && conv_stats_supported(pl)) {
         float* stats = in_stats_scratch(B, C, Fout, T, st);
         run_conv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
-        launch_instnorm_prelu_stats(y, out, n.g, n.b, n.s, stats, Fout * ((T + 31) / 32), B, C, Fout * T, st, res);
+        launch_instnorm_prelu_stats(y, out, n.g, n.b, n.s, stats, Fout * ((T + 31) / 32), B, C, Fout * T, st, res, T);
         return;
     }
     run_conv(pl, s0, s1, y, C, Fout, B, T, T, st, pf);
@@ -87,7 +89,7 @@ inline void deconv_norm2d_prelu(const DeconvPlan& pl, const NormAct& n, const Ac
     if (!n.cum && in_stats_enabled() && deconv_stats_supported(pl)) {
         float* stats = in_stats_scratch(B, C, Fout, T, st);
         run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
-        launch_instnorm_prelu_stats(y, out, n.g, n.b, n.s, stats, Fout * ((T + 31) / 32), B, C, Fout * T, st, res);
+        launch_instnorm_prelu_stats(y, out, n.g, n.b, n.s, stats, Fout * ((T + 31) / 32), B, C, Fout * T, st, res, T);
         return;
     }
     run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf);
@@ -100,13 +102,13 @@ inline void conv_stats_nrm(const GCPlan& pl, const NormAct& n, const Act4& s0, c
                            int B, int T, hipStream_t st, Profiler* pf) {
     float* stats = in_stats_scratch(B, C, Fout, T, st);
     run_conv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
-    launch_instnorm_finalize(stats, Fout * ((T + 31) / 32), n.g, n.b, n.s, nrm, B, C, Fout * T, st);
+    launch_instnorm_finalize(stats, Fout * ((T + 31) / 32), n.g, n.b, n.s, nrm, B, C, Fout * T, st, T);
 }
 inline void deconv_stats_nrm(const DeconvPlan& pl, const NormAct& n, const Act4& s0, const Act4* s1, float* y, float* nrm, int C,
                              int Fout, int B, int T, hipStream_t st, Profiler* pf) {
     float* stats = in_stats_scratch(B, C, Fout, T, st);
     run_deconv(pl, s0, s1, y, C, Fout, B, T, T, st, pf, stats);
-    launch_instnorm_finalize(stats, Fout * ((T + 31) / 32), n.g, n.b, n.s, nrm, B, C, Fout * T, st);
+    launch_instnorm_finalize(stats, Fout * ((T + 31) / 32), n.g, n.b, n.s, nrm, B, C, Fout * T, st, T);
 }
 // PReLU -> norm -> shared FIR on x [B][C][T]
 inline void tcm_head(const NormAct& n, const float* fir, int K, const float* x, float* y, int B, int C, int T, hipStream_t st) {

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             utab[4 * tid + 0] = bk_ - b;
             utab[4 * tid + 1] = p.t_base + (u_ - bk_ * p.flat_upr) * 32;
             utab[4 * tid + 2] = u_ < p.flat_units ? 1 : 0;
-            utab[4 * tid + 3] = 0;
+            utab[4 * tid + 3] = p.tlen ? p.tlen[min(bk_, p.B - 1)] : 0x7fffffff;      // the unit's row: its own frame count (ragged batches)
         }
     }
     for (int i = tid; i < nbuf * Bs_sz / 4; i += 256) reinterpret_cast<floatx4*>(Bs)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
         // (an odd row count leaves the second row of the last two-row tile outside the plane: nothing of it is stored)
         const int Mo = (q + wq < p.Q) ? ((EPI == EPI_GLU) ? (p.M >> 1) : p.M) : 0;
         // p.tlen (ragged batches, layers in front of operators that look ahead): frames >= tlen[b] of the output are zeros
-        const int tvalid = p.tlen ? p.tlen[b] : 0x7fffffff;
+        const int tvalid0 = p.tlen ? p.tlen[b] : 0x7fffffff;
         const float* __restrict__ res =
             (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_CMB) ? p.aux + (long)z * p.aux_z + (long)b * p.x_b + (long)fow * p.x_f : nullptr;
         const float cmb_sg = (EPI == EPI_CMB && ((p.cmb_neg >> z) & 1)) ? -1.f : 1.f;
@@ -710,6 +710,9 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             const long dbJ = FLAT ? utab[4 * uk] : 0;
             const int tj0 = FLAT ? utab[4 * uk + 1] : t0 + wt * (TN * 32) + j * 32;
             const int MoJ = (!FLAT || utab[4 * uk + 2]) ? Mo : 0;
+            // frames >= the row's own count are stored as zeros and do not count in the statistics riders (ragged batches)
+            const int tvalid = FLAT ? utab[4 * uk + 3] : tvalid0;
+            const int tstat = min(p.Tout, tvalid);
             float* __restrict__ dstJ = dst + dbJ * p.d_b;
             const float* __restrict__ resJ = res ? res + dbJ * p.x_b : nullptr;
             const float* __restrict__ cmbiJ = cmbi ? cmbi + dbJ * p.d_b : nullptr;
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                     if (p.cstats && m < MoJ) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float xk = (tg + k < p.Tout) ? v[k] : 0.f;
+                            const float xk = (tg + k < tstat) ? v[k] : 0.f;
                             ccs[k] += xk;
                             ccq[k] = fmaf(xk, xk, ccq[k]);
                         }
@@ -810,7 +813,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                         float s = 0.f, q = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const float xk = (tg + k < p.Tout) ? v[k] : 0.f;
+                            const float xk = (tg + k < tstat) ? v[k] : 0.f;
                             s += xk;
                             q = fmaf(xk, xk, q);
                         }
@@ -1952,7 +1955,7 @@ static void gc_launch_e(const GCParams& p_in, hipStream_t stream) {
     const GCParams& p = p_in;
     if (p.flat_upr) {        // unit-flattened column tiles (gc_launch decided; only the instantiated variants get here)
         const int uw = p.Wp / (BN / 32);
-        SE_CHECK(!RES && !p.fz && !p.trim && !p.tlen && !p.qt2 && p.pw4 && p.t_base == 0, "gc_launch: flattened tiles on a launch they do not cover");
+        SE_CHECK(!RES && !p.fz && !p.trim && !p.qt2 && p.pw4 && p.t_base == 0, "gc_launch: flattened tiles on a launch they do not cover");
         const bool nrm = p.nrm0 || p.nrm1;
         if constexpr (!RES && gc_flat_inst(BM, BN, EPI, 36)) {
             if (uw == 36) {
@@ -2177,7 +2180,7 @@ void gc_launch(const GCPlan& pl, GCParams p, hipStream_t stream) {
         static const long qt2_min_f = getenv("SE_GC_QT2_MIN") ? atol(getenv("SE_GC_QT2_MIN")) : 4096;
         const bool would_qt2 = qt2_env_f && pl.qt2.BN == 64 && pl.BN == 128 && p.Q >= 2 && !p.stats && !p.cstats && p.pad_lo == 0 &&
                                !p.nrm0 && !p.nrm1 && nblk >= qt2_min_f;
-        if (flat_env && pl.BM == 64 && pl.flat_uw && tb == 0 && !p.tlen && p.pw4 && !p.trim && !p.fz && p.Z == 1 && nblk >= flat_min && p.B > 1 &&
+        if (flat_env && pl.BM == 64 && pl.flat_uw && tb == 0 && p.pw4 && !p.trim && !p.fz && p.Z == 1 && nblk >= flat_min && p.B > 1 &&
             true) {
             // tile width as the plain path would choose it
             const bool wide = pl.BM == 64 && pl.flat[1].BN == 256 && nblk >= wide_min && gc_flat_supported(64, 256, p.epi, pl.flat_uw);

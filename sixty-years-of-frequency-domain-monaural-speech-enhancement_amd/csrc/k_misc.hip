@@ -423,9 +423,12 @@ __global__ __launch_bounds__(256) void instnorm_prelu_stats_kernel(const float* 
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
                                                                    const float* __restrict__ slope, const float* res,
-                                                                   const float* __restrict__ stats, int nslot, int C, int P) {
+                                                                   const float* __restrict__ stats, int nslot, int C, int P,
+                                                                   const int* __restrict__ tlen, int T) {
     __shared__ double sh[4];
     const int c = blockIdx.x % C;
+    // ragged batch: the epilogue's partial sums were cut at the row's own frame count (gc_kernel: tstat), so is the divisor
+    const double Pn = tlen ? (double)(P / T) * min(tlen[blockIdx.x / C], T) : (double)P;
     const float* xp = x + (long)blockIdx.x * P;
     float* yp = y + (long)blockIdx.x * P;
     const float* rp = res ? res + (long)blockIdx.x * P : nullptr;
@@ -436,17 +439,18 @@ __global__ __launch_bounds__(256) void instnorm_prelu_stats_kernel(const float* 
         s += v.x;
         q += v.y;
     }
-    const double mu = block_sum_d(s, sh) / P;
-    const double var = fmax(block_sum_d(q, sh) / P - mu * mu, 0.0);
+    const double mu = block_sum_d(s, sh) / Pn;
+    const double var = fmax(block_sum_d(q, sh) / Pn - mu * mu, 0.0);
     const float rs = (float)(1.0 / sqrt(var + 1e-5)), muf = (float)mu;
     const float g = gamma[c], bt = beta[c], sl = slope ? slope[c] : 1.f;
     norm_apply_pass(xp, yp, rp, P, muf, rs, g, bt, sl);
 }
 void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, const float* beta, const float* slope,
-                                 const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res) {
-    SE_CHECK(!ragged_ctx(), "epilogue statistics cannot be length-masked: ragged batches take the norm's own statistics pass");
+                                 const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res, int T) {
+    const Ragged* rg = ragged_ctx();
+    SE_CHECK(!rg || (T > 0 && P % T == 0), "ragged InstanceNorm from epilogue statistics needs the frame count of the plane's lines");
     hipLaunchKernelGGL(instnorm_prelu_stats_kernel, dim3(B * C), dim3(256), 0, s, x, y, gamma, beta, slope, res, stats, nslot,
-                       C, P);
+                       C, P, rg ? rg->tlen : nullptr, T);
     SE_HIP(hipGetLastError());
 }
 // ---- InstanceNorm folded into the consumers (round 5) ---------------------------------------------------------------------------
@@ -455,7 +459,8 @@ void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, c
 // per (b, c) plane combines the nslot (sum, sum of squares) pairs in fp64 in a fixed order, like instnorm_prelu_stats_kernel.
 __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __restrict__ stats, int nslot, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ slope,
-                                                                float* __restrict__ nrm, int C, int P, int planes) {
+                                                                float* __restrict__ nrm, int C, int P, int planes,
+                                                                const int* __restrict__ tlen, int T) {
     const int pl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pl >= planes) return;
     const float2* sp = reinterpret_cast<const float2*>(stats) + (long)pl * nslot;
@@ -471,7 +476,8 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
     }
     if (lane == 0) {
         const int c = pl % C;
-        const double mu = s / P, var = fmax(q / P - mu * mu, 0.0);
+        const double Pn = tlen ? (double)(P / T) * min(tlen[pl / C], T) : (double)P;      // (ragged batch: the row's own frames)
+        const double mu = s / Pn, var = fmax(q / Pn - mu * mu, 0.0);
         const double sc = (1.0 / sqrt(var + 1e-5)) * (double)gamma[c], sh = (double)beta[c] - mu * sc;
         // x0: the raw value that normalises to (numerically) zero - what a left-pad frame is staged as.  A zero gain has no such
         // value; the fold is not used for such a layer (blocks.h checks gamma at load time), the field is then unused
@@ -479,11 +485,12 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* __r
     }
 }
 void launch_instnorm_finalize(const float* stats, int nslot, const float* gamma, const float* beta, const float* slope, float* nrm,
-                              int B, int C, int P, hipStream_t s) {
-    SE_CHECK(!ragged_ctx(), "epilogue statistics cannot be length-masked: ragged batches take the norm's own statistics pass");
+                              int B, int C, int P, hipStream_t s, int T) {
+    const Ragged* rg = ragged_ctx();
+    SE_CHECK(!rg || (T > 0 && P % T == 0), "ragged InstanceNorm from epilogue statistics needs the frame count of the plane's lines");
     const int planes = B * C;
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((planes + 3) / 4), dim3(256), 0, s, stats, nslot, gamma, beta, slope, nrm, C, P,
-                       planes);
+                       planes, rg ? rg->tlen : nullptr, T);
     SE_HIP(hipGetLastError());
 }
 // y = f_a(xa) + f_b(xb) over one (b, c) plane per block, f = the on-the-fly normalisation of gc_kernel NRM (same two fused

@@ -197,12 +197,13 @@ void launch_instnorm_prelu(const float* x, float* y, const float* gamma, const f
 // InstanceNorm folded into the consumers: statistics -> per-(b, c) {scale, shift, slope - 1, x0} (GCParams::nrm0 / nrm1), and the
 // elementwise pass y = f_a(xa) (+ f_b(xb)) for tensors that still have to exist normalised
 void launch_instnorm_finalize(const float* stats, int nslot, const float* gamma, const float* beta, const float* slope, float* nrm,
-                              int B, int C, int P, hipStream_t s);
+                              int B, int C, int P, hipStream_t s, int T = 0);      // (T: as launch_instnorm_prelu - ragged batches)
 void launch_instnorm_apply2(const float* xa, const float* na, const float* xb, const float* nb, float* y, int B, int C, int P,
                             hipStream_t s);
 // statistics from the producing conv (nslot (sum, sum of squares) pairs per (b, c) plane, GCParams::stats)
 void launch_instnorm_prelu_stats(const float* x, float* y, const float* gamma, const float* beta, const float* slope,
-                                 const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res = nullptr);
+                                 const float* stats, int nslot, int B, int C, int P, hipStream_t s, const float* res = nullptr,
+                                 int T = 0);
 
 // TCM branch head (CTSNet/Step1_network.py:161-176): y = ShareSepConv( InstanceNorm1d( PReLU(x) ) ) per (b, c) row of
 // T frames; fir [K] is the single FIR shared by all channels (causal, left pad K-1), K = 0 -> no FIR.

@@ -105,9 +105,17 @@ inline int causal_work_frames(int T, bool causal_all) {
     if (!causal_all || m <= 1 || ragged_ctx() || stream_ctx()) return T;
     return (T + m - 1) / m * m;
 }
+// The InstanceNorm flavours of the same networks cannot be zero-extended (the statistics run over the whole utterance): their
+// equal-length batches run as ragged rows of ONE length (PadFrames below, multiple SE_IN_PAD, default 32, 1 = off) - every
+// reduction over time stops at the row's own frame count (the norm kernels, the fused TCM block and, since round 6, the conv
+// epilogue's statistics riders), everything else is causal.
+inline int in_pad_multiple() {
+    static const int m = getenv("SE_IN_PAD") ? std::max(1, atoi(getenv("SE_IN_PAD"))) : 32;
+    return m <= 1 ? 1 : std::max(4, (m + 3) & ~3);
+}
 inline int causal_frame_multiple(bool causal_all) {
     static const int m = getenv("SE_CLN_PAD") ? std::max(1, atoi(getenv("SE_CLN_PAD"))) : 32;
-    return causal_all ? std::max(4, (m + 3) & ~3) : 4;
+    return std::max(4, causal_all ? ((m + 3) & ~3) : in_pad_multiple());
 }
 struct PadFrames {
     Ragged rg;
@@ -115,7 +123,7 @@ struct PadFrames {
     int T;                  // frame count (row pitch) to run with
     PadFrames(EngineCtx& ctx, int B, int L, int Lpad, int T_true, int olen, hipStream_t st, int mult = 4) : T(T_true) {
         static const bool env = !(getenv("SE_PAD_FRAMES") && atoi(getenv("SE_PAD_FRAMES")) == 0);
-        const int m = pad_frames_mult(mult);
+        const int m = mult == 1 ? 1 : pad_frames_mult(mult);      // (mult 1: never pad - the caller's switch is off)
         if (!env || T_true % m == 0) return;
         T = (T_true + m - 1) / m * m;
         if (ragged_ctx()) return;          // rows of different lengths already carry their sizes

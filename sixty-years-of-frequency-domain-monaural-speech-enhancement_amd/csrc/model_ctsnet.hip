@@ -154,20 +154,23 @@ class CtsNet final : public Model {
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         SE_CHECK(has1 && has2, "CTSNet decode needs both stages' weights");
         const int Lpad = padded_samples(L), T = 1 + Lpad / HOP;
-        const int Tw = causal_work_frames(T, cum);          // cLN weights: rows zero-extended to whole 128 B lines (model.h)
+        // InstanceNorm weights: rows of whole 128 B lines as ragged rows of one length; cLN weights: zero-extended (model.h)
+        PadFrames pad(ctx, B, L, Lpad, T, L, st, cum ? 1 : in_pad_multiple());
+        const int Tw = cum ? causal_work_frames(T, true) : pad.T;
+        const int Ts = cum ? T : Tw;          // frames the STFT / iSTFT walk (ragged rows: zeros behind a row's own last frame)
         Bufs& b = bufs(B, Tw);
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // :63-64
-        if (Tw != T) {
+        if (Tw != T && cum) {
             SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
             SE_HIP(hipMemsetAsync(b.mag, 0, (size_t)B * NBIN * Tw * sizeof(float), st));
         }
-        launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, b.mag, T, Tw, st);    // :65-76
+        launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, b.mag, Ts, Tw, st);    // :65-76
         step1(b, b.mag, b.est1, st);                                                               // :79
         launch_mag_phase(b.est1, b.spec, b.s1, B, NBIN, Tw, 1.f, st);                              // :80-81
         step2(b, b.spec, b.s1, b.est, st);                                                         // :82-83
         launch_add(b.est, b.s1, b.est, (long)B * 2 * NBIN * Tw, st);                               // :84
         launch_polar_pow(b.est, b.est, B, NBIN, Tw, ctx.p_out, st);                                // :87-90
-        launch_istft(ctx.geom, b.est, B, T, Tw, b.frames, b.c, out, out_pitch, L, st);             // :93-96 ([:wav_len])
+        launch_istft(ctx.geom, b.est, B, Ts, Tw, b.frames, b.c, out, out_pitch, L, st);             // :93-96 ([:wav_len])
     }
 
     // ---- frame-online mode (CTSNet_new: every norm is a cumulative LayerNorm, so the whole network is causal).  The chunk

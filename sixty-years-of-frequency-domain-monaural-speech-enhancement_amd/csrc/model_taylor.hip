@@ -130,14 +130,17 @@ class TaylorSENet final : public Model {
     int frame_multiple() const override { return causal_frame_multiple(cum); }
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int Lpad = padded_samples(L), T = 1 + Lpad / HOP;
-        const int Tw = causal_work_frames(T, cum);          // cLN weights: rows zero-extended to whole 128 B lines (model.h)
+        // InstanceNorm weights: rows of whole 128 B lines as ragged rows of one length; cLN weights: zero-extended (model.h)
+        PadFrames pad(ctx, B, L, Lpad, T, L, st, cum ? 1 : in_pad_multiple());
+        const int Tw = cum ? causal_work_frames(T, true) : pad.T;
+        const int Ts = cum ? T : Tw;          // frames the STFT / iSTFT walk (ragged rows: zeros behind a row's own last frame)
         Bufs& b = bufs(B, Tw);
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // :27-28
-        if (Tw != T) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
-        launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, nullptr, T, Tw, st);  // :30-41
+        if (Tw != T && cum) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
+        launch_stft(ctx.geom, wav, pitch, B, L, Lpad, b.c, ctx.p_in, b.spec, nullptr, Ts, Tw, st);  // :30-41
         network(b, st);                                                                            // :42
         launch_polar_pow(b.est, b.est, B, NBIN, Tw, ctx.p_out, st);                                // :44-45
-        launch_istft(ctx.geom, b.est, B, T, Tw, b.frames, b.c, out, out_pitch, L, st);             // :48-51
+        launch_istft(ctx.geom, b.est, B, Ts, Tw, b.frames, b.c, out, out_pitch, L, st);             // :48-51
     }
 
     // ---- frame-online mode (TaylorSENet_new: cumulative LayerNorms only).  Windows of SH history columns + n new frames

@@ -69,14 +69,21 @@ class Crn final : public Model {
         launch_transpose_akt(b.D[5], out, NBIN, B, T, T, (long)NBIN * T, NBIN, (long)T * NBIN, st);
     }
 
+    // (the network is causal end to end - eval BatchNorm is folded - so an equal-length batch runs with its rows zero-extended to
+    // whole 128 B lines, model.h causal_work_frames; the LSTMs still walk the clip's own T frames: Bufs::Tl)
+    int frame_multiple() const override { return causal_frame_multiple(true); }
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int T = 1 + L / HOP;
-        Bufs& b = bufs(B, T);
+        const int Tw = causal_work_frames(T, true);
+        Bufs& b = bufs(B, Tw);
+        b.Tl = T;
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // crn_decode_vb.py:34-35
-        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, b.mag, T, T, st);        // :36-39
+        if (Tw != T) SE_HIP(hipMemsetAsync(b.mag, 0, (size_t)B * NBIN * Tw * sizeof(float), st));
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, b.mag, T, Tw, st);       // :36-39
         network(b, st);                                                                            // :43
-        launch_mag_phase(b.D[5], b.spec, b.est, B, NBIN, T, ctx.p_out, st);                        // :46-49
-        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :50-52
+        launch_mag_phase(b.D[5], b.spec, b.est, B, NBIN, Tw, ctx.p_out, st);                       // :46-49
+        launch_istft(ctx.geom, b.est, B, T, Tw, b.frames, b.c, out, out_pitch, L, st);             // :50-52
+        b.Tl = 0;
     }
 
     // ---- frame-online mode (model.h): every conv / deconv looks back exactly one frame (CRN.py:38 ConstantPad2d top 1 +
@@ -139,6 +146,7 @@ class Crn final : public Model {
   private:
     struct Bufs {
         int B = 0, T = 0;
+        int Tl = 0;      // > 0: the clip's own frame count when the rows are zero-extended to T (offline equal-length batches)
         float *c, *spec, *mag, *est, *frames, *E[5], *D[6], *X, *G, *Hs[2], *cell;
     } cur;
     GCPlan enc[5];
@@ -180,6 +188,7 @@ class Crn final : public Model {
     // b.mag [B][161][T] -> b.D[5] [B][1][161][T]
     void network(Bufs& b, hipStream_t st) {
         const int B = b.B, T = b.T;
+        const int Tl = b.Tl > 0 ? b.Tl : T;      // frames the recurrent section walks (rows may be zero-extended: enhance())
         Profiler* pf = &ctx.prof;
         const int EC[5] = {16, 32, 64, 128, 256}, EF[5] = {80, 39, 19, 9, 4};
         Act4 x = act4(b.mag, 1, NBIN, T);
@@ -190,23 +199,23 @@ class Crn final : public Model {
         // CRN.py:27-31  [B,256,T,4] -> [B,T,1024] -> LSTM x2 -> back;  engine: [B][1024][T] <-> [T][1024][B]
         if (lstm[0].fm_ok(B) && lstm[1].fm_ok(B)) {
             // feature-major [1024][T][B] (rnn.h run_fm): the two 4096 x 1024 input projections are full-width GEMMs
-            launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, B, (long)T * B, st);
+            launch_transpose_akt(b.E[4], b.X, B, 1024, Tl, 1024L * T, T, B, (long)Tl * B, st);
             const LstmBig* ly[2] = {&lstm[0], &lstm[1]};
             float* outs2[2] = {b.Hs[0], b.Hs[1]};
-            if (B == 1 && lstm_stack_fm(ly, 2, b.X, b.G, b.Hs[1], T, st, pf)) {
+            if (B == 1 && lstm_stack_fm(ly, 2, b.X, b.G, b.Hs[1], Tl, st, pf)) {
                 // (one clip: both layers as one wavefront launch, rnn.h)
-            } else if (lstm_stack_chunked_fm(ly, 2, b.X, b.G, b.cell, outs2, T, B, st, pf)) {
+            } else if (lstm_stack_chunked_fm(ly, 2, b.X, b.G, b.cell, outs2, Tl, B, st, pf)) {
                 // (up to 64 clips: the two layers as a pipeline over chunks of frames, one cooperative launch per chunk, rnn.h)
             } else {
-                lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
-                lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
+                lstm[0].run_fm(b.X, b.G, b.cell, b.Hs[0], Tl, B, st, pf);
+                lstm[1].run_fm(b.Hs[0], b.G, b.cell, b.Hs[1], Tl, B, st, pf);
             }
-            launch_transpose_akt(b.Hs[1], b.D[0], T, 1024, B, B, (long)T * B, 1024L * T, T, st);
+            launch_transpose_akt(b.Hs[1], b.D[0], Tl, 1024, B, B, (long)Tl * B, 1024L * T, T, st);
         } else {
-            launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, 1024L * B, B, st);
-            lstm[0].run(b.X, b.G, b.cell, b.Hs[0], T, B, st, pf);
-            lstm[1].run(b.Hs[0], b.G, b.cell, b.Hs[1], T, B, st, pf);
-            launch_transpose_akt(b.Hs[1], b.D[0], T, 1024, B, 1024L * B, B, 1024L * T, T, st);
+            launch_transpose_akt(b.E[4], b.X, B, 1024, Tl, 1024L * T, T, 1024L * B, B, st);
+            lstm[0].run(b.X, b.G, b.cell, b.Hs[0], Tl, B, st, pf);
+            lstm[1].run(b.Hs[0], b.G, b.cell, b.Hs[1], Tl, B, st, pf);
+            launch_transpose_akt(b.Hs[1], b.D[0], Tl, 1024, B, 1024L * B, B, 1024L * T, T, st);
         }
         const int DCo[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
         int cin = 256, fin = 4;

@@ -104,14 +104,22 @@ class Dpcrn final : public Model {
         launch_transpose_akt(b.est, out, NBIN, 2 * B, T, T, (long)NBIN * T, NBIN, (long)T * NBIN, st);
     }
 
+    // (causal end to end - eval BatchNorm folded, the intra-frame BiLSTM and both LayerNorms work inside one frame - so an
+    // equal-length batch runs with its rows zero-extended to whole 128 B lines, model.h causal_work_frames; the inter-frame LSTMs
+    // walk the clip's own frames: Bufs::Tl)
+    int frame_multiple() const override { return causal_frame_multiple(true); }
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int T = 1 + L / HOP;
-        Bufs& b = bufs(B, T);
+        const int Tw = causal_work_frames(T, true);
+        Bufs& b = bufs(B, Tw);
+        b.Tl = T;
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // dpcrn_decode_vb.py:34-35
-        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, nullptr, T, T, st);      // :37-45
+        if (Tw != T) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, nullptr, T, Tw, st);     // :37-45
         network(b, st);                                                                            // :47
-        launch_cmask_apply(b.D[5], b.spec, b.est, B, NBIN, T, ctx.p_out, st);                      // model :33-42 + :48-57
-        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :58-60
+        launch_cmask_apply(b.D[5], b.spec, b.est, B, NBIN, Tw, ctx.p_out, st);                     // model :33-42 + :48-57
+        launch_istft(ctx.geom, b.est, B, T, Tw, b.frames, b.c, out, out_pitch, L, st);             // :58-60
+        b.Tl = 0;
     }
 
     // ---- frame-online mode (model.h): (de)convs look back one frame (DPCRN.py:94-166, same pad / chomp scheme as CRN), the
@@ -184,6 +192,7 @@ class Dpcrn final : public Model {
     }
     struct Bufs {
         int B = 0, T = 0;
+        int Tl = 0;      // > 0: the clip's own frame count when the rows are zero-extended to T (offline equal-length batches)
         float *c, *spec, *est, *frames, *E[5], *D[6];
         float *Gi, *Hi[2], *Y, *R1, *Xt, *Gt, *Ht[2], *Yt, *R2, *P1;
     } cur;
@@ -232,7 +241,8 @@ class Dpcrn final : public Model {
     // `pass` continue from their carried state
     void dprnn(Bufs& b, const float* x, float* out, hipStream_t st, int n_stream = 0, int pass = 0) {
         const int B = b.B, T = b.T;
-        const int nT = n_stream > 0 ? n_stream : T, c0 = T - nT;        // inter-frame steps and their first column
+        // inter-frame steps and their first column (frame-online: the last n_stream columns; zero-extended rows: the clip's own frames)
+        const int nT = n_stream > 0 ? n_stream : (b.Tl > 0 ? b.Tl : T), c0 = n_stream > 0 ? T - nT : 0;
         Profiler* pf = &ctx.prof;
         const long plane = (long)NF * T;            // one channel
         // ---- intra: BiLSTM(128 -> 64 x2, 2 layers) over F for every (b, t)

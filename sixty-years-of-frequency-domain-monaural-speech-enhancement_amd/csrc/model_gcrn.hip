@@ -100,14 +100,21 @@ class Gcrn final : public Model {
         launch_transpose_akt(b.est, out, NBIN, 2 * B, T, T, (long)NBIN * T, NBIN, (long)T * NBIN, st);
     }
 
+    // (causal end to end - the convs have no extent in time, eval BatchNorm is folded, LayerNorm is per frame - so an equal-length
+    // batch runs with its rows zero-extended to whole 128 B lines, model.h causal_work_frames; the LSTMs walk the clip's own frames)
+    int frame_multiple() const override { return causal_frame_multiple(true); }
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int T = 1 + L / HOP;
-        Bufs& b = bufs(B, T);
+        const int Tw = causal_work_frames(T, true);
+        Bufs& b = bufs(B, Tw);
+        b.Tl = T;
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // gcrn_decode_vb.py:35-36
-        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, nullptr, T, T, st);      // :37-44
+        if (Tw != T) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, nullptr, T, Tw, st);     // :37-44
         network(b, st);                                                                            // :46
-        launch_polar_pow(b.est, b.est, B, NBIN, T, ctx.p_out, st);                                 // :47-55
-        launch_istft(ctx.geom, b.est, B, T, T, b.frames, b.c, out, out_pitch, L, st);              // :56-58
+        launch_polar_pow(b.est, b.est, B, NBIN, Tw, ctx.p_out, st);                                // :47-55
+        launch_istft(ctx.geom, b.est, B, T, Tw, b.frames, b.c, out, out_pitch, L, st);             // :56-58
+        b.Tl = 0;
     }
 
     // ---- frame-online mode (model.h): the (1,3) convs have no extent in time (GCRN_noncprs.py:42-83), LayerNorm is per
@@ -146,6 +153,7 @@ class Gcrn final : public Model {
   private:
     struct Bufs {
         int B = 0, T = 0;
+        int Tl = 0;      // > 0: the clip's own frame count when the rows are zero-extended to T (offline equal-length batches)
         float *c, *spec, *est, *frames, *E[5], *EE[4], *D[2][5], *X, *Y, *Z, *G, *cell, *L0;
     } cur;
     StreamState ss;
@@ -241,15 +249,16 @@ class Gcrn final : public Model {
             launch_layernorm_cf(b.Y, nullptr, ln_w[1], ln_b[1], b.Z, n, 1024, 1, (int)S, 1e-5f, st);
             launch_transpose_akt(b.Z, b.L0 + c0, n, 1024, B, 1024L * S, S, 1024L * T, T, st);
         } else {
-        launch_transpose_akt(b.E[4], b.X, B, 1024, T, 1024L * T, T, 1024L * S, S, st);
+        const int Tl = b.Tl > 0 ? b.Tl : T;      // frames the recurrent section walks (rows may be zero-extended: enhance())
+        launch_transpose_akt(b.E[4], b.X, B, 1024, Tl, 1024L * T, T, 1024L * S, S, st);
         // group i reads features [512i, 512i+512); outputs interleaved (row 2j+i) :26-29; both groups in one launch
-        run_lstm_pair(l1[0], l1[1], whh_pair[0], b.X, b.X + 512L * S, 1024L * S, b.G, b.cell, b.Y, S, 1024L * S, 2, T, (int)S,
+        run_lstm_pair(l1[0], l1[1], whh_pair[0], b.X, b.X + 512L * S, 1024L * S, b.G, b.cell, b.Y, S, 1024L * S, 2, Tl, (int)S,
                       st, pf);
-        launch_layernorm_cf(b.Y, nullptr, ln_w[0], ln_b[0], b.Z, T, 1024, 1, (int)S, 1e-5f, st);
-        run_lstm_pair(l2[0], l2[1], whh_pair[1], b.Z, b.Z + 512L * S, 1024L * S, b.G, b.cell, b.Y, 512L * S, 1024L * S, 1, T,
+        launch_layernorm_cf(b.Y, nullptr, ln_w[0], ln_b[0], b.Z, Tl, 1024, 1, (int)S, 1e-5f, st);
+        run_lstm_pair(l2[0], l2[1], whh_pair[1], b.Z, b.Z + 512L * S, 1024L * S, b.G, b.cell, b.Y, 512L * S, 1024L * S, 1, Tl,
                       (int)S, st, pf);                                                             // :32-33 (cat)
-        launch_layernorm_cf(b.Y, nullptr, ln_w[1], ln_b[1], b.Z, T, 1024, 1, (int)S, 1e-5f, st);
-        launch_transpose_akt(b.Z, b.L0, T, 1024, B, 1024L * S, S, 1024L * T, T, st);
+        launch_layernorm_cf(b.Y, nullptr, ln_w[1], ln_b[1], b.Z, Tl, 1024, 1, (int)S, 1e-5f, st);
+        launch_transpose_akt(b.Z, b.L0, Tl, 1024, B, 1024L * S, S, 1024L * T, T, st);
         }
         // ---- two decoders
         const int DCO[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};

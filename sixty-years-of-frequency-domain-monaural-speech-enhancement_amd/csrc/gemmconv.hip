@@ -1667,9 +1667,7 @@ GCPlan gc_make_plan(int M, int Cin, const TapSpec& taps, const std::vector<float
         // pointwise layers stage 16 B groups (4x the slots) and size the chunk by the LDS budget of 3 blocks per CU
         const bool pw = taps.ntaps == 1 && pw_chunks;
         const int kmax = pw ? (pl.BM >= 128 ? 24 : 32) : gc_kcp_max(pl.BM);
-        // (SE_GC_CAP4=1, experiment: size the chunks of every causal layer for 16 B staging groups - 4 x the slots)
-        static const int cap4_env = getenv("SE_GC_CAP4") ? atoi(getenv("SE_GC_CAP4")) : 0;
-        const int cap = gc_bld_max(pl.BM) * 256 * ((pw || cap4_env) ? 4 : 1);
+        const int cap = gc_bld_max(pl.BM) * 256 * (pw ? 4 : 1);
         if (kcp > std::min(kmax, kcp_cap) || c * p.nrows * p.Wp > cap) continue;
         // 64-row layers: keep the chunk small enough for the 64 x 256 tile's patch (3 workgroups per CU) when that still
         // leaves >= 12 K rows per barrier - G2Net's 3-tap convs would stage 8 channels x 3 rows and fall back to 64 x 128

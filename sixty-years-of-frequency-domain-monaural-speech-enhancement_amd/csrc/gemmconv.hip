@@ -231,8 +231,12 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
     }
     const int mt = lid % p.n_mtiles;
     int rest = lid / p.n_mtiles;
-    const int ttile = rest % p.n_ttiles;
-    rest /= p.n_ttiles;
+    // (FLAT: the output rows q of one unit group are neighbours in the block order - rows q and q + 1 of a stride-2 layer share
+    // an input row, and with the B * 13 / 8 tiles of a whole batch between them that row came from HBM twice: the round-6 PMC pass
+    // of TaylorSENet read 1.44 GB per launch of the 64 x 256 tile against 0.96 GB with plain tiles)
+    const int ttile = FLAT ? (rest / p.Qt) % p.n_ttiles : rest % p.n_ttiles;
+    if (FLAT) rest = (rest % p.Qt) + (rest / (p.Qt * p.n_ttiles)) * p.Qt;
+    else rest /= p.n_ttiles;
     // two-row tiles (p.qt2, gc_launch): the tile's columns are 2 output rows x BN / 2 frames - neighbouring output rows share
     // most of their input rows (5 taps at stride 2: 7 staged rows instead of 10), so a chunk stages ~30 % fewer bytes for the
     // same matrix work.  The waves of the upper column half take the second row; only block-level scalars differ.

@@ -16,5 +16,9 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_
     timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o p -- \
         python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-profile > $D.log 2>&1
 done
-ls -la $OUT $OUT/pmc/*/ | head -40
+# the summaries are made here (the raw counter files are tens of MB each: gpurun merges back at most 64 MiB)
+python $ROOT/tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc_dccrn --steps 3 | cut -c1-200
+cp $OUT/kt/s_kernel_stats.csv $OUT/${TAG}_dccrn_b256_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/pmc/*/p_*.csv $OUT/kt/s_kernel_trace.csv
+ls -la $OUT | head -20
 tail -c 600 $OUT/bench.json

@@ -15,6 +15,6 @@ for spec in "$@"; do
         python $ROOT/tools/sweep.py --models $1 --batch $2 --steps 1 --no-profile > $D.log 2>&1
   done
   python $ROOT/tools/pmc_summary.py $OUT $ROOT/gpurun_out/${TAG}_pmc_$1_b$2 --steps 3 | cut -c1-200
-  rm -rf $OUT/*/p_kernel_trace.csv
+  rm -rf $OUT/*/p_kernel_trace.csv $OUT/*/p_counter_collection.csv
   du -sh $OUT | cut -c1-60
 done

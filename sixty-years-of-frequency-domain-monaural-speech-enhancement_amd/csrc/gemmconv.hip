@@ -745,11 +745,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // plain PReLU path hopped over them value by value: 22 500 instructions (180 KB) per kernel, a multiple of the
             // instruction cache, fetched again by every workgroup.  LIN: identity / ReLU / PReLU as one `v >= 0 ? v : s v`.
             auto write_strip = [&](auto ACT_) __attribute__((always_inline)) {
-                constexpr int ACT = decltype(ACT_)::value;      // -1: the linear family, else the activation itself
+                constexpr int ACT = decltype(ACT_)::value;      // -1: the linear family, -2: identity (no slope read), else the activation itself
                 auto actf = [&](float v, float sl) __attribute__((always_inline)) -> float {
-                    if constexpr (ACT < 0) return v >= 0.f ? v : sl * v;
+                    if constexpr (ACT == -2) return v;
+                    else if constexpr (ACT < 0) return v >= 0.f ? v : sl * v;
                     else return act_apply(v, ACT, sl);
                 };
+                // (round 6) a lane's 16 rows of a 32 x 32 tile are four groups of four consecutive rows: their parameters come as
+                // 16 B / 8 B LDS reads - 8 instead of 32 (plain) and 16 instead of 40 (gated) per tile and lane
+                typedef float floatx2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     if (EPI == EPI_CMB) {        // raw products: scale / shift / PReLU follow the sum with k1 in the read-back
@@ -760,30 +764,43 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                         }
                     } else if (EPI != EPI_GLU) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
-                            const float v = acc[i][j][r] + ep[mw + dm];
-                            strip[(4 * hi + dm) * OST + l31] = actf(v, ep[BM + mw + dm]);
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int dm0 = i * 32 + 8 * g4;
+                            const floatx4 b4 = *reinterpret_cast<const floatx4*>(ep + mw + dm0);
+                            floatx4 s4 = {1.f, 1.f, 1.f, 1.f};
+                            if constexpr (ACT != -2) s4 = *reinterpret_cast<const floatx4*>(ep + BM + mw + dm0);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float v = acc[i][j][4 * g4 + k] + b4[k];
+                                strip[(4 * hi + dm0 + k) * OST + l31] = actf(v, s4[k]);
+                            }
                         }
                     } else {
 #pragma unroll
-                        for (int r2 = 0; r2 < 8; ++r2) {
-                            const int r = 2 * r2;
-                            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);      // even row (value), dm + 1 = its gate
-                            const float a = acc[i][j][r] + ep[mw + dm];
-                            const float g = acc[i][j][r + 1] + ep[mw + dm + 1];
-                            const int ol = (mw + dm) >> 1;
-                            float v = a * fsig_(g);          // hardware exp + reciprocal (as in the LSTM cells): the libm pair was ~15 % of a small-K GLU tile
-                            v = v * ep[2 * BM + ol] + ep[3 * BM + ol];
-                            strip[((4 * hi + dm) >> 1) * OST + l31] = actf(v, ep[BM + ol]);
+                        for (int g4 = 0; g4 < 4; ++g4) {      // rows dm0 .. dm0 + 3 = (value, gate) x 2 outputs ol0, ol0 + 1
+                            const int dm0 = i * 32 + 8 * g4;
+                            const int ol0 = (mw + dm0) >> 1;
+                            const floatx4 b4 = *reinterpret_cast<const floatx4*>(ep + mw + dm0);
+                            const floatx2 sc2 = *reinterpret_cast<const floatx2*>(ep + 2 * BM + ol0);
+                            const floatx2 sh2 = *reinterpret_cast<const floatx2*>(ep + 3 * BM + ol0);
+                            floatx2 sl2 = {1.f, 1.f};
+                            if constexpr (ACT != -2) sl2 = *reinterpret_cast<const floatx2*>(ep + BM + ol0);
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const float a = acc[i][j][4 * g4 + 2 * k] + b4[2 * k];
+                                const float g = acc[i][j][4 * g4 + 2 * k + 1] + b4[2 * k + 1];
+                                float v = a * fsig_(g);          // hardware exp + reciprocal (as in the LSTM cells): the libm pair was ~15 % of a small-K GLU tile
+                                v = v * sc2[k] + sh2[k];
+                                strip[(((4 * hi + dm0) >> 1) + k) * OST + l31] = actf(v, sl2[k]);
+                            }
                         }
                     }
                 }
             };
             switch (p.act) {
-                case ACT_NONE:
+                case ACT_NONE: write_strip(std::integral_constant<int, -2>{}); break;       // (raw layers: the norm-folded U^2-Net levels, k1 planes, projections)
                 case ACT_RELU:
-                case ACT_PRELU: write_strip(std::integral_constant<int, -1>{}); break;      // (slopes 1 / 0 / the layer's: see `ep`)
+                case ACT_PRELU: write_strip(std::integral_constant<int, -1>{}); break;      // (slopes 0 / the layer's: see `ep`)
                 case ACT_ELU: write_strip(std::integral_constant<int, ACT_ELU>{}); break;
                 case ACT_SOFTPLUS: write_strip(std::integral_constant<int, ACT_SOFTPLUS>{}); break;
                 case ACT_SIGMOID: write_strip(std::integral_constant<int, ACT_SIGMOID>{}); break;

@@ -813,8 +813,15 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
             // frame-by-frame tail - were 6 KB of instructions per kernel that every workgroup streamed through once)
             constexpr int RB_UNROLL = (PRE || FZ) ? OROWS / 8 : 1;
             float ccs[GC_STATS ? 4 : 1] = {}, ccq[GC_STATS ? 4 : 1] = {};      // GCParams::cstats: this lane's 4 frames over its rows
+            // (round 6) the row's offsets run along with the loop: as `(long)m * p.d_c` inside the rolled loop every iteration paid
+            // two 64-bit multiply-adds and a dozen v_readlane for their spilled scalars
+            long doff = (long)(mo0 + lr) * p.d_c + tg;                 // dst / dst_elu / cmb_s offset of (row m, frame tg)
+            const long dstep = 8L * p.d_c;
+            long soff = 0;
+            if constexpr (GC_STATS) soff = (long)(b + dbJ) * p.st_b + (long)(mo0 + lr) * p.st_c + (long)fow * p.st_f + (tj0 >> 5) * 2;
+            const long sstep = GC_STATS ? 8L * p.st_c : 0;
 #pragma unroll RB_UNROLL
-            for (int it = 0; it < OROWS / 8; ++it) {
+            for (int it = 0; it < OROWS / 8; ++it, doff += dstep, soff += sstep) {
                 const int row = it * 8 + lr, m = mo0 + row;
                 floatx4 v = *reinterpret_cast<const floatx4*>(strip + row * OST + lc);
                 if constexpr (GC_STATS) {
@@ -840,16 +847,16 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                         }
                         s = dpp_add8(s);
                         q = dpp_add8(q);
-                        const int tb = tg - lc;                  // first frame of the sub-tile
+                        const int tb = tg - lc;                  // first frame of the sub-tile (= tj0)
                         if ((lane & 7) == 0 && m < MoJ && tb < p.Tout) {
-                            float* sp = p.stats + (long)(b + dbJ) * p.st_b + (long)m * p.st_c + (long)fow * p.st_f + (tb >> 5) * 2;
+                            float* sp = p.stats + soff;
                             sp[0] = s;
                             sp[1] = q;
                         }
                     }
                 }
                 if (m < MoJ) {
-                    float* __restrict__ dp = dstJ + (long)m * p.d_c + tg;
+                    float* __restrict__ dp = dstJ + doff;
                     if (__builtin_expect(tg + 3 < p.Tout, 1)) {
                         if (EPI == EPI_ADD || EPI == EPI_MUL) v = (EPI == EPI_ADD) ? v + rvp[it] : v * rvp[it];
                         if (EPI == EPI_CMB) {
@@ -885,7 +892,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                             floatx4 e4;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) e4[k] = v[k] > 0.f ? v[k] : fm_expm1(v[k]);
-                            *reinterpret_cast<floatx4*>(deluJ + (long)m * p.d_c + tg) = e4;
+                            *reinterpret_cast<floatx4*>(deluJ + doff) = e4;
                         }
                         if (EPI == EPI_CMB && cmbsJ) {
                             floatx4 s4 = v + ivp[it];
@@ -893,7 +900,7 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) s4[k] = (tg + k < tvalid) ? s4[k] : 0.f;
                             }
-                            *reinterpret_cast<floatx4*>(cmbsJ + (long)m * p.d_c + tg) = s4;
+                            *reinterpret_cast<floatx4*>(cmbsJ + doff) = s4;
                         }
                     } else {
 #pragma unroll
@@ -910,10 +917,10 @@ __global__ __launch_bounds__(256, RES ? 1 : (FZ || (BM >= 128 && BN >= 256)) ? (
                                 o = (tg + k < tvalid) ? o : 0.f;
                                 if (FZ) o = gc_fuse1(o, fzb + (long)m * p.fz_c + tg + k, p.fz_im, p.fz_s);
                                 dp[k] = o;
-                                if (EPI == EPI_GLU && deluJ) deluJ[(long)m * p.d_c + tg + k] = o > 0.f ? o : fm_expm1(o);
+                                if (EPI == EPI_GLU && deluJ) deluJ[doff + k] = o > 0.f ? o : fm_expm1(o);
                                 if (EPI == EPI_CMB && cmbsJ) {
-                                    const float iv = cmbiJ[(long)m * p.d_c + tg + k];
-                                    cmbsJ[(long)m * p.d_c + tg + k] = (tg + k < tvalid) ? o + iv : 0.f;
+                                    const float iv = cmbiJ[doff + k];
+                                    cmbsJ[doff + k] = (tg + k < tvalid) ? o + iv : 0.f;
                                 }
                             }
                     }

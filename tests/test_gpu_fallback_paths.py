@@ -48,16 +48,19 @@ def test_reference_fixtures_with_the_round5_switches_thrown():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-# round 6: unit-flattened column tiles of the 64-row layers (GCParams::flat_upr) are the default from 1 024 workgroups on - the
-# batch-256 fixtures run them; here the same fixtures with the plain tiles
-SWITCHES_R6 = {'SE_GC_FLAT': '0'}
+# round 6: unit-flattened column tiles of the 64-row layers (GCParams::flat_upr) are the default from 1 024 workgroups on, and
+# equal-length batches run with rows of whole 128 B lines (zero-extended: the cLN variants, CRN, GCRN, DPCRN; as ragged rows of one
+# length: the InstanceNorm networks) - the batch-256 and 4 s fixtures run all of that; here the same fixtures with plain tiles and
+# unpadded rows
+SWITCHES_R6 = {'SE_GC_FLAT': '0', 'SE_CLN_PAD': '1', 'SE_IN_PAD': '1'}
 
 
 @pytest.mark.gpu
 def test_reference_fixtures_with_the_round6_switches_thrown():
     env = dict(os.environ, **SWITCHES_R6)
     cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
-           os.path.join(ROOT, 'tests', 'test_gpu_b256_fixture.py'), '-k', 'g2net or taylor or uformer or dpcrn or gcrn']
+           os.path.join(ROOT, 'tests', 'test_gpu_b256_fixture.py'), os.path.join(ROOT, 'tests', 'test_gpu_full_fixture.py'),
+           '-k', 'g2net or taylor or ctsnet or uformer or dpcrn or gcrn or crn']
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

@@ -102,7 +102,8 @@ inline int pad_frames_mult(int model_default = 4) {
 // 64 -> 64 layer alone - SE_GC_DBG=4 - 1.17 -> 0.81 ms).  SE_CLN_PAD=n: multiple (default 32, 1 = off).
 inline int causal_work_frames(int T, bool causal_all) {
     static const int m = getenv("SE_CLN_PAD") ? std::max(1, atoi(getenv("SE_CLN_PAD"))) : 32;
-    if (!causal_all || m <= 1 || ragged_ctx() || stream_ctx()) return T;
+    // (ragged calls too: the rows' own lengths travel in the ragged context, the STFT writes zeros behind each row's last frame)
+    if (!causal_all || m <= 1 || stream_ctx()) return T;
     return (T + m - 1) / m * m;
 }
 // The InstanceNorm flavours of the same networks cannot be zero-extended (the statistics run over the whole utterance): their

@@ -75,14 +75,16 @@ class Crn final : public Model {
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int T = 1 + L / HOP;
         const int Tw = causal_work_frames(T, true);
+        const bool rag = ragged_ctx() != nullptr;
+        const int Ts = rag ? Tw : T;          // frames the STFT / iSTFT walk (ragged rows: zeros behind a row's own last frame)
         Bufs& b = bufs(B, Tw);
         b.Tl = T;
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // crn_decode_vb.py:34-35
-        if (Tw != T) SE_HIP(hipMemsetAsync(b.mag, 0, (size_t)B * NBIN * Tw * sizeof(float), st));
-        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, b.mag, T, Tw, st);       // :36-39
+        if (Tw != T && !rag) SE_HIP(hipMemsetAsync(b.mag, 0, (size_t)B * NBIN * Tw * sizeof(float), st));
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, b.mag, Ts, Tw, st);       // :36-39
         network(b, st);                                                                            // :43
         launch_mag_phase(b.D[5], b.spec, b.est, B, NBIN, Tw, ctx.p_out, st);                       // :46-49
-        launch_istft(ctx.geom, b.est, B, T, Tw, b.frames, b.c, out, out_pitch, L, st);             // :50-52
+        launch_istft(ctx.geom, b.est, B, Ts, Tw, b.frames, b.c, out, out_pitch, L, st);             // :50-52
         b.Tl = 0;
     }
 

@@ -157,10 +157,11 @@ class CtsNet final : public Model {
         // InstanceNorm weights: rows of whole 128 B lines as ragged rows of one length; cLN weights: zero-extended (model.h)
         PadFrames pad(ctx, B, L, Lpad, T, L, st, cum ? 1 : in_pad_multiple());
         const int Tw = cum ? causal_work_frames(T, true) : pad.T;
-        const int Ts = cum ? T : Tw;          // frames the STFT / iSTFT walk (ragged rows: zeros behind a row's own last frame)
+        const bool rag = ragged_ctx() != nullptr;
+        const int Ts = (cum && !rag) ? T : Tw;          // frames the STFT / iSTFT walk (ragged rows: zeros behind a row's own last frame)
         Bufs& b = bufs(B, Tw);
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // :63-64
-        if (Tw != T && cum) {
+        if (Tw != T && cum && !rag) {
             SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
             SE_HIP(hipMemsetAsync(b.mag, 0, (size_t)B * NBIN * Tw * sizeof(float), st));
         }

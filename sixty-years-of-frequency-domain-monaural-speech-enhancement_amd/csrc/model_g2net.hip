@@ -123,10 +123,11 @@ class G2Net final : public Model {
         // InstanceNorm weights: rows of whole 128 B lines as ragged rows of one length; cLN weights: zero-extended (model.h)
         PadFrames pad(ctx, B, L, L, T, L, st, cum ? 1 : in_pad_multiple());
         const int Tw = cum ? causal_work_frames(T, true) : pad.T;
-        const int Ts = cum ? T : Tw;          // frames the STFT / iSTFT walk (ragged rows: zeros behind a row's own last frame)
+        const bool rag = ragged_ctx() != nullptr;
+        const int Ts = (cum && !rag) ? T : Tw;          // frames the STFT / iSTFT walk (ragged rows: zeros behind a row's own last frame)
         Bufs& b = bufs(B, Tw);
         launch_rms_scale(wav, B, L, pitch, b.c, st);        // c_engine = 1 / RMS: x * c_engine == x / RMS (:43-44), y / c_engine == y * RMS (:88)
-        if (Tw != T && cum) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
+        if (Tw != T && cum && !rag) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
         launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, nullptr, Ts, Tw, st);     // :49-61
         const float* y = network(b, st);                                                           // :66-69
         launch_polar_pow(y, b.est, B, NBIN, Tw, ctx.p_out, st);                                    // :76-82

@@ -106,14 +106,16 @@ class Gcrn final : public Model {
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int T = 1 + L / HOP;
         const int Tw = causal_work_frames(T, true);
+        const bool rag = ragged_ctx() != nullptr;
+        const int Ts = rag ? Tw : T;          // frames the STFT / iSTFT walk (ragged rows: zeros behind a row's own last frame)
         Bufs& b = bufs(B, Tw);
         b.Tl = T;
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                               // gcrn_decode_vb.py:35-36
-        if (Tw != T) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
-        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, nullptr, T, Tw, st);     // :37-44
+        if (Tw != T && !rag) SE_HIP(hipMemsetAsync(b.spec, 0, (size_t)B * 2 * NBIN * Tw * sizeof(float), st));
+        launch_stft(ctx.geom, wav, pitch, B, L, L, b.c, ctx.p_in, b.spec, nullptr, Ts, Tw, st);     // :37-44
         network(b, st);                                                                            // :46
         launch_polar_pow(b.est, b.est, B, NBIN, Tw, ctx.p_out, st);                                // :47-55
-        launch_istft(ctx.geom, b.est, B, T, Tw, b.frames, b.c, out, out_pitch, L, st);             // :56-58
+        launch_istft(ctx.geom, b.est, B, Ts, Tw, b.frames, b.c, out, out_pitch, L, st);             // :56-58
         b.Tl = 0;
     }
 

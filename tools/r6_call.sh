@@ -32,6 +32,8 @@ for step in "$@"; do
       (export SE_R6=1 ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 5 --no-profile --fsn-max-batch 256 2>&1 | grep utt_per_s | cut -c1-100 | sed "s/^/[$c] /") ;;
     len)   # len:<model>:<B>:<samples>[,env=val..]
       (IFS=, read -r smp envs <<< "$c"; export SE_R6=1 ${envs:+${envs//;/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 5 --no-profile --samples $smp 2>&1 | grep utt_per_s | cut -c1-100 | sed "s/^/[L=$smp $envs] /") ;;
+    rag)   # rag:<model>:<B>[:env=val,..]: the ragged pass of tools/sweep.py (512 clips of 512 lengths through the batch plan)
+      (export SE_R6=1 ${c:+${c//,/ }}; timeout 400 python $ROOT/tools/sweep.py --models $a --batch $b --steps 2 --no-profile --ragged 512 2>&1 | grep utt_per_s | python -c "import sys,json; [print('[${c:-}]', d['model'], 'ragged utt/s', d.get('ragged_utt_per_s'), 'x rt', d.get('ragged_x_realtime')) for d in map(json.loads, sys.stdin)]") ;;
     fsnsweep)
       : > $OUT/r06_fsn_batch_sweep.jsonl
       for B in $(seq $a $b); do

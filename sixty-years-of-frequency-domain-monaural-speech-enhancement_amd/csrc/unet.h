@@ -147,6 +147,15 @@ struct UnetModule {     // En_unet_module (TaylorSENet.py:441-496)
             ok = !enco[i].na.cum && !deco[i].na.cum && enco[i].na.gain_nonzero && deco[i].na.gain_nonzero &&
                  conv_stats_supported(enco[i].plan) && conv_nrm_supported(enco[i].plan) && deconv_stats_supported(deco[i].plan) &&
                  deconv_nrm_supported(deco[i].plan);
+        // (round 6) the fold is a per-module decision taken from the consumers' taps: the on-the-fly normalisation costs three vector
+        // instructions per B VALUE, i.e. per staged input value times the taps that read it at different FRAMES (frequency taps are
+        // different patch rows); the pass it deletes costs one read + one write per value.  With kernels that have no extent in time
+        // (G2Net's (1, 3)) every staged value is normalised once and the fold wins (6 382 against 6 216 utt/s at batch 256); with two
+        // time taps (TaylorSENet's k2 = (2, 3)) it is normalised twice - its U^2-Net levels run at 87-92 TFLOP/s folded against
+        // 105-109 unfolded and the whole model 2 372 against 2 395 - so such modules keep the apply pass.  SE_IN_FOLD=2: always.
+        static const int fold_env = getenv("SE_IN_FOLD") ? atoi(getenv("SE_IN_FOLD")) : 1;
+        if (fold_env != 2)
+            for (int i = 0; i < scale && ok; ++i) ok = enco[i].plan.p.causal && enco[i].plan.lookback == 0;
         return ok;
     }
     // InstanceNorm + PReLU of every tensor inside the module applied by its consumers (gc_kernel NRM): the nested U-Net's tensors

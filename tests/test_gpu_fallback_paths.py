@@ -98,3 +98,16 @@ def test_lstm_short_kernel_against_projection_plus_persistent_path(tmp_path, B, 
     err = float(np.sqrt(np.mean((a - b) ** 2))) / max(float(np.sqrt(np.mean(b ** 2))), 1e-12)
     print('lstm_short vs two-launch form, B', B, 'T', T, 'relative rms', err)
     assert err < 2e-5
+
+
+@pytest.mark.gpu
+def test_taylorsenet_with_the_instancenorm_fold_forced():
+    """Round 6: the consumer-side InstanceNorm fold is a per-module decision (unet.h: only where the nested convs have no extent in
+    time - G2Net); TaylorSENet's (2, 3) kernels keep the apply pass by default.  SE_IN_FOLD=2 forces the fold - the `NRM` tiles with a
+    36-column unit halo only run there - on the 4 s and the batch-256 fixtures."""
+    env = dict(os.environ, SE_IN_FOLD='2')
+    cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+           os.path.join(ROOT, 'tests', 'test_gpu_b256_fixture.py'), os.path.join(ROOT, 'tests', 'test_gpu_full_fixture.py'),
+           '-k', 'taylor']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -54,6 +54,8 @@ for step in "$@"; do
       $PKG/gcbench_timing step $a $b 2>&1 | tail -2 ;;
     bench)
       (cd $ROOT && timeout 900 python bench.py --steps ${a:-10} --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; python tools/bench_digest.py $OUT/bench.json) ;;
+    benchz)   # benchz[:env=val,..]: bench.py (3 steps), zoo rows only in the digest
+      (cd $ROOT && export SE_R6=1 ${a:+${a//,/ }}; timeout 900 python bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/benchz.json 2> $OUT/benchz.err; python tools/bench_digest.py $OUT/benchz.json | grep -E "taylor|g2net|dccrn" | sed "s/^/[${a:-}] /") ;;
     corpus)
       (cd $ROOT && timeout 600 python tools/corpus_bench.py > $OUT/r06_corpus.json 2> $OUT/corpus.err; tail -c 600 $OUT/r06_corpus.json) ;;
     stream)

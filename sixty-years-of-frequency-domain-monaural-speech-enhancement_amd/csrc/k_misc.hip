@@ -674,6 +674,39 @@ __global__ __launch_bounds__(256) void cln_stats_kernel(const float* __restrict_
     }
 }
 
+// In-LDS inclusive prefix sums of sc[c0 .. T) and sc[T + c0 .. 2T), starting from (a0, q0), by ONE wave: a lane sums its contiguous
+// segment, the 64 segment totals are scanned on the shuffle network, the lane walks its segment again with its offset.  The serial
+// loop of rounds 2-5 (thread 0 over all frames, two dependent LDS round trips per frame) was 29 us for T = 416 - hidden behind the
+// other utterances' blocks at batch 256, but 144 launches x 29 us = 4.2 of the 10 ms of a single clip's decode (round 6).
+// Sums in double precision; only the association order differs from the serial loop (~1e-16 relative).
+__device__ __forceinline__ void cln_wave_scan(double* sc, int T, int c0, double a0, double q0) {
+    const int lane = threadIdx.x;            // (called by threads 0..63)
+    const int n = T - c0, L = (n + 63) >> 6;
+    const int lo = c0 + lane * L, hi = min(lo + L, T);
+    double a = 0.0, q = 0.0;
+    for (int t = lo; t < hi; ++t) {
+        a += sc[t];
+        q += sc[T + t];
+    }
+    double ia = a, iq = q;                   // inclusive scan of the segment totals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double ua = __shfl_up(ia, o, 64), uq = __shfl_up(iq, o, 64);
+        if (lane >= o) {
+            ia += ua;
+            iq += uq;
+        }
+    }
+    a = a0 + (ia - a);                       // exclusive offset of this lane's segment
+    q = q0 + (iq - q);
+    for (int t = lo; t < hi; ++t) {
+        a += sc[t];
+        q += sc[T + t];
+        sc[t] = a;
+        sc[T + t] = q;
+    }
+}
+
 __global__ __launch_bounds__(256) void cln_scan_kernel(const double* __restrict__ sum, const double* __restrict__ sq,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int R, int T,
                                                        int c0, long tg0, int n_new, double* __restrict__ carry) {
@@ -685,17 +718,14 @@ __global__ __launch_bounds__(256) void cln_scan_kernel(const double* __restrict_
         sc[T + t] = live ? sq[(long)b * T + t] : 0.0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = carry ? carry[2 * b] : 0.0, q = carry ? carry[2 * b + 1] : 0.0;
-        for (int t = c0; t < T; ++t) {
-            a += sc[t];
-            q += sc[T + t];
-            sc[t] = a;
-            sc[T + t] = q;
-            if (carry && t == c0 + n_new - 1) {
-                carry[2 * b] = a;
-                carry[2 * b + 1] = q;
-            }
+    if (threadIdx.x < 64 && c0 < T) {
+        cln_wave_scan(sc, T, c0, carry ? carry[2 * b] : 0.0, carry ? carry[2 * b + 1] : 0.0);
+        // (the carry was read by every lane before any lane writes it: the wave runs in lockstep through the scan)
+        const int tc = c0 + n_new - 1;
+        const int L = (T - c0 + 63) >> 6;
+        if (carry && tc >= c0 && tc < T && (int)threadIdx.x == (tc - c0) / L) {
+            carry[2 * b] = sc[tc];
+            carry[2 * b + 1] = sc[T + tc];
         }
     }
     __syncthreads();
@@ -736,15 +766,7 @@ __global__ __launch_bounds__(256) void cln_scan_parts_kernel(const float* __rest
         sc[T + t] = q;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0.0, q = 0.0;
-        for (int t = 0; t < T; ++t) {
-            a += sc[t];
-            q += sc[T + t];
-            sc[t] = a;
-            sc[T + t] = q;
-        }
-    }
+    if (threadIdx.x < 64) cln_wave_scan(sc, T, 0, 0.0, 0.0);
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += 256) {
         const double cnt = (double)R * (double)(t + 1), mu = sc[t] / cnt;

@@ -27,7 +27,7 @@ for step in "$@"; do
       head -8 $OUT/r06_${a}_b${b}_kernel_stats.csv | cut -c1-150
       rm -rf $D ;;
     profl)
-      (export SE_PROF_DUMP=1 ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 2 --fsn-max-batch 256 2>&1 | python $ROOT/tools/profl.py > $OUT/profl_${a}_b${b}${c:+_${c//[=,]/_}}.txt; head -14 $OUT/profl_${a}_b${b}${c:+_${c//[=,]/_}}.txt) ;;
+      (export SE_PROF_DUMP=1 SE_R6=1 ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 2 --fsn-max-batch 256 2>&1 | python $ROOT/tools/profl.py > $OUT/profl_${a}_b${b}${c:+_${c//[=,]/_}}.txt; head -14 $OUT/profl_${a}_b${b}${c:+_${c//[=,]/_}}.txt) ;;
     dbg)
       (export SE_R6=1 ${c:+${c//,/ }}; timeout 300 python $ROOT/tools/sweep.py --models $a --batch $b --steps 5 --no-profile --fsn-max-batch 256 2>&1 | grep utt_per_s | cut -c1-100 | sed "s/^/[$c] /") ;;
     len)   # len:<model>:<B>:<samples>[,env=val..]

@@ -262,13 +262,18 @@ class Gcrn final : public Model {
         launch_layernorm_cf(b.Y, nullptr, ln_w[1], ln_b[1], b.Z, Tl, 1024, 1, (int)S, 1e-5f, st);
         launch_transpose_akt(b.Z, b.L0, Tl, 1024, B, 1024L * S, S, 1024L * T, T, st);
         }
-        // ---- two decoders
+        // ---- two decoders (real, imaginary: :147-163) - independent chains over the same inputs with their own tensors.  Offline
+        // the imaginary one runs on a second stream (fork / join through events, as TaylorSENet's separate encoder): the deep levels'
+        // launches fill a fraction of the chip each and the two chains fill each other's tails.  SE_GCRN_FORK=0: one stream; with
+        // hipGraph replay asked for the model stays on one stream (graph_capturable)
         const int DCO[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
-        for (int br = 0; br < 2; ++br) {
+        static const bool fork_env = !(getenv("SE_GCRN_FORK") && atoi(getenv("SE_GCRN_FORK")) == 0);
+        const bool fork = fork_env && n_stream == 0 && !stream_ctx() && !ctx.graphs_wanted();
+        auto decoder = [&](int br, hipStream_t sd, Profiler* pd) {
             Act4 a0 = act4(b.L0, 256, 4, T);
             Act4 a1 = act4(b.E[4], 256, 4, T);          // cat((out, e5)) without ELU :147
             for (int i = 0; i < 5; ++i) {
-                run_deconv(dec[br][i], a0, &a1, b.D[br][i], DCO[i], DF[i], B, T, T, st, pf, nullptr, tb);
+                run_deconv(dec[br][i], a0, &a1, b.D[br][i], DCO[i], DF[i], B, T, T, sd, pd, nullptr, tb);
                 a0 = act4(b.D[br][i], DCO[i], DF[i], T);
                 if (i < 4) a1 = act4(b.EE[3 - i], EC[4 - i], EF[3 - i], T);
             }
@@ -277,7 +282,19 @@ class Gcrn final : public Model {
             p.src0 = b.D[br][4]; p.s0_b = (long)NBIN * T; p.s0_c = T; p.s0_f = 0; p.src1 = nullptr;
             p.Fin = 1; p.Tin = T; p.B = B; p.Q = 1; p.Tout = T; p.t_base = tb;
             p.dst = b.est + (long)br * NBIN * T; p.d_b = 2L * NBIN * T; p.d_c = T; p.d_f = 0;
-            gc_launch_prof(fc[br], p, st, pf);
+            gc_launch_prof(fc[br], p, sd, pd);
+        };
+        if (fork) {
+            hipStream_t s2 = ctx.aux_stream(0);
+            SE_HIP(hipEventRecord(ctx.ev_fork, st));
+            SE_HIP(hipStreamWaitEvent(s2, ctx.ev_fork, 0));
+            decoder(1, s2, &ctx.aux_prof[0]);
+            SE_HIP(hipEventRecord(ctx.ev_join[0], s2));
+            decoder(0, st, pf);
+            SE_HIP(hipStreamWaitEvent(st, ctx.ev_join[0], 0));
+        } else {
+            decoder(0, st, pf);
+            decoder(1, st, pf);
         }
     }
 };

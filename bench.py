@@ -207,10 +207,11 @@ def run_other_configs(torch, local_rank, steps, configs=None):
         wav = torch.from_numpy(np.tile(base, ((B + 15) // 16, 1))[:B].copy()).cuda()
         out = torch.empty((B, eng.output_samples(CLIP_SAMPLES)), dtype=torch.float32, device=wav.device)
         # untimed warm-up: kernel attributes, lazily grown scratch - and the clocks, which fall back while the host packs the next
-        # model's weights: at least three calls and a quarter of a second of work (round 6: G2Net_new's first timed pass read
-        # 47.0 ms against 40.6 for the second after two warm-up calls)
+        # model's weights: at least three calls and one second of work (round 6: G2Net_new's first timed pass read 47.0 ms against
+        # 40.6 for the second after two warm-up calls; with three calls / 0.25 s TaylorSENet - 105 ms a call, the longest weight
+        # packing of the zoo in front of it - still read 112.9 then 106.9 ms)
         t_w, n_w = time.perf_counter(), 0
-        while n_w < 3 or (time.perf_counter() - t_w < 0.25 and n_w < 200):
+        while n_w < 3 or (time.perf_counter() - t_w < 1.0 and n_w < 400):
             eng.enhance_batch(wav, out)
             torch.cuda.synchronize()
             n_w += 1

@@ -89,7 +89,8 @@ struct TrackedSD {
 // are all equal (measured against trimming the straddling groups in LDS: DCCRN + 2 %, Uformer + 1.7 % at batch 256).
 // The multiple itself: 4 (whole 16 B groups).  Uformer rounds to 16 - 401 -> 416 frames are rows of 1 664 B = 13 whole 128 B
 // lines: 3.7 % more frames and still + 1.1 % at batch 256 (its many low-channel layers and elementwise passes move whole
-// lines); DCCRN (501 -> 512 against 504) gains nothing over 4.  SE_PAD_FRAMES_TO=n overrides both.
+// lines); DCCRN (501 -> 512 against 504) gained nothing over 4 in rounds 3-5; with round 6's epilogue it does (2 669 / 2 672 -> 2 697 utt/s
+// at batch 256: rows of 2 048 B, whole tiles) and rounds to 16 too.  SE_PAD_FRAMES_TO=n overrides both.
 inline int pad_frames_mult(int model_default = 4) {
     static const int m = getenv("SE_PAD_FRAMES_TO") ? std::max(4, atoi(getenv("SE_PAD_FRAMES_TO")) & ~3) : 0;
     return m ? m : model_default;

@@ -61,6 +61,7 @@ class Dccrn final : public Model {
         return (frame_num - 1) * HOP;
     }
     int64_t output_samples(int L) const override { return padded_samples(L); }   // :59-64 (not trimmed to L)
+    int frame_multiple() const override { return 16; }
 
     void finalize(const TrackedSD& sd) override {
         const int tout = 501;
@@ -259,7 +260,7 @@ class Dccrn final : public Model {
 
     void enhance(const float* wav, long pitch, int B, int L, float* out, long out_pitch, hipStream_t st) override {
         const int Lpad = padded_samples(L);
-        PadFrames pad(ctx, B, L, Lpad, 1 + Lpad / HOP, Lpad, st);       // the decoder looks ahead: rows of whole 16 B groups
+        PadFrames pad(ctx, B, L, Lpad, 1 + Lpad / HOP, Lpad, st, 16);   // the decoder looks ahead: rows of whole 16 B groups - and, since round 6, whole 64 B sectors (501 -> 512 frames: whole 128 / 256-column tiles, rows of 2 048 B)
         const int T = pad.T;
         Bufs& b = bufs(B, T);
         launch_rms_scale(wav, B, L, pitch, b.c, st);                                           // :27

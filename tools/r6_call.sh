@@ -62,6 +62,22 @@ for step in "$@"; do
       (cd $ROOT && timeout 600 python tools/stream_latency.py > $OUT/r06_stream_latency.jsonl 2> $OUT/stream.err; cut -c1-140 $OUT/r06_stream_latency.jsonl | head -30) ;;
     sweep)
       (cd $ROOT && timeout 900 python tools/sweep.py --batch $a --models lstm,crn,gcrn,dpcrn,dccrn,fullsubnet,ctsnet,g2net,taylorsenet,uformer,ctsnet_new,g2net_new,taylorsenet_new > $OUT/r06_sweep_b$a.jsonl 2> $OUT/sweep.err; cut -c1-110 $OUT/r06_sweep_b$a.jsonl) ;;
+    slat)   # slat:<models>[:env=val,..]: one-frame / eight-frame push latencies, 1 and 16 streams
+      (cd $ROOT && export SE_R6=1 ${b:+${b//,/ }}; timeout 400 python tools/stream_latency.py --models $a 2>&1 | grep ms_per_push | cut -c1-112 | sed "s/^/[${b:-}] /") ;;
+    sprof)   # sprof:<model>[:env=val,..]: kernel summary of one-frame pushes (1 stream, 1 s of audio, 2 passes = 200 pushes)
+      D=$OUT/sprof_$a
+      (export SE_R6=1 ${b:+${b//,/ }}; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o s -- python $ROOT/tools/stream_latency.py --models $a --batch 1 --chunk 1 --seconds 1 > $D.log 2>&1)
+      grep ms_per_push $D.log | cut -c1-120
+      python - $D/s_kernel_stats.csv <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+calls = sum(int(r['Calls']) for r in rows); tot = sum(float(r['TotalDurationNs']) for r in rows)
+print('launches / push ~', round(calls / 200.0, 1), ' GPU us / push ~', round(tot / 200.0 / 1e3, 1))
+for r in rows[:14]:
+    print('%6d %9.1f us/push  avg %7.2f us  %s' % (int(r['Calls']), float(r['TotalDurationNs']) / 200e3, float(r['AverageNs']) / 1e3, r['Name'][:90]))
+PY
+      cp $D/s_kernel_stats.csv $OUT/r06_push_${a}_kernel_stats.csv 2>/dev/null
+      rm -rf $D ;;
     *) echo "unknown step $step" ;;
   esac
 done

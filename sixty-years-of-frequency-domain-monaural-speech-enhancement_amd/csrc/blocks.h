@@ -30,7 +30,9 @@ struct NormAct {
 inline void norm2d_prelu(const NormAct& n, const float* x, float* y, int B, int C, int F, int T, hipStream_t st,
                          const float* res = nullptr) {
     if (n.cum) {
-        if (res && !stream_ctx()) {       // offline: the residual rides on the apply pass (k_misc.hip: cln_apply_plane_kernel)
+        // the residual rides on the apply pass (offline, k_misc.hip: cln_apply_plane_kernel) or on the one- / two-frame register
+        // kernel of a frame-online push
+        if (res && (!stream_ctx() || cln_stream_takes_res(C, F))) {
             launch_cln(x, y, n.g, n.b, nullptr, n.s, nullptr, 0, B, C, F, T, st, res);
             return;
         }

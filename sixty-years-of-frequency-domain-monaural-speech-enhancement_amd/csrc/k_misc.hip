@@ -1002,19 +1002,45 @@ template <int W, int VPT>
 __global__ __launch_bounds__(256) void cln_window_reg_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ gain, const float* __restrict__ bias,
                                                              const float* __restrict__ post_slope, int R, int F, int T, int c0,
-                                                             long tg0, double* __restrict__ carry) {
+                                                             long tg0, double* __restrict__ carry, const float* res) {
     __shared__ double sh[4][2 * W];
     __shared__ float s_mu[W], s_rs[W];
+    __shared__ float s_par[3][256];          // gain, bias, PReLU slope per channel (C = R / F <= 256, checked by the launcher)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = R * W;
     const float* xb = x + (long)b * R * T + c0;
     float* yb = y + (long)b * R * T + c0;
-    float v[VPT];
+    // Everything the kernel reads from global memory is requested here, in ONE batch: the frame, the running sums and the
+    // channel parameters.  (Round 5 read the sums behind the block reduction and the parameters behind the second barrier: three
+    // dependent round trips in a kernel whose floor is one - 6.6 us a launch, 75 launches per one-frame push of TaylorSENet_new.)
+    float v[VPT], rv[VPT];
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int e = tid + 256 * u;
         const int ec = e < N ? e : 0;
         v[u] = xb[(long)(ec / W) * T + (ec % W)];
+    }
+    // res (optional, may be y itself: an element is read and written by one thread): the residual of a module's last layer rides
+    // here instead of on an add_kernel launch behind this one (12 per one-frame push of TaylorSENet_new)
+    const float* rb = res ? res + (long)b * R * T + c0 : nullptr;
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int e = tid + 256 * u;
+        const int ec = e < N ? e : 0;
+        rv[u] = rb ? rb[(long)(ec / W) * T + (ec % W)] : 0.f;
+    }
+    double ca = 0.0, cq = 0.0;
+    if (tid == 0) {
+        ca = carry[2 * b];
+        cq = carry[2 * b + 1];
+    }
+    {
+        const int C = R / F;
+        const float pg = tid < C ? gain[tid] : 0.f, pb = tid < C ? bias[tid] : 0.f;
+        const float ps = (tid < C && post_slope) ? post_slope[tid] : 1.f;
+        s_par[0][tid] = pg;
+        s_par[1][tid] = pb;
+        s_par[2][tid] = ps;
     }
     double s[W], q[W];
 #pragma unroll
@@ -1048,7 +1074,7 @@ __global__ __launch_bounds__(256) void cln_window_reg_kernel(const float* __rest
     }
     __syncthreads();
     if (tid == 0) {
-        double a = carry[2 * b], qq = carry[2 * b + 1];
+        double a = ca, qq = cq;
 #pragma unroll
         for (int t = 0; t < W; ++t) {
             a += (sh[0][2 * t] + sh[1][2 * t]) + (sh[2][2 * t] + sh[3][2 * t]);
@@ -1062,18 +1088,26 @@ __global__ __launch_bounds__(256) void cln_window_reg_kernel(const float* __rest
         carry[2 * b + 1] = qq;
     }
     __syncthreads();
+    const bool act = post_slope != nullptr;
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
         const int e = tid + 256 * u;
         if (e < N) {
             const int r = e / W, t = e % W, c = r / F;
-            float o = (v[u] - s_mu[t]) * s_rs[t] * gain[c] + bias[c];
-            if (post_slope) o = o >= 0.f ? o : post_slope[c] * o;
-            yb[(long)r * T + t] = o;
+            float o = (v[u] - s_mu[t]) * s_rs[t] * s_par[0][c] + s_par[1][c];
+            if (act) o = o >= 0.f ? o : s_par[2][c] * o;
+            yb[(long)r * T + t] = o + rv[u];
         }
     }
 }
 
+// frame-online chunk: launch_cln(..., res) adds the residual in its own launch (the one- / two-frame register form)
+bool cln_stream_takes_res(int C, int F) {
+    const StreamCtx* cx = stream_ctx();
+    static const bool reg_on = !(getenv("SE_CLN_REG") && atoi(getenv("SE_CLN_REG")) == 0);
+    static const bool res_on = !(getenv("SE_CLN_STREAM_RES") && atoi(getenv("SE_CLN_STREAM_RES")) == 0);
+    return cx && reg_on && res_on && cx->n <= 2 && (long)C * F <= 256L * 41 && C <= 256;
+}
 void launch_cln(const float* x, float* y, const float* gain, const float* bias, const float* pre_slope,
                 const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s, const float* res) {
     SE_CHECK(!res || (K <= 0 && !pre_slope), "cLN: the residual rides on the plain 2-D form only");
@@ -1098,17 +1132,18 @@ void launch_cln(const float* x, float* y, const float* gain, const float* bias, 
         double* carry = static_cast<double*>(cx->slot((size_t)B * 2 * sizeof(double), s));
         const long tg0 = cx->t0 - cx->H;
         static const bool reg_on = !(getenv("SE_CLN_REG") && atoi(getenv("SE_CLN_REG")) == 0);
-        if (reg_on && K <= 0 && !pre_slope && cx->n <= 2 && (long)R * cx->n <= 256L * 41 * cx->n && R <= 256 * 41) {
+        if (reg_on && K <= 0 && !pre_slope && cx->n <= 2 && (long)R * cx->n <= 256L * 41 * cx->n && R <= 256 * 41 && C <= 256) {
             // (every frame of the chunk is live: tg0 + c0 = the stream index of the first new frame >= 0)
             if (cx->n == 1)
                 hipLaunchKernelGGL((cln_window_reg_kernel<1, 41>), dim3(B), dim3(256), 0, s, x, y, gain, bias, post_slope, R, F, T,
-                                   c0, tg0, carry);
+                                   c0, tg0, carry, res);
             else
                 hipLaunchKernelGGL((cln_window_reg_kernel<2, 82>), dim3(B), dim3(256), 0, s, x, y, gain, bias, post_slope, R, F, T,
-                                   c0, tg0, carry);
+                                   c0, tg0, carry, res);
             SE_HIP(hipGetLastError());
             return;
         }
+        SE_CHECK(!res, "frame-online cLN: the residual rides on the register form only (ask cln_stream_takes_res first)");
         if ((long)R * (T - c0) <= 32768 && (K <= 0 || (size_t)R * (T - c0) * 4 + (size_t)T * 24 <= 60000)) {   // small windows: one launch
             const size_t lds = (size_t)T * 24 + (K > 0 ? (size_t)R * (T - c0) * 4 : 0);
             hipLaunchKernelGGL(cln_window_kernel, dim3(B), dim3(256), lds, s, x, y, gain, bias, pre_slope, post_slope,
@@ -1322,6 +1357,61 @@ void stream_exchange(float* x, long sb, long sc, long sf, int B, int C, int F, i
     const int rpb = 256 / KP;
     hipLaunchKernelGGL(stream_hist_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, x, state, sb, sc, sf, C,
                        F, need, KP, cx->H, cx->n, rows);
+    SE_HIP(hipGetLastError());
+}
+
+// Both sources of a concatenating layer (the decoders' skip inputs) in one launch: blockIdx.y picks the tensor.
+struct HistPair {
+    float* x[2];
+    float* state[2];
+    long sb[2], sc[2], sf[2], rows[2];
+    int C[2], F[2];
+};
+__global__ __launch_bounds__(256) void stream_hist_pair_kernel(const HistPair a, int need, int KP, int H, int n) {
+    const int s = blockIdx.y;
+    const int k = threadIdx.x % KP;
+    const long r = (long)blockIdx.x * (256 / KP) + threadIdx.x / KP;
+    const bool on = r < a.rows[s] && k < need;
+    float old = 0.f, nxt = 0.f;
+    float* xp = nullptr;
+    float* sp = nullptr;
+    if (on) {
+        const int f = (int)(r % a.F[s]);
+        const long q = r / a.F[s];
+        const int c = (int)(q % a.C[s]);
+        const long b = q / a.C[s];
+        xp = a.x[s] + b * a.sb[s] + c * a.sc[s] + f * a.sf[s];
+        sp = a.state[s] + r * need;
+        old = sp[k];
+        nxt = (k + n < need) ? sp[k + n] : xp[H + n - need + k];
+    }
+    __syncthreads();
+    if (on) {
+        xp[H - need + k] = old;
+        sp[k] = nxt;
+    }
+}
+void stream_exchange_pair(float* x0, long sb0, long sc0, long sf0, int C0, int F0, float* x1, long sb1, long sc1, long sf1, int C1,
+                          int F1, int B, int need, hipStream_t st) {
+    static const bool pair_on = !(getenv("SE_STREAM_HIST_PAIR") && atoi(getenv("SE_STREAM_HIST_PAIR")) == 0);
+    if (!pair_on) {
+        stream_exchange(x0, sb0, sc0, sf0, B, C0, F0, need, st);
+        stream_exchange(x1, sb1, sc1, sf1, B, C1, F1, need, st);
+        return;
+    }
+    StreamCtx* cx = stream_ctx();
+    SE_CHECK(cx && need > 0 && need <= cx->H && need <= 256, "stream_exchange: history deeper than the window keeps");
+    HistPair a;
+    a.x[0] = x0; a.sb[0] = sb0; a.sc[0] = sc0; a.sf[0] = sf0; a.C[0] = C0; a.F[0] = F0; a.rows[0] = (long)B * C0 * F0;
+    a.x[1] = x1; a.sb[1] = sb1; a.sc[1] = sc1; a.sf[1] = sf1; a.C[1] = C1; a.F[1] = F1; a.rows[1] = (long)B * C1 * F1;
+    a.state[0] = static_cast<float*>(cx->slot((size_t)a.rows[0] * need * sizeof(float), st));
+    a.state[1] = static_cast<float*>(cx->slot((size_t)a.rows[1] * need * sizeof(float), st));
+    int KP = 1;
+    while (KP < need) KP <<= 1;
+    const int rpb = 256 / KP;
+    const long rmax = a.rows[0] > a.rows[1] ? a.rows[0] : a.rows[1];
+    hipLaunchKernelGGL(stream_hist_pair_kernel, dim3((unsigned)((rmax + rpb - 1) / rpb), 2), dim3(256), 0, st, a, need, KP, cx->H,
+                       cx->n);
     SE_HIP(hipGetLastError());
 }
 

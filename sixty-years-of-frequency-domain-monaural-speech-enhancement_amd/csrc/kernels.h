@@ -120,6 +120,9 @@ void set_stream_ctx(StreamCtx* c);
 // x [B][C][F][H + n] (strides in floats, frames contiguous): columns [H - need, H) <- slot, then slot <- the last `need`
 // columns of the window
 void stream_exchange(float* x, long sb, long sc, long sf, int B, int C, int F, int need, hipStream_t st);
+// the two sources of a concatenating layer in one launch (same state slots, in the same order, as two calls)
+void stream_exchange_pair(float* x0, long sb0, long sc0, long sf0, int C0, int F0, float* x1, long sb1, long sc1, long sf1, int C1,
+                          int F1, int B, int need, hipStream_t st);
 
 // Model-side owner of the state slots and RAII publisher of one chunk's context
 struct StreamSlots {
@@ -245,6 +248,8 @@ void launch_tcm_chain(const TcmStreamW* const* f, const TcmFusedHeads* hd, const
 // statistics of all C*F values of frames 0..t;  x [B][C][F][T] (F = 1 for 1-D), gain / bias [C].
 //   y = FIR_K( cLN( PReLU_pre(x) ) )   (TCM branch head, K > 0, not in place)   or   y = PReLU_post( cLN(x) )
 // res (optional, offline, plain 2-D form only; may alias y): y = PReLU_post( cLN(x) ) + res
+// frame-online chunk: true when launch_cln(..., res) adds the residual in its own launch (one- / two-frame register form)
+bool cln_stream_takes_res(int C, int F);
 void launch_cln(const float* x, float* y, const float* gain, const float* bias, const float* pre_slope,
                 const float* post_slope, const float* fir, int K, int B, int C, int F, int T, hipStream_t s,
                 const float* res = nullptr);

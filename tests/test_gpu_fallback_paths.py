@@ -65,6 +65,31 @@ def test_reference_fixtures_with_the_round6_switches_thrown():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+def test_dccrn_fixtures_with_frames_rounded_to_four_and_to_thirty_two():
+    """DCCRN's equal-length batches run on frames rounded to 16 since round 6 (501 -> 512; rounds 3-5: 4): the fixtures - batch 256
+    with the reference's clip riding in a row, the full 4 s clip - must not depend on the multiple (the decoder's look-ahead sees
+    the same zeros behind every clip's last frame whichever it is)."""
+    for mult in ('4', '32'):
+        env = dict(os.environ, SE_PAD_FRAMES_TO=mult)
+        cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+               os.path.join(ROOT, 'tests', 'test_gpu_b256_fixture.py'), os.path.join(ROOT, 'tests', 'test_gpu_full_fixture.py'),
+               '-k', 'dccrn']
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, mult + ': ' + r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_cln_variants_stream_with_the_round6_push_fusions_off():
+    """A one-frame push of the cLN variants carries its residual adds inside the cLN window kernel and exchanges the history of a
+    concatenating layer's two sources in one launch (round 6); the same streamed-vs-offline tests with both off."""
+    env = dict(os.environ, SE_CLN_STREAM_RES='0', SE_STREAM_HIST_PAIR='0')
+    cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+           os.path.join(ROOT, 'tests', 'test_gpu_streaming.py'), '-k', 'cln_variants or long_stream']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 _LSTM_SHORT_CHILD = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)

@@ -2,6 +2,7 @@
 # round-6 GPU calls (through gpurun): bash tools/r6_call.sh <step> ...
 #   steps: tests[:k-expr] parity measure pmc:<model>:<B> prof:<model>:<B> profl:<model>:<B>[:env=val,..] dbg:<model>:<B>:<env=val,..>
 #          fsnsweep:<lo>:<hi> step:<H>:<S>[:env=val,..] stept:<H>:<S> bench[:steps] corpus stream sweep:<B>
+#          slat:<models>[:env=val,..] (push latencies) sprof:<model>[:env=val,..] (kernel summary of 200 one-frame pushes)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/r6

@@ -213,6 +213,7 @@ class CtsNet final : public Model {
     struct Bufs {
         int B = 0, T = 0;
         float *c, *spec, *mag, *est1, *s1, *est, *frames, *E[5], *D[5], *X[2], *acc;
+        float* D2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // frame-online windows only: the imaginary decoder's own tensors
         TcmScratch ts;
     } cur;
     bool has1 = false, has2 = false;
@@ -238,6 +239,8 @@ class CtsNet final : public Model {
         b.frames = nullptr;      // the fused iSTFT keeps its frames in LDS (k_stft.hip); kept in the struct for the launcher signature
         for (int i = 0; i < 5; ++i) b.E[i] = a.alloc_f(BT * 64 * EF[i]);
         for (int i = 0; i < 5; ++i) b.D[i] = a.alloc_f(BT * 64 * DF[i]);
+        if (T <= 64)
+            for (int i = 0; i < 5; ++i) b.D2[i] = a.alloc_f(BT * 64 * DF[i]);
         b.X[0] = a.alloc_f(BT * 256);
         b.X[1] = a.alloc_f(BT * 256);
         b.acc = a.alloc_f(BT * 256);
@@ -270,6 +273,27 @@ class CtsNet final : public Model {
         Act4 a1 = act4(s1, 2, NBIN, b.T);
         en2.run(act4(spec, 2, NBIN, b.T), &a1, b.E, b.B, b.T, st, &ctx.prof);
         tcm_stack(b, tcm2.data(), R2, X2, st);
+        // Frame-online (round 6): the real and the imaginary decoder are two chains of 16 launches that read the same inputs;
+        // in a one- / two-frame push they run side by side, the imaginary one on an auxiliary stream with its own tensors.  It is
+        // ENQUEUED first in every frame-online chunk, forked or not (the host is ~0.1 ms ahead of the device per decoder: the
+        // chain enqueued second starts that much later), so the state slots are taken in one order whatever the chunk length.
+        // Offline their 128-row gated layers fill the chip by themselves (profiles/r06_experiments.md).  SE_CTSNET_STREAM_FORK=0.
+        static const bool sfork_env = !(getenv("SE_CTSNET_STREAM_FORK") && atoi(getenv("SE_CTSNET_STREAM_FORK")) == 0);
+        if (const StreamCtx* scx = stream_ctx()) {
+            const bool fork = sfork_env && scx->n <= 2 && b.D2[0] && !ctx.graphs_wanted();
+            if (fork) {
+                hipStream_t s2 = ctx.aux_stream(0);
+                SE_HIP(hipEventRecord(ctx.ev_fork, st));
+                SE_HIP(hipStreamWaitEvent(s2, ctx.ev_fork, 0));
+                de2i.run(b.acc, b.E, b.D2, est + (long)NBIN * b.T, 2L * NBIN * b.T, b.B, b.T, s2, &ctx.aux_prof[0]);
+                SE_HIP(hipEventRecord(ctx.ev_join[0], s2));
+            } else {
+                de2i.run(b.acc, b.E, b.D, est + (long)NBIN * b.T, 2L * NBIN * b.T, b.B, b.T, st, &ctx.prof);
+            }
+            de2r.run(b.acc, b.E, b.D, est, 2L * NBIN * b.T, b.B, b.T, st, &ctx.prof);
+            if (fork) SE_HIP(hipStreamWaitEvent(st, ctx.ev_join[0], 0));
+            return;
+        }
         de2r.run(b.acc, b.E, b.D, est, 2L * NBIN * b.T, b.B, b.T, st, &ctx.prof);
         de2i.run(b.acc, b.E, b.D, est + (long)NBIN * b.T, 2L * NBIN * b.T, b.B, b.T, st, &ctx.prof);
     }

@@ -171,6 +171,10 @@ class G2Net final : public Model {
         float *c, *spec, *est, *frames, *ens[5], *pre[2], *gain, *resi, *hx, *X[2];
         UnetScratch us;
         TcmScratch ts;
+        // frame-online windows only (T small): the glance branch's own input, and a second / third set of TCM scratch, so that the
+        // three TCM sequences of a stage can run side by side (network())
+        float *hxg = nullptr, *Xg[2] = {nullptr, nullptr}, *Xi[2] = {nullptr, nullptr};
+        TcmScratch tsg{}, tsi{};
     } cur;
     U2Encoder en;
     std::vector<GafStage> st_;
@@ -201,17 +205,31 @@ class G2Net final : public Model {
         b.ts.a = a.alloc_f(BT * 64);
         b.ts.r = a.alloc_f(BT * 64);
         b.ts.m = a.alloc_f(BT * 64);
+        if (T <= 64) {
+            b.hxg = a.alloc_f(BT * 256);
+            for (float** X : {b.Xg, b.Xi}) {
+                X[0] = a.alloc_f(BT * 256);
+                X[1] = a.alloc_f(BT * 256);
+            }
+            for (TcmScratch* t : {&b.tsg, &b.tsi}) {
+                t->h = a.alloc_f(BT * 64);
+                t->a = a.alloc_f(BT * 64);
+                t->r = a.alloc_f(BT * 64);
+                t->m = a.alloc_f(BT * 64);
+            }
+        }
         cur = b;
         return cur;
     }
 
-    void gate_in(const GCPlan& pl, const float* feat, const float* pre, float* dst, int B, int T, hipStream_t st) {
+    void gate_in(const GCPlan& pl, const float* feat, const float* pre, float* dst, int B, int T, hipStream_t st,
+                 Profiler* pf = nullptr) {
         GCParams p = pl.p;
         p.src0 = feat; p.s0_b = 256L * T; p.s0_c = T; p.s0_f = 0; p.C0 = 256;
         p.src1 = pre; p.s1_b = 2L * NBIN * T; p.s1_c = T; p.s1_f = 0; p.C1 = 2 * NBIN;
         p.Fin = 1; p.Tin = T; p.B = B; p.Q = 1; p.Tout = T;
         p.dst = dst; p.d_b = 256L * T; p.d_c = T; p.d_f = 0;
-        gc_launch_prof(pl, p, st, &ctx.prof);
+        gc_launch_prof(pl, p, st, pf ? pf : &ctx.prof);
     }
 
     // b.spec [B][2][161][T] -> pointer to the last stage output [B][2][161][T]
@@ -222,12 +240,37 @@ class G2Net final : public Model {
         const float* feat = b.ens[4];            // [B][256][T]
         const float* pre = b.spec;               // inpt.transpose(-2,-1) is the engine layout already (:78)
         const long plane = (long)NBIN * T, tot = plane * B;
+        // Frame-online (round 6): a stage's three TCM sequences - glance, focus real, focus imaginary - are three chains of
+        // ~50 us that depend only on the stage's input; offline at batch 256 each of them fills the chip by itself, in a push
+        // each is ONE workgroup per stream.  They run side by side on the caller's stream and two auxiliary ones (fork / join
+        // through events; the calls are enqueued in the order of the one-stream form, so the state slots are taken in the same
+        // order either way): one-frame push 0.96 -> 0.7 ms.  SE_G2NET_STREAM_FORK=0: one stream.
+        static const bool sfork_env = !(getenv("SE_G2NET_STREAM_FORK") && atoi(getenv("SE_G2NET_STREAM_FORK")) == 0);
+        const bool fork = sfork_env && stream_ctx() && tcm_chain_enabled() && b.hxg && !ctx.graphs_wanted();
         for (int s = 0; s < (int)st_.size(); ++s) {
-            gate_in(st_[s].gin, feat, pre, b.hx, B, T, st);
-            st_[s].glance.run(b.hx, b.X, b.ts, b.gain, plane, B, T, st, pf);
-            gate_in(st_[s].fin, feat, pre, b.hx, B, T, st);
-            st_[s].fr.run(b.hx, b.X, b.ts, b.resi, 2 * plane, B, T, st, pf);
-            st_[s].fi.run(b.hx, b.X, b.ts, b.resi + plane, 2 * plane, B, T, st, pf);
+            if (fork) {
+                hipStream_t sg = ctx.aux_stream(0), si = ctx.aux_stream(1);
+                (void)ctx.aux_stream(2);                                   // (its join event marks "focus input ready")
+                SE_HIP(hipEventRecord(ctx.ev_fork, st));
+                SE_HIP(hipStreamWaitEvent(sg, ctx.ev_fork, 0));
+                gate_in(st_[s].gin, feat, pre, b.hxg, B, T, sg, &ctx.aux_prof[0]);
+                st_[s].glance.run(b.hxg, b.Xg, b.tsg, b.gain, plane, B, T, sg, &ctx.aux_prof[0]);
+                SE_HIP(hipEventRecord(ctx.ev_join[0], sg));
+                gate_in(st_[s].fin, feat, pre, b.hx, B, T, st);
+                SE_HIP(hipEventRecord(ctx.ev_join[2], st));
+                st_[s].fr.run(b.hx, b.X, b.ts, b.resi, 2 * plane, B, T, st, pf);
+                SE_HIP(hipStreamWaitEvent(si, ctx.ev_join[2], 0));
+                st_[s].fi.run(b.hx, b.Xi, b.tsi, b.resi + plane, 2 * plane, B, T, si, &ctx.aux_prof[1]);
+                SE_HIP(hipEventRecord(ctx.ev_join[1], si));
+                SE_HIP(hipStreamWaitEvent(st, ctx.ev_join[0], 0));
+                SE_HIP(hipStreamWaitEvent(st, ctx.ev_join[1], 0));
+            } else {
+                gate_in(st_[s].gin, feat, pre, b.hx, B, T, st);
+                st_[s].glance.run(b.hx, b.X, b.ts, b.gain, plane, B, T, st, pf);
+                gate_in(st_[s].fin, feat, pre, b.hx, B, T, st);
+                st_[s].fr.run(b.hx, b.X, b.ts, b.resi, 2 * plane, B, T, st, pf);
+                st_[s].fi.run(b.hx, b.X, b.ts, b.resi + plane, 2 * plane, B, T, st, pf);
+            }
             float* nxt = b.pre[s & 1];
             hipLaunchKernelGGL(gaf_combine_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b.gain, pre, b.resi, nxt,
                                plane, tot);

@@ -235,8 +235,36 @@ class TaylorSENet final : public Model {
         // U^2-Net levels fill a fraction of the chip each (F = 4 ... 19: one to three rounds of workgroups, a tail per launch) -
         // two independent chains fill each other's tails.  SE_TAYLOR_FORK=0: one stream.
         static const bool fork_env = !(getenv("SE_TAYLOR_FORK") && atoi(getenv("SE_TAYLOR_FORK")) == 0);
-        const bool fork = fork_env && !stream_ctx() && !ctx.graphs_wanted();
-        if (fork) {
+        // Frame-online (round 6): a push is a chain of ~235 dependent launches of a few microseconds each, a third of them the
+        // separate encoder's - the two chains side by side shorten the push by that third.  One- / two-frame chunks only (longer
+        // ones take the cLN path that owns a device-wide scratch buffer); the encoder is ENQUEUED first in every frame-online
+        // chunk, forked or not, so that the state slots are taken in one order whatever the chunk length.  SE_TAYLOR_STREAM_FORK=0.
+        static const bool sfork_env = !(getenv("SE_TAYLOR_STREAM_FORK") && atoi(getenv("SE_TAYLOR_STREAM_FORK")) == 0);
+        const StreamCtx* scx = stream_ctx();
+        const bool fork = fork_env && !ctx.graphs_wanted() && (!scx || (sfork_env && scx->n <= 2));
+        const bool sen_first = fork || scx;
+        if (scx) {
+            // (the two encoders are enqueued module by module in turn: the host is ~3.5 us per launch ahead of nothing - a chain
+            // whose ~80 launches are enqueued behind the other's starts 0.27 ms late)
+            hipStream_t s2 = fork ? ctx.aux_stream(0) : st;
+            if (fork) {
+                SE_HIP(hipEventRecord(ctx.ev_fork, st));
+                SE_HIP(hipStreamWaitEvent(s2, ctx.ev_fork, 0));
+            }
+            const int EF[5] = {79, 39, 19, 9, 4};
+            for (int i = 0; i < 5; ++i)
+                for (int which = 0; which < 2; ++which) {
+                    const U2Encoder& e = which ? zen : sen;
+                    float* const* ens = which ? b.ens : b.sens;
+                    const UnetScratch& us = (which || !fork) ? b.us : b.us2;
+                    hipStream_t s = which ? st : s2;
+                    Profiler* p = (which || !fork) ? pf : &ctx.aux_prof[0];
+                    const Act4 x = i == 0 ? act4(b.spec, 2, NBIN, T) : act4(ens[i - 1], 64, EF[i - 1], T);
+                    if (i < 4) e.m[i].run(x, nullptr, ens[i], us, B, T, s, p);
+                    else conv_norm2d_prelu(e.last.plan, e.last.na, x, nullptr, ens[4], ens[4], 64, 4, B, T, s, p);
+                }
+            if (fork) SE_HIP(hipEventRecord(ctx.ev_join[0], s2));
+        } else if (fork) {
             hipStream_t s2 = ctx.aux_stream(0);
             SE_HIP(hipEventRecord(ctx.ev_fork, st));
             SE_HIP(hipStreamWaitEvent(s2, ctx.ev_fork, 0));
@@ -244,7 +272,7 @@ class TaylorSENet final : public Model {
             SE_HIP(hipEventRecord(ctx.ev_join[0], s2));
         }
         // ---- zero-order block (:139-153)
-        zen.run(act4(b.spec, 2, NBIN, T), b.ens, b.us, B, T, st, pf);
+        if (!scx) zen.run(act4(b.spec, 2, NBIN, T), b.ens, b.us, B, T, st, pf);
         const float* x = ztcm.run(b.ens[4], b.X, b.ts, B, T, st, pf);      // [B][64*4][T] view of the bottleneck
         Act4 a0 = act4(x, 64, 4, T);
         int F = 4;
@@ -265,7 +293,7 @@ class TaylorSENet final : public Model {
                            plane, tot);
         // ---- separate encoder (:78-82) and the high-order recurrence (:84-93); `zero` doubles as pre_term
         if (fork) SE_HIP(hipStreamWaitEvent(st, ctx.ev_join[0], 0));
-        else sen.run(act4(b.spec, 2, NBIN, T), b.sens, b.us, B, T, st, pf);
+        else if (!sen_first) sen.run(act4(b.spec, 2, NBIN, T), b.sens, b.us, B, T, st, pf);
         float fact = 1.f;
         for (int k = 0; k < (int)htcm.size(); ++k) {
             GCParams p = h_in[k].p;      // in_conv over cat(feature_head [B][256][T], pre [B][322][T])

@@ -81,9 +81,12 @@ def test_dccrn_fixtures_with_frames_rounded_to_four_and_to_thirty_two():
 
 @pytest.mark.gpu
 def test_cln_variants_stream_with_the_round6_push_fusions_off():
-    """A one-frame push of the cLN variants carries its residual adds inside the cLN window kernel and exchanges the history of a
-    concatenating layer's two sources in one launch (round 6); the same streamed-vs-offline tests with both off."""
-    env = dict(os.environ, SE_CLN_STREAM_RES='0', SE_STREAM_HIST_PAIR='0')
+    """A one-frame push of the cLN variants carries its residual adds inside the cLN window kernel, exchanges the history of a
+    concatenating layer's two sources in one launch and runs its independent chains (TaylorSENet's separate encoder, CTSNet's
+    imaginary decoder, the three TCM sequences of a G2Net stage) on auxiliary streams (round 6); the same streamed-vs-offline tests
+    with all of that off."""
+    env = dict(os.environ, SE_CLN_STREAM_RES='0', SE_STREAM_HIST_PAIR='0', SE_TAYLOR_STREAM_FORK='0', SE_CTSNET_STREAM_FORK='0',
+               SE_G2NET_STREAM_FORK='0')
     cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
            os.path.join(ROOT, 'tests', 'test_gpu_streaming.py'), '-k', 'cln_variants or long_stream']
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)

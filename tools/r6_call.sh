@@ -64,7 +64,7 @@ for step in "$@"; do
     sweep)
       (cd $ROOT && timeout 900 python tools/sweep.py --batch $a --models lstm,crn,gcrn,dpcrn,dccrn,fullsubnet,ctsnet,g2net,taylorsenet,uformer,ctsnet_new,g2net_new,taylorsenet_new > $OUT/r06_sweep_b$a.jsonl 2> $OUT/sweep.err; cut -c1-110 $OUT/r06_sweep_b$a.jsonl) ;;
     slat)   # slat:<models>[:env=val,..]: one-frame / eight-frame push latencies, 1 and 16 streams
-      (cd $ROOT && export SE_R6=1 ${b:+${b//,/ }}; timeout 400 python tools/stream_latency.py --models $a 2>&1 | grep ms_per_push | cut -c1-112 | sed "s/^/[${b:-}] /") ;;
+      (cd $ROOT && export SE_R6=1 ${b:+${b//,/ }}; timeout 400 python tools/stream_latency.py --models $a 2>&1 | grep ms_per_push | python -c "import sys,json; [print(\"[${b:-}]\", d[\"model\"], \"streams\", d[\"streams\"], \"frames\", d[\"frames_per_push\"], \"ms\", d[\"ms_per_push\"], \"p95\", d[\"p95_ms\"], \"host enqueue\", d.get(\"host_enqueue_ms\")) for d in map(json.loads, sys.stdin)]") ;;
     sprof)   # sprof:<model>[:env=val,..]: kernel summary of one-frame pushes (1 stream, 1 s of audio, 2 passes = 200 pushes)
       D=$OUT/sprof_$a
       (export SE_R6=1 ${b:+${b//,/ }}; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o s -- python $ROOT/tools/stream_latency.py --models $a --batch 1 --chunk 1 --seconds 1 > $D.log 2>&1)

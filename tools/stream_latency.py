@@ -1,6 +1,7 @@
 """Frame-online decode cost per model: wall time of one se_stream_push that completes `chunk` STFT frames, for B parallel
 streams (synthetic weights, seeded clips).  Prints one JSON line per (model, B, chunk):
-  ms_per_push, frames per push, x_realtime = audio time of the push / its wall time (per stream), launches are not counted.
+  ms_per_push, frames per push, x_realtime = audio time of the push / its wall time (per stream), host_enqueue_ms = the part of it the
+  call itself takes (everything enqueued, nothing waited for); launches are not counted.
 Usage: python tools/stream_latency.py [--models crn,dccrn,ctsnet_new] [--batch 1,16] [--chunk 1,8]"""
 import argparse
 import json
@@ -49,17 +50,20 @@ def main():
                 times = []
                 for rep in range(2):           # first pass warms up (lazy state slots, kernel attributes)
                     eng.stream_begin(B, c=c, max_chunk_frames=chunk)
-                    times = []
+                    times, enq = [], []
                     for p in range(0, L - piece + 1, piece):
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
                         eng.stream_push(x[:, p:p + piece])
+                        t1 = time.perf_counter()          # the call has returned: everything is enqueued
                         torch.cuda.synchronize()
                         times.append(time.perf_counter() - t0)
+                        enq.append(t1 - t0)
                     eng.stream_flush()
                 t = float(np.median(times[4:]))
                 print(json.dumps({'model': name, 'streams': B, 'frames_per_push': chunk, 'ms_per_push': round(t * 1e3, 3),
                                   'p95_ms': round(float(np.percentile(times[4:], 95)) * 1e3, 3),
+                                  'host_enqueue_ms': round(float(np.median(enq[4:])) * 1e3, 3),
                                   'x_realtime_per_stream': round(piece / 16000 / t, 2),
                                   'x_realtime_all_streams': round(B * piece / 16000 / t, 1)}), flush=True)
             del m, eng

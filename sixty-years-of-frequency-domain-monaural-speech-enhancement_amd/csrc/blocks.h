@@ -178,9 +178,16 @@ struct TcmScratch {
 
 // x [B][256][T] -> y [B][256][T]
 // batch from which one workgroup per utterance beats the multi-launch path (SE_TCM_FUSED_MINB; 0 = never fuse)
-inline int tcm_fused_min_batch() {
-    static const int v = getenv("SE_TCM_FUSED_MINB") ? atoi(getenv("SE_TCM_FUSED_MINB")) : 96;
+// (a model that runs several TCM sequences side by side lowers it for its own calls - G2Net, round 6: with three sequences in
+// flight the one-workgroup-per-utterance kernel wins from one clip on; the environment variable overrides both)
+inline int& tcm_fused_min_override() {
+    static thread_local int v = 0;
     return v;
+}
+inline int tcm_fused_min_batch() {
+    static const int env = getenv("SE_TCM_FUSED_MINB") ? atoi(getenv("SE_TCM_FUSED_MINB")) : -1;
+    if (env >= 0) return env;
+    return tcm_fused_min_override() > 0 ? tcm_fused_min_override() : 96;
 }
 inline void run_tcm(const TcmBlock& k, const float* x, float* y, const TcmScratch& s, int B, int T, hipStream_t st, Profiler* pf) {
     if (stream_ctx() && k.sfused.w_in && k.nL.cum && k.nO.cum && tcm_stream_enabled()) {

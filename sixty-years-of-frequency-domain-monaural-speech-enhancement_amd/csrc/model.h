@@ -42,11 +42,26 @@ struct EngineCtx {
     static constexpr int MAX_AUX = 3;
     hipStream_t aux[MAX_AUX] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_AUX] = {};
+    // The auxiliary streams are PROCESS-wide (one set per device, created on first use, never destroyed); the events are the
+    // engine's own.  Round 6: with a set per engine, a process that builds one engine after the other (bench.py's zoo, tools/sweep.py)
+    // saw every engine that forks after G2Net's three-stream fork slow down - TaylorSENet 2 377 -> 2 275 utt/s at batch 256, one clip
+    // 4.6 -> 13 ms - streams created behind destroyed ones did not run side by side with the caller's any more.  Work of two
+    // engines that share a stream is ordered by each engine's own fork / join events; the rest is false sharing at worst.
+    static hipStream_t shared_aux(int dev, int i) {
+        static std::mutex mu;
+        static hipStream_t pool[16][MAX_AUX] = {};
+        SE_CHECK(dev >= 0 && dev < 16, "device index");
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pool[dev][i]) SE_HIP(hipStreamCreateWithFlags(&pool[dev][i], hipStreamNonBlocking));
+        return pool[dev][i];
+    }
     hipStream_t aux_stream(int i) {
         SE_CHECK(i >= 0 && i < MAX_AUX, "aux stream index");
         if (!ev_fork) SE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         if (!aux[i]) {
-            SE_HIP(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+            int dev = 0;
+            SE_HIP(hipGetDevice(&dev));
+            aux[i] = shared_aux(dev, i);
             SE_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
         }
         return aux[i];
@@ -57,7 +72,7 @@ struct EngineCtx {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (int i = 0; i < MAX_AUX; ++i)
             if (aux[i]) {
-                (void)hipStreamDestroy(aux[i]);
+                (void)hipStreamSynchronize(aux[i]);      // (shared with other engines: only this engine's work is waited for in effect)
                 (void)hipEventDestroy(ev_join[i]);
             }
     }

@@ -205,7 +205,8 @@ class G2Net final : public Model {
         b.ts.a = a.alloc_f(BT * 64);
         b.ts.r = a.alloc_f(BT * 64);
         b.ts.m = a.alloc_f(BT * 64);
-        if (T <= 64) {
+        static const bool ofork_env = !(getenv("SE_G2NET_FORK") && atoi(getenv("SE_G2NET_FORK")) == 0);
+        if (T <= 64 || ofork_env) {
             b.hxg = a.alloc_f(BT * 256);
             for (float** X : {b.Xg, b.Xi}) {
                 X[0] = a.alloc_f(BT * 256);
@@ -246,7 +247,27 @@ class G2Net final : public Model {
         // through events; the calls are enqueued in the order of the one-stream form, so the state slots are taken in the same
         // order either way): one-frame push 0.96 -> 0.7 ms.  SE_G2NET_STREAM_FORK=0: one stream.
         static const bool sfork_env = !(getenv("SE_G2NET_STREAM_FORK") && atoi(getenv("SE_G2NET_STREAM_FORK")) == 0);
-        const bool fork = sfork_env && stream_ctx() && tcm_chain_enabled() && b.hxg && !ctx.graphs_wanted();
+        // Offline, from the batch on at which every TCM block runs as the one-workgroup-per-utterance kernel (which owns no
+        // scratch): the same fork.  Two such kernels do not fit a CU together (104 KB of LDS each) and their matrix pipe is busy
+        // half of the time (3.3); the neighbours' launches and the 1 x 1 layers in between fill the gaps: G2Net 6 376 / 6 384 ->
+        // 6 579 / 6 577 utt/s at batch 256, G2Net_new 6 387 -> 6 597 (+ 3.1 ... 3.3 %; 0.76 GB more arena).  SE_G2NET_FORK=0: one
+        // stream (also under the profiler: its kernel summaries are single-stream durations).
+        static const bool ofork_env = !(getenv("SE_G2NET_FORK") && atoi(getenv("SE_G2NET_FORK")) == 0);
+        // With three sequences in flight that kernel wins from ONE clip on (batch 1 ... 4: even; 8: + 4.5 %, 32: + 12 %, 64: + 25 %,
+        // 96: + 40 %, 128: + 29 %; G2Net_new one clip 5.77 -> 4.20 ms, batch 8 + 38 %, 64 + 36 %), so the model lowers the batch
+        // threshold of blocks.h: run_tcm to 1 for its own calls (CTSNet / TaylorSENet, whose TCM groups feed each other, keep 96).
+        struct MinBatch {
+            const int old = tcm_fused_min_override();
+            explicit MinBatch(bool on) { if (on) tcm_fused_min_override() = 1; }
+            ~MinBatch() { tcm_fused_min_override() = old; }
+        } min_batch(ofork_env && !stream_ctx() && b.hxg && tcm_fused_supported(T));      // (the KERNELS do not depend on the profiler
+                                                                                       // or on graph replay - only the fork does:
+                                                                                       // a replayed decode stays bit-identical)
+        const bool ofork = ofork_env && !stream_ctx() && B >= tcm_fused_min_batch() && tcm_fused_supported(T) &&
+                           st_[0].glance.blk[0].fused.w1 && !(pf && pf->on);
+        // (offline the fork is captured into a replayed decode's hipGraph like any other work: the auxiliary streams join the
+        // capture through the fork event and leave it through the join events)
+        const bool fork = ((sfork_env && stream_ctx() && tcm_chain_enabled() && !ctx.graphs_wanted()) || ofork) && b.hxg;
         for (int s = 0; s < (int)st_.size(); ++s) {
             if (fork) {
                 hipStream_t sg = ctx.aux_stream(0), si = ctx.aux_stream(1);

@@ -52,7 +52,7 @@ def test_reference_fixtures_with_the_round5_switches_thrown():
 # equal-length batches run with rows of whole 128 B lines (zero-extended: the cLN variants, CRN, GCRN, DPCRN; as ragged rows of one
 # length: the InstanceNorm networks) - the batch-256 and 4 s fixtures run all of that; here the same fixtures with plain tiles and
 # unpadded rows
-SWITCHES_R6 = {'SE_GC_FLAT': '0', 'SE_CLN_PAD': '1', 'SE_IN_PAD': '1'}
+SWITCHES_R6 = {'SE_GC_FLAT': '0', 'SE_CLN_PAD': '1', 'SE_IN_PAD': '1', 'SE_G2NET_FORK': '0'}
 
 
 @pytest.mark.gpu

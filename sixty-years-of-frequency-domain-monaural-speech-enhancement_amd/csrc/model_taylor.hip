@@ -243,9 +243,10 @@ class TaylorSENet final : public Model {
         const StreamCtx* scx = stream_ctx();
         const bool fork = fork_env && !ctx.graphs_wanted() && (!scx || (sfork_env && scx->n <= 2));
         const bool sen_first = fork || scx;
-        if (scx) {
+        const bool turns = scx || fork;
+        if (turns) {
             // (the two encoders are enqueued module by module in turn: the host is ~3.5 us per launch ahead of nothing - a chain
-            // whose ~80 launches are enqueued behind the other's starts 0.27 ms late)
+            // whose ~80 launches are enqueued behind the other's starts 0.27 ms late; offline that is 5 % of a single clip's decode)
             hipStream_t s2 = fork ? ctx.aux_stream(0) : st;
             if (fork) {
                 SE_HIP(hipEventRecord(ctx.ev_fork, st));
@@ -264,15 +265,9 @@ class TaylorSENet final : public Model {
                     else conv_norm2d_prelu(e.last.plan, e.last.na, x, nullptr, ens[4], ens[4], 64, 4, B, T, s, p);
                 }
             if (fork) SE_HIP(hipEventRecord(ctx.ev_join[0], s2));
-        } else if (fork) {
-            hipStream_t s2 = ctx.aux_stream(0);
-            SE_HIP(hipEventRecord(ctx.ev_fork, st));
-            SE_HIP(hipStreamWaitEvent(s2, ctx.ev_fork, 0));
-            sen.run(act4(b.spec, 2, NBIN, T), b.sens, b.us2, B, T, s2, &ctx.aux_prof[0]);
-            SE_HIP(hipEventRecord(ctx.ev_join[0], s2));
         }
         // ---- zero-order block (:139-153)
-        if (!scx) zen.run(act4(b.spec, 2, NBIN, T), b.ens, b.us, B, T, st, pf);
+        if (!turns) zen.run(act4(b.spec, 2, NBIN, T), b.ens, b.us, B, T, st, pf);
         const float* x = ztcm.run(b.ens[4], b.X, b.ts, B, T, st, pf);      // [B][64*4][T] view of the bottleneck
         Act4 a0 = act4(x, 64, 4, T);
         int F = 4;

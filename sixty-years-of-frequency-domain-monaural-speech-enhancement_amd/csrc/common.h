@@ -177,4 +177,11 @@ inline float* to_device(const std::vector<float>& v) {
     return d;
 }
 
+// a model's offline fork onto auxiliary streams is captured into a replayed decode's hipGraph (SE_GRAPH_FORK=0: replayed decodes
+// stay on one stream, the round-5 rule)
+inline bool graph_fork_enabled() {
+    static const bool on = !(getenv("SE_GRAPH_FORK") && atoi(getenv("SE_GRAPH_FORK")) == 0);
+    return on;
+}
+
 }  // namespace se

@@ -267,7 +267,8 @@ class G2Net final : public Model {
                            st_[0].glance.blk[0].fused.w1 && !(pf && pf->on);
         // (offline the fork is captured into a replayed decode's hipGraph like any other work: the auxiliary streams join the
         // capture through the fork event and leave it through the join events)
-        const bool fork = ((sfork_env && stream_ctx() && tcm_chain_enabled() && !ctx.graphs_wanted()) || ofork) && b.hxg;
+        const bool fork = ((sfork_env && stream_ctx() && tcm_chain_enabled() && !ctx.graphs_wanted()) ||
+                           (ofork && (!ctx.graphs_wanted() || graph_fork_enabled()))) && b.hxg;
         for (int s = 0; s < (int)st_.size(); ++s) {
             if (fork) {
                 hipStream_t sg = ctx.aux_stream(0), si = ctx.aux_stream(1);

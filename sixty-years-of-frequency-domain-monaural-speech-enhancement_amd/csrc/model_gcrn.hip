@@ -264,11 +264,11 @@ class Gcrn final : public Model {
         }
         // ---- two decoders (real, imaginary: :147-163) - independent chains over the same inputs with their own tensors.  Offline
         // the imaginary one runs on a second stream (fork / join through events, as TaylorSENet's separate encoder): the deep levels'
-        // launches fill a fraction of the chip each and the two chains fill each other's tails.  SE_GCRN_FORK=0: one stream; with
-        // hipGraph replay asked for the model stays on one stream (graph_capturable)
+        // launches fill a fraction of the chip each and the two chains fill each other's tails.  SE_GCRN_FORK=0: one stream; under
+        // hipGraph replay the fork is captured with the rest (SE_GRAPH_FORK=0: one stream then)
         const int DCO[5] = {128, 64, 32, 16, 1}, DF[5] = {9, 19, 39, 80, 161};
         static const bool fork_env = !(getenv("SE_GCRN_FORK") && atoi(getenv("SE_GCRN_FORK")) == 0);
-        const bool fork = fork_env && n_stream == 0 && !stream_ctx() && !ctx.graphs_wanted();
+        const bool fork = fork_env && n_stream == 0 && !stream_ctx() && (!ctx.graphs_wanted() || graph_fork_enabled());
         auto decoder = [&](int br, hipStream_t sd, Profiler* pd) {
             Act4 a0 = act4(b.L0, 256, 4, T);
             Act4 a1 = act4(b.E[4], 256, 4, T);          // cat((out, e5)) without ELU :147

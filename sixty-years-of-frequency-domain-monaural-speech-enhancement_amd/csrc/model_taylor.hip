@@ -75,9 +75,9 @@ class TaylorSENet final : public Model {
     }
     StftGeom default_geom() const override { return StftGeom{NFFT, HOP, NFFT}; }
     int padded_samples(int L) const override { return ((L + HOP - 1) / HOP) * HOP; }   // taylorsenet_decode_vb.py:31-35
-    // network() forks the separate encoder onto a second stream - unless hipGraph replay is asked for: then it stays on one
-    // stream and the decode is captured (fork and graphs are mutually exclusive per engine)
-    bool graph_capturable() const override { return ctx.graphs_wanted(); }
+    // network() forks the separate encoder onto a second stream; under hipGraph replay the fork is captured with the rest (the
+    // auxiliary stream joins the capture through the fork event and leaves it through the join event - round 5 kept the two
+    // mutually exclusive; SE_GRAPH_FORK=0 restores that)
 
     void finalize(const TrackedSD& sd) override {
         zen.load(sd, "zeroorderblock.en.", 2);
@@ -241,7 +241,7 @@ class TaylorSENet final : public Model {
         // chunk, forked or not, so that the state slots are taken in one order whatever the chunk length.  SE_TAYLOR_STREAM_FORK=0.
         static const bool sfork_env = !(getenv("SE_TAYLOR_STREAM_FORK") && atoi(getenv("SE_TAYLOR_STREAM_FORK")) == 0);
         const StreamCtx* scx = stream_ctx();
-        const bool fork = fork_env && !ctx.graphs_wanted() && (!scx || (sfork_env && scx->n <= 2));
+        const bool fork = fork_env && (!ctx.graphs_wanted() || (!scx && graph_fork_enabled())) && (!scx || (sfork_env && scx->n <= 2));
         const bool sen_first = fork || scx;
         const bool turns = scx || fork;
         if (turns) {

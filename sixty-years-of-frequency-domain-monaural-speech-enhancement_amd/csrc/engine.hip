@@ -36,6 +36,15 @@ struct se_engine {
     int rag_next = 0;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Two half-batches side by side (round 6, Uformer and DPCRN): a second instance of the model with its own context and
+    // workspace decodes rows [B / 2, B) of a se_enhance_batch call on a process-wide auxiliary stream while the first decodes
+    // rows [0, B / 2) on the caller's - a decode is ~400 launches of very different shapes, two of them in flight fill each
+    // other's tails and launch gaps (Uformer + 3.8 %, DPCRN + 1.3 % at batch 256; rows are independent, the results are the
+    // rows' own).  Not under the profiler (per-launch durations of concurrent launches are not what a roofline prices), not
+    // for graph replay, ragged or frame-online calls.  SE_BATCH_SPLIT=0 / 1: off / on for every model.
+    std::unique_ptr<EngineCtx> ctx2;
+    std::unique_ptr<Model> twin;
+    hipEvent_t ev_tfork = nullptr, ev_tjoin = nullptr;
     // se_stream_*: the samples received so far ([batch][max_samples]), frames transformed, samples emitted
     struct Stream {
         bool active = false;
@@ -123,6 +132,28 @@ int32_t se_abi_version(void) { return 5; }
 
 const char* se_last_error(const se_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
 
+static std::unique_ptr<Model> make_model(int id, EngineCtx& c) {
+    switch (id) {
+        case SE_MODEL_DCCRN: return make_dccrn(c);
+        case SE_MODEL_CRN: return make_crn(c);
+        case SE_MODEL_LSTM: return make_lstm(c);
+        case SE_MODEL_DPCRN: return make_dpcrn(c);
+        case SE_MODEL_GCRN: return make_gcrn(c);
+        case SE_MODEL_CTSNET: return make_ctsnet(c);
+        case SE_MODEL_TAYLORSENET: return make_taylorsenet(c);
+        case SE_MODEL_G2NET: return make_g2net(c);
+        case SE_MODEL_UFORMER: return make_uformer(c);
+        case SE_MODEL_FULLSUBNET: return make_fullsubnet(c);
+        default: SE_CHECK(false, "model id " + std::to_string(id) + " is not built into this engine yet");
+    }
+    return nullptr;
+}
+// The stream the second half-batch runs on: the first of the process-wide auxiliary streams (model.h) - the models that split
+// do not fork, so it is free during their decodes.  NOT a stream of its own: the runtime maps streams onto four hardware queues
+// by default; with a fifth stream in the process (caller's + three auxiliary + this one) two of them shared a queue and G2Net's
+// three-stream fork, built later in the same process, ran slower than on one stream (0.448 -> 0.417 in bench.py's zoo).
+static hipStream_t twin_stream(int dev) { return EngineCtx::shared_aux(dev, 0); }
+
 int se_engine_create(const se_config* cfg, se_engine** out) {
     se_engine* e = nullptr;
     int prev_dev = -1;
@@ -145,23 +176,25 @@ int se_engine_create(const se_config* cfg, se_engine** out) {
         e->ctx.p_in = cfg->p_in > 0.f ? cfg->p_in : 1.f;
         e->ctx.p_out = cfg->p_out > 0.f ? cfg->p_out : 1.f;
         e->ctx.flags = cfg->flags;
-        switch (cfg->model) {
-            case SE_MODEL_DCCRN: e->model = make_dccrn(e->ctx); break;
-            case SE_MODEL_CRN: e->model = make_crn(e->ctx); break;
-            case SE_MODEL_LSTM: e->model = make_lstm(e->ctx); break;
-            case SE_MODEL_DPCRN: e->model = make_dpcrn(e->ctx); break;
-            case SE_MODEL_GCRN: e->model = make_gcrn(e->ctx); break;
-            case SE_MODEL_CTSNET: e->model = make_ctsnet(e->ctx); break;
-            case SE_MODEL_TAYLORSENET: e->model = make_taylorsenet(e->ctx); break;
-            case SE_MODEL_G2NET: e->model = make_g2net(e->ctx); break;
-            case SE_MODEL_UFORMER: e->model = make_uformer(e->ctx); break;
-            case SE_MODEL_FULLSUBNET: e->model = make_fullsubnet(e->ctx); break;
-            default: SE_CHECK(false, "model id " + std::to_string(cfg->model) + " is not built into this engine yet");
-        }
+        e->model = make_model(cfg->model, e->ctx);
         e->ctx.geom = e->model->default_geom();
         if (cfg->n_fft > 0) {
             SE_CHECK(cfg->n_fft == e->ctx.geom.n_fft, "n_fft override must match the model's front end");
             e->ctx.geom = StftGeom{cfg->n_fft, cfg->hop > 0 ? cfg->hop : e->ctx.geom.hop, cfg->win > 0 ? cfg->win : cfg->n_fft};
+        }
+        static const int split_env = getenv("SE_BATCH_SPLIT") ? atoi(getenv("SE_BATCH_SPLIT")) : -1;
+        const bool split = split_env >= 0 ? split_env != 0 : (cfg->model == SE_MODEL_UFORMER || cfg->model == SE_MODEL_DPCRN);
+        if (split && e->ctx.max_batch >= 64) {
+            e->ctx2.reset(new EngineCtx());
+            e->ctx2->max_batch = (e->ctx.max_batch + 1) / 2;
+            e->ctx2->max_samples = e->ctx.max_samples;
+            e->ctx2->p_in = e->ctx.p_in;
+            e->ctx2->p_out = e->ctx.p_out;
+            e->ctx2->flags = e->ctx.flags;
+            e->twin = make_model(cfg->model, *e->ctx2);
+            e->ctx2->geom = e->ctx.geom;
+            SE_HIP(hipEventCreateWithFlags(&e->ev_tfork, hipEventDisableTiming));
+            SE_HIP(hipEventCreateWithFlags(&e->ev_tjoin, hipEventDisableTiming));
         }
         *out = e;
         scratch_engine_created(cfg->device);
@@ -199,6 +232,11 @@ int se_engine_destroy(se_engine* e) {
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     if (e->ctx.arena.base()) gc_unregister_overread_range(e->ctx.arena.base());
+    if (e->ctx2 && e->ctx2->arena.base()) gc_unregister_overread_range(e->ctx2->arena.base());
+    if (e->ev_tfork) (void)hipEventDestroy(e->ev_tfork);
+    if (e->ev_tjoin) (void)hipEventDestroy(e->ev_tjoin);
+    e->twin.reset();          // (the model before its context)
+    e->ctx2.reset();
     const int dev = e->cfg.device;
     delete e;
     scratch_engine_destroyed(dev);      // the device's last engine takes the engine-lifetime scratch slots with it
@@ -262,6 +300,19 @@ int se_engine_finalize(se_engine* e) {
         e->ctx.arena.reserve(need + (1 << 20));
         gc_register_overread_range(e->ctx.arena.base(), e->ctx.arena.capacity());
         e->model->plan_buffers(e->ctx.max_batch, T);
+        if (e->twin) {          // the second instance: the same tensors, a workspace for half the batch (offline decodes only)
+            TrackedSD tsd2(e->sd);
+            e->twin->finalize(tsd2);
+            size_t need2 = 0;
+            for (int bq : {e->ctx2->max_batch, std::min(e->ctx2->max_batch, 15)}) {
+                e->ctx2->arena.measure_begin();
+                e->twin->plan_buffers(bq, Tr);
+                need2 = std::max(need2, e->ctx2->arena.measure_end());
+            }
+            e->ctx2->arena.reserve(need2 + (1 << 20));
+            gc_register_overread_range(e->ctx2->arena.base(), e->ctx2->arena.capacity());
+            e->twin->plan_buffers(e->ctx2->max_batch, T);
+        }
         e->sd.clear();
         SE_HIP(hipDeviceSynchronize());
         e->finalized = true;
@@ -341,6 +392,18 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
         const bool want_graph = (graphs_env >= 0 ? graphs_env != 0 : (e->cfg.flags & SE_CFG_GRAPHS) != 0) && !e->ctx.prof.on &&
                                 e->model->graph_capturable();
         if (!want_graph) {
+            if (e->twin && !e->ctx.prof.on && batch >= 64) {
+                const int B0 = (batch + 1) / 2, B1 = batch - B0;
+                hipStream_t s2 = twin_stream(e->cfg.device);
+                SE_HIP(hipEventRecord(e->ev_tfork, st));
+                SE_HIP(hipStreamWaitEvent(s2, e->ev_tfork, 0));
+                e->twin->enhance(wav_in_dev + (size_t)B0 * in_pitch, in_pitch, B1, n_samples, wav_out_dev + (size_t)B0 * out_pitch,
+                                 out_pitch, s2);
+                SE_HIP(hipEventRecord(e->ev_tjoin, s2));
+                e->model->enhance(wav_in_dev, in_pitch, B0, n_samples, wav_out_dev, out_pitch, st);
+                SE_HIP(hipStreamWaitEvent(st, e->ev_tjoin, 0));
+                return;
+            }
             e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch, st);
             return;
         }

@@ -139,3 +139,41 @@ def test_taylorsenet_with_the_instancenorm_fold_forced():
            '-k', 'taylor']
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+_SPLIT_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import se_amd
+from se_amd import synth
+from se_amd.models import MODEL_CLASSES
+name, B, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+L = 16000
+m = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(1)
+x = np.stack([synth.synth_clip(700 + b, 'speech', L) for b in range(B)])
+y = m.engine.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
+np.save(out, y)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,B', [('uformer', 64), ('dpcrn', 65), ('uformer', 67)])
+def test_two_half_batches_side_by_side_equal_one_batch(tmp_path, name, B):
+    """Round 6: Uformer and DPCRN decode an equal-length batch of 64 clips or more as two half-batches on two streams (a second
+    instance of the model with its own workspace, csrc/engine.hip).  Rows are independent: every row of the split decode - first
+    half, second half, odd batch sizes - against the one-batch decode (SE_BATCH_SPLIT=0)."""
+    import numpy as np
+    outs = []
+    for split in ('1', '0'):
+        out = str(tmp_path / f'{name}_{B}_{split}.npy')
+        env = dict(os.environ, SE_BATCH_SPLIT=split)
+        r = subprocess.run([sys.executable, '-c', _SPLIT_CHILD % ROOT, name, str(B), out], env=env, cwd=ROOT, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert a.shape == b.shape and np.isfinite(a).all()
+    scale = float(np.sqrt(np.mean(b.astype(np.float64) ** 2)))
+    err = float(np.abs(a.astype(np.float64) - b).max())
+    # (the two forms run different tile shapes on some layers - the batch enters the tile choice - so not bit-for-bit)
+    assert err <= 2e-5 * max(scale, 1e-3), (name, B, err, scale)

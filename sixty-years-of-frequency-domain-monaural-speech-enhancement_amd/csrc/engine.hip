@@ -36,10 +36,10 @@ struct se_engine {
     int rag_next = 0;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // Two half-batches side by side (round 6, Uformer and DPCRN): a second instance of the model with its own context and
+    // Two half-batches side by side (round 6: Uformer, DPCRN, CTSNet): a second instance of the model with its own context and
     // workspace decodes rows [B / 2, B) of a se_enhance_batch call on a process-wide auxiliary stream while the first decodes
     // rows [0, B / 2) on the caller's - a decode is ~400 launches of very different shapes, two of them in flight fill each
-    // other's tails and launch gaps (Uformer + 3.8 %, DPCRN + 1.3 % at batch 256; rows are independent, the results are the
+    // other's tails and launch gaps (Uformer + 3 %, DPCRN + 2 %, CTSNet + 2.9 % at batch 256; rows are independent, the results are the
     // rows' own).  Not under the profiler (per-launch durations of concurrent launches are not what a roofline prices), not
     // for graph replay, ragged or frame-online calls.  SE_BATCH_SPLIT=0 / 1: off / on for every model.
     std::unique_ptr<EngineCtx> ctx2;
@@ -183,7 +183,8 @@ int se_engine_create(const se_config* cfg, se_engine** out) {
             e->ctx.geom = StftGeom{cfg->n_fft, cfg->hop > 0 ? cfg->hop : e->ctx.geom.hop, cfg->win > 0 ? cfg->win : cfg->n_fft};
         }
         static const int split_env = getenv("SE_BATCH_SPLIT") ? atoi(getenv("SE_BATCH_SPLIT")) : -1;
-        const bool split = split_env >= 0 ? split_env != 0 : (cfg->model == SE_MODEL_UFORMER || cfg->model == SE_MODEL_DPCRN);
+        const bool split = split_env >= 0 ? split_env != 0
+                                          : (cfg->model == SE_MODEL_UFORMER || cfg->model == SE_MODEL_DPCRN || cfg->model == SE_MODEL_CTSNET);
         if (split && e->ctx.max_batch >= 64) {
             e->ctx2.reset(new EngineCtx());
             e->ctx2->max_batch = (e->ctx.max_batch + 1) / 2;

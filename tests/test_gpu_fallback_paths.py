@@ -149,7 +149,11 @@ from se_amd import synth
 from se_amd.models import MODEL_CLASSES
 name, B, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 L = 16000
-m = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(1)
+if name == 'ctsnet':
+    from se_amd.models import CTSNet
+    m = CTSNet(max_batch=B, max_samples=L).load_synthetic(17, 18)
+else:
+    m = MODEL_CLASSES[name](max_batch=B, max_samples=L).load_synthetic(1)
 x = np.stack([synth.synth_clip(700 + b, 'speech', L) for b in range(B)])
 y = m.engine.enhance_batch(torch.from_numpy(x).cuda()).cpu().numpy()
 np.save(out, y)
@@ -157,9 +161,9 @@ np.save(out, y)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,B', [('uformer', 64), ('dpcrn', 65), ('uformer', 67)])
+@pytest.mark.parametrize('name,B', [('uformer', 64), ('dpcrn', 65), ('uformer', 67), ('ctsnet', 66)])
 def test_two_half_batches_side_by_side_equal_one_batch(tmp_path, name, B):
-    """Round 6: Uformer and DPCRN decode an equal-length batch of 64 clips or more as two half-batches on two streams (a second
+    """Round 6: Uformer, DPCRN and CTSNet decode an equal-length batch of 64 clips or more as two half-batches on two streams (a second
     instance of the model with its own workspace, csrc/engine.hip).  Rows are independent: every row of the split decode - first
     half, second half, odd batch sizes - against the one-batch decode (SE_BATCH_SPLIT=0)."""
     import numpy as np

@@ -23,9 +23,9 @@ else
   bash $ROOT/tools/r6_call.sh prof:g2net:256 prof:g2net_new:256 2>&1 | grep utt_per_s | cut -c1-90
   unset SE_G2NET_FORK
   export SE_BATCH_SPLIT=0
-  bash $ROOT/tools/r6_call.sh prof:uformer:256 prof:dpcrn:256 2>&1 | grep utt_per_s | cut -c1-90
+  bash $ROOT/tools/r6_call.sh prof:uformer:256 prof:dpcrn:256 prof:ctsnet:256 prof:ctsnet_new:256 2>&1 | grep utt_per_s | cut -c1-90
   unset SE_BATCH_SPLIT
-  bash $ROOT/tools/r6_call.sh prof:ctsnet:256 prof:ctsnet_new:256 prof:gcrn:256 prof:crn:64 2>&1 | grep utt_per_s | cut -c1-90
+  bash $ROOT/tools/r6_call.sh prof:gcrn:256 prof:crn:64 2>&1 | grep utt_per_s | cut -c1-90
   cd $ROOT
   ALL=lstm,crn,gcrn,dpcrn,dccrn,fullsubnet,ctsnet,g2net,taylorsenet,uformer,ctsnet_new,g2net_new,taylorsenet_new
   for B in 1 64 256; do

@@ -36,7 +36,7 @@ struct se_engine {
     int rag_next = 0;
     hipStream_t cap_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // Two half-batches side by side (round 6: Uformer, DPCRN, CTSNet): a second instance of the model with its own context and
+    // Two half-batches side by side (round 6: Uformer, DPCRN, CTSNet, TaylorSENet): a second instance of the model with its own context and
     // workspace decodes rows [B / 2, B) of a se_enhance_batch call on a process-wide auxiliary stream while the first decodes
     // rows [0, B / 2) on the caller's - a decode is ~400 launches of very different shapes, two of them in flight fill each
     // other's tails and launch gaps (Uformer + 3 %, DPCRN + 2 %, CTSNet + 2.9 % at batch 256; rows are independent, the results are the
@@ -184,7 +184,8 @@ int se_engine_create(const se_config* cfg, se_engine** out) {
         }
         static const int split_env = getenv("SE_BATCH_SPLIT") ? atoi(getenv("SE_BATCH_SPLIT")) : -1;
         const bool split = split_env >= 0 ? split_env != 0
-                                          : (cfg->model == SE_MODEL_UFORMER || cfg->model == SE_MODEL_DPCRN || cfg->model == SE_MODEL_CTSNET);
+                                          : (cfg->model == SE_MODEL_UFORMER || cfg->model == SE_MODEL_DPCRN || cfg->model == SE_MODEL_CTSNET ||
+                                             cfg->model == SE_MODEL_TAYLORSENET);
         if (split && e->ctx.max_batch >= 64) {
             e->ctx2.reset(new EngineCtx());
             e->ctx2->max_batch = (e->ctx.max_batch + 1) / 2;
@@ -396,6 +397,10 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
             if (e->twin && !e->ctx.prof.on && batch >= 64) {
                 const int B0 = (batch + 1) / 2, B1 = batch - B0;
                 hipStream_t s2 = twin_stream(e->cfg.device);
+                struct Active {
+                    Active() { batch_split_active() = true; }
+                    ~Active() { batch_split_active() = false; }
+                } active;
                 SE_HIP(hipEventRecord(e->ev_tfork, st));
                 SE_HIP(hipStreamWaitEvent(s2, e->ev_tfork, 0));
                 e->twin->enhance(wav_in_dev + (size_t)B0 * in_pitch, in_pitch, B1, n_samples, wav_out_dev + (size_t)B0 * out_pitch,

@@ -241,7 +241,8 @@ class TaylorSENet final : public Model {
         // chunk, forked or not, so that the state slots are taken in one order whatever the chunk length.  SE_TAYLOR_STREAM_FORK=0.
         static const bool sfork_env = !(getenv("SE_TAYLOR_STREAM_FORK") && atoi(getenv("SE_TAYLOR_STREAM_FORK")) == 0);
         const StreamCtx* scx = stream_ctx();
-        const bool fork = fork_env && (!ctx.graphs_wanted() || (!scx && graph_fork_enabled())) && (!scx || (sfork_env && scx->n <= 2));
+        const bool fork = fork_env && !batch_split_active() && (!ctx.graphs_wanted() || (!scx && graph_fork_enabled())) &&
+                          (!scx || (sfork_env && scx->n <= 2));
         const bool sen_first = fork || scx;
         const bool turns = scx || fork;
         if (turns) {

@@ -161,9 +161,9 @@ np.save(out, y)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,B', [('uformer', 64), ('dpcrn', 65), ('uformer', 67), ('ctsnet', 66)])
+@pytest.mark.parametrize('name,B', [('uformer', 64), ('dpcrn', 65), ('uformer', 67), ('ctsnet', 66), ('taylorsenet', 64)])
 def test_two_half_batches_side_by_side_equal_one_batch(tmp_path, name, B):
-    """Round 6: Uformer, DPCRN and CTSNet decode an equal-length batch of 64 clips or more as two half-batches on two streams (a second
+    """Round 6: Uformer, DPCRN, CTSNet and TaylorSENet decode an equal-length batch of 64 clips or more as two half-batches on two streams (a second
     instance of the model with its own workspace, csrc/engine.hip).  Rows are independent: every row of the split decode - first
     half, second half, odd batch sizes - against the one-batch decode (SE_BATCH_SPLIT=0)."""
     import numpy as np

@@ -12,13 +12,13 @@ PART=${1:-a}
 if [ "$PART" = a ]; then
   bash $ROOT/tools/measure_round.sh r06 2>&1 | tail -3 | cut -c1-300
   bash $ROOT/tools/r6_call.sh parity
-  bash $ROOT/tools/pmc_models.sh r06 "taylorsenet 256" "fullsubnet 128" 2>&1 | grep -v "^declare" | tail -4 | cut -c1-200
+  SE_BATCH_SPLIT=0 bash $ROOT/tools/pmc_models.sh r06 "taylorsenet 256" "fullsubnet 128" 2>&1 | grep -v "^declare" | tail -4 | cut -c1-200
   SE_BATCH_SPLIT=0 bash $ROOT/tools/pmc_models.sh r06 "uformer 256" 2>&1 | grep -v "^declare" | tail -2 | cut -c1-200      # (one stream: per-kernel busy cycles)
   SE_G2NET_FORK=0 bash $ROOT/tools/pmc_models.sh r06 "g2net 256" 2>&1 | grep -v "^declare" | tail -2 | cut -c1-200      # (one stream: per-kernel busy cycles)
 else
-  export SE_TAYLOR_FORK=0 SE_FSN_SPLIT=1
+  export SE_TAYLOR_FORK=0 SE_FSN_SPLIT=1 SE_BATCH_SPLIT=0
   bash $ROOT/tools/r6_call.sh prof:taylorsenet:256 prof:taylorsenet_new:256 prof:fullsubnet:128 2>&1 | grep utt_per_s | cut -c1-90
-  unset SE_TAYLOR_FORK SE_FSN_SPLIT
+  unset SE_TAYLOR_FORK SE_FSN_SPLIT SE_BATCH_SPLIT
   export SE_G2NET_FORK=0
   bash $ROOT/tools/r6_call.sh prof:g2net:256 prof:g2net_new:256 2>&1 | grep utt_per_s | cut -c1-90
   unset SE_G2NET_FORK

@@ -42,9 +42,12 @@ struct se_engine {
     // other's tails and launch gaps (Uformer + 3 %, DPCRN + 2 %, CTSNet + 2.9 % at batch 256; rows are independent, the results are the
     // rows' own).  Not under the profiler (per-launch durations of concurrent launches are not what a roofline prices), not
     // for graph replay, ragged or frame-online calls.  SE_BATCH_SPLIT=0 / 1: off / on for every model.
-    std::unique_ptr<EngineCtx> ctx2;
-    std::unique_ptr<Model> twin;
-    hipEvent_t ev_tfork = nullptr, ev_tjoin = nullptr;
+    // (Uformer and DPCRN: THREE parts - + 1.5 % over two; CTSNet and TaylorSENet: two - a third loses for TaylorSENet)
+    static constexpr int MAX_TWINS = 2;
+    int ntwins = 0;
+    std::unique_ptr<EngineCtx> ctx2[MAX_TWINS];
+    std::unique_ptr<Model> twin[MAX_TWINS];
+    hipEvent_t ev_tfork = nullptr, ev_tjoin[MAX_TWINS] = {};
     // se_stream_*: the samples received so far ([batch][max_samples]), frames transformed, samples emitted
     struct Stream {
         bool active = false;
@@ -152,7 +155,7 @@ static std::unique_ptr<Model> make_model(int id, EngineCtx& c) {
 // do not fork, so it is free during their decodes.  NOT a stream of its own: the runtime maps streams onto four hardware queues
 // by default; with a fifth stream in the process (caller's + three auxiliary + this one) two of them shared a queue and G2Net's
 // three-stream fork, built later in the same process, ran slower than on one stream (0.448 -> 0.417 in bench.py's zoo).
-static hipStream_t twin_stream(int dev) { return EngineCtx::shared_aux(dev, 0); }
+static hipStream_t twin_stream(int dev, int i = 0) { return EngineCtx::shared_aux(dev, i); }
 
 int se_engine_create(const se_config* cfg, se_engine** out) {
     se_engine* e = nullptr;
@@ -187,16 +190,23 @@ int se_engine_create(const se_config* cfg, se_engine** out) {
                                           : (cfg->model == SE_MODEL_UFORMER || cfg->model == SE_MODEL_DPCRN || cfg->model == SE_MODEL_CTSNET ||
                                              cfg->model == SE_MODEL_TAYLORSENET);
         if (split && e->ctx.max_batch >= 64) {
-            e->ctx2.reset(new EngineCtx());
-            e->ctx2->max_batch = (e->ctx.max_batch + 1) / 2;
-            e->ctx2->max_samples = e->ctx.max_samples;
-            e->ctx2->p_in = e->ctx.p_in;
-            e->ctx2->p_out = e->ctx.p_out;
-            e->ctx2->flags = e->ctx.flags;
-            e->twin = make_model(cfg->model, *e->ctx2);
-            e->ctx2->geom = e->ctx.geom;
+            static const int parts_env = getenv("SE_BATCH_PARTS") ? atoi(getenv("SE_BATCH_PARTS")) : 0;
+            const int parts = parts_env >= 2 && parts_env <= 1 + se_engine::MAX_TWINS
+                                  ? parts_env
+                                  : ((cfg->model == SE_MODEL_UFORMER || cfg->model == SE_MODEL_DPCRN) ? 3 : 2);
+            e->ntwins = parts - 1;
             SE_HIP(hipEventCreateWithFlags(&e->ev_tfork, hipEventDisableTiming));
-            SE_HIP(hipEventCreateWithFlags(&e->ev_tjoin, hipEventDisableTiming));
+            for (int i = 0; i < e->ntwins; ++i) {
+                e->ctx2[i].reset(new EngineCtx());
+                e->ctx2[i]->max_batch = (e->ctx.max_batch + i + 1) / (i + 2);      // the first: a half (two-part calls), the second: a third
+                e->ctx2[i]->max_samples = e->ctx.max_samples;
+                e->ctx2[i]->p_in = e->ctx.p_in;
+                e->ctx2[i]->p_out = e->ctx.p_out;
+                e->ctx2[i]->flags = e->ctx.flags;
+                e->twin[i] = make_model(cfg->model, *e->ctx2[i]);
+                e->ctx2[i]->geom = e->ctx.geom;
+                SE_HIP(hipEventCreateWithFlags(&e->ev_tjoin[i], hipEventDisableTiming));
+            }
         }
         *out = e;
         scratch_engine_created(cfg->device);
@@ -234,11 +244,13 @@ int se_engine_destroy(se_engine* e) {
     if (e->stage_in) (void)hipFree(e->stage_in);
     if (e->stage_out) (void)hipFree(e->stage_out);
     if (e->ctx.arena.base()) gc_unregister_overread_range(e->ctx.arena.base());
-    if (e->ctx2 && e->ctx2->arena.base()) gc_unregister_overread_range(e->ctx2->arena.base());
     if (e->ev_tfork) (void)hipEventDestroy(e->ev_tfork);
-    if (e->ev_tjoin) (void)hipEventDestroy(e->ev_tjoin);
-    e->twin.reset();          // (the model before its context)
-    e->ctx2.reset();
+    for (int i = 0; i < se_engine::MAX_TWINS; ++i) {
+        if (e->ctx2[i] && e->ctx2[i]->arena.base()) gc_unregister_overread_range(e->ctx2[i]->arena.base());
+        if (e->ev_tjoin[i]) (void)hipEventDestroy(e->ev_tjoin[i]);
+        e->twin[i].reset();          // (the model before its context)
+        e->ctx2[i].reset();
+    }
     const int dev = e->cfg.device;
     delete e;
     scratch_engine_destroyed(dev);      // the device's last engine takes the engine-lifetime scratch slots with it
@@ -302,18 +314,18 @@ int se_engine_finalize(se_engine* e) {
         e->ctx.arena.reserve(need + (1 << 20));
         gc_register_overread_range(e->ctx.arena.base(), e->ctx.arena.capacity());
         e->model->plan_buffers(e->ctx.max_batch, T);
-        if (e->twin) {          // the second instance: the same tensors, a workspace for half the batch (offline decodes only)
+        for (int i = 0; i < e->ntwins; ++i) {          // the other instances: the same tensors, a workspace for their part of the batch (offline decodes only)
             TrackedSD tsd2(e->sd);
-            e->twin->finalize(tsd2);
+            e->twin[i]->finalize(tsd2);
             size_t need2 = 0;
-            for (int bq : {e->ctx2->max_batch, std::min(e->ctx2->max_batch, 15)}) {
-                e->ctx2->arena.measure_begin();
-                e->twin->plan_buffers(bq, Tr);
-                need2 = std::max(need2, e->ctx2->arena.measure_end());
+            for (int bq : {e->ctx2[i]->max_batch, std::min(e->ctx2[i]->max_batch, 15)}) {
+                e->ctx2[i]->arena.measure_begin();
+                e->twin[i]->plan_buffers(bq, Tr);
+                need2 = std::max(need2, e->ctx2[i]->arena.measure_end());
             }
-            e->ctx2->arena.reserve(need2 + (1 << 20));
-            gc_register_overread_range(e->ctx2->arena.base(), e->ctx2->arena.capacity());
-            e->twin->plan_buffers(e->ctx2->max_batch, T);
+            e->ctx2[i]->arena.reserve(need2 + (1 << 20));
+            gc_register_overread_range(e->ctx2[i]->arena.base(), e->ctx2[i]->arena.capacity());
+            e->twin[i]->plan_buffers(e->ctx2[i]->max_batch, T);
         }
         e->sd.clear();
         SE_HIP(hipDeviceSynchronize());
@@ -394,20 +406,28 @@ int se_enhance_batch(se_engine* e, const float* wav_in_dev, int64_t in_pitch, in
         const bool want_graph = (graphs_env >= 0 ? graphs_env != 0 : (e->cfg.flags & SE_CFG_GRAPHS) != 0) && !e->ctx.prof.on &&
                                 e->model->graph_capturable();
         if (!want_graph) {
-            if (e->twin && !e->ctx.prof.on && batch >= 64) {
-                const int B0 = (batch + 1) / 2, B1 = batch - B0;
-                hipStream_t s2 = twin_stream(e->cfg.device);
+            if (e->ntwins > 0 && !e->ctx.prof.on && batch >= 64) {
+                // three parts from 192 clips on where the model has them (at 64 clips a third part loses: DPCRN - 3 %), else two
+                const int parts = (e->ntwins >= 2 && batch >= 192) ? 3 : 2;
+                const int Bp = (batch + parts - 1) / parts;           // rows per part (the last part may be shorter)
                 struct Active {
                     Active() { batch_split_active() = true; }
                     ~Active() { batch_split_active() = false; }
                 } active;
                 SE_HIP(hipEventRecord(e->ev_tfork, st));
-                SE_HIP(hipStreamWaitEvent(s2, e->ev_tfork, 0));
-                e->twin->enhance(wav_in_dev + (size_t)B0 * in_pitch, in_pitch, B1, n_samples, wav_out_dev + (size_t)B0 * out_pitch,
-                                 out_pitch, s2);
-                SE_HIP(hipEventRecord(e->ev_tjoin, s2));
-                e->model->enhance(wav_in_dev, in_pitch, B0, n_samples, wav_out_dev, out_pitch, st);
-                SE_HIP(hipStreamWaitEvent(st, e->ev_tjoin, 0));
+                int njoin = 0;
+                for (int i = 0; i < parts - 1; ++i) {
+                    const int r0 = (i + 1) * Bp, nr = std::min(Bp, batch - r0);
+                    if (nr <= 0) break;
+                    hipStream_t s2 = twin_stream(e->cfg.device, i);
+                    SE_HIP(hipStreamWaitEvent(s2, e->ev_tfork, 0));
+                    e->twin[i]->enhance(wav_in_dev + (size_t)r0 * in_pitch, in_pitch, nr, n_samples, wav_out_dev + (size_t)r0 * out_pitch,
+                                        out_pitch, s2);
+                    SE_HIP(hipEventRecord(e->ev_tjoin[i], s2));
+                    njoin = i + 1;
+                }
+                e->model->enhance(wav_in_dev, in_pitch, std::min(Bp, batch), n_samples, wav_out_dev, out_pitch, st);
+                for (int i = 0; i < njoin; ++i) SE_HIP(hipStreamWaitEvent(st, e->ev_tjoin[i], 0));
                 return;
             }
             e->model->enhance(wav_in_dev, in_pitch, batch, n_samples, wav_out_dev, out_pitch, st);

@@ -161,11 +161,13 @@ np.save(out, y)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,B', [('uformer', 64), ('dpcrn', 65), ('uformer', 67), ('ctsnet', 66), ('taylorsenet', 64)])
+@pytest.mark.parametrize('name,B', [('uformer', 64), ('dpcrn', 65), ('uformer', 67), ('ctsnet', 66), ('taylorsenet', 64), ('dpcrn', 193),
+                                    ('uformer', 200)])
 def test_two_half_batches_side_by_side_equal_one_batch(tmp_path, name, B):
     """Round 6: Uformer, DPCRN, CTSNet and TaylorSENet decode an equal-length batch of 64 clips or more as two half-batches on two streams (a second
     instance of the model with its own workspace, csrc/engine.hip).  Rows are independent: every row of the split decode - first
-    half, second half, odd batch sizes - against the one-batch decode (SE_BATCH_SPLIT=0)."""
+    half, second half, odd batch sizes, and the three parts Uformer / DPCRN use from 192 clips on - against the one-batch decode
+    (SE_BATCH_SPLIT=0)."""
     import numpy as np
     outs = []
     for split in ('1', '0'):
